@@ -1,0 +1,250 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under simdjson-java_amd/ may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+ST_UTF8, ST_UNCLOSED, ST_UNESCAPED = 1, 2, 4
+
+
+def build(force=False):
+    """Compile liboracle.so with gcc (portable flags so the .so also runs on the GPU box)."""
+    src = os.path.join(_HERE, "sj_oracle.c")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src),
+                                                   os.path.getmtime(os.path.join(_HERE, "sj_oracle.h")))):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "portable"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+class _Doc(C.Structure):
+    _fields_ = [("tape", C.POINTER(C.c_uint64)), ("tape_len", C.c_uint64),
+                ("string_buffer", C.POINTER(C.c_uint8)), ("string_len", C.c_uint64),
+                ("error", C.c_int), ("error_pos", C.c_uint64), ("stage1_status", C.c_uint32), ("n_structurals", C.c_uint64)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        u8p, u32p, u64p = C.c_void_p, C.c_void_p, C.c_void_p
+        L.sjo_error_message.restype = C.c_char_p
+        L.sjo_error_message.argtypes = [C.c_int]
+        for name in ("sjo_index_blocks",):
+            f = getattr(L, name)
+            f.restype = C.c_int
+            f.argtypes = [u8p, C.c_uint64, u32p, C.c_uint64, u64p, u32p, u64p]
+        for name in ("sjo_index_bytewise", "sjo_stage1"):
+            f = getattr(L, name)
+            f.restype = C.c_int
+            f.argtypes = [u8p, C.c_uint64, u32p, C.c_uint64, u64p, u32p]
+        L.sjo_utf8_validate_lookup.restype = C.c_int
+        L.sjo_utf8_validate_lookup.argtypes = [u8p, C.c_uint64, C.c_int]
+        L.sjo_utf8_validate_strict.restype = C.c_int
+        L.sjo_utf8_validate_strict.argtypes = [u8p, C.c_uint64]
+        L.sjo_parse_string.restype = C.c_int64
+        L.sjo_parse_string.argtypes = [u8p, C.c_uint64, u8p, C.c_uint64, C.c_uint64]
+        L.sjo_unescape_all.restype = C.c_uint64
+        L.sjo_unescape_all.argtypes = [u8p, u32p, C.c_uint64, u8p, C.c_uint64, u64p, u64p,
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+        L.sjo_parse.restype = C.c_int
+        L.sjo_parse.argtypes = [u8p, C.c_uint64, C.c_int, C.POINTER(_Doc)]
+        L.sjo_stage2.restype = C.c_int
+        L.sjo_stage2.argtypes = [u8p, C.c_uint64, u32p, C.c_uint64, C.c_int, C.POINTER(_Doc)]
+        L.sjo_doc_free.restype = None
+        L.sjo_doc_free.argtypes = [C.POINTER(_Doc)]
+        L.sjo_fnv1a64_u32.restype = C.c_uint64
+        L.sjo_fnv1a64_u32.argtypes = [u32p, C.c_uint64]
+        _lib = L
+    return _lib
+
+
+def _as_u8(data):
+    if isinstance(data, np.ndarray):
+        a = np.ascontiguousarray(data, dtype=np.uint8)
+    else:
+        a = np.frombuffer(bytes(data), dtype=np.uint8)
+    if a.size == 0:
+        a = np.zeros(1, dtype=np.uint8)[:0]
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data if a.size else np.zeros(1, dtype=a.dtype).ctypes.data
+
+
+def error_message(code):
+    return lib().sjo_error_message(code).decode("utf-8")
+
+
+def index_blocks(data, length=None, want_masks=False):
+    """-> (indexes[np.uint32, count], status, masks or None). StructuralIndexer.index + BitIndexes."""
+    a = _as_u8(data)
+    n = a.size if length is None else length
+    cap = n + 2
+    idx = np.empty(cap, dtype=np.uint32)
+    cnt = C.c_uint64(0)
+    st = C.c_uint32(0)
+    masks = np.zeros((n // 64 + 1, 6), dtype=np.uint64) if want_masks else None
+    r = lib().sjo_index_blocks(_ptr(a), n, idx.ctypes.data, cap, C.addressof(cnt), C.addressof(st),
+                               masks.ctypes.data if want_masks else None)
+    assert r == 0
+    assert idx[cnt.value] == 0
+    return idx[:cnt.value].copy(), st.value, masks
+
+
+def index_bytewise(data, length=None):
+    a = _as_u8(data)
+    n = a.size if length is None else length
+    cap = n + 2
+    idx = np.empty(cap, dtype=np.uint32)
+    cnt = C.c_uint64(0)
+    st = C.c_uint32(0)
+    r = lib().sjo_index_bytewise(_ptr(a), n, idx.ctypes.data, cap, C.addressof(cnt), C.addressof(st))
+    assert r == 0
+    return idx[:cnt.value].copy(), st.value
+
+
+def utf8_lookup(data, length=None, species=64):
+    a = _as_u8(data)
+    n = a.size if length is None else length
+    return bool(lib().sjo_utf8_validate_lookup(_ptr(a), n, species))
+
+
+def utf8_strict(data, length=None):
+    a = _as_u8(data)
+    n = a.size if length is None else length
+    return bool(lib().sjo_utf8_validate_strict(_ptr(a), n))
+
+
+def stage1(data, length=None):
+    """SimdJsonParser.stage1: -> (indexes incl. nothing past count, status bits)."""
+    a = _as_u8(data)
+    n = a.size if length is None else length
+    cap = n + 2
+    idx = np.empty(cap, dtype=np.uint32)
+    cnt = C.c_uint64(0)
+    st = C.c_uint32(0)
+    r = lib().sjo_stage1(_ptr(a), n, idx.ctypes.data, cap, C.addressof(cnt), C.addressof(st))
+    assert r == 0
+    return idx[:cnt.value].copy(), st.value
+
+
+def fnv1a64_u32(arr):
+    a = np.ascontiguousarray(arr, dtype=np.uint32)
+    return int(lib().sjo_fnv1a64_u32(_ptr(a), a.size))
+
+
+def unescape_all(padded, indexes):
+    """-> (string_buffer bytes, offsets[np.uint64], first_error_ordinal, first_error_code)."""
+    a = _as_u8(padded)
+    ix = np.ascontiguousarray(indexes, dtype=np.uint32)
+    cap = a.size + 4 * ix.size + 128
+    sb = np.zeros(cap, dtype=np.uint8)
+    offs = np.zeros(ix.size + 1, dtype=np.uint64)
+    nstr = C.c_uint64(0)
+    feo = C.c_int64(0)
+    fec = C.c_int(0)
+    total = lib().sjo_unescape_all(_ptr(a), _ptr(ix), ix.size, sb.ctypes.data, cap, offs.ctypes.data,
+                                   C.addressof(nstr), C.byref(feo), C.byref(fec))
+    return sb[:total].tobytes(), offs[:nstr.value].copy(), feo.value, fec.value
+
+
+class Parsed:
+    """Result of the oracle's SimdJsonParser.parse: tape + string buffer (+ error)."""
+
+    def __init__(self, tape, strings, error, stage1_status, n_structurals, error_pos=0):
+        self.error_pos = error_pos
+        self.tape = tape
+        self.strings = strings
+        self.error = error
+        self.stage1_status = stage1_status
+        self.n_structurals = n_structurals
+
+    @property
+    def message(self):
+        return error_message(self.error).replace('%d', str(self.error_pos))
+
+    # -- JsonValue-like read-only walk (JsonValue.java:32-111), returns python objects ------
+    def to_python(self):
+        assert self.error == 0
+        val, _ = self._value(1)
+        return val
+
+    def _str(self, tape_idx):
+        off = int(self.tape[tape_idx]) & 0x00FFFFFFFFFFFFFF
+        ln = int.from_bytes(self.strings[off:off + 4], "big")
+        return self.strings[off + 4:off + 4 + ln]
+
+    def _value(self, i):
+        w = int(self.tape[i])
+        t = chr(w >> 56)
+        if t == '"':
+            return ("s", self._str(i)), i + 1
+        if t == 'l':
+            v = int(self.tape[i + 1])
+            return ("l", v - (1 << 64) if v >= (1 << 63) else v), i + 2
+        if t == 'd':
+            return ("d", int(self.tape[i + 1])), i + 2  # raw IEEE bits
+        if t in "tfn":
+            return (t,), i + 1
+        if t == '[':
+            end = (w & 0xFFFFFFFF) - 1
+            size = (w >> 32) & 0xFFFFFF
+            out = []
+            j = i + 1
+            while j < end:
+                v, j = self._value(j)
+                out.append(v)
+            return ("a", size, out), end + 1
+        if t == '{':
+            end = (w & 0xFFFFFFFF) - 1
+            size = (w >> 32) & 0xFFFFFF
+            out = []
+            j = i + 1
+            while j < end:
+                k = self._str(j)
+                v, j = self._value(j + 1)
+                out.append((k, v))
+            return ("o", size, out), end + 1
+        raise AssertionError("bad tape type %r at %d" % (t, i))
+
+
+def _doc_to_parsed(d):
+    tape = np.ctypeslib.as_array(d.tape, shape=(max(d.tape_len, 1),))[:d.tape_len].copy() if d.tape_len else np.zeros(0, np.uint64)
+    strings = bytes(np.ctypeslib.as_array(d.string_buffer, shape=(max(d.string_len, 1),))[:d.string_len]) if d.string_len else b""
+    return Parsed(tape, strings, d.error, d.stage1_status, d.n_structurals, d.error_pos)
+
+
+def parse(data, length=None, max_depth=1024):
+    a = _as_u8(data)
+    n = a.size if length is None else length
+    d = _Doc()
+    lib().sjo_parse(_ptr(a), n, max_depth, C.byref(d))
+    p = _doc_to_parsed(d)
+    lib().sjo_doc_free(C.byref(d))
+    return p
+
+
+def stage2(padded, length, indexes, max_depth=1024):
+    a = _as_u8(padded)
+    ix = np.ascontiguousarray(indexes, dtype=np.uint32)
+    d = _Doc()
+    lib().sjo_stage2(_ptr(a), length, _ptr(ix), ix.size, max_depth, C.byref(d))
+    p = _doc_to_parsed(d)
+    lib().sjo_doc_free(C.byref(d))
+    return p
