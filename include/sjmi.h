@@ -1,0 +1,91 @@
+/*
+ * sjmi.h -- C ABI of libsjmi.so: the MI355X (gfx950) stage-1 engine behind
+ * simdjson-java's SimdJsonParser.parse(byte[], int).
+ *
+ * The reference has no FFI: its narrowest seam is the private method
+ *     SimdJsonParser.stage1(byte[] buffer, int length)
+ *         /root/reference/src/main/java/org/simdjson/SimdJsonParser.java:55-58
+ * whose only observable effects are (a) BitIndexes.indexes[0..writeIdx] (ascending byte
+ * offsets + a 0 sentinel, BitIndexes.java:14-41,82-96) and (b) one of three
+ * JsonParsingExceptions (Utf8Validator.java:165-167, StructuralIndexer.java:297-302).
+ * Every entry point below is what a Panama/JNI binding of that seam calls; INTEGRATION.md
+ * shows the Java side.  Plain pointers and sizes only; no callbacks; no exceptions.
+ *
+ * Return value: 0 = the call ran (JSON-level verdicts are in `status`), < 0 = infrastructure
+ * error (HIP failure, bad argument, capacity) -- never conflated with a JSON error.
+ */
+#ifndef SJMI_H
+#define SJMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SJMI_PADDING 64u /* readable bytes required after len; SimdJsonParser.java:5 (PADDING) */
+
+/* status bits; the Java shim throws the lowest set bit first (reference order of checks) */
+#define SJMI_ST_UTF8 1u       /* "The input is not valid UTF-8"                      Utf8Validator.java:165-167 */
+#define SJMI_ST_UNCLOSED 2u   /* "Unclosed string. A string is opened, but never closed." StructuralIndexer.java:297-299 */
+#define SJMI_ST_UNESCAPED 4u  /* "Unescaped characters. Within strings, ..."         StructuralIndexer.java:300-302 */
+#define SJMI_ST_CAPACITY 0x100u /* index_capacity < count+1 (the reference throws AIOOBE here) */
+#define SJMI_ST_INTERNAL 0x200u /* engine fault (look-back timeout); results invalid */
+
+/* return codes */
+#define SJMI_OK 0
+#define SJMI_ERR_HIP (-1)
+#define SJMI_ERR_ARG (-2)
+#define SJMI_ERR_CAPACITY (-3)
+#define SJMI_ERR_INTERNAL (-4)
+#define SJMI_ERR_NO_DEVICE (-5)
+
+typedef struct sjmi_ctx sjmi_ctx;
+
+/* device-side result record of one stage-1 call */
+typedef struct sjmi_stage1_result {
+    uint64_t count;   /* BitIndexes.writeIdx */
+    uint32_t status;  /* SJMI_ST_* */
+    uint32_t reserved;
+} sjmi_stage1_result;
+
+/* One context per host thread (SimdJsonParser is not thread-safe either: SimdJsonParser.java:9-13
+ * shares one BitIndexes).  capacity_bytes = largest document, as the reference's ctor argument
+ * `capacity` (SimdJsonParser.java:19-26). Owns a HIP stream, device staging buffers and the
+ * tile-state workspace. Fails with SJMI_ERR_NO_DEVICE when no gfx950 device is usable: there is
+ * no CPU fallback. */
+int sjmi_create(sjmi_ctx** out, int device, uint64_t capacity_bytes);
+void sjmi_destroy(sjmi_ctx* ctx);
+const char* sjmi_last_error(const sjmi_ctx* ctx);
+const char* sjmi_version(void);
+
+/* Replaces SimdJsonParser.stage1 (+ padIfNeeded) for HOST buffers: copies buf[0,len) to the
+ * device (padding handled internally: bytes >= len are never read from `buf`), runs the fused
+ * kernel, copies indexes[0..count] (sentinel included) and the verdict back.
+ * indexes must hold index_capacity entries; needs index_capacity >= count+1. */
+int sjmi_stage1(sjmi_ctx* ctx, const uint8_t* buf, uint64_t len, uint32_t* indexes, uint64_t index_capacity,
+                uint64_t* count, uint32_t* status);
+
+/* Same path on DEVICE-resident data (roofline runs, pipelines that already hold the document in
+ * HBM). d_buf must be 16-byte aligned with SJMI_PADDING readable bytes after len (contents
+ * ignored); d_indexes holds index_capacity u32; d_result is a device sjmi_stage1_result.
+ * Asynchronous on `stream` (a hipStream_t, may be NULL = the context's stream). len < 2^32. */
+int sjmi_stage1_device(sjmi_ctx* ctx, const void* d_buf, uint64_t len, void* d_indexes, uint64_t index_capacity,
+                       void* d_result, void* stream);
+
+/* Run the on-device self-test of the bit-plane transposition; *mismatches == 0 on success. */
+int sjmi_selftest(sjmi_ctx* ctx, uint32_t* mismatches);
+
+/* tuning knob for tests: force the number of 16 KiB steps per tile (1, 2 or 4; 0 = automatic) */
+int sjmi_set_tile_steps(sjmi_ctx* ctx, int steps);
+
+/* Measurement hooks for bench.py: when on, every sjmi_stage1_device launch is bracketed by HIP events
+ * on the launch stream (kernel only); sjmi_kernel_time returns their summed duration and count. */
+int sjmi_set_profiling(sjmi_ctx* ctx, int on);
+int sjmi_kernel_time(sjmi_ctx* ctx, double* sum_ms, uint32_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SJMI_H */

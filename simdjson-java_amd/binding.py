@@ -1,0 +1,153 @@
+"""ctypes binding of libsjmi.so (C ABI: include/sjmi.h).  No compute happens in Python and nothing
+here falls back to a CPU path: a missing library or GPU raises SjmiError."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_CSRC = os.path.join(_HERE, "csrc")
+_LIB = os.path.join(_HERE, "libsjmi.so")
+SOURCES = ["stage1.hip", "sjmi_api.hip"]
+
+ST_UTF8, ST_UNCLOSED, ST_UNESCAPED, ST_CAPACITY, ST_INTERNAL = 1, 2, 4, 0x100, 0x200
+PADDING = 64
+
+_MESSAGES = {  # exact reference messages (Utf8Validator.java:166, StructuralIndexer.java:298,301)
+    ST_UTF8: "The input is not valid UTF-8",
+    ST_UNCLOSED: "Unclosed string. A string is opened, but never closed.",
+    ST_UNESCAPED: "Unescaped characters. Within strings, there are characters that should be escaped.",
+}
+
+
+class SjmiError(RuntimeError):
+    pass
+
+
+def status_message(status):
+    """Message of the JsonParsingException SimdJsonParser.stage1 would throw (first check wins)."""
+    for bit in (ST_UTF8, ST_UNCLOSED, ST_UNESCAPED):
+        if status & bit:
+            return _MESSAGES[bit]
+    return None
+
+
+def lib_path():
+    return _LIB
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> simdjson-java_amd/libsjmi.so (in-tree; cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(_CSRC, h) for h in os.listdir(_CSRC) if h.endswith(".h")] + \
+        [os.path.join(_ROOT, "include", "sjmi.h")]
+    if not force and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= max(os.path.getmtime(d) for d in deps):
+        return _LIB
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I", os.path.join(_ROOT, "include")] + srcs + ["-o", _LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return _LIB
+
+
+_lib = None
+
+EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sjmi_stage1", "sjmi_stage1_device",
+           "sjmi_selftest", "sjmi_set_tile_steps", "sjmi_set_profiling", "sjmi_kernel_time"]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise SjmiError("libsjmi.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(_LIB)
+        L.sjmi_create.restype = C.c_int
+        L.sjmi_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_uint64]
+        L.sjmi_destroy.restype = None
+        L.sjmi_destroy.argtypes = [C.c_void_p]
+        L.sjmi_last_error.restype = C.c_char_p
+        L.sjmi_last_error.argtypes = [C.c_void_p]
+        L.sjmi_version.restype = C.c_char_p
+        L.sjmi_stage1.restype = C.c_int
+        L.sjmi_stage1.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.sjmi_stage1_device.restype = C.c_int
+        L.sjmi_stage1_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                         C.c_void_p]
+        L.sjmi_selftest.restype = C.c_int
+        L.sjmi_selftest.argtypes = [C.c_void_p, C.c_void_p]
+        L.sjmi_set_tile_steps.restype = C.c_int
+        L.sjmi_set_tile_steps.argtypes = [C.c_void_p, C.c_int]
+        L.sjmi_set_profiling.restype = C.c_int
+        L.sjmi_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.sjmi_kernel_time.restype = C.c_int
+        L.sjmi_kernel_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class Context:
+    """One sjmi_ctx: the engine-side state of one SimdJsonParser (SimdJsonParser.java:19-26)."""
+
+    def __init__(self, device=0, capacity=34 * 1024 * 1024):
+        self._h = C.c_void_p()
+        rc = lib().sjmi_create(C.byref(self._h), device, capacity)
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise SjmiError("sjmi_create failed (rc=%d): no usable MI355X / HIP device; there is no CPU fallback" % rc)
+        self.capacity = capacity
+
+    def close(self):
+        if self._h:
+            lib().sjmi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise SjmiError("%s failed (rc=%d): %s" % (what, rc, lib().sjmi_last_error(self._h).decode()))
+
+    def selftest(self):
+        mm = C.c_uint32(1)
+        self._check(lib().sjmi_selftest(self._h, C.addressof(mm)), "sjmi_selftest")
+        return mm.value
+
+    def set_tile_steps(self, steps):
+        self._check(lib().sjmi_set_tile_steps(self._h, steps), "sjmi_set_tile_steps")
+
+    def stage1(self, data, length=None, index_capacity=None):
+        """Host-buffer path (SimdJsonParser.stage1 + padIfNeeded): -> (indexes incl. sentinel stripped, status)."""
+        a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, np.uint8)
+        n = a.size if length is None else length
+        cap = (n + 2) if index_capacity is None else index_capacity
+        idx = np.empty(max(cap, 1), dtype=np.uint32)
+        cnt = C.c_uint64(0)
+        st = C.c_uint32(0)
+        ptr = a.ctypes.data if a.size else None
+        self._check(lib().sjmi_stage1(self._h, ptr, n, idx.ctypes.data, cap, C.addressof(cnt), C.addressof(st)),
+                    "sjmi_stage1")
+        assert idx[cnt.value] == 0, "sentinel missing"
+        return idx[:cnt.value].copy(), st.value
+
+    def stage1_device(self, d_buf, length, d_indexes, index_capacity, d_result, stream=0):
+        """Device-resident path; arguments are raw device pointers (ints) and a hipStream_t handle."""
+        self._check(lib().sjmi_stage1_device(self._h, d_buf, length, d_indexes, index_capacity, d_result, stream),
+                    "sjmi_stage1_device")
+
+    def set_profiling(self, on):
+        self._check(lib().sjmi_set_profiling(self._h, 1 if on else 0), "sjmi_set_profiling")
+
+    def kernel_time(self):
+        """-> (sum of stage-1 kernel durations in ms since profiling was enabled, number of launches)."""
+        ms = C.c_double(0)
+        n = C.c_uint32(0)
+        self._check(lib().sjmi_kernel_time(self._h, C.addressof(ms), C.addressof(n)), "sjmi_kernel_time")
+        return ms.value, n.value

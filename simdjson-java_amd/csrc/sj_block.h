@@ -1,0 +1,233 @@
+// sj_block.h -- per-64-byte-block stage-1 algebra, bit-plane ("transposed") form.
+//
+// One GPU lane owns one 64-byte block of the document, exactly the unit one iteration of
+// the reference's StructuralIndexer.index512 loop consumes
+// (/root/reference/src/main/java/org/simdjson/StructuralIndexer.java:206-253), but instead of
+// the reference's 5 vector compares + 2 nibble shuffles the block is first transposed into
+// 8 bit planes (plane k, bit i = bit k of byte i).  Every character class of
+// StructuralIndexer (:210,:231-232,:237-240) and the whole of Utf8Validator.validate
+// (Utf8Validator.java:54-168) then become 64-bit boolean algebra on the planes, which is what
+// a CDNA4 lane is good at (no byte shuffles / byte compares in the VALU).
+//
+// Everything cross-block is passed in explicitly:
+//   e_in  -- is byte 0 of the block escaped   (reference: prevEscaped,  :197-201)
+//   p_in  -- was the previous byte a non-quote scalar (reference: prevScalar)
+//   Utf8Carry -- what the previous 3 bytes expect from this block (reference: previous 4 bytes
+//            + previousIncomplete, Utf8Validator.java:55-57)
+// and the in-string parity (reference: prevInString) is NOT an input: the block returns masks
+// for an incoming parity of 0; the caller flips them once the parity prefix is known
+// (structurals(p=1) = pot & sm0, structurals(p=0) = pot & ~sm0).
+//
+// Compiles as plain C++ (host fuzzing against the oracle: tests/host_sim) and as HIP device code.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SJ_HD __host__ __device__ __forceinline__
+#else
+#define SJ_HD inline
+#endif
+
+typedef unsigned long long sj_u64;
+
+struct SjUtf8Carry {
+    uint32_t c1;   // bit0: position 0 must be a continuation because byte -1 is a 2/3/4-byte lead
+    uint32_t c2;   // bit0: byte -2 is a 3/4-byte lead; bit1: byte -1 is a 3/4-byte lead
+    uint32_t c3;   // bit0: byte -3 is a 4-byte lead; bit1: byte -2 is; bit2: byte -1 is
+    uint32_t sec;  // byte -1 is: bit0 0xE0, bit1 0xED, bit2 0xF0, bit3 0xF4 (second-byte range checks)
+};
+
+struct SjBlockMasks {
+    sj_u64 pot;      // potential structural starts: op | scalar start        (StructuralIndexer.java:243-248)
+    sj_u64 sm0;      // (inString ^ quote) for incoming parity 0              (:233,:251)
+    uint32_t qpar;   // parity of unescaped quotes in the block               (:234)
+    uint32_t ue0;    // unescaped control char inside a string, if parity 0   (:231,:252)
+    uint32_t ue1;    // ... if incoming parity is 1
+    uint32_t utf8;   // block contains a UTF-8 error                          (Utf8Validator.java:109-110,165)
+};
+
+SJ_HD sj_u64 sj_prefix_xor(sj_u64 m) {  // StructuralIndexer.java:311-319
+    m ^= m << 1;
+    m ^= m << 2;
+    m ^= m << 4;
+    m ^= m << 8;
+    m ^= m << 16;
+    m ^= m << 32;
+    return m;
+}
+
+// Bytes at index >= valid are invisible: the reference copies the tail into a space-filled
+// block for indexing (StructuralIndexer.java:305-309) and zero-pads it for UTF-8
+// (Utf8Validator.java:115-117); both views agree on "ASCII, not a continuation", which is all
+// the UTF-8 algebra below looks at, so one space-padded view serves both.
+SJ_HD void sj_mask_tail(sj_u64 p[8], uint32_t valid) {
+    if (valid >= 64) return;
+    const sj_u64 vm = (1ull << valid) - 1ull;
+    for (int k = 0; k < 8; ++k) p[k] &= vm;
+    p[5] |= ~vm;  // 0x20
+}
+
+SJ_HD SjBlockMasks sj_block(const sj_u64 p[8], uint32_t e_in, uint32_t p_in, SjUtf8Carry uc) {
+    const sj_u64 p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4], p5 = p[5], p6 = p[6], p7 = p[7];
+    const sj_u64 a = ~p7 & ~p6;  // 0x00..0x3F
+    const sj_u64 b = ~p7 & p6;   // 0x40..0x7F
+    // low-nibble decodes
+    const sj_u64 n00 = ~p3 & ~p2, n11 = p3 & p2, n10 = p3 & ~p2;
+    const sj_u64 n_0000 = n00 & ~p1 & ~p0;
+    const sj_u64 n_0010 = n00 & p1 & ~p0;
+    const sj_u64 n_1100 = n11 & ~p1 & ~p0;
+    const sj_u64 n_1101 = n11 & ~p1 & p0;
+    const sj_u64 n_1001 = n10 & ~p1 & p0;
+    const sj_u64 n_1010 = n10 & p1 & ~p0;
+    const sj_u64 n_1011 = n10 & p1 & p0;
+
+    // ---- character classes (StructuralIndexer.java:210,231-232,237-240) ---------------------
+    sj_u64 bs = b & ~p5 & p4 & n_1100;            // '\\' 0x5C
+    const sj_u64 rawquote = a & p5 & ~p4 & n_0010; // '"'  0x22
+    const sj_u64 ctrl = a & ~p5;                   // <= 0x1F
+    // whitespace table (:23-25) matches exactly {0x20, 0x09, 0x0A, 0x0D}
+    const sj_u64 ws = a & ~p4 & ((p5 & n_0000) | (~p5 & (n_1001 | n_1010 | n_1101)));
+    // (c|0x20) == OP_TABLE[c&15] (:26-28,:239-240): { , : [ ] { } } and also 0x0C, 0x1A
+    const sj_u64 op = (a & ~p4 & n_1100) | (a & p4 & n_1010) | (b & p4 & (n_1011 | n_1101));
+
+    // ---- escapes (:211-229); prevEscaped = e_in. The bs==0 branch is the same formula. ----
+    bs &= ~(sj_u64)e_in;
+    const sj_u64 follows_escape = (bs << 1) | e_in;
+    const sj_u64 EVEN = 0x5555555555555555ull;
+    const sj_u64 odd_starts = bs & ~EVEN & ~follows_escape;
+    const sj_u64 seq_even = odd_starts + bs;
+    const sj_u64 escaped = (EVEN ^ (seq_even << 1)) & follows_escape;
+
+    // ---- strings (:232-234) ------------------------------------------------------------------
+    const sj_u64 quote = rawquote & ~escaped;
+    const sj_u64 in0 = sj_prefix_xor(quote);  // in-string mask for incoming parity 0
+
+    // ---- scalars / structural starts (:243-248) -------------------------------------------
+    const sj_u64 scalar = ~(op | ws);
+    const sj_u64 nqs = scalar & ~quote;
+    const sj_u64 follows_nqs = (nqs << 1) | p_in;
+    const sj_u64 pot = op | (scalar & ~follows_nqs);
+
+    // ---- UTF-8 (Utf8Validator.java:54-168 as plane algebra; == strict RFC 3629) ------------
+    const sj_u64 cont = p7 & ~p6;
+    const sj_u64 lead = p7 & p6;
+    const sj_u64 L2 = lead & ~p5;
+    const sj_u64 L3 = lead & p5 & ~p4;
+    const sj_u64 L4 = lead & p5 & p4 & ~p3;
+    sj_u64 err = lead & p5 & p4 & p3;                      // 0xF8..0xFF
+    const sj_u64 E1 = ((L2 | L3 | L4) << 1) | uc.c1;       // expected 1st continuation
+    const sj_u64 E2 = ((L3 | L4) << 2) | uc.c2;            // expected 2nd
+    const sj_u64 E3 = (L4 << 3) | uc.c3;                   // expected 3rd
+    err |= cont ^ (E1 | E2 | E3);                          // TOO_SHORT / TOO_LONG / TWO_CONTINUATIONS
+    err |= L2 & ~p4 & n00 & ~p1;                           // 0xC0, 0xC1            (OVERLONG_2BYTE)
+    err |= L4 & p2 & (p1 | p0);                            // 0xF5..0xF7            (TOO_LARGE)
+    const sj_u64 sE0 = ((L3 & n_0000) << 1) | (uc.sec & 1u);
+    const sj_u64 sED = ((L3 & n_1101) << 1) | ((uc.sec >> 1) & 1u);
+    const sj_u64 sF0 = ((L4 & ~p2 & ~p1 & ~p0) << 1) | ((uc.sec >> 2) & 1u);
+    const sj_u64 sF4 = ((L4 & p2 & ~p1 & ~p0) << 1) | ((uc.sec >> 3) & 1u);
+    err |= sE0 & ~p5;                                      // E0 80..9F             (OVERLONG_3BYTE)
+    err |= sED & p5;                                       // ED A0..BF             (SURROGATE)
+    err |= sF0 & ~p5 & ~p4;                                // F0 80..8F             (OVERLONG_4BYTE)
+    err |= sF4 & (p5 | p4);                                // F4 90..BF             (TOO_LARGE)
+
+    SjBlockMasks r;
+    r.pot = pot;
+    r.sm0 = in0 ^ quote;
+    r.qpar = (uint32_t)(in0 >> 63);
+    r.ue0 = (ctrl & in0) != 0;
+    r.ue1 = (ctrl & ~in0) != 0;
+    r.utf8 = err != 0;
+    return r;
+}
+
+// ---- carries from the bytes before the block -------------------------------------------------
+// halo = the 8 bytes preceding the block, little-endian (byte -1 is bits 56..63).
+
+SJ_HD uint32_t sj_lead_len(uint32_t b) { return b >= 0xF0 ? 4u : b >= 0xE0 ? 3u : b >= 0xC0 ? 2u : 0u; }
+
+SJ_HD SjUtf8Carry sj_utf8_carry(sj_u64 halo) {
+    const uint32_t h1 = (uint32_t)(halo >> 56) & 0xFF, h2 = (uint32_t)(halo >> 48) & 0xFF,
+                   h3 = (uint32_t)(halo >> 40) & 0xFF;
+    const uint32_t l1 = sj_lead_len(h1), l2 = sj_lead_len(h2), l3 = sj_lead_len(h3);
+    SjUtf8Carry c;
+    c.c1 = l1 >= 2;
+    c.c2 = (uint32_t)(l2 >= 3) | ((uint32_t)(l1 >= 3) << 1);
+    c.c3 = (uint32_t)(l3 == 4) | ((uint32_t)(l2 == 4) << 1) | ((uint32_t)(l1 == 4) << 2);
+    c.sec = (uint32_t)(h1 == 0xE0) | ((uint32_t)(h1 == 0xED) << 1) | ((uint32_t)(h1 == 0xF0) << 2) |
+            ((uint32_t)(h1 == 0xF4) << 3);
+    return c;
+}
+
+// bit j-1 set iff byte -j is a backslash (j = 1..8)
+SJ_HD uint32_t sj_halo_bs_mask(sj_u64 halo) {
+    uint32_t m = 0;
+    for (int j = 1; j <= 8; ++j) m |= (uint32_t)(((halo >> (64 - 8 * j)) & 0xFF) == 0x5C) << (j - 1);
+    return m;
+}
+
+SJ_HD uint32_t sj_is_ws_or_op(uint32_t c) {
+    return c == 0x20 || c == 0x09 || c == 0x0A || c == 0x0D || c == ',' || c == ':' || c == '[' || c == ']' ||
+           c == '{' || c == '}' || c == 0x0C || c == 0x1A;
+}
+
+// Resolve e_in / p_in from the 8-byte halo.  Returns false when the backslash run reaches past
+// the halo (then the caller counts the run from memory: sj_count_backslashes_before).
+//   e_in = (length of the backslash run ending at byte -1) is odd
+//   p_in = byte -1 is a scalar that is not an (unescaped) quote
+SJ_HD bool sj_carry_from_halo(sj_u64 halo, uint32_t* e_in, uint32_t* p_in) {
+    const uint32_t bm = sj_halo_bs_mask(halo);
+    const uint32_t h1 = (uint32_t)(halo >> 56) & 0xFF;
+    if (bm & 1u) {  // byte -1 is a backslash: scalar, never a quote
+        if (bm == 0xFFu) return false;
+        uint32_t run = 0;
+        while ((bm >> run) & 1u) ++run;
+        *e_in = run & 1u;
+        *p_in = 1;
+        return true;
+    }
+    *e_in = 0;
+    if (h1 == 0x22) {  // a quote: non-quote scalar only if it is escaped
+        const uint32_t bm2 = bm >> 1;
+        if (bm2 == 0x7Fu) return false;
+        uint32_t run = 0;
+        while ((bm2 >> run) & 1u) ++run;
+        *p_in = run & 1u;
+        return true;
+    }
+    *p_in = !sj_is_ws_or_op(h1);
+    return true;
+}
+
+// Slow path (backslash run longer than the halo): parity of the run of backslashes that ends
+// right before buf[pos] and does not extend below buf[lo].
+SJ_HD uint32_t sj_backslash_run_parity(const uint8_t* buf, sj_u64 lo, sj_u64 pos) {
+    uint32_t par = 0;
+    while (pos > lo && buf[pos - 1] == 0x5C) {
+        par ^= 1u;
+        --pos;
+    }
+    return par;
+}
+
+SJ_HD void sj_carry_slow(const uint8_t* buf, sj_u64 doc_lo, sj_u64 start, uint32_t* e_in, uint32_t* p_in) {
+    const uint32_t h1 = buf[start - 1];
+    if (h1 == 0x5C) {
+        *e_in = sj_backslash_run_parity(buf, doc_lo, start);
+        *p_in = 1;
+    } else if (h1 == 0x22) {
+        *e_in = 0;
+        *p_in = sj_backslash_run_parity(buf, doc_lo, start - 1);
+    } else {
+        *e_in = 0;
+        *p_in = !sj_is_ws_or_op(h1);
+    }
+}
+
+// portable transposition (host + reference for the device fast path's self-test)
+SJ_HD void sj_transpose_ref(const uint32_t w[16], sj_u64 p[8]) {
+    for (int k = 0; k < 8; ++k) p[k] = 0;
+    for (int i = 0; i < 64; ++i) {
+        const uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xFF;
+        for (int k = 0; k < 8; ++k) p[k] |= (sj_u64)((c >> k) & 1u) << i;
+    }
+}

@@ -1,0 +1,227 @@
+// sjmi_api.hip -- the C ABI of libsjmi.so (see include/sjmi.h).  Host-side HIP runtime code only.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "stage1.h"
+
+struct sjmi_ctx {
+    int device = 0;
+    uint64_t capacity = 0;
+    hipStream_t stream = nullptr;
+    uint8_t* d_in = nullptr;      // capacity + padding
+    uint32_t* d_idx = nullptr;    // capacity + 1 entries (host-buffer path)
+    void* d_ws = nullptr;         // tile-state workspace
+    size_t ws_bytes = 0;
+    void* d_ws_dev = nullptr;     // workspace for the device-resident path (grown on demand)
+    size_t ws_dev_bytes = 0;
+    sjmi_stage1_result* h_res = nullptr;  // pinned
+    int forced_steps = 0;
+    bool profiling = false;  // bracket every stage-1 kernel with HIP events (bench.py roofline)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    std::string err;
+};
+
+namespace {
+
+bool fail(sjmi_ctx* c, const char* what, hipError_t e) {
+    if (e == hipSuccess) return false;
+    char b[256];
+    snprintf(b, sizeof b, "%s: %s", what, hipGetErrorString(e));
+    c->err = b;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sjmi_version(void) { return "sjmi 0.1 (gfx950)"; }
+
+int sjmi_create(sjmi_ctx** out, int device, uint64_t capacity_bytes) {
+    if (!out) return SJMI_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return SJMI_ERR_NO_DEVICE;
+    sjmi_ctx* c = new (std::nothrow) sjmi_ctx();
+    if (!c) return SJMI_ERR_ARG;
+    c->device = device;
+    c->capacity = capacity_bytes;
+    const size_t in_bytes = ((capacity_bytes + 63) / 64) * 64 + 2 * SJMI_PADDING;
+    c->ws_bytes = sjmi::stage1_workspace_bytes(capacity_bytes, 1);
+    if (fail(c, "hipSetDevice", hipSetDevice(device)) ||
+        fail(c, "hipStreamCreate", hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) ||
+        fail(c, "hipMalloc(in)", hipMalloc((void**)&c->d_in, in_bytes)) ||
+        fail(c, "hipMalloc(idx)", hipMalloc((void**)&c->d_idx, (capacity_bytes + 2) * sizeof(uint32_t))) ||
+        fail(c, "hipMalloc(ws)", hipMalloc(&c->d_ws, c->ws_bytes)) ||
+        fail(c, "hipHostMalloc", hipHostMalloc((void**)&c->h_res, sizeof(sjmi_stage1_result)))) {
+        fprintf(stderr, "sjmi_create: %s\n", c->err.c_str());
+        sjmi_destroy(c);
+        return SJMI_ERR_HIP;
+    }
+    *out = c;
+    return SJMI_OK;
+}
+
+void sjmi_destroy(sjmi_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->d_idx) (void)hipFree(c->d_idx);
+    if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->d_ws_dev) (void)hipFree(c->d_ws_dev);
+    if (c->h_res) (void)hipHostFree(c->h_res);
+    for (auto& e : c->events) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* sjmi_last_error(const sjmi_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int sjmi_set_tile_steps(sjmi_ctx* c, int steps) {
+    if (!c || !(steps == 0 || steps == 1 || steps == 2 || steps == 4)) return SJMI_ERR_ARG;
+    c->forced_steps = steps;
+    return SJMI_OK;
+}
+
+int sjmi_stage1(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes, uint64_t index_capacity,
+                uint64_t* count, uint32_t* status) {
+    if (!c || (!buf && len) || !indexes || !count || !status) return SJMI_ERR_ARG;
+    if (len > c->capacity || len >= (1ull << 32)) {
+        c->err = "document larger than the context capacity";
+        return SJMI_ERR_CAPACITY;
+    }
+    if (index_capacity < 1) return SJMI_ERR_CAPACITY;
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    // padIfNeeded (SimdJsonParser.java:42-48): only buf[0,len) is ever read from the caller
+    if (len && fail(c, "H2D", hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
+    const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(len);
+    const uint64_t dev_cap = c->capacity + 2 < index_capacity ? c->capacity + 2 : index_capacity;
+    if (fail(c, "launch", sjmi::stage1_launch(c->d_in, len, c->d_idx, dev_cap, c->d_ws, steps, c->stream, nullptr, nullptr)))
+        return SJMI_ERR_HIP;
+    if (fail(c, "D2H(result)",
+             hipMemcpyAsync(c->h_res, (uint8_t*)c->d_ws + sjmi::WS_RESULT_OFFSET, sizeof(sjmi_stage1_result),
+                            hipMemcpyDeviceToHost, c->stream)) ||
+        fail(c, "sync", hipStreamSynchronize(c->stream)))
+        return SJMI_ERR_HIP;
+    *status = c->h_res->status & 0xFFu;
+    *count = c->h_res->count;
+    if (c->h_res->status & SJMI_ST_INTERNAL) {
+        c->err = "look-back timeout";
+        return SJMI_ERR_INTERNAL;
+    }
+    if (c->h_res->status & SJMI_ST_CAPACITY) {
+        c->err = "index_capacity too small";
+        return SJMI_ERR_CAPACITY;
+    }
+    if (fail(c, "D2H(indexes)",
+             hipMemcpyAsync(indexes, c->d_idx, (c->h_res->count + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                            c->stream)) ||
+        fail(c, "sync", hipStreamSynchronize(c->stream)))
+        return SJMI_ERR_HIP;
+    return SJMI_OK;
+}
+
+int sjmi_stage1_device(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_indexes, uint64_t index_capacity,
+                       void* d_result, void* stream) {
+    if (!c || !d_buf || !d_indexes || !d_result) return SJMI_ERR_ARG;
+    if (len >= (1ull << 32) || ((uintptr_t)d_buf & 15)) return SJMI_ERR_ARG;
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(len);
+    const size_t need = sjmi::stage1_workspace_bytes(len, steps);
+    if (need > c->ws_dev_bytes) {  // grown outside any timed loop on first use of a given size
+        if (c->d_ws_dev) (void)hipFree(c->d_ws_dev);
+        c->d_ws_dev = nullptr;
+        c->ws_dev_bytes = 0;
+        if (fail(c, "hipMalloc(ws_dev)", hipMalloc(&c->d_ws_dev, need))) return SJMI_ERR_HIP;
+        c->ws_dev_bytes = need;
+    }
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (c->profiling) {
+        if (c->events_used == c->events.size()) {
+            hipEvent_t a, b;
+            if (fail(c, "hipEventCreate", hipEventCreate(&a)) || fail(c, "hipEventCreate", hipEventCreate(&b)))
+                return SJMI_ERR_HIP;
+            c->events.emplace_back(a, b);
+        }
+        ev0 = c->events[c->events_used].first;
+        ev1 = c->events[c->events_used].second;
+        ++c->events_used;
+    }
+    if (fail(c, "launch", sjmi::stage1_launch((const uint8_t*)d_buf, len, (uint32_t*)d_indexes, index_capacity,
+                                              c->d_ws_dev, steps, st, ev0, ev1)))
+        return SJMI_ERR_HIP;
+    if (fail(c, "D2D(result)",
+             hipMemcpyAsync(d_result, (uint8_t*)c->d_ws_dev + sjmi::WS_RESULT_OFFSET, sizeof(sjmi_stage1_result),
+                            hipMemcpyDeviceToDevice, st)))
+        return SJMI_ERR_HIP;
+    return SJMI_OK;
+}
+
+int sjmi_set_profiling(sjmi_ctx* c, int on) {
+    if (!c) return SJMI_ERR_ARG;
+    c->profiling = on != 0;
+    c->events_used = 0;
+    return SJMI_OK;
+}
+
+int sjmi_kernel_time(sjmi_ctx* c, double* sum_ms, uint32_t* launches) {
+    if (!c || !sum_ms || !launches) return SJMI_ERR_ARG;
+    double total = 0;
+    for (size_t i = 0; i < c->events_used; ++i) {
+        float ms = 0;
+        if (fail(c, "hipEventSynchronize", hipEventSynchronize(c->events[i].second)) ||
+            fail(c, "hipEventElapsedTime", hipEventElapsedTime(&ms, c->events[i].first, c->events[i].second)))
+            return SJMI_ERR_HIP;
+        total += ms;
+    }
+    *sum_ms = total;
+    *launches = (uint32_t)c->events_used;
+    return SJMI_OK;
+}
+
+int sjmi_selftest(sjmi_ctx* c, uint32_t* mismatches) {
+    if (!c || !mismatches) return SJMI_ERR_ARG;
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    const uint32_t nblocks = 4096;
+    std::vector<uint32_t> words((size_t)nblocks * 16);
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    for (size_t i = 0; i < words.size(); ++i) {  // xorshift64*
+        x ^= x >> 12;
+        x ^= x << 25;
+        x ^= x >> 27;
+        words[i] = (uint32_t)((x * 0x2545F4914F6CDD1Dull) >> 32);
+    }
+    for (int i = 0; i < 16; ++i) {  // all-ones / all-zero / single-bit blocks
+        words[i] = 0xFFFFFFFFu;
+        words[16 + i] = 0;
+        words[32 + i] = 0x80808080u;
+        words[48 + i] = 0x01010101u;
+    }
+    uint32_t *d_w = nullptr, *d_m = nullptr;
+    int rc = SJMI_OK;
+    if (fail(c, "hipMalloc", hipMalloc((void**)&d_w, words.size() * 4)) ||
+        fail(c, "hipMalloc", hipMalloc((void**)&d_m, 4)) ||
+        fail(c, "H2D", hipMemcpyAsync(d_w, words.data(), words.size() * 4, hipMemcpyHostToDevice, c->stream)) ||
+        fail(c, "memset", hipMemsetAsync(d_m, 0, 4, c->stream)) ||
+        fail(c, "launch", sjmi::transpose_selftest_launch(d_w, nblocks, d_m, c->stream)) ||
+        fail(c, "D2H", hipMemcpyAsync(mismatches, d_m, 4, hipMemcpyDeviceToHost, c->stream)) ||
+        fail(c, "sync", hipStreamSynchronize(c->stream)))
+        rc = SJMI_ERR_HIP;
+    if (d_w) (void)hipFree(d_w);
+    if (d_m) (void)hipFree(d_m);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,205 @@
+"""GPU parity tests of the fused stage-1 kernel, through the C ABI (include/sjmi.h), against the
+CPU oracle on the same seeded inputs.  Bit-exact: indexes, sentinel, count and the three status bits."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.conftest import load_fixture
+from tests.golden import vectors as V
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import simdjson_java_amd as S
+    c = S.Context(device=0, capacity=96 * 1024 * 1024)
+    yield c
+    c.close()
+
+
+def _check(ctx, d, length=None):
+    want_idx, want_st = O.stage1(d, length)
+    got_idx, got_st = ctx.stage1(d, length)
+    assert got_st == want_st, (got_st, want_st, bytes(d[:120]).hex())
+    assert got_idx.size == want_idx.size, (got_idx.size, want_idx.size)
+    if not np.array_equal(got_idx, want_idx):
+        bad = int(np.nonzero(got_idx != want_idx)[0][0])
+        raise AssertionError("first index mismatch at %d: got %d want %d" % (bad, got_idx[bad], want_idx[bad]))
+
+
+def test_native_library_is_loaded():
+    import simdjson_java_amd as S
+    import os
+    assert os.path.exists(S.lib_path())
+    assert S.lib().sjmi_version().startswith(b"sjmi")
+
+
+def test_transpose_selftest(ctx):
+    assert ctx.selftest() == 0
+
+
+@pytest.mark.parametrize("case", V.STRUCTURAL_INDEXER, ids=[c[0] for c in V.STRUCTURAL_INDEXER])
+def test_reference_structural_indexer_vectors(ctx, case):
+    import simdjson_java_amd as S
+    name, data, want_idx, want_msg, cite = case
+    idx, st = ctx.stage1(data)
+    if want_msg is not None:
+        assert S.status_message(st) == want_msg, cite
+    else:
+        assert st == 0 and idx.tolist() == want_idx, cite
+    _check(ctx, data)
+
+
+@pytest.mark.parametrize("steps", [1, 2, 4])
+@pytest.mark.parametrize("name", ["twitter.json", "github_events.json", "wide_bench.json", "malformed.txt"])
+def test_reference_files(ctx, name, steps):
+    ctx.set_tile_steps(steps)
+    try:
+        d = load_fixture(name)
+        _check(ctx, d)
+        if name in V.FILES:
+            idx, st = ctx.stage1(d)
+            assert idx.size == V.FILES[name][1] and st == 0
+    finally:
+        ctx.set_tile_steps(0)
+
+
+def test_len_shorter_than_buffer_is_invisible(ctx):
+    d = b'[1,2,3]"\\{{{{\xff\xfe' * 40
+    for n in (0, 1, 7, 8, 9, 63, 64, 65, 100, 400):
+        _check(ctx, d, n)
+
+
+@pytest.mark.parametrize("steps", [1, 4])
+def test_fuzz_small(ctx, steps):
+    ctx.set_tile_steps(steps)
+    try:
+        rng = random.Random(100 + steps)
+        alphabet = b'\\\\\\"""{}[]:, \t\n\r\x0c\x1a\x01abc019.-e\xc3\xa9'
+        for it in range(300):
+            n = rng.choice([0, 1, 63, 64, 65, 127, 128, 129, 4095, 4096, 4097, rng.randint(0, 3000)])
+            mode = it % 5
+            if mode == 0:
+                d = bytes(rng.choice(alphabet) for _ in range(n))
+            elif mode == 1:
+                d = bytes(rng.choice(b'\\"a ') for _ in range(n))
+            elif mode == 2:
+                d = b"a" * rng.randint(0, 70) + b"\\" * rng.randint(1, 300) + rng.choice([b'"', b"x", b""]) + b'"x' * rng.randint(0, 40)
+            elif mode == 3:
+                d = bytes(rng.getrandbits(8) for _ in range(n))
+            else:
+                s = "".join(rng.choice(["a", "é", "€", "한", "😀", '"', "\\\\", " ", ","]) for _ in range(n // 2))
+                d = s.encode()
+            _check(ctx, d)
+    finally:
+        ctx.set_tile_steps(0)
+
+
+def _json_like(rng, n):
+    """Dense synthetic JSON-ish text with strings, escapes, non-ASCII and numbers."""
+    parts = []
+    size = 0
+    words = ['"name"', '"va\\"lue"', '"x\\\\"', '"é€한😀"', "12345", "-1.5e10", "true", "false", "null", '"\\u00e9\\ud83d\\ude00"',
+             '"' + "abc def " * 9 + '"', '""']
+    while size < n:
+        k = rng.random()
+        if k < 0.5:
+            p = rng.choice(words)
+        elif k < 0.8:
+            p = rng.choice(["{", "}", "[", "]", ":", ",", " ", "\n", "  "])
+        else:
+            p = '"' + "".join(rng.choice("abcdefghij klmnop") for _ in range(rng.randint(0, 200))) + '"'
+        parts.append(p)
+        size += len(p)
+    return "".join(parts).encode()[:n]
+
+
+@pytest.mark.parametrize("steps", [1, 2, 4])
+def test_fuzz_tile_boundaries(ctx, steps):
+    """Sizes around multiples of the tile (steps * 16 KiB) with strings / escapes / multi-byte
+    characters straddling block, wave, workgroup and tile boundaries."""
+    ctx.set_tile_steps(steps)
+    try:
+        rng = random.Random(7 + steps)
+        tile = steps * 16384
+        for it in range(24):
+            n = rng.choice([tile - 1, tile, tile + 1, 2 * tile - 64, 2 * tile + 63, 3 * tile + rng.randint(-70, 70),
+                            5 * tile + rng.randint(0, 5000)])
+            d = bytearray(_json_like(rng, n))
+            # plant hazards exactly at tile / wave boundaries
+            for b in (tile, 2 * tile, 4096, 8192, tile + 4096):
+                if b + 8 < len(d) and b >= 8:
+                    kind = rng.randrange(6)
+                    if kind == 0:
+                        d[b - 1:b + 1] = b'\\"'
+                    elif kind == 1:
+                        d[b - 3:b + 1] = b'\\\\\\"'
+                    elif kind == 2:
+                        d[b - 2:b + 2] = "😀".encode()
+                    elif kind == 3:
+                        d[b - 1:b + 2] = "€".encode()
+                    elif kind == 4:
+                        d[b - 5:b + 5] = b"\\" * 10
+                    else:
+                        d[b - 1:b + 1] = b'""'
+            _check(ctx, bytes(d))
+    finally:
+        ctx.set_tile_steps(0)
+
+
+def test_adversarial_runs(ctx):
+    n = 200 * 1024
+    for d in (b'"' * n, b"\\" * n, b"\\" * (n - 1) + b'"', b'"' + b"\\" * (n - 3) + b'"x', b"[" * n, b" " * n, b"a" * n,
+              b'"' + b"\x01" * n + b'"', ("é" * (n // 2)).encode(), ("€" * (n // 3)).encode()[:-1], b"\xf0\x9f\x98" * 1000):
+        _check(ctx, d)
+
+
+def test_many_tiles_parity_chain(ctx):
+    """A single string opened in tile 0 and closed ~40 MB later: every tile in between must see
+    parity 1 through the look-back chain; then a second document half full of lone quotes."""
+    body = (b'{"k": [1, 2, {"a": "b"}], "s": "x y z"} ' * 1000)
+    d = b'["' + body.replace(b'"', b"'") * 1000 + b'", 1, 2]'
+    ctx.set_tile_steps(1)
+    try:
+        _check(ctx, d)
+        rng = random.Random(11)
+        d2 = bytearray(b'{"a":[1,2,3],"b":"c"} ' * 1_000_000)
+        for _ in range(3000):
+            d2[rng.randrange(len(d2))] = 0x22
+        _check(ctx, bytes(d2))
+    finally:
+        ctx.set_tile_steps(0)
+    _check(ctx, d)
+
+
+def test_index_capacity_error(ctx):
+    import simdjson_java_amd as S
+    with pytest.raises(S.SjmiError):
+        ctx.stage1(b"[1,2,3,4,5,6,7,8]", index_capacity=4)
+
+
+def test_device_path_twitter_x64(ctx, twitter):
+    """Device-resident path: twitter.json x 64 (40 MB); closed form index[k*S+j] = k*N + index0[j]
+    (scaled)."""
+    import torch
+    reps = 64
+    n0 = len(twitter)
+    idx0, st0 = O.stage1(twitter)
+    assert st0 == 0
+    host = torch.frombuffer(bytearray(twitter), dtype=torch.uint8)
+    buf = torch.zeros(n0 * reps + 128, dtype=torch.uint8, device="cuda")
+    buf[:n0 * reps] = host.cuda().repeat(reps)
+    cap = idx0.size * reps + 1
+    out = torch.empty(cap, dtype=torch.int32, device="cuda")
+    res = torch.zeros(2, dtype=torch.int64, device="cuda")
+    ctx.stage1_device(buf.data_ptr(), n0 * reps, out.data_ptr(), cap, res.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    r = res.cpu().numpy()
+    assert int(r[0]) == idx0.size * reps and (int(r[1]) & 0xFFFFFFFF) == 0
+    want = (torch.from_numpy(idx0.astype(np.int64)).cuda()[None, :] + (torch.arange(reps, device="cuda") * n0)[:, None]).flatten()
+    got = out[:idx0.size * reps].to(torch.int64) & 0xFFFFFFFF
+    assert torch.equal(got, want)
+    assert int(out[idx0.size * reps].item()) == 0
