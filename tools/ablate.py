@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Performance ablation of k_stage1 (experiments only): times the kernel with parts switched off."""
+import gzip, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import simdjson_java_amd as S
+
+doc = gzip.open(os.path.join(ROOT, "tests/golden/data/twitter.json.gz")).read()
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+n = len(doc) * reps
+buf = torch.zeros(n + 128, dtype=torch.uint8, device="cuda")
+buf[:n] = torch.frombuffer(bytearray(doc), dtype=torch.uint8).cuda().repeat(reps)
+cap = 55263 * reps + 1
+out = torch.empty(cap + 6000 * 4 * 64, dtype=torch.int32, device="cuda")
+res = torch.zeros(2, dtype=torch.int64, device="cuda")
+ctx = S.Context(0, 1 << 20)
+st = torch.cuda.current_stream().cuda_stream
+# reference: plain device copy bandwidth
+dst = torch.empty_like(buf)
+for _ in range(3): dst.copy_(buf)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10): dst.copy_(buf)
+torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 10
+print("torch copy: %.3f ms  read %.0f GB/s (r+w %.0f GB/s)" % (t * 1e3, n / t / 1e9, 2 * n / t / 1e9))
+del dst
+for steps, ticket in ((2, 0), (4, 0), (8, 0)):
+    ctx.set_tile_steps(steps)
+    print("steps", steps, "persistent grid=%d" % ctx.persistent_grid(steps))
+    for flags, name in [(0, "full"), (1, "no_write"), (2, "no_lookback"), (3, "no_lookback+no_write")]:
+        ctx.debug_set_flags(flags)
+        for _ in range(3):
+            ctx.stage1_device(buf.data_ptr(), n, out.data_ptr(), out.numel(), res.data_ptr(), st)
+        ctx.set_profiling(True)
+        for _ in range(10):
+            ctx.stage1_device(buf.data_ptr(), n, out.data_ptr(), out.numel(), res.data_ptr(), st)
+        torch.cuda.synchronize()
+        ms, k = ctx.kernel_time()
+        ctx.set_profiling(False)
+        print("steps=%d %-22s %.4f ms  %.0f GB/s" % (steps, name, ms / k, n / (ms / k) / 1e6))
+    ctx.debug_set_flags(8)
+    torch.cuda.synchronize()
+    ctx.stage1_device(buf.data_ptr(), n, out.data_ptr(), out.numel(), res.data_ptr(), st)
+    torch.cuda.synchronize()
+    tm = ctx.debug_read_timing()
+    nt = max(int(tm[4]), 1)
+    print("   per-tile cycles: load+classify %d  scans %d  lookback %d  expand+store %d  (tiles %d)" % (tm[0] // nt, tm[1] // nt, tm[2] // nt, tm[3] // nt, nt))
