@@ -77,24 +77,15 @@ int sjmi_stage1_device(sjmi_ctx* ctx, const void* d_buf, uint64_t len, void* d_i
 /* Run the on-device self-test of the bit-plane transposition; *mismatches == 0 on success. */
 int sjmi_selftest(sjmi_ctx* ctx, uint32_t* mismatches);
 
-/* tuning knob for tests: force the number of 4 KiB steps per (wave) tile: 2, 4 or 8; 0 = automatic */
+/* tuning knob for tests: force the tile size = steps x 16 KiB per workgroup (1, 2 or 4; 0 = automatic) */
 int sjmi_set_tile_steps(sjmi_ctx* ctx, int steps);
-
-/* The kernel runs as persistent waves that draw tiles from atomic tickets; the grid (workgroups of 256
- * threads) is sized from the occupancy query. Any grid >= 2 is correct; tests shrink it to stress the
- * tile chain (0 = automatic). sjmi_persistent_grid reports the automatic size for a tile-steps value. */
-int sjmi_set_grid(sjmi_ctx* ctx, uint32_t workgroups);
-int sjmi_persistent_grid(const sjmi_ctx* ctx, int steps);
 
 /* Measurement hooks for bench.py: when on, every sjmi_stage1_device launch is bracketed by HIP events
  * on the launch stream (kernel only); sjmi_kernel_time returns their summed duration and count. */
 int sjmi_set_profiling(sjmi_ctx* ctx, int on);
-/* performance-ablation switches for sjmi_stage1_device (1 = no index stores, 2 = no look-back,
- * 4 = no compute); results are INVALID while any is set. Experiments only. */
+/* performance-ablation switches for sjmi_stage1_device (1 = no index stores, 2 = no look-back);
+ * results are INVALID while any is set. Experiments only. */
 int sjmi_debug_set_flags(sjmi_ctx* ctx, uint32_t flags);
-/* with flag 8: per-phase shader-clock sums of the LAST sjmi_stage1_device launch:
- * {load+classify, in-tile scans, look-back, expand+store, tiles} */
-int sjmi_debug_read_timing(sjmi_ctx* ctx, uint64_t out[8]);
 int sjmi_kernel_time(sjmi_ctx* ctx, double* sum_ms, uint32_t* launches);
 
 #ifdef __cplusplus

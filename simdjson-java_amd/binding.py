@@ -56,8 +56,7 @@ def build(force=False, verbose=False):
 _lib = None
 
 EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sjmi_stage1", "sjmi_stage1_device",
-           "sjmi_selftest", "sjmi_set_tile_steps", "sjmi_set_profiling", "sjmi_kernel_time", "sjmi_debug_set_flags",
-           "sjmi_set_grid", "sjmi_persistent_grid", "sjmi_debug_read_timing"]
+           "sjmi_selftest", "sjmi_set_tile_steps", "sjmi_set_profiling", "sjmi_kernel_time", "sjmi_debug_set_flags"]
 
 
 def lib():
@@ -92,12 +91,6 @@ def lib():
         L.sjmi_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.sjmi_debug_set_flags.restype = C.c_int
         L.sjmi_debug_set_flags.argtypes = [C.c_void_p, C.c_uint32]
-        L.sjmi_set_grid.restype = C.c_int
-        L.sjmi_set_grid.argtypes = [C.c_void_p, C.c_uint32]
-        L.sjmi_persistent_grid.restype = C.c_int
-        L.sjmi_persistent_grid.argtypes = [C.c_void_p, C.c_int]
-        L.sjmi_debug_read_timing.restype = C.c_int
-        L.sjmi_debug_read_timing.argtypes = [C.c_void_p, C.c_void_p]
         L.sjmi_kernel_time.restype = C.c_int
         L.sjmi_kernel_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -156,17 +149,6 @@ class Context:
         """Device-resident path; arguments are raw device pointers (ints) and a hipStream_t handle."""
         self._check(lib().sjmi_stage1_device(self._h, d_buf, length, d_indexes, index_capacity, d_result, stream),
                     "sjmi_stage1_device")
-
-    def set_grid(self, workgroups):
-        self._check(lib().sjmi_set_grid(self._h, workgroups), "sjmi_set_grid")
-
-    def persistent_grid(self, steps):
-        return lib().sjmi_persistent_grid(self._h, steps)
-
-    def debug_read_timing(self):
-        a = np.zeros(8, dtype=np.uint64)
-        self._check(lib().sjmi_debug_read_timing(self._h, a.ctypes.data), "sjmi_debug_read_timing")
-        return a
 
     def debug_set_flags(self, flags):
         self._check(lib().sjmi_debug_set_flags(self._h, flags), "sjmi_debug_set_flags")

@@ -24,9 +24,6 @@ struct sjmi_ctx {
     sjmi_stage1_result* h_res = nullptr;  // pinned
     int forced_steps = 0;
     uint32_t dbg = 0;  // ablation flags (sjmi_debug_set_flags)
-    int num_cus = 0;
-    uint32_t grid[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // workgroups that fit on the chip, for steps 2/4/8
-    uint32_t grid_override = 0;  // tests: force a (small) persistent grid
     bool profiling = false;  // bracket every stage-1 kernel with HIP events (bench.py roofline)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
@@ -44,20 +41,6 @@ bool fail(sjmi_ctx* c, const char* what, hipError_t e) {
 }
 
 
-// Persistent grid for `steps` = what the occupancy query says fits on the chip.  Only speed depends
-// on it: the dynamic tile tickets make any grid >= 2 workgroups correct (stage1.hip).
-void setup_persistent_grid(sjmi_ctx* c, int steps) {
-    int per_cu = 0;
-    if (sjmi::stage1_resident_blocks(steps, &per_cu) != hipSuccess || per_cu <= 0) per_cu = 2;
-    if (per_cu > 8) per_cu = 8;
-    c->grid[steps] = (uint32_t)per_cu * (uint32_t)c->num_cus;
-}
-
-uint32_t grid_for(const sjmi_ctx* c, int steps) {
-    const uint32_t g = c->grid_override ? c->grid_override : c->grid[steps];
-    return g < 3 ? 3 : g;
-}
-
 }  // namespace
 
 extern "C" {
@@ -74,7 +57,7 @@ int sjmi_create(sjmi_ctx** out, int device, uint64_t capacity_bytes) {
     c->device = device;
     c->capacity = capacity_bytes;
     const size_t in_bytes = ((capacity_bytes + 63) / 64) * 64 + 2 * SJMI_PADDING;
-    c->ws_bytes = sjmi::stage1_workspace_bytes(capacity_bytes, 2);
+    c->ws_bytes = sjmi::stage1_workspace_bytes(capacity_bytes, 1);
     if (fail(c, "hipSetDevice", hipSetDevice(device)) ||
         fail(c, "hipStreamCreate", hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) ||
         fail(c, "hipMalloc(in)", hipMalloc((void**)&c->d_in, in_bytes)) ||
@@ -85,13 +68,6 @@ int sjmi_create(sjmi_ctx** out, int device, uint64_t capacity_bytes) {
         sjmi_destroy(c);
         return SJMI_ERR_HIP;
     }
-    hipDeviceProp_t prop;
-    if (fail(c, "hipGetDeviceProperties", hipGetDeviceProperties(&prop, device))) {
-        sjmi_destroy(c);
-        return SJMI_ERR_HIP;
-    }
-    c->num_cus = prop.multiProcessorCount;
-    for (int steps : {2, 4, 8}) setup_persistent_grid(c, steps);
     *out = c;
     return SJMI_OK;
 }
@@ -116,7 +92,7 @@ void sjmi_destroy(sjmi_ctx* c) {
 const char* sjmi_last_error(const sjmi_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 int sjmi_set_tile_steps(sjmi_ctx* c, int steps) {
-    if (!c || !(steps == 0 || steps == 2 || steps == 4 || steps == 8)) return SJMI_ERR_ARG;
+    if (!c || !(steps == 0 || steps == 1 || steps == 2 || steps == 4)) return SJMI_ERR_ARG;
     c->forced_steps = steps;
     return SJMI_OK;
 }
@@ -134,8 +110,7 @@ int sjmi_stage1(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes
     if (len && fail(c, "H2D", hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
     const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(len);
     const uint64_t dev_cap = c->capacity + 2 < index_capacity ? c->capacity + 2 : index_capacity;
-    if (fail(c, "launch", sjmi::stage1_launch(c->d_in, len, c->d_idx, dev_cap, c->d_ws, steps, grid_for(c, steps), c->stream, nullptr,
-                                              nullptr)))
+    if (fail(c, "launch", sjmi::stage1_launch(c->d_in, len, c->d_idx, dev_cap, c->d_ws, steps, c->stream, nullptr, nullptr)))
         return SJMI_ERR_HIP;
     if (fail(c, "D2H(result)",
              hipMemcpyAsync(c->h_res, (uint8_t*)c->d_ws + sjmi::WS_RESULT_OFFSET, sizeof(sjmi_stage1_result),
@@ -188,32 +163,13 @@ int sjmi_stage1_device(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_ind
         ++c->events_used;
     }
     if (fail(c, "launch", sjmi::stage1_launch((const uint8_t*)d_buf, len, (uint32_t*)d_indexes, index_capacity,
-                                              c->d_ws_dev, steps, grid_for(c, steps), st, ev0, ev1, c->dbg)))
+                                              c->d_ws_dev, steps, st, ev0, ev1, c->dbg)))
         return SJMI_ERR_HIP;
     if (fail(c, "D2D(result)",
              hipMemcpyAsync(d_result, (uint8_t*)c->d_ws_dev + sjmi::WS_RESULT_OFFSET, sizeof(sjmi_stage1_result),
                             hipMemcpyDeviceToDevice, st)))
         return SJMI_ERR_HIP;
     return SJMI_OK;
-}
-
-int sjmi_debug_read_timing(sjmi_ctx* c, uint64_t out[8]) {
-    if (!c || !out || !c->d_ws_dev) return SJMI_ERR_ARG;
-    if (fail(c, "sync", hipStreamSynchronize(c->stream)) ||
-        fail(c, "D2H", hipMemcpy(out, (uint8_t*)c->d_ws_dev + sjmi::WS_TIMING_OFFSET, 64, hipMemcpyDeviceToHost)))
-        return SJMI_ERR_HIP;
-    return SJMI_OK;
-}
-
-int sjmi_set_grid(sjmi_ctx* c, uint32_t workgroups) {
-    if (!c) return SJMI_ERR_ARG;
-    c->grid_override = workgroups;
-    return SJMI_OK;
-}
-
-int sjmi_persistent_grid(const sjmi_ctx* c, int steps) {
-    if (!c || !(steps == 2 || steps == 4 || steps == 8)) return SJMI_ERR_ARG;
-    return (int)c->grid[steps];
 }
 
 int sjmi_debug_set_flags(sjmi_ctx* c, uint32_t flags) {

@@ -17,26 +17,20 @@ struct Stage1Result {
 static_assert(sizeof(Stage1Result) == sizeof(sjmi_stage1_result), "ABI struct mismatch");
 
 // ablation switches for performance experiments only (results are NOT valid with any of them set)
-constexpr uint32_t DBG_NO_WRITE = 1, DBG_NO_LOOKBACK = 2, DBG_NO_COMPUTE = 4;
-constexpr uint32_t DBG_TIMING = 8;      // accumulate s_memtime deltas per phase into the workspace header
+constexpr uint32_t DBG_NO_WRITE = 1, DBG_NO_LOOKBACK = 2;
 
 constexpr uint32_t STAGE_CAP = 1024;  // indexes staged in LDS per wave and round (4 KiB)
 
 // workspace layout (zeroed by one hipMemsetAsync per launch)
 constexpr size_t WS_RESULT_OFFSET = 0;        // Stage1Result
-constexpr size_t WS_TIMING_OFFSET = 64;       // 8 x u64 phase-cycle accumulators (DBG_TIMING only)
-constexpr size_t WS_TICKET_OFFSET = 128;      // NUM_TICKETS tile counters, one per 64-byte line
-constexpr uint32_t NUM_TICKETS = 8;
-constexpr size_t WS_TILE_STATE_OFFSET = 1024; // u64 per tile
+constexpr size_t WS_TICKET_OFFSET = 64;       // u32 tile ticket, alone in its 64-byte line
+constexpr size_t WS_TILE_STATE_OFFSET = 128;  // u64 per tile
 
 size_t stage1_workspace_bytes(uint64_t len, int steps);
 int stage1_pick_steps(uint64_t len);
-// max_grid = workgroups that fit on the chip (persistent waves; affects speed only, never correctness).
 // ev_start/ev_stop (optional) bracket the kernel only (not the workspace memset)
 hipError_t stage1_launch(const uint8_t* d_buf, uint64_t len, uint32_t* d_out, uint64_t out_cap, void* d_ws, int steps,
-                         uint32_t max_grid, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop,
-                         uint32_t dbg = 0);
-hipError_t stage1_resident_blocks(int steps, int* blocks_per_cu);
+                         hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg = 0);
 hipError_t transpose_selftest_launch(const uint32_t* d_words, uint32_t nblocks, uint32_t* d_mismatches,
                                      hipStream_t stream);
 

@@ -53,7 +53,7 @@ def test_reference_structural_indexer_vectors(ctx, case):
     _check(ctx, data)
 
 
-@pytest.mark.parametrize("steps", [2, 4, 8])
+@pytest.mark.parametrize("steps", [1, 2, 4])
 @pytest.mark.parametrize("name", ["twitter.json", "github_events.json", "wide_bench.json", "malformed.txt"])
 def test_reference_files(ctx, name, steps):
     ctx.set_tile_steps(steps)
@@ -73,7 +73,7 @@ def test_len_shorter_than_buffer_is_invisible(ctx):
         _check(ctx, d, n)
 
 
-@pytest.mark.parametrize("steps", [2, 8])
+@pytest.mark.parametrize("steps", [1, 4])
 def test_fuzz_small(ctx, steps):
     ctx.set_tile_steps(steps)
     try:
@@ -117,14 +117,14 @@ def _json_like(rng, n):
     return "".join(parts).encode()[:n]
 
 
-@pytest.mark.parametrize("steps", [2, 4, 8])
+@pytest.mark.parametrize("steps", [1, 2, 4])
 def test_fuzz_tile_boundaries(ctx, steps):
-    """Sizes around multiples of the (wave) tile (steps * 4 KiB) with strings / escapes / multi-byte
+    """Sizes around multiples of the tile (steps * 16 KiB) with strings / escapes / multi-byte
     characters straddling block, wave, workgroup and tile boundaries."""
     ctx.set_tile_steps(steps)
     try:
         rng = random.Random(7 + steps)
-        tile = steps * 4096
+        tile = steps * 16384
         for it in range(24):
             n = rng.choice([tile - 1, tile, tile + 1, 2 * tile - 64, 2 * tile + 63, 3 * tile + rng.randint(-70, 70),
                             5 * tile + rng.randint(0, 5000)])
@@ -162,7 +162,7 @@ def test_many_tiles_parity_chain(ctx):
     parity 1 through the look-back chain; then a second document half full of lone quotes."""
     body = (b'{"k": [1, 2, {"a": "b"}], "s": "x y z"} ' * 1000)
     d = b'["' + body.replace(b'"', b"'") * 1000 + b'", 1, 2]'
-    ctx.set_tile_steps(2)
+    ctx.set_tile_steps(1)
     try:
         _check(ctx, d)
         rng = random.Random(11)
@@ -173,21 +173,6 @@ def test_many_tiles_parity_chain(ctx):
     finally:
         ctx.set_tile_steps(0)
     _check(ctx, d)
-
-
-@pytest.mark.parametrize("grid", [2, 3, 7, 64])
-def test_small_persistent_grids(ctx, grid):
-    """Correctness must not depend on how many workgroups run (dynamic tickets): stress the tile chain
-    with tiny grids, where every wave processes hundreds of tiles."""
-    rng = random.Random(grid)
-    d = _json_like(rng, 3_000_000)
-    ctx.set_grid(grid)
-    ctx.set_tile_steps(2)
-    try:
-        _check(ctx, d)
-    finally:
-        ctx.set_grid(0)
-        ctx.set_tile_steps(0)
 
 
 def test_index_capacity_error(ctx):

@@ -24,9 +24,8 @@ for _ in range(10): dst.copy_(buf)
 torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 10
 print("torch copy: %.3f ms  read %.0f GB/s (r+w %.0f GB/s)" % (t * 1e3, n / t / 1e9, 2 * n / t / 1e9))
 del dst
-for steps, ticket in ((2, 0), (4, 0), (8, 0)):
+for steps in (1, 2, 4):
     ctx.set_tile_steps(steps)
-    print("steps", steps, "persistent grid=%d" % ctx.persistent_grid(steps))
     for flags, name in [(0, "full"), (1, "no_write"), (2, "no_lookback"), (3, "no_lookback+no_write")]:
         ctx.debug_set_flags(flags)
         for _ in range(3):
@@ -38,10 +37,4 @@ for steps, ticket in ((2, 0), (4, 0), (8, 0)):
         ms, k = ctx.kernel_time()
         ctx.set_profiling(False)
         print("steps=%d %-22s %.4f ms  %.0f GB/s" % (steps, name, ms / k, n / (ms / k) / 1e6))
-    ctx.debug_set_flags(8)
-    torch.cuda.synchronize()
-    ctx.stage1_device(buf.data_ptr(), n, out.data_ptr(), out.numel(), res.data_ptr(), st)
-    torch.cuda.synchronize()
-    tm = ctx.debug_read_timing()
-    nt = max(int(tm[4]), 1)
-    print("   per-tile cycles: load+classify %d  scans %d  lookback %d  expand+store %d  (tiles %d)" % (tm[0] // nt, tm[1] // nt, tm[2] // nt, tm[3] // nt, nt))
+ctx.debug_set_flags(0)

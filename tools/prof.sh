@@ -15,12 +15,14 @@ find $out -name "*.csv" | head -30
 python - <<PY
 import csv, glob, collections
 for f in sorted(glob.glob("$out/trace/**/*kernel_stats.csv", recursive=True)):
-    print(f); print(open(f).read()[:1500])
+    for r in csv.DictReader(open(f)):
+        if "k_stage1" in r["Name"] or "memset" in r["Name"].lower() or "fill" in r["Name"].lower():
+            print("stats:", r["Name"][:60], "calls", r["Calls"], "avg_ns", r["AverageNs"], "min", r["MinNs"], "max", r["MaxNs"])
 for d in ("pmc_sq","pmc_fetch","pmc_write","pmc_mem"):
     for f in sorted(glob.glob("$out/%s/**/*counter_collection.csv" % d, recursive=True)):
         agg = collections.defaultdict(lambda: [0.0,0])
         for r in csv.DictReader(open(f)):
-            if "k_stage1" in r.get("Kernel_Name",""):
+            if "k_stage1" in r.get("Kernel_Name","") and int(r.get("Grid_Size", "0")) > 100000:
                 a = agg[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
-        print(d, {k: round(v[0]/max(v[1],1),1) for k,v in agg.items()})
+        print(d, "(per big launch)", {k: round(v[0]/max(v[1],1),1) for k,v in agg.items()}, "launches", max([v[1] for v in agg.values()] or [0]))
 PY
