@@ -41,6 +41,14 @@ extern "C" {
 #define SJMI_ERR_INTERNAL (-4)
 #define SJMI_ERR_NO_DEVICE (-5)
 
+/* string / stage-2 error codes (numbering follows oracle/sj_oracle.h so that parity tests compare ints) */
+#define SJMI_E_ESCAPE_UNEXPECTED 4       /* "Escaped unexpected character: "     CharacterUtils.java:74-83 */
+#define SJMI_E_INVALID_UNICODE_ESCAPE 5  /* "Invalid unicode escape sequence."   StringParser.java:127-129 */
+#define SJMI_E_LOW_SURROGATE_RESERVED 6  /* StringParser.java:53-55 */
+#define SJMI_E_LOW_SURROGATE_NO_U 7      /* StringParser.java:113-115 */
+#define SJMI_E_LOW_SURROGATE_RANGE 8     /* StringParser.java:118-122 */
+#define SJMI_E_INTERNAL 100              /* engine invariant violated (never for status == 0 input) */
+
 typedef struct sjmi_ctx sjmi_ctx;
 
 /* device-side result record of one stage-1 call */
@@ -73,6 +81,29 @@ int sjmi_stage1(sjmi_ctx* ctx, const uint8_t* buf, uint64_t len, uint32_t* index
  * Asynchronous on `stream` (a hipStream_t, may be NULL = the context's stream). len < 2^32. */
 int sjmi_stage1_device(sjmi_ctx* ctx, const void* d_buf, uint64_t len, void* d_indexes, uint64_t index_capacity,
                        void* d_result, void* stream);
+
+/* device-side result record of one unescape call */
+typedef struct sjmi_unescape_result {
+    uint64_t total_bytes;      /* bytes of [be32 length][unescaped bytes] records written */
+    uint64_t first_error_inv;  /* 0 = every string is fine; else ~((position in indexes[] << 8) | SJMI_E_* code) */
+    uint32_t flags;            /* bit 0: string_buffer capacity exceeded */
+    uint32_t reserved;
+} sjmi_unescape_result;
+
+/* Batched replacement of the per-string StringParser.parseString calls (StringParser.java:18-68) that
+ * the reference's stage 2 makes for every '"' structural (TapeBuilder.java:174-177): for every index i with
+ * buf[indexes[i]] == '"', in order, appends [be32 length][unescaped UTF-8 bytes] to string_buffer, so that
+ * record k starts at sum_{j<k}(4 + len_j) -- exactly the STRING tape payloads of a valid document.
+ * Requires a stage-1 status of 0 for this document (closed strings). Device-resident form, asynchronous on
+ * `stream`; d_result is a device sjmi_unescape_result. */
+int sjmi_unescape_device(sjmi_ctx* ctx, const void* d_buf, uint64_t len, const void* d_indexes, uint64_t count,
+                         void* d_string_buffer, uint64_t string_capacity, void* d_result, void* stream);
+
+/* Host form: unescapes the strings of the document given to the LAST sjmi_stage1 call on this context
+ * (its bytes and indexes are still resident on the device) into string_buffer[0, *total_bytes).
+ * *first_error_index = position in indexes[] of the first failing string or UINT64_MAX; *first_error_code = SJMI_E_*. */
+int sjmi_unescape(sjmi_ctx* ctx, uint8_t* string_buffer, uint64_t string_capacity, uint64_t* total_bytes,
+                  uint64_t* first_error_index, uint32_t* first_error_code);
 
 /* Run the on-device self-test of the bit-plane transposition; *mismatches == 0 on success. */
 int sjmi_selftest(sjmi_ctx* ctx, uint32_t* mismatches);

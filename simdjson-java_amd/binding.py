@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _CSRC = os.path.join(_HERE, "csrc")
 _LIB = os.path.join(_HERE, "libsjmi.so")
-SOURCES = ["stage1.hip", "sjmi_api.hip"]
+SOURCES = ["stage1.hip", "unescape.hip", "sjmi_api.hip"]
 
 ST_UTF8, ST_UNCLOSED, ST_UNESCAPED, ST_CAPACITY, ST_INTERNAL = 1, 2, 4, 0x100, 0x200
 PADDING = 64
@@ -56,7 +56,8 @@ def build(force=False, verbose=False):
 _lib = None
 
 EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sjmi_stage1", "sjmi_stage1_device",
-           "sjmi_selftest", "sjmi_set_tile_steps", "sjmi_set_profiling", "sjmi_kernel_time", "sjmi_debug_set_flags"]
+           "sjmi_selftest", "sjmi_set_tile_steps", "sjmi_set_profiling", "sjmi_kernel_time", "sjmi_debug_set_flags",
+           "sjmi_unescape", "sjmi_unescape_device"]
 
 
 def lib():
@@ -91,6 +92,11 @@ def lib():
         L.sjmi_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.sjmi_debug_set_flags.restype = C.c_int
         L.sjmi_debug_set_flags.argtypes = [C.c_void_p, C.c_uint32]
+        L.sjmi_unescape.restype = C.c_int
+        L.sjmi_unescape.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sjmi_unescape_device.restype = C.c_int
+        L.sjmi_unescape_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                           C.c_void_p, C.c_void_p]
         L.sjmi_kernel_time.restype = C.c_int
         L.sjmi_kernel_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -144,6 +150,22 @@ class Context:
                     "sjmi_stage1")
         assert idx[cnt.value] == 0, "sentinel missing"
         return idx[:cnt.value].copy(), st.value
+
+    def unescape(self, string_capacity):
+        """Unescape every string of the document of the last stage1() call.
+        -> (string_buffer bytes, first_error_index or None, first_error_code)."""
+        sb = np.empty(max(string_capacity, 1), dtype=np.uint8)
+        total = C.c_uint64(0)
+        fei = C.c_uint64(0)
+        fec = C.c_uint32(0)
+        self._check(lib().sjmi_unescape(self._h, sb.ctypes.data, string_capacity, C.addressof(total), C.addressof(fei),
+                                        C.addressof(fec)), "sjmi_unescape")
+        idx = None if fei.value == 0xFFFFFFFFFFFFFFFF else fei.value
+        return sb[:total.value].tobytes(), idx, fec.value
+
+    def unescape_device(self, d_buf, length, d_indexes, count, d_sb, sb_capacity, d_result, stream=0):
+        self._check(lib().sjmi_unescape_device(self._h, d_buf, length, d_indexes, count, d_sb, sb_capacity, d_result,
+                                               stream), "sjmi_unescape_device")
 
     def stage1_device(self, d_buf, length, d_indexes, index_capacity, d_result, stream=0):
         """Device-resident path; arguments are raw device pointers (ints) and a hipStream_t handle."""

@@ -22,6 +22,13 @@ struct sjmi_ctx {
     void* d_ws_dev = nullptr;     // workspace for the device-resident path (grown on demand)
     size_t ws_dev_bytes = 0;
     sjmi_stage1_result* h_res = nullptr;  // pinned
+    uint64_t last_len = 0, last_count = 0;  // document of the last sjmi_stage1 call (still on the device)
+    bool last_valid = false;
+    uint8_t* d_sb = nullptr;      // string buffer (host path), grown on demand
+    size_t sb_bytes = 0;
+    void* d_ws_str = nullptr;     // unescape workspace, grown on demand
+    size_t ws_str_bytes = 0;
+    sjmi_unescape_result* d_ures = nullptr;
     int forced_steps = 0;
     uint32_t dbg = 0;  // ablation flags (sjmi_debug_set_flags)
     bool profiling = false;  // bracket every stage-1 kernel with HIP events (bench.py roofline)
@@ -80,6 +87,9 @@ void sjmi_destroy(sjmi_ctx* c) {
     if (c->d_idx) (void)hipFree(c->d_idx);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_ws_dev) (void)hipFree(c->d_ws_dev);
+    if (c->d_sb) (void)hipFree(c->d_sb);
+    if (c->d_ws_str) (void)hipFree(c->d_ws_str);
+    if (c->d_ures) (void)hipFree(c->d_ures);
     if (c->h_res) (void)hipHostFree(c->h_res);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.first);
@@ -132,6 +142,75 @@ int sjmi_stage1(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes
                             c->stream)) ||
         fail(c, "sync", hipStreamSynchronize(c->stream)))
         return SJMI_ERR_HIP;
+    c->last_len = len;
+    c->last_count = c->h_res->count;
+    c->last_valid = true;
+    return SJMI_OK;
+}
+
+namespace {
+bool grow(sjmi_ctx* c, void** p, size_t* have, size_t need, const char* what) {
+    if (need <= *have) return true;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+    if (fail(c, what, hipMalloc(p, need))) return false;
+    *have = need;
+    return true;
+}
+}  // namespace
+
+int sjmi_unescape_device(sjmi_ctx* c, const void* d_buf, uint64_t len, const void* d_indexes, uint64_t count,
+                         void* d_string_buffer, uint64_t string_capacity, void* d_result, void* stream) {
+    if (!c || !d_buf || !d_indexes || !d_string_buffer || !d_result || len >= (1ull << 32)) return SJMI_ERR_ARG;
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    if (!grow(c, &c->d_ws_str, &c->ws_str_bytes, sjmi::unescape_workspace_bytes(count), "hipMalloc(ws_str)"))
+        return SJMI_ERR_HIP;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (fail(c, "unescape launch",
+             sjmi::unescape_launch((const uint8_t*)d_buf, len, (const uint32_t*)d_indexes, count,
+                                   (uint8_t*)d_string_buffer, string_capacity, c->d_ws_str,
+                                   (sjmi::UnescapeResult*)d_result, st)))
+        return SJMI_ERR_HIP;
+    return SJMI_OK;
+}
+
+int sjmi_unescape(sjmi_ctx* c, uint8_t* string_buffer, uint64_t string_capacity, uint64_t* total_bytes,
+                  uint64_t* first_error_index, uint32_t* first_error_code) {
+    if (!c || !string_buffer || !total_bytes || !first_error_index || !first_error_code) return SJMI_ERR_ARG;
+    if (!c->last_valid) {
+        c->err = "sjmi_unescape needs a preceding successful sjmi_stage1 on this context";
+        return SJMI_ERR_ARG;
+    }
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    const size_t need_sb = (size_t)c->last_len + 4 * (size_t)c->last_count + 64;  // sum(4+len_k) <= len + 4*#strings
+    if (!grow(c, (void**)&c->d_sb, &c->sb_bytes, need_sb, "hipMalloc(sb)")) return SJMI_ERR_HIP;
+    if (!c->d_ures && fail(c, "hipMalloc(ures)", hipMalloc((void**)&c->d_ures, sizeof(sjmi_unescape_result))))
+        return SJMI_ERR_HIP;
+    int rc = sjmi_unescape_device(c, c->d_in, c->last_len, c->d_idx, c->last_count, c->d_sb, c->sb_bytes, c->d_ures,
+                                  c->stream);
+    if (rc != SJMI_OK) return rc;
+    sjmi_unescape_result r;
+    if (fail(c, "D2H(ures)", hipMemcpyAsync(&r, c->d_ures, sizeof r, hipMemcpyDeviceToHost, c->stream)) ||
+        fail(c, "sync", hipStreamSynchronize(c->stream)))
+        return SJMI_ERR_HIP;
+    *total_bytes = r.total_bytes;
+    if (r.first_error_inv) {
+        const uint64_t v = ~r.first_error_inv;
+        *first_error_index = v >> 8;
+        *first_error_code = (uint32_t)(v & 0xFF);
+    } else {
+        *first_error_index = ~0ull;
+        *first_error_code = 0;
+    }
+    if (r.total_bytes > string_capacity || (r.flags & 1u)) {
+        c->err = "string_capacity too small";
+        return SJMI_ERR_CAPACITY;
+    }
+    if (r.total_bytes &&
+        (fail(c, "D2H(sb)", hipMemcpyAsync(string_buffer, c->d_sb, r.total_bytes, hipMemcpyDeviceToHost, c->stream)) ||
+         fail(c, "sync", hipStreamSynchronize(c->stream))))
+        return SJMI_ERR_HIP;
     return SJMI_OK;
 }
 
@@ -145,6 +224,9 @@ int sjmi_stage1_device(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_ind
     const size_t need = sjmi::stage1_workspace_bytes(len, steps);
     if (need > c->ws_dev_bytes) {  // grown outside any timed loop on first use of a given size
         if (c->d_ws_dev) (void)hipFree(c->d_ws_dev);
+    if (c->d_sb) (void)hipFree(c->d_sb);
+    if (c->d_ws_str) (void)hipFree(c->d_ws_str);
+    if (c->d_ures) (void)hipFree(c->d_ures);
         c->d_ws_dev = nullptr;
         c->ws_dev_bytes = 0;
         if (fail(c, "hipMalloc(ws_dev)", hipMalloc(&c->d_ws_dev, need))) return SJMI_ERR_HIP;

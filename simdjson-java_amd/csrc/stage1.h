@@ -16,6 +16,15 @@ struct Stage1Result {
 };
 static_assert(sizeof(Stage1Result) == sizeof(sjmi_stage1_result), "ABI struct mismatch");
 
+// device-side result of one unescape call; mirrors sjmi_unescape_result in include/sjmi.h
+struct UnescapeResult {
+    unsigned long long total_bytes;      // bytes of [be32 len][bytes] records
+    unsigned long long first_error_inv;  // 0 = no error, else ~((structural position << 8) | SJMI_E_* code)
+    uint32_t flags;                      // bit0: string buffer capacity exceeded
+    uint32_t reserved;
+};
+static_assert(sizeof(UnescapeResult) == sizeof(sjmi_unescape_result), "ABI struct mismatch");
+
 // ablation switches for performance experiments only (results are NOT valid with any of them set)
 constexpr uint32_t DBG_NO_WRITE = 1, DBG_NO_LOOKBACK = 2;
 
@@ -31,6 +40,9 @@ int stage1_pick_steps(uint64_t len);
 // ev_start/ev_stop (optional) bracket the kernel only (not the workspace memset)
 hipError_t stage1_launch(const uint8_t* d_buf, uint64_t len, uint32_t* d_out, uint64_t out_cap, void* d_ws, int steps,
                          hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg = 0);
+size_t unescape_workspace_bytes(uint64_t count);
+hipError_t unescape_launch(const uint8_t* d_buf, uint64_t len, const uint32_t* d_idx, uint64_t count, uint8_t* d_sb,
+                           uint64_t sb_cap, void* d_ws, UnescapeResult* d_res, hipStream_t stream);
 hipError_t transpose_selftest_launch(const uint32_t* d_words, uint32_t nblocks, uint32_t* d_mismatches,
                                      hipStream_t stream);
 

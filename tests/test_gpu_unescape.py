@@ -1,0 +1,93 @@
+"""GPU parity tests of the batched string-unescape kernels (C ABI sjmi_unescape) against the oracle's
+StringParser restatement: string_buffer[0,total) bit-identical, same first failing string and error code."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.conftest import load_fixture
+from tests.golden import vectors as V
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import simdjson_java_amd as S
+    c = S.Context(device=0, capacity=64 * 1024 * 1024)
+    yield c
+    c.close()
+
+
+def _check(ctx, doc):
+    doc = bytes(doc)
+    idx, st = ctx.stage1(doc)
+    assert st == 0, "test documents must pass stage 1"
+    padded = doc + b"\0" * 64
+    want_sb, want_offs, want_feo, want_fec = O.unescape_all(padded, idx)
+    got_sb, got_fei, got_fec = ctx.unescape(len(doc) + 4 * idx.size + 64)
+    if want_feo < 0:
+        assert got_fei is None and got_fec == 0
+        assert got_sb == want_sb
+    else:
+        # oracle: ordinal among strings; GPU: position in indexes[]
+        quote_positions = [i for i in range(idx.size) if doc[idx[i]] == 0x22]
+        assert got_fei == quote_positions[want_feo]
+        assert got_fec == want_fec
+        assert got_sb[:len(want_sb)] == want_sb  # records before the failing string
+
+
+@pytest.mark.parametrize("name", ["twitter.json", "github_events.json", "wide_bench.json"])
+def test_reference_files(ctx, name):
+    _check(ctx, load_fixture(name))
+
+
+def test_every_code_point_escape(ctx):
+    """StringParsingTest.java:51-70: every non-surrogate code point as \\uXXXX / surrogate pair."""
+    parts = []
+    for cp in list(range(0, 0x10000, 3)) + list(range(0x10000, 0x110000, 101)) + [0x7F, 0x80, 0x7FF, 0x800, 0xFFFF, 0x10FFFF]:
+        if 0xD800 <= cp <= 0xDFFF:
+            continue
+        if cp < 0x10000:
+            parts.append('"\\u%04X"' % cp if cp % 2 else '"\\u%04x"' % cp)
+        else:
+            v = cp - 0x10000
+            parts.append('"\\u%04X\\u%04X"' % (0xD800 + (v >> 10), 0xDC00 + (v & 0x3FF)))
+    _check(ctx, ("[" + ",".join(parts) + "]").encode())
+
+
+def test_random_strings(ctx):
+    rng = random.Random(31337)
+    esc = ['\\"', "\\\\", "\\/", "\\b", "\\f", "\\n", "\\r", "\\t", "\\u00e9", "\\uD83D\\uDE00", "\\u0000"]
+    chars = ["a", "b", " ", "é", "€", "한", "😀", "x" * 70, "{", "]", ":", ","]
+    parts = []
+    for _ in range(20000):
+        n = rng.choice([0, 1, 2, 5, 20, 63, 64, 65, 200])
+        parts.append('"' + "".join(rng.choice(esc) if rng.random() < 0.2 else rng.choice(chars) for _ in range(n)) + '"')
+    doc = ("[" + (",\n " .join(parts)) + "]").encode()
+    _check(ctx, doc)
+    _check(ctx, b'{"k" : "v" , "a":"b"   }')
+    _check(ctx, b'"root string \\n"')
+    _check(ctx, b'"root"   ')
+    _check(ctx, b"[1,2,3]")
+    _check(ctx, b"")
+
+
+@pytest.mark.parametrize("case", [c for c in V.STRING_ERRORS if c[1] not in (V.MSG_TRAILING, V.MSG_UNCLOSED)],
+                         ids=lambda c: repr(c[0]))
+def test_reference_error_vectors(ctx, case):
+    text, msg, cite = case
+    doc = text.encode()
+    _check(ctx, doc)
+    idx, st = ctx.stage1(doc)
+    _, fei, fec = ctx.unescape(len(doc) + 4 * idx.size + 64)
+    assert fei is not None and O.error_message(fec).startswith(msg[:20]), cite
+
+
+def test_first_error_is_the_lowest_position(ctx):
+    good = '"ok\\n"'
+    doc = ("[" + ",".join([good] * 500 + ['"\\uD800x"'] + [good] * 500 + ['"\\q"'] + [good] * 10) + "]").encode()
+    _check(ctx, doc)
+    for s in ['"\\uDC00"', '"\\uD800\\u0041"', '"\\u12G4"', '"\\x"']:
+        _check(ctx, ("[" + ",".join([good] * 100 + [s] + [good] * 100) + "]").encode())
