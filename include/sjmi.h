@@ -47,6 +47,30 @@ extern "C" {
 #define SJMI_E_LOW_SURROGATE_RESERVED 6  /* StringParser.java:53-55 */
 #define SJMI_E_LOW_SURROGATE_NO_U 7      /* StringParser.java:113-115 */
 #define SJMI_E_LOW_SURROGATE_RANGE 8     /* StringParser.java:118-122 */
+#define SJMI_E_UTF8 1
+#define SJMI_E_UNCLOSED_STRING 2
+#define SJMI_E_UNESCAPED_CHARS 3
+#define SJMI_E_NO_STRUCTURAL 9           /* JsonIterator.java:27-29; 10..21: grammar errors JsonIterator.java / TapeBuilder.java */
+#define SJMI_E_UNCLOSED_OBJECT 10
+#define SJMI_E_UNCLOSED_ARRAY 11
+#define SJMI_E_OBJECT_NO_KEY 12
+#define SJMI_E_MISSING_COLON 13
+#define SJMI_E_KEY_MISSING 14
+#define SJMI_E_NO_COMMA_OBJECT 15
+#define SJMI_E_NO_COMMA_ARRAY 16
+#define SJMI_E_TRAILING_CONTENT 17
+#define SJMI_E_UNRECOGNIZED_PRIMITIVE 18
+#define SJMI_E_INVALID_TRUE 19
+#define SJMI_E_INVALID_FALSE 20
+#define SJMI_E_INVALID_NULL 21
+#define SJMI_E_NUM_MINUS 22              /* 22..27: NumberParser.java:34-72, ExponentParser.java:27-29 */
+#define SJMI_E_NUM_LEADING_ZERO 23
+#define SJMI_E_NUM_DECIMAL_POINT 24
+#define SJMI_E_NUM_EXPONENT 25
+#define SJMI_E_NUM_FOLLOWED 26
+#define SJMI_E_NUM_LONG_RANGE 27
+#define SJMI_E_DEPTH 28                  /* the reference throws ArrayIndexOutOfBoundsException (JsonIterator.java:69-70) */
+#define SJMI_E_CAPACITY 29
 #define SJMI_E_INTERNAL 100              /* engine invariant violated (never for status == 0 input) */
 
 typedef struct sjmi_ctx sjmi_ctx;
@@ -104,6 +128,18 @@ int sjmi_unescape_device(sjmi_ctx* ctx, const void* d_buf, uint64_t len, const v
  * *first_error_index = position in indexes[] of the first failing string or UINT64_MAX; *first_error_code = SJMI_E_*. */
 int sjmi_unescape(sjmi_ctx* ctx, uint8_t* string_buffer, uint64_t string_capacity, uint64_t* total_bytes,
                   uint64_t* first_error_index, uint32_t* first_error_code);
+
+/* ---- whole parse: SimdJsonParser.parse(byte[], int) (SimdJsonParser.java:35-40) ----------------------------
+ * GPU stage 1 + GPU string unescape + the host stage-2 tree builder (C++ mirror of JsonIterator / TapeBuilder /
+ * Tape: simdjson-java_amd/csrc/host/simdjson_parser.h).  The tape (Tape.java:5-47 word layout) and string
+ * buffer views stay valid until the next parse on this parser (like the reference's JsonValue).
+ * Returns 0, or > 0 = SJMI_E_* JSON error (message: sjmi_parser_last_message, exact reference text), or < 0. */
+typedef struct sjmi_parser sjmi_parser;
+int sjmi_parser_create(sjmi_parser** out, int capacity, int max_depth, int device);
+void sjmi_parser_destroy(sjmi_parser* p);
+int sjmi_parser_parse(sjmi_parser* p, const uint8_t* buf, uint64_t len, const uint64_t** tape, uint64_t* tape_len,
+                      const uint8_t** strings, uint64_t* strings_len, uint64_t* error_pos);
+const char* sjmi_parser_last_message(const sjmi_parser* p);
 
 /* Run the on-device self-test of the bit-plane transposition; *mismatches == 0 on success. */
 int sjmi_selftest(sjmi_ctx* ctx, uint32_t* mismatches);

@@ -6,4 +6,5 @@ Only what the hot path needs lives here:
 There is deliberately NO CPU fallback: without libsjmi.so + a GPU every call raises.
 """
 from .binding import (Context, SjmiError, build, lib, lib_path, ST_CAPACITY, ST_INTERNAL, ST_UNCLOSED,  # noqa: F401
-                      ST_UNESCAPED, ST_UTF8, PADDING, status_message)
+                      ST_UNESCAPED, ST_UTF8, PADDING, status_message, SimdJsonParser, JsonParsingException,
+                      ParsedDocument)

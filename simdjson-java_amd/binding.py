@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _CSRC = os.path.join(_HERE, "csrc")
 _LIB = os.path.join(_HERE, "libsjmi.so")
-SOURCES = ["stage1.hip", "unescape.hip", "sjmi_api.hip"]
+SOURCES = ["stage1.hip", "unescape.hip", "sjmi_api.hip", "host/simdjson_parser.cpp"]
 
 ST_UTF8, ST_UNCLOSED, ST_UNESCAPED, ST_CAPACITY, ST_INTERNAL = 1, 2, 4, 0x100, 0x200
 PADDING = 64
@@ -42,6 +42,7 @@ def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> simdjson-java_amd/libsjmi.so (in-tree; cross-compiles without a GPU)."""
     srcs = [os.path.join(_CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(_CSRC, h) for h in os.listdir(_CSRC) if h.endswith(".h")] + \
+        [os.path.join(_CSRC, "host", "simdjson_parser.h")] + \
         [os.path.join(_ROOT, "include", "sjmi.h")]
     if not force and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= max(os.path.getmtime(d) for d in deps):
         return _LIB
@@ -57,7 +58,8 @@ _lib = None
 
 EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sjmi_stage1", "sjmi_stage1_device",
            "sjmi_selftest", "sjmi_set_tile_steps", "sjmi_set_profiling", "sjmi_kernel_time", "sjmi_debug_set_flags",
-           "sjmi_unescape", "sjmi_unescape_device"]
+           "sjmi_unescape", "sjmi_unescape_device",
+           "sjmi_parser_create", "sjmi_parser_destroy", "sjmi_parser_parse", "sjmi_parser_last_message"]
 
 
 def lib():
@@ -97,6 +99,15 @@ def lib():
         L.sjmi_unescape_device.restype = C.c_int
         L.sjmi_unescape_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                            C.c_void_p, C.c_void_p]
+        L.sjmi_parser_create.restype = C.c_int
+        L.sjmi_parser_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
+        L.sjmi_parser_destroy.restype = None
+        L.sjmi_parser_destroy.argtypes = [C.c_void_p]
+        L.sjmi_parser_parse.restype = C.c_int
+        L.sjmi_parser_parse.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]
+        L.sjmi_parser_last_message.restype = C.c_char_p
+        L.sjmi_parser_last_message.argtypes = [C.c_void_p]
         L.sjmi_kernel_time.restype = C.c_int
         L.sjmi_kernel_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -184,3 +195,64 @@ class Context:
         n = C.c_uint32(0)
         self._check(lib().sjmi_kernel_time(self._h, C.addressof(ms), C.addressof(n)), "sjmi_kernel_time")
         return ms.value, n.value
+
+
+class JsonParsingException(Exception):
+    """org.simdjson.JsonParsingException (JsonParsingException.java:3-12); .code = SJMI_E_*."""
+
+    def __init__(self, code, message, position=0):
+        super().__init__(message)
+        self.code = code
+        self.position = position
+
+
+class ParsedDocument:
+    """Tape + string buffer of one parse (views copied out of the parser)."""
+
+    def __init__(self, tape, strings):
+        self.tape = tape
+        self.strings = strings
+
+
+class SimdJsonParser:
+    """Python handle on the C++ host mirror org_simdjson::SimdJsonParser (csrc/host/simdjson_parser.h):
+    parse(buffer, len) = GPU stage 1 + GPU string unescape + host stage 2 (SimdJsonParser.java:35-40)."""
+
+    DEFAULT_CAPACITY = 34 * 1024 * 1024
+    DEFAULT_MAX_DEPTH = 1024
+
+    def __init__(self, capacity=DEFAULT_CAPACITY, max_depth=DEFAULT_MAX_DEPTH, device=0):
+        self._h = C.c_void_p()
+        rc = lib().sjmi_parser_create(C.byref(self._h), capacity, max_depth, device)
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise SjmiError("sjmi_parser_create failed (rc=%d): no usable MI355X; there is no CPU fallback" % rc)
+
+    def close(self):
+        if self._h:
+            lib().sjmi_parser_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def parse(self, buffer, length=None):
+        a = np.frombuffer(bytes(buffer), dtype=np.uint8)
+        n = a.size if length is None else length
+        tape_p = C.POINTER(C.c_uint64)()
+        sb_p = C.POINTER(C.c_uint8)()
+        tape_len = C.c_uint64(0)
+        sb_len = C.c_uint64(0)
+        err_pos = C.c_uint64(0)
+        rc = lib().sjmi_parser_parse(self._h, a.ctypes.data if a.size else None, n, C.byref(tape_p), C.byref(tape_len),
+                                     C.byref(sb_p), C.byref(sb_len), C.byref(err_pos))
+        if rc > 0:
+            raise JsonParsingException(rc, lib().sjmi_parser_last_message(self._h).decode("utf-8"), err_pos.value)
+        if rc < 0:
+            raise SjmiError("sjmi_parser_parse failed (rc=%d): %s" % (rc, lib().sjmi_parser_last_message(self._h).decode()))
+        tape = np.ctypeslib.as_array(tape_p, shape=(tape_len.value,)).copy()
+        strings = bytes(np.ctypeslib.as_array(sb_p, shape=(max(sb_len.value, 1),))[:sb_len.value])
+        return ParsedDocument(tape, strings)

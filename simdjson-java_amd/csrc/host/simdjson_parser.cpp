@@ -1,0 +1,468 @@
+// simdjson_parser.cpp -- host side of SimdJsonParser.parse: GPU stage 1 + GPU string unescape through the
+// C ABI, then the reference's sequential stage 2 (JsonIterator + TapeBuilder + Tape + number grammar)
+// re-implemented in C++.  Citations: /root/reference/src/main/java/org/simdjson/<file>:<lines>.
+#include "simdjson_parser.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+namespace org_simdjson {
+
+enum {  // same numbering as include/sjmi.h SJMI_E_*
+    E_UTF8 = 1, E_UNCLOSED_STRING = 2, E_UNESCAPED_CHARS = 3, E_ESCAPE_UNEXPECTED = 4, E_INVALID_UNICODE_ESCAPE = 5,
+    E_LOW_SURROGATE_RESERVED = 6, E_LOW_SURROGATE_NO_U = 7, E_LOW_SURROGATE_RANGE = 8, E_NO_STRUCTURAL = 9,
+    E_UNCLOSED_OBJECT = 10, E_UNCLOSED_ARRAY = 11, E_OBJECT_NO_KEY = 12, E_MISSING_COLON = 13, E_KEY_MISSING = 14,
+    E_NO_COMMA_OBJECT = 15, E_NO_COMMA_ARRAY = 16, E_TRAILING_CONTENT = 17, E_UNRECOGNIZED_PRIMITIVE = 18,
+    E_INVALID_TRUE = 19, E_INVALID_FALSE = 20, E_INVALID_NULL = 21, E_NUM_MINUS = 22, E_NUM_LEADING_ZERO = 23,
+    E_NUM_DECIMAL_POINT = 24, E_NUM_EXPONENT = 25, E_NUM_FOLLOWED = 26, E_NUM_LONG_RANGE = 27, E_DEPTH = 28,
+    E_CAPACITY = 29
+};
+
+const char* errorMessage(int code) {
+    switch (code) {
+    case E_UTF8: return "The input is not valid UTF-8";                                   // Utf8Validator.java:166
+    case E_UNCLOSED_STRING: return "Unclosed string. A string is opened, but never closed.";  // StructuralIndexer.java:298
+    case E_UNESCAPED_CHARS:
+        return "Unescaped characters. Within strings, there are characters that should be escaped.";  // :301
+    case E_ESCAPE_UNEXPECTED: return "Escaped unexpected character: ";                     // CharacterUtils.java:76,80
+    case E_INVALID_UNICODE_ESCAPE: return "Invalid unicode escape sequence.";              // StringParser.java:128
+    case E_LOW_SURROGATE_RESERVED:
+        return "Invalid code point. The range U+DC00\xe2\x80\x93U+DFFF is reserved for low surrogate.";  // :54
+    case E_LOW_SURROGATE_NO_U: return "Low surrogate should start with '\\u'";              // :114
+    case E_LOW_SURROGATE_RANGE:
+        return "Invalid code point. Low surrogate should be in the range U+DC00\xe2\x80\x93U+DFFF.";  // :121
+    case E_NO_STRUCTURAL: return "No structural element found.";                           // JsonIterator.java:28
+    case E_UNCLOSED_OBJECT: return "Unclosed object. Missing '}' for starting '{'.";       // :40
+    case E_UNCLOSED_ARRAY: return "Unclosed array. Missing ']' for starting '['.";         // :52
+    case E_OBJECT_NO_KEY: return "Object does not start with a key";                       // :76
+    case E_MISSING_COLON: return "Missing colon after key in object";                      // :85
+    case E_KEY_MISSING: return "Key string missing at beginning of field in object";       // :122
+    case E_NO_COMMA_OBJECT: return "No comma between object fields";                       // :131
+    case E_NO_COMMA_ARRAY: return "Missing comma between array values";                    // :189
+    case E_TRAILING_CONTENT:
+        return "More than one JSON value at the root of the document, or extra characters at the end of the JSON!";  // :197
+    case E_UNRECOGNIZED_PRIMITIVE:
+        return "Unrecognized primitive. Expected: string, number, 'true', 'false' or 'null'.";  // TapeBuilder.java:66,77
+    case E_INVALID_TRUE: return "Invalid value starting at %d. Expected 'true'.";          // :103,111
+    case E_INVALID_FALSE: return "Invalid value starting at %d. Expected 'false'.";        // :126,134
+    case E_INVALID_NULL: return "Invalid value starting at %d. Expected 'null'.";          // :150,158
+    case E_NUM_MINUS: return "Invalid number. Minus has to be followed by a digit.";        // NumberParser.java:35
+    case E_NUM_LEADING_ZERO: return "Invalid number. Leading zeroes are not allowed.";     // :38
+    case E_NUM_DECIMAL_POINT: return "Invalid number. Decimal point has to be followed by a digit.";  // :52
+    case E_NUM_EXPONENT: return "Invalid number. Exponent indicator has to be followed by a digit.";  // ExponentParser.java:28
+    case E_NUM_FOLLOWED: return "Number has to be followed by a structural character or whitespace.";  // NumberParser.java:64
+    case E_NUM_LONG_RANGE:
+        return "Number value is out of long range ([-9223372036854775808, 9223372036854775807]).";  // :71
+    case E_DEPTH: return "ArrayIndexOutOfBoundsException (max depth exceeded)";             // JsonIterator.java:69-70
+    case E_CAPACITY: return "capacity exceeded";
+    default: return "unknown";
+    }
+}
+
+static JsonParsingException fail(int code, uint64_t pos = 0) {
+    std::string m = errorMessage(code);
+    const size_t at = m.find("%d");
+    if (at != std::string::npos) m.replace(at, 2, std::to_string(pos));
+    return JsonParsingException(code, m, pos);
+}
+
+void Tape::appendDouble(double v) {
+    append(0, DOUBLE);
+    uint64_t bits;
+    memcpy(&bits, &v, 8);
+    tape_[idx_++] = bits;
+}
+double Tape::getDouble(size_t i) const {
+    double d;
+    memcpy(&d, &tape_[i + 1], 8);
+    return d;
+}
+size_t Tape::computeNextIndex(size_t i) const {  // Tape.java:86-98
+    switch (getType(i)) {
+    case START_ARRAY:
+    case START_OBJECT: return getMatchingBraceIndex(i);
+    case INT64:
+    case DOUBLE: return i + 2;
+    default: return i + 1;
+    }
+}
+
+std::string JsonValue::asString() const {  // JsonValue.java:79-89, IntegerUtils.toInt :5-10
+    const size_t off = (size_t)tape_->getValue(idx_);
+    const uint32_t len = ((uint32_t)sb_[off] << 24) | ((uint32_t)sb_[off + 1] << 16) | ((uint32_t)sb_[off + 2] << 8) | sb_[off + 3];
+    return std::string(reinterpret_cast<const char*>(sb_ + off + 4), len);
+}
+
+bool JsonValue::get(const std::string& name, JsonValue* out) const {  // JsonValue.java:91-107 (linear key scan)
+    size_t i = idx_ + 1;
+    const size_t end = tape_->getMatchingBraceIndex(idx_) - 1;
+    while (i < end) {
+        const size_t off = (size_t)tape_->getValue(i);
+        const uint32_t len = ((uint32_t)sb_[off] << 24) | ((uint32_t)sb_[off + 1] << 16) | ((uint32_t)sb_[off + 2] << 8) | sb_[off + 3];
+        const size_t val = tape_->computeNextIndex(i);
+        i = tape_->computeNextIndex(val);
+        if (len == name.size() && memcmp(sb_ + off + 4, name.data(), len) == 0) {
+            *out = JsonValue(tape_, val, sb_);
+            return true;
+        }
+    }
+    return false;
+}
+
+SimdJsonParser::SimdJsonParser(int capacity, int maxDepth, int device)
+    : capacity_(capacity), maxDepth_(maxDepth), bitIndexes_((size_t)capacity + 2), tape_((size_t)capacity + 8),
+      paddedBuffer_((size_t)capacity + PADDING), openContainers_((size_t)maxDepth), isArray_((size_t)maxDepth) {
+    const int rc = sjmi_create(&ctx_, device, (uint64_t)capacity);
+    if (rc != SJMI_OK) throw std::runtime_error("SimdJsonParser: no usable MI355X device (sjmi_create rc=" + std::to_string(rc) + "); there is no CPU fallback");
+}
+
+SimdJsonParser::~SimdJsonParser() { sjmi_destroy(ctx_); }
+
+// SimdJsonParser.stage1 (SimdJsonParser.java:55-58) on the GPU + the string records stage 2 will need
+void SimdJsonParser::stage1(const uint8_t* buffer, size_t len) {
+    uint64_t count = 0;
+    uint32_t status = 0;
+    int rc = sjmi_stage1(ctx_, buffer, len, bitIndexes_.array(), bitIndexes_.capacity(), &count, &status);
+    if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_stage1: ") + sjmi_last_error(ctx_));
+    bitIndexes_.setWriteIdx((size_t)count);
+    if (status & SJMI_ST_UTF8) throw fail(E_UTF8);                 // Utf8Validator.java:165-167 (checked first)
+    if (status & SJMI_ST_UNCLOSED) throw fail(E_UNCLOSED_STRING);  // StructuralIndexer.java:297-299
+    if (status & SJMI_ST_UNESCAPED) throw fail(E_UNESCAPED_CHARS); // :300-302
+    const size_t need = len + 4 * (size_t)count + 64;
+    if (stringBuffer_.size() < need) stringBuffer_.resize(need);
+    uint64_t total = 0, fei = 0;
+    uint32_t fec = 0;
+    rc = sjmi_unescape(ctx_, stringBuffer_.data(), stringBuffer_.size(), &total, &fei, &fec);
+    if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_unescape: ") + sjmi_last_error(ctx_));
+    stringBufferLen_ = (size_t)total;
+    firstStringError_ = fei;
+    firstStringErrorCode_ = fec;
+}
+
+JsonValue SimdJsonParser::parse(const uint8_t* buffer, size_t len) {
+    if (len > (size_t)capacity_) throw fail(E_CAPACITY);
+    // padIfNeeded (SimdJsonParser.java:42-48): the C++ caller's buffer has no known slack, so always copy
+    memcpy(paddedBuffer_.data(), buffer, len);
+    memset(paddedBuffer_.data() + len, 0, PADDING);
+    // reset (:50-53)
+    bitIndexes_.reset();
+    tape_.reset();
+    stringBufferIdx_ = 0;
+    memset(isArray_.data(), 0, isArray_.size());
+    stage1(paddedBuffer_.data(), len);
+    walkDocument(len);
+    return JsonValue(&tape_, 1, stringBuffer_.data());  // TapeBuilder.createJsonValue :215-217
+}
+
+// TapeBuilder.visitString (TapeBuilder.java:174-177): the record [be32 len][bytes] was produced on the GPU at
+// exactly the offset the sequential StringParser would have used; only the bookkeeping remains.
+void SimdJsonParser::visitString(uint32_t idx, size_t indexPos) {
+    (void)idx;
+    tape_.append(stringBufferIdx_, Tape::STRING);
+    if ((uint64_t)indexPos == firstStringError_) throw fail((int)firstStringErrorCode_);
+    const uint8_t* r = stringBuffer_.data() + stringBufferIdx_;
+    const uint32_t n = ((uint32_t)r[0] << 24) | ((uint32_t)r[1] << 16) | ((uint32_t)r[2] << 8) | r[3];
+    stringBufferIdx_ += 4 + (size_t)n;
+}
+
+static inline bool isStructuralOrWhitespace(uint8_t b) {  // CharacterUtils.java:6-50
+    switch (b) {
+    case 0x09: case 0x0A: case 0x0D: case 0x20: case ',': case ':': case '[': case ']': case '{': case '}': return true;
+    default: return false;
+    }
+}
+static inline bool isTrue(const uint8_t* b) { return b[0] == 't' && b[1] == 'r' && b[2] == 'u' && b[3] == 'e'; }
+static inline bool isFalse(const uint8_t* b) { return b[0] == 'f' && b[1] == 'a' && b[2] == 'l' && b[3] == 's' && b[4] == 'e'; }
+static inline bool isNull(const uint8_t* b) { return b[0] == 'n' && b[1] == 'u' && b[2] == 'l' && b[3] == 'l'; }
+
+// NumberParser.parseNumber (NumberParser.java:23-74), ExponentParser.parse (ExponentParser.java:14-69),
+// isOutOfLongRange (NumberParser.java:313-328).  Doubles: the reference's DoubleParser is a correctly rounded,
+// saturating decimal->binary64 conversion (DoubleParser.java:79-330); strtod has the same contract.
+void SimdJsonParser::parseNumber(const uint8_t* p) {
+    const uint8_t* start = p;
+    const bool negative = *p == '-';
+    if (negative) ++p;
+    const uint8_t* digitsStart = p;
+    uint64_t digits = 0;
+    while ((uint8_t)(*p - '0') <= 9) { digits = 10 * digits + (uint64_t)(*p - '0'); ++p; }
+    const ptrdiff_t digitCount = p - digitsStart;
+    if (digitCount == 0) throw fail(E_NUM_MINUS);
+    if (*digitsStart == '0' && digitCount > 1) throw fail(E_NUM_LEADING_ZERO);
+    bool floating = false;
+    if (*p == '.') {
+        floating = true;
+        ++p;
+        const uint8_t* after = p;
+        while ((uint8_t)(*p - '0') <= 9) ++p;
+        if (p == after) throw fail(E_NUM_DECIMAL_POINT);
+    }
+    if (*p == 'e' || *p == 'E') {
+        floating = true;
+        ++p;
+        if (*p == '-' || *p == '+') ++p;
+        const uint8_t* es = p;
+        while ((uint8_t)(*p - '0') <= 9) ++p;
+        if (p == es) throw fail(E_NUM_EXPONENT);
+    }
+    if (!isStructuralOrWhitespace(*p)) throw fail(E_NUM_FOLLOWED);
+    if (floating) {
+        std::string text(reinterpret_cast<const char*>(start), (size_t)(p - start));
+        tape_.appendDouble(strtod(text.c_str(), nullptr));
+    } else {
+        bool out = false;
+        if (digitCount > 19) out = true;
+        else if (digitCount == 19) out = (negative && digits == 0x8000000000000000ull) ? false : ((int64_t)digits < 0);
+        if (out) throw fail(E_NUM_LONG_RANGE);
+        tape_.appendInt64((int64_t)(negative ? (~digits + 1) : digits));
+    }
+}
+
+void SimdJsonParser::visitPrimitive(uint32_t idx, size_t indexPos) {  // TapeBuilder.java:70-79
+    const uint8_t* b = paddedBuffer_.data() + idx;
+    switch (*b) {
+    case '"': visitString(idx, indexPos); break;
+    case 't':
+        if (!(isTrue(b) && isStructuralOrWhitespace(b[4]))) throw fail(E_INVALID_TRUE, idx);
+        tape_.append(0, Tape::TRUE_VALUE);
+        break;
+    case 'f':
+        if (!(isFalse(b) && isStructuralOrWhitespace(b[5]))) throw fail(E_INVALID_FALSE, idx);
+        tape_.append(0, Tape::FALSE_VALUE);
+        break;
+    case 'n':
+        if (!(isNull(b) && isStructuralOrWhitespace(b[4]))) throw fail(E_INVALID_NULL, idx);
+        tape_.append(0, Tape::NULL_VALUE);
+        break;
+    case '-': case '0': case '1': case '2': case '3': case '4': case '5': case '6': case '7': case '8': case '9':
+        parseNumber(b);
+        break;
+    default: throw fail(E_UNRECOGNIZED_PRIMITIVE);
+    }
+}
+
+void SimdJsonParser::visitRootPrimitive(uint32_t idx, size_t indexPos, size_t len) {  // TapeBuilder.java:59-68
+    const uint8_t* b = paddedBuffer_.data() + idx;
+    switch (*b) {
+    case '"': visitString(idx, indexPos); break;
+    case 't':
+        if (!(idx + 4 <= len && isTrue(b) && (idx + 4 == len || isStructuralOrWhitespace(b[4])))) throw fail(E_INVALID_TRUE, idx);
+        tape_.append(0, Tape::TRUE_VALUE);
+        break;
+    case 'f':
+        if (!(idx + 5 <= len && isFalse(b) && (idx + 5 == len || isStructuralOrWhitespace(b[5])))) throw fail(E_INVALID_FALSE, idx);
+        tape_.append(0, Tape::FALSE_VALUE);
+        break;
+    case 'n':
+        if (!(idx + 4 <= len && isNull(b) && (idx + 4 == len || isStructuralOrWhitespace(b[4])))) throw fail(E_INVALID_NULL, idx);
+        tape_.append(0, Tape::NULL_VALUE);
+        break;
+    case '-': case '0': case '1': case '2': case '3': case '4': case '5': case '6': case '7': case '8': case '9': {
+        // visitRootNumber :183-189: the number is re-parsed from a copy padded with 64 spaces
+        std::vector<uint8_t> copy(len - idx + PADDING, 0x20);
+        memcpy(copy.data(), b, len - idx);
+        parseNumber(copy.data());
+        break;
+    }
+    default: throw fail(E_UNRECOGNIZED_PRIMITIVE);
+    }
+}
+
+void SimdJsonParser::emptyContainer(char start, char end) {  // TapeBuilder.java:205-208
+    tape_.append(tape_.getCurrentIdx() + 2, start);
+    tape_.append(tape_.getCurrentIdx(), end);
+}
+
+// JsonIterator.walkDocument (JsonIterator.java:26-200), state for state
+void SimdJsonParser::walkDocument(size_t len) {
+    enum { OBJECT_BEGIN, ARRAY_BEGIN, DOCUMENT_END, OBJECT_FIELD, OBJECT_CONTINUE, SCOPE_END, ARRAY_CONTINUE, ARRAY_VALUE };
+    const uint8_t* buffer = paddedBuffer_.data();
+    BitIndexes& indexer = bitIndexes_;
+    if (indexer.isEnd()) throw fail(E_NO_STRUCTURAL);
+    auto startContainer = [&](int depth) {  // TapeBuilder.java:191-195
+        openContainers_[(size_t)depth].tapeIndex = tape_.getCurrentIdx();
+        openContainers_[(size_t)depth].count = 0;
+        tape_.skip();
+    };
+    auto endContainer = [&](char start, char end, int depth) {  // :197-203
+        const size_t st = openContainers_[(size_t)depth].tapeIndex;
+        tape_.append(st, end);
+        uint32_t count = openContainers_[(size_t)depth].count;
+        if (count > 0xFFFFFF) count = 0xFFFFFF;
+        tape_.write(st, tape_.getCurrentIdx() | ((uint64_t)count << 32), start);
+    };
+    startContainer(0);  // visitDocumentStart :41-43
+    int depth = 0, state;
+    size_t pos = indexer.readIdx();
+    uint32_t idx = indexer.getAndAdvance();
+    switch (buffer[idx]) {
+    case '{':
+        if (buffer[indexer.getLast()] != '}') throw fail(E_UNCLOSED_OBJECT);
+        if (buffer[indexer.peek()] == '}') { indexer.advance(); emptyContainer('{', '}'); state = DOCUMENT_END; }
+        else state = OBJECT_BEGIN;
+        break;
+    case '[':
+        if (buffer[indexer.getLast()] != ']') throw fail(E_UNCLOSED_ARRAY);
+        if (buffer[indexer.peek()] == ']') { indexer.advance(); emptyContainer('[', ']'); state = DOCUMENT_END; }
+        else state = ARRAY_BEGIN;
+        break;
+    default:
+        visitRootPrimitive(idx, pos, len);
+        state = DOCUMENT_END;
+    }
+    while (state != DOCUMENT_END) {
+        if (state == OBJECT_BEGIN) {
+            ++depth;
+            if (depth >= maxDepth_) throw fail(E_DEPTH);
+            isArray_[(size_t)depth] = 0;
+            startContainer(depth);
+            pos = indexer.readIdx();
+            const uint32_t keyIdx = indexer.getAndAdvance();
+            if (buffer[keyIdx] != '"') throw fail(E_OBJECT_NO_KEY);
+            openContainers_[(size_t)depth].count++;
+            visitString(keyIdx, pos);
+            state = OBJECT_FIELD;
+        }
+        if (state == OBJECT_FIELD) {
+            if (buffer[indexer.getAndAdvance()] != ':') throw fail(E_MISSING_COLON);
+            pos = indexer.readIdx();
+            idx = indexer.getAndAdvance();
+            switch (buffer[idx]) {
+            case '{':
+                if (buffer[indexer.peek()] == '}') { indexer.advance(); emptyContainer('{', '}'); state = OBJECT_CONTINUE; }
+                else state = OBJECT_BEGIN;
+                break;
+            case '[':
+                if (buffer[indexer.peek()] == ']') { indexer.advance(); emptyContainer('[', ']'); state = OBJECT_CONTINUE; }
+                else state = ARRAY_BEGIN;
+                break;
+            default:
+                visitPrimitive(idx, pos);
+                state = OBJECT_CONTINUE;
+            }
+        }
+        if (state == OBJECT_CONTINUE) {
+            switch (buffer[indexer.getAndAdvance()]) {
+            case ',': {
+                openContainers_[(size_t)depth].count++;
+                pos = indexer.readIdx();
+                const uint32_t keyIdx = indexer.getAndAdvance();
+                if (buffer[keyIdx] != '"') throw fail(E_KEY_MISSING);
+                visitString(keyIdx, pos);
+                state = OBJECT_FIELD;
+                break;
+            }
+            case '}':
+                endContainer('{', '}', depth);
+                state = SCOPE_END;
+                break;
+            default: throw fail(E_NO_COMMA_OBJECT);
+            }
+        }
+        if (state == SCOPE_END) {
+            --depth;
+            if (depth == 0) state = DOCUMENT_END;
+            else if (isArray_[(size_t)depth]) state = ARRAY_CONTINUE;
+            else state = OBJECT_CONTINUE;
+        }
+        if (state == ARRAY_BEGIN) {
+            ++depth;
+            if (depth >= maxDepth_) throw fail(E_DEPTH);
+            isArray_[(size_t)depth] = 1;
+            startContainer(depth);
+            openContainers_[(size_t)depth].count++;
+            state = ARRAY_VALUE;
+        }
+        if (state == ARRAY_VALUE) {
+            pos = indexer.readIdx();
+            idx = indexer.getAndAdvance();
+            switch (buffer[idx]) {
+            case '{':
+                if (buffer[indexer.peek()] == '}') { indexer.advance(); emptyContainer('{', '}'); state = ARRAY_CONTINUE; }
+                else state = OBJECT_BEGIN;
+                break;
+            case '[':
+                if (buffer[indexer.peek()] == ']') { indexer.advance(); emptyContainer('[', ']'); state = ARRAY_CONTINUE; }
+                else state = ARRAY_BEGIN;
+                break;
+            default:
+                visitPrimitive(idx, pos);
+                state = ARRAY_CONTINUE;
+            }
+        }
+        if (state == ARRAY_CONTINUE) {
+            switch (buffer[indexer.getAndAdvance()]) {
+            case ',':
+                openContainers_[(size_t)depth].count++;
+                state = ARRAY_VALUE;
+                break;
+            case ']':
+                endContainer('[', ']', depth);
+                state = SCOPE_END;
+                break;
+            default: throw fail(E_NO_COMMA_ARRAY);
+            }
+        }
+    }
+    tape_.append(0, Tape::ROOT);                       // visitDocumentEnd :45-48
+    tape_.write(0, tape_.getCurrentIdx(), Tape::ROOT);
+    if (!indexer.isEnd()) throw fail(E_TRAILING_CONTENT);  // JsonIterator.java:196-198
+}
+
+}  // namespace org_simdjson
+
+// ---- C ABI of the parser (include/sjmi.h) ------------------------------------------------------
+struct sjmi_parser {
+    org_simdjson::SimdJsonParser* p;
+    std::string msg;
+};
+
+extern "C" {
+
+int sjmi_parser_create(sjmi_parser** out, int capacity, int max_depth, int device) {
+    if (!out) return SJMI_ERR_ARG;
+    *out = nullptr;
+    try {
+        sjmi_parser* h = new sjmi_parser();
+        h->p = new org_simdjson::SimdJsonParser(capacity, max_depth, device);
+        *out = h;
+        return SJMI_OK;
+    } catch (const std::exception&) {
+        return SJMI_ERR_NO_DEVICE;
+    }
+}
+
+void sjmi_parser_destroy(sjmi_parser* h) {
+    if (!h) return;
+    delete h->p;
+    delete h;
+}
+
+const char* sjmi_parser_last_message(const sjmi_parser* h) { return h ? h->msg.c_str() : ""; }
+
+int sjmi_parser_parse(sjmi_parser* h, const uint8_t* buf, uint64_t len, const uint64_t** tape, uint64_t* tape_len,
+                      const uint8_t** strings, uint64_t* strings_len, uint64_t* error_pos) {
+    if (!h || (!buf && len) || !tape || !tape_len || !strings || !strings_len) return SJMI_ERR_ARG;
+    *tape = nullptr;
+    *tape_len = 0;
+    *strings = nullptr;
+    *strings_len = 0;
+    if (error_pos) *error_pos = 0;
+    h->msg.clear();
+    try {
+        h->p->parse(buf, (size_t)len);
+        *tape = h->p->tape().data();
+        *tape_len = h->p->tape().getCurrentIdx();
+        *strings = h->p->stringBuffer().data();
+        *strings_len = h->p->stringBufferLen();
+        return 0;
+    } catch (const org_simdjson::JsonParsingException& e) {
+        h->msg = e.what();
+        if (error_pos) *error_pos = e.position();
+        return e.code();  // > 0: a JSON error (SJMI_E_*)
+    } catch (const std::exception& e) {
+        h->msg = e.what();
+        return SJMI_ERR_HIP;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,160 @@
+// simdjson_parser.h -- C++ host-side mirror of the reference's public interface for the hot path:
+//   org.simdjson.SimdJsonParser.parse(byte[], int) -> JsonValue
+//   (/root/reference/src/main/java/org/simdjson/SimdJsonParser.java:15-58, JsonValue.java:25-111)
+// Same class names, same argument meaning, same error messages.  Stage 1 (UTF-8 validation, structural
+// indexing) and string unescaping run on the MI355X through the C ABI (include/sjmi.h); the sequential
+// stage-2 tree builder (JsonIterator + TapeBuilder + Tape) stays on the host, as in the reference.
+// There is no CPU implementation of stage 1 / string unescape here: without a GPU the constructor throws.
+#pragma once
+#include <stdint.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/sjmi.h"
+
+namespace org_simdjson {
+
+// JsonParsingException.java:3-12 (unchecked; the message is part of the tested contract)
+class JsonParsingException : public std::runtime_error {
+public:
+    JsonParsingException(int code, const std::string& msg, uint64_t pos = 0)
+        : std::runtime_error(msg), code_(code), pos_(pos) {}
+    int code() const { return code_; }
+    uint64_t position() const { return pos_; }
+
+private:
+    int code_;
+    uint64_t pos_;
+};
+
+// BitIndexes.java:5-101 -- stage-1 output container + stage-2 cursor
+class BitIndexes {
+public:
+    explicit BitIndexes(size_t capacity) : indexes_(capacity) {}
+    uint32_t* array() { return indexes_.data(); }           // filled by the engine (replaces write(), :14-41)
+    size_t capacity() const { return indexes_.size(); }
+    void setWriteIdx(size_t n) { writeIdx_ = n; }            // replaces finish() (:82-96): sentinel written by the engine
+    void advance() { ++readIdx_; }                                                    // :47-49
+    uint32_t getAndAdvance() { return at(readIdx_++); }                               // :51-54
+    uint32_t getLast() const { return indexes_[writeIdx_ - 1]; }                      // :56-58
+    uint32_t peek() const { return at(readIdx_); }                                    // :65-68
+    bool isEnd() const { return writeIdx_ == readIdx_; }                              // :74-76
+    size_t readIdx() const { return readIdx_; }
+    size_t writeIdx() const { return writeIdx_; }
+    void reset() { writeIdx_ = 0; readIdx_ = 0; }                                     // :98-101
+
+private:
+    // reads past the sentinel (never observed for any input: the sentinel read already fails the grammar) are defined as 0
+    uint32_t at(size_t i) const { return i <= writeIdx_ ? indexes_[i] : 0u; }
+    std::vector<uint32_t> indexes_;
+    size_t writeIdx_ = 0, readIdx_ = 0;
+};
+
+// Tape.java:5-98
+class Tape {
+public:
+    static constexpr char ROOT = 'r', START_ARRAY = '[', START_OBJECT = '{', END_ARRAY = ']', END_OBJECT = '}',
+                          STRING = '"', INT64 = 'l', DOUBLE = 'd', TRUE_VALUE = 't', FALSE_VALUE = 'f', NULL_VALUE = 'n';
+    explicit Tape(size_t capacity) : tape_(capacity) {}
+    void append(uint64_t val, char type) { tape_[idx_++] = val | ((uint64_t)(uint8_t)type << 56); }  // :28-31
+    void appendInt64(int64_t v) { append(0, INT64); tape_[idx_++] = (uint64_t)v; }                   // :33-37
+    void appendDouble(double v);                                                                      // :39-43
+    void write(size_t i, uint64_t val, char type) { tape_[i] = val | ((uint64_t)(uint8_t)type << 56); }  // :45-47
+    void skip() { ++idx_; }
+    void reset() { idx_ = 0; }
+    size_t getCurrentIdx() const { return idx_; }
+    char getType(size_t i) const { return (char)(tape_[i] >> 56); }
+    uint64_t getValue(size_t i) const { return tape_[i] & 0x00FFFFFFFFFFFFFFull; }
+    int64_t getInt64Value(size_t i) const { return (int64_t)tape_[i + 1]; }
+    double getDouble(size_t i) const;
+    size_t getMatchingBraceIndex(size_t i) const { return (size_t)(uint32_t)tape_[i]; }
+    int getScopeCount(size_t i) const { return (int)((tape_[i] >> 32) & 0xFFFFFF); }
+    size_t computeNextIndex(size_t i) const;                                                          // :86-98
+    const uint64_t* data() const { return tape_.data(); }
+    size_t capacity() const { return tape_.size(); }
+
+private:
+    std::vector<uint64_t> tape_;
+    size_t idx_ = 0;
+};
+
+class SimdJsonParser;
+
+// JsonValue.java:18-221 -- read-only DOM view over (tape, tapeIdx, stringBuffer)
+class JsonValue {
+public:
+    JsonValue(const Tape* tape, size_t tapeIdx, const uint8_t* stringBuffer) : tape_(tape), idx_(tapeIdx), sb_(stringBuffer) {}
+    bool isArray() const { return tape_->getType(idx_) == Tape::START_ARRAY; }
+    bool isObject() const { return tape_->getType(idx_) == Tape::START_OBJECT; }
+    bool isLong() const { return tape_->getType(idx_) == Tape::INT64; }
+    bool isDouble() const { return tape_->getType(idx_) == Tape::DOUBLE; }
+    bool isBoolean() const { char t = tape_->getType(idx_); return t == Tape::TRUE_VALUE || t == Tape::FALSE_VALUE; }
+    bool isNull() const { return tape_->getType(idx_) == Tape::NULL_VALUE; }
+    bool isString() const { return tape_->getType(idx_) == Tape::STRING; }
+    int64_t asLong() const { return tape_->getInt64Value(idx_); }
+    double asDouble() const { return tape_->getDouble(idx_); }
+    bool asBoolean() const { return tape_->getType(idx_) == Tape::TRUE_VALUE; }
+    std::string asString() const;                    // :79-89
+    bool get(const std::string& name, JsonValue* out) const;  // :91-107 (returns false where Java returns null)
+    int getSize() const { return tape_->getScopeCount(idx_); }
+    // iteration (arrayIterator / objectIterator, :143-194)
+    size_t firstChild() const { return idx_ + 1; }
+    size_t endChild() const { return tape_->getMatchingBraceIndex(idx_) - 1; }
+    size_t next(size_t childIdx) const { return tape_->computeNextIndex(childIdx); }
+    JsonValue at(size_t tapeIdx) const { return JsonValue(tape_, tapeIdx, sb_); }
+    size_t tapeIdx() const { return idx_; }
+
+private:
+    const Tape* tape_;
+    size_t idx_;
+    const uint8_t* sb_;
+};
+
+// SimdJsonParser.java:3-59
+class SimdJsonParser {
+public:
+    static constexpr int PADDING = 64;                        // :5
+    static constexpr int DEFAULT_CAPACITY = 34 * 1024 * 1024;  // :6
+    static constexpr int DEFAULT_MAX_DEPTH = 1024;            // :7
+    SimdJsonParser() : SimdJsonParser(DEFAULT_CAPACITY, DEFAULT_MAX_DEPTH) {}
+    SimdJsonParser(int capacity, int maxDepth, int device = 0);
+    ~SimdJsonParser();
+    SimdJsonParser(const SimdJsonParser&) = delete;
+    SimdJsonParser& operator=(const SimdJsonParser&) = delete;
+
+    // parse(byte[] buffer, int len) :35-40.  Only buffer[0,len) is read.  The returned JsonValue aliases
+    // parser-owned memory and is invalidated by the next parse(), exactly like the reference.
+    JsonValue parse(const uint8_t* buffer, size_t len);
+
+    const Tape& tape() const { return tape_; }
+    const std::vector<uint8_t>& stringBuffer() const { return stringBuffer_; }
+    size_t stringBufferLen() const { return stringBufferLen_; }
+    const BitIndexes& bitIndexes() const { return bitIndexes_; }
+
+private:
+    void stage1(const uint8_t* buffer, size_t len);   // :55-58 -> GPU
+    void walkDocument(size_t len);                    // JsonIterator.walkDocument, JsonIterator.java:26-200
+    void visitString(uint32_t idx, size_t indexPos);  // TapeBuilder.visitString :174-177 (record already on the GPU-made buffer)
+    void visitPrimitive(uint32_t idx, size_t indexPos);
+    void visitRootPrimitive(uint32_t idx, size_t indexPos, size_t len);
+    void parseNumber(const uint8_t* p);
+    void emptyContainer(char start, char end);
+
+    sjmi_ctx* ctx_ = nullptr;
+    int capacity_, maxDepth_;
+    BitIndexes bitIndexes_;
+    Tape tape_;
+    std::vector<uint8_t> stringBuffer_, paddedBuffer_;
+    size_t stringBufferLen_ = 0, stringBufferIdx_ = 0;
+    uint64_t firstStringError_ = ~0ull;
+    uint32_t firstStringErrorCode_ = 0;
+    struct OpenContainer { size_t tapeIndex; uint32_t count; };
+    std::vector<OpenContainer> openContainers_;
+    std::vector<uint8_t> isArray_;
+};
+
+const char* errorMessage(int code);
+
+}  // namespace org_simdjson
