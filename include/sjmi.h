@@ -129,6 +129,21 @@ int sjmi_unescape_device(sjmi_ctx* ctx, const void* d_buf, uint64_t len, const v
 int sjmi_unescape(sjmi_ctx* ctx, uint8_t* string_buffer, uint64_t string_capacity, uint64_t* total_bytes,
                   uint64_t* first_error_index, uint32_t* first_error_code);
 
+/* ---- batched documents ---------------------------------------------------------------------------------
+ * n_docs documents packed in one buffer, document k at [doc_offsets[k], doc_offsets[k+1]), each followed by at
+ * least one JSON whitespace byte inside its range (NDJSON style; doc_offsets[n_docs] = total length).
+ * One stage-1 launch indexes the whole buffer; index_offsets[k] (n_docs+1 entries) then delimits document k's
+ * indexes, which stay ABSOLUTE byte offsets (subtract doc_offsets[k] for the reference's per-document values).
+ * status is the verdict of the whole batch (exact whenever every document passes stage 1; see batch.hip).
+ * Device form, asynchronous on `stream`. */
+int sjmi_stage1_batch_device(sjmi_ctx* ctx, const void* d_buf, uint64_t total_len, const void* d_doc_offsets,
+                             uint64_t n_docs, void* d_indexes, uint64_t index_capacity, void* d_index_offsets,
+                             void* d_result, void* stream);
+/* Host form: copies the batch in, returns indexes[0..count], index_offsets[0..n_docs], count and status. */
+int sjmi_stage1_batch(sjmi_ctx* ctx, const uint8_t* buf, uint64_t total_len, const uint64_t* doc_offsets, uint64_t n_docs,
+                      uint32_t* indexes, uint64_t index_capacity, uint64_t* index_offsets, uint64_t* count,
+                      uint32_t* status);
+
 /* ---- whole parse: SimdJsonParser.parse(byte[], int) (SimdJsonParser.java:35-40) ----------------------------
  * GPU stage 1 + GPU string unescape + the host stage-2 tree builder (C++ mirror of JsonIterator / TapeBuilder /
  * Tape: simdjson-java_amd/csrc/host/simdjson_parser.h).  The tape (Tape.java:5-47 word layout) and string
@@ -140,6 +155,13 @@ void sjmi_parser_destroy(sjmi_parser* p);
 int sjmi_parser_parse(sjmi_parser* p, const uint8_t* buf, uint64_t len, const uint64_t** tape, uint64_t* tape_len,
                       const uint8_t** strings, uint64_t* strings_len, uint64_t* error_pos);
 const char* sjmi_parser_last_message(const sjmi_parser* p);
+/* Batched parse (BASELINE.json configs[4]): one GPU stage-1 + unescape pass over the whole batch, then the host
+ * stage 2 per document.  Document k's tape is tape[tape_offsets[k] .. tape_offsets[k+1]) (its STRING payloads are
+ * offsets into the shared `strings` buffer) and errors[k] is 0 or its SJMI_E_* grammar error.  A stage-1 error
+ * anywhere in the batch is returned as the call's result (> 0) -- see sjmi_stage1_batch. */
+int sjmi_parser_parse_batch(sjmi_parser* p, const uint8_t* buf, uint64_t total_len, const uint64_t* doc_offsets,
+                            uint64_t n_docs, const uint64_t** tape, const uint64_t** tape_offsets,
+                            const uint8_t** strings, uint64_t* strings_len, const int32_t** errors);
 
 /* Run the on-device self-test of the bit-plane transposition; *mismatches == 0 on success. */
 int sjmi_selftest(sjmi_ctx* ctx, uint32_t* mismatches);

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _CSRC = os.path.join(_HERE, "csrc")
 _LIB = os.path.join(_HERE, "libsjmi.so")
-SOURCES = ["stage1.hip", "unescape.hip", "sjmi_api.hip", "host/simdjson_parser.cpp"]
+SOURCES = ["stage1.hip", "unescape.hip", "batch.hip", "sjmi_api.hip", "host/simdjson_parser.cpp"]
 
 ST_UTF8, ST_UNCLOSED, ST_UNESCAPED, ST_CAPACITY, ST_INTERNAL = 1, 2, 4, 0x100, 0x200
 PADDING = 64
@@ -59,7 +59,8 @@ _lib = None
 EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sjmi_stage1", "sjmi_stage1_device",
            "sjmi_selftest", "sjmi_set_tile_steps", "sjmi_set_profiling", "sjmi_kernel_time", "sjmi_debug_set_flags",
            "sjmi_unescape", "sjmi_unescape_device",
-           "sjmi_parser_create", "sjmi_parser_destroy", "sjmi_parser_parse", "sjmi_parser_last_message"]
+           "sjmi_parser_create", "sjmi_parser_destroy", "sjmi_parser_parse", "sjmi_parser_last_message",
+           "sjmi_stage1_batch", "sjmi_stage1_batch_device", "sjmi_parser_parse_batch"]
 
 
 def lib():
@@ -108,6 +109,15 @@ def lib():
                                         C.c_void_p]
         L.sjmi_parser_last_message.restype = C.c_char_p
         L.sjmi_parser_last_message.argtypes = [C.c_void_p]
+        L.sjmi_stage1_batch.restype = C.c_int
+        L.sjmi_stage1_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sjmi_stage1_batch_device.restype = C.c_int
+        L.sjmi_stage1_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sjmi_parser_parse_batch.restype = C.c_int
+        L.sjmi_parser_parse_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]
         L.sjmi_kernel_time.restype = C.c_int
         L.sjmi_kernel_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -161,6 +171,21 @@ class Context:
                     "sjmi_stage1")
         assert idx[cnt.value] == 0, "sentinel missing"
         return idx[:cnt.value].copy(), st.value
+
+    def stage1_batch(self, data, doc_offsets):
+        """Batched host path: -> (indexes, index_offsets[np.uint64 n+1], status)."""
+        a = np.frombuffer(bytes(data), dtype=np.uint8)
+        offs = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+        n = offs.size - 1
+        cap = a.size + 2
+        idx = np.empty(max(cap, 1), dtype=np.uint32)
+        io = np.zeros(n + 1, dtype=np.uint64)
+        cnt = C.c_uint64(0)
+        st = C.c_uint32(0)
+        self._check(lib().sjmi_stage1_batch(self._h, a.ctypes.data if a.size else None, a.size, offs.ctypes.data, n,
+                                            idx.ctypes.data, cap, io.ctypes.data, C.addressof(cnt), C.addressof(st)),
+                    "sjmi_stage1_batch")
+        return idx[:cnt.value].copy(), io, st.value
 
     def unescape(self, string_capacity):
         """Unescape every string of the document of the last stage1() call.
@@ -256,3 +281,26 @@ class SimdJsonParser:
         tape = np.ctypeslib.as_array(tape_p, shape=(tape_len.value,)).copy()
         strings = bytes(np.ctypeslib.as_array(sb_p, shape=(max(sb_len.value, 1),))[:sb_len.value])
         return ParsedDocument(tape, strings)
+
+    def parse_batch(self, buffer, doc_offsets):
+        """-> (list of per-document tapes (np.uint64) or None where errors[k] != 0, shared strings bytes, errors)."""
+        a = np.frombuffer(bytes(buffer), dtype=np.uint8)
+        offs = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+        n = offs.size - 1
+        tape_p = C.POINTER(C.c_uint64)()
+        to_p = C.POINTER(C.c_uint64)()
+        sb_p = C.POINTER(C.c_uint8)()
+        err_p = C.POINTER(C.c_int32)()
+        sb_len = C.c_uint64(0)
+        rc = lib().sjmi_parser_parse_batch(self._h, a.ctypes.data if a.size else None, a.size, offs.ctypes.data, n,
+                                           C.byref(tape_p), C.byref(to_p), C.byref(sb_p), C.byref(sb_len), C.byref(err_p))
+        if rc > 0:
+            raise JsonParsingException(rc, lib().sjmi_parser_last_message(self._h).decode("utf-8"))
+        if rc < 0:
+            raise SjmiError("sjmi_parser_parse_batch failed (rc=%d): %s" % (rc, lib().sjmi_parser_last_message(self._h).decode()))
+        to = np.ctypeslib.as_array(to_p, shape=(n + 1,)).copy()
+        errors = np.ctypeslib.as_array(err_p, shape=(max(n, 1),))[:n].copy()
+        alltape = np.ctypeslib.as_array(tape_p, shape=(max(int(to[-1]), 1),))[:int(to[-1])].copy()
+        strings = bytes(np.ctypeslib.as_array(sb_p, shape=(max(sb_len.value, 1),))[:sb_len.value])
+        tapes = [alltape[int(to[k]):int(to[k + 1])] if errors[k] == 0 else None for k in range(n)]
+        return tapes, strings, errors

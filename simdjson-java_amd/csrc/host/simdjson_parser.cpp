@@ -128,15 +128,18 @@ void SimdJsonParser::stage1(const uint8_t* buffer, size_t len) {
     if (status & SJMI_ST_UTF8) throw fail(E_UTF8);                 // Utf8Validator.java:165-167 (checked first)
     if (status & SJMI_ST_UNCLOSED) throw fail(E_UNCLOSED_STRING);  // StructuralIndexer.java:297-299
     if (status & SJMI_ST_UNESCAPED) throw fail(E_UNESCAPED_CHARS); // :300-302
+    unescapeStrings(len, count);
+}
+
+// every string of the document(s) just indexed, unescaped on the GPU into stringBuffer_[0, stringBufferLen_)
+void SimdJsonParser::unescapeStrings(size_t len, uint64_t count) {
     const size_t need = len + 4 * (size_t)count + 64;
     if (stringBuffer_.size() < need) stringBuffer_.resize(need);
     uint64_t total = 0, fei = 0;
     uint32_t fec = 0;
-    rc = sjmi_unescape(ctx_, stringBuffer_.data(), stringBuffer_.size(), &total, &fei, &fec);
+    const int rc = sjmi_unescape(ctx_, stringBuffer_.data(), stringBuffer_.size(), &total, &fei, &fec);
     if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_unescape: ") + sjmi_last_error(ctx_));
     stringBufferLen_ = (size_t)total;
-    firstStringError_ = fei;
-    firstStringErrorCode_ = fec;
 }
 
 JsonValue SimdJsonParser::parse(const uint8_t* buffer, size_t len) {
@@ -148,20 +151,69 @@ JsonValue SimdJsonParser::parse(const uint8_t* buffer, size_t len) {
     bitIndexes_.reset();
     tape_.reset();
     stringBufferIdx_ = 0;
+    docBase_ = 0;
     memset(isArray_.data(), 0, isArray_.size());
     stage1(paddedBuffer_.data(), len);
     walkDocument(len);
     return JsonValue(&tape_, 1, stringBuffer_.data());  // TapeBuilder.createJsonValue :215-217
 }
 
+void SimdJsonParser::parseBatch(const uint8_t* buffer, size_t totalLen, const uint64_t* docOffsets, size_t nDocs) {
+    if (totalLen > (size_t)capacity_) throw fail(E_CAPACITY);
+    memcpy(paddedBuffer_.data(), buffer, totalLen);
+    memset(paddedBuffer_.data() + totalLen, 0, PADDING);
+    bitIndexes_.reset();
+    indexOffsets_.assign(nDocs + 1, 0);
+    uint64_t count = 0;
+    uint32_t status = 0;
+    const int rc = sjmi_stage1_batch(ctx_, paddedBuffer_.data(), totalLen, docOffsets, nDocs, bitIndexes_.array(),
+                                     bitIndexes_.capacity(), indexOffsets_.data(), &count, &status);
+    if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_stage1_batch: ") + sjmi_last_error(ctx_));
+    if (status & SJMI_ST_UTF8) throw fail(E_UTF8);
+    if (status & SJMI_ST_UNCLOSED) throw fail(E_UNCLOSED_STRING);
+    if (status & SJMI_ST_UNESCAPED) throw fail(E_UNESCAPED_CHARS);
+    unescapeStrings(totalLen, count);
+    batchTape_.clear();
+    batchTapeOffsets_.assign(1, 0);
+    batchErrors_.assign(nDocs, 0);
+    const uint8_t* buf = paddedBuffer_.data();
+    const uint32_t* ix = bitIndexes_.array();
+    size_t cursor = 0;  // string-buffer offset of the current document's first record
+    for (size_t k = 0; k < nDocs; ++k) {
+        const size_t from = (size_t)indexOffsets_[k], to = (size_t)indexOffsets_[k + 1];
+        docBase_ = (size_t)docOffsets[k];
+        tape_.reset();
+        memset(isArray_.data(), 0, isArray_.size());
+        bitIndexes_.window(from, to, (uint32_t)docBase_);
+        stringBufferIdx_ = cursor;
+        try {
+            walkDocument((size_t)docOffsets[k + 1]);
+            batchTape_.insert(batchTape_.end(), tape_.data(), tape_.data() + tape_.getCurrentIdx());
+        } catch (const JsonParsingException& e) {
+            batchErrors_[k] = e.code();
+        }
+        batchTapeOffsets_.push_back(batchTape_.size());
+        // records are laid out in structural order over the whole batch: step over this document's strings
+        for (size_t pos = from; pos < to; ++pos) {
+            if (buf[ix[pos]] != '"') continue;
+            const uint8_t* r = stringBuffer_.data() + cursor;
+            const uint32_t n = ((uint32_t)r[0] << 24) | ((uint32_t)r[1] << 16) | ((uint32_t)r[2] << 8) | r[3];
+            cursor += 4 + (n >= 0xFFFFFF00u ? 0 : (size_t)n);
+        }
+    }
+    docBase_ = 0;
+}
+
 // TapeBuilder.visitString (TapeBuilder.java:174-177): the record [be32 len][bytes] was produced on the GPU at
 // exactly the offset the sequential StringParser would have used; only the bookkeeping remains.
 void SimdJsonParser::visitString(uint32_t idx, size_t indexPos) {
     (void)idx;
+    (void)indexPos;
     tape_.append(stringBufferIdx_, Tape::STRING);
-    if ((uint64_t)indexPos == firstStringError_) throw fail((int)firstStringErrorCode_);
     const uint8_t* r = stringBuffer_.data() + stringBufferIdx_;
     const uint32_t n = ((uint32_t)r[0] << 24) | ((uint32_t)r[1] << 16) | ((uint32_t)r[2] << 8) | r[3];
+    // a string the reference's StringParser would have thrown on is marked FF FF FF <SJMI_E_* code> by the kernel
+    if (n >= 0xFFFFFF00u) throw fail((int)(n & 0xFFu));
     stringBufferIdx_ += 4 + (size_t)n;
 }
 
@@ -222,15 +274,15 @@ void SimdJsonParser::visitPrimitive(uint32_t idx, size_t indexPos) {  // TapeBui
     switch (*b) {
     case '"': visitString(idx, indexPos); break;
     case 't':
-        if (!(isTrue(b) && isStructuralOrWhitespace(b[4]))) throw fail(E_INVALID_TRUE, idx);
+        if (!(isTrue(b) && isStructuralOrWhitespace(b[4]))) throw fail(E_INVALID_TRUE, idx - docBase_);
         tape_.append(0, Tape::TRUE_VALUE);
         break;
     case 'f':
-        if (!(isFalse(b) && isStructuralOrWhitespace(b[5]))) throw fail(E_INVALID_FALSE, idx);
+        if (!(isFalse(b) && isStructuralOrWhitespace(b[5]))) throw fail(E_INVALID_FALSE, idx - docBase_);
         tape_.append(0, Tape::FALSE_VALUE);
         break;
     case 'n':
-        if (!(isNull(b) && isStructuralOrWhitespace(b[4]))) throw fail(E_INVALID_NULL, idx);
+        if (!(isNull(b) && isStructuralOrWhitespace(b[4]))) throw fail(E_INVALID_NULL, idx - docBase_);
         tape_.append(0, Tape::NULL_VALUE);
         break;
     case '-': case '0': case '1': case '2': case '3': case '4': case '5': case '6': case '7': case '8': case '9':
@@ -240,20 +292,20 @@ void SimdJsonParser::visitPrimitive(uint32_t idx, size_t indexPos) {  // TapeBui
     }
 }
 
-void SimdJsonParser::visitRootPrimitive(uint32_t idx, size_t indexPos, size_t len) {  // TapeBuilder.java:59-68
+void SimdJsonParser::visitRootPrimitive(uint32_t idx, size_t indexPos, size_t len) {  // TapeBuilder.java:59-68 (len = end offset)
     const uint8_t* b = paddedBuffer_.data() + idx;
     switch (*b) {
     case '"': visitString(idx, indexPos); break;
     case 't':
-        if (!(idx + 4 <= len && isTrue(b) && (idx + 4 == len || isStructuralOrWhitespace(b[4])))) throw fail(E_INVALID_TRUE, idx);
+        if (!(idx + 4 <= len && isTrue(b) && (idx + 4 == len || isStructuralOrWhitespace(b[4])))) throw fail(E_INVALID_TRUE, idx - docBase_);
         tape_.append(0, Tape::TRUE_VALUE);
         break;
     case 'f':
-        if (!(idx + 5 <= len && isFalse(b) && (idx + 5 == len || isStructuralOrWhitespace(b[5])))) throw fail(E_INVALID_FALSE, idx);
+        if (!(idx + 5 <= len && isFalse(b) && (idx + 5 == len || isStructuralOrWhitespace(b[5])))) throw fail(E_INVALID_FALSE, idx - docBase_);
         tape_.append(0, Tape::FALSE_VALUE);
         break;
     case 'n':
-        if (!(idx + 4 <= len && isNull(b) && (idx + 4 == len || isStructuralOrWhitespace(b[4])))) throw fail(E_INVALID_NULL, idx);
+        if (!(idx + 4 <= len && isNull(b) && (idx + 4 == len || isStructuralOrWhitespace(b[4])))) throw fail(E_INVALID_NULL, idx - docBase_);
         tape_.append(0, Tape::NULL_VALUE);
         break;
     case '-': case '0': case '1': case '2': case '3': case '4': case '5': case '6': case '7': case '8': case '9': {
@@ -438,6 +490,29 @@ void sjmi_parser_destroy(sjmi_parser* h) {
 }
 
 const char* sjmi_parser_last_message(const sjmi_parser* h) { return h ? h->msg.c_str() : ""; }
+
+int sjmi_parser_parse_batch(sjmi_parser* h, const uint8_t* buf, uint64_t total_len, const uint64_t* doc_offsets,
+                            uint64_t n_docs, const uint64_t** tape, const uint64_t** tape_offsets,
+                            const uint8_t** strings, uint64_t* strings_len, const int32_t** errors) {
+    if (!h || (!buf && total_len) || !doc_offsets || !tape || !tape_offsets || !strings || !strings_len || !errors)
+        return SJMI_ERR_ARG;
+    h->msg.clear();
+    try {
+        h->p->parseBatch(buf, (size_t)total_len, doc_offsets, (size_t)n_docs);
+        *tape = h->p->batchTape().data();
+        *tape_offsets = h->p->batchTapeOffsets().data();
+        *strings = h->p->stringBuffer().data();
+        *strings_len = h->p->stringBufferLen();
+        *errors = h->p->batchErrors().data();
+        return 0;
+    } catch (const org_simdjson::JsonParsingException& e) {
+        h->msg = e.what();
+        return e.code();
+    } catch (const std::exception& e) {
+        h->msg = e.what();
+        return SJMI_ERR_HIP;
+    }
+}
 
 int sjmi_parser_parse(sjmi_parser* h, const uint8_t* buf, uint64_t len, const uint64_t** tape, uint64_t* tape_len,
                       const uint8_t** strings, uint64_t* strings_len, uint64_t* error_pos) {

@@ -36,20 +36,26 @@ public:
     uint32_t* array() { return indexes_.data(); }           // filled by the engine (replaces write(), :14-41)
     size_t capacity() const { return indexes_.size(); }
     void setWriteIdx(size_t n) { writeIdx_ = n; }            // replaces finish() (:82-96): sentinel written by the engine
+    // batch: restrict the cursor to one document's slice [from, to) of the shared index array; the sentinel read
+    // (index `to`) must land on the document's first structural, as BitIndexes.finish arranges (:82-96)
+    void window(size_t from, size_t to, uint32_t docStart) { readIdx_ = from; base_ = from; writeIdx_ = to; sentinel_ = docStart; }
     void advance() { ++readIdx_; }                                                    // :47-49
     uint32_t getAndAdvance() { return at(readIdx_++); }                               // :51-54
     uint32_t getLast() const { return indexes_[writeIdx_ - 1]; }                      // :56-58
     uint32_t peek() const { return at(readIdx_); }                                    // :65-68
     bool isEnd() const { return writeIdx_ == readIdx_; }                              // :74-76
+    bool isEmpty() const { return writeIdx_ == base_; }
     size_t readIdx() const { return readIdx_; }
     size_t writeIdx() const { return writeIdx_; }
-    void reset() { writeIdx_ = 0; readIdx_ = 0; }                                     // :98-101
+    void reset() { writeIdx_ = 0; readIdx_ = 0; base_ = 0; sentinel_ = 0; }                          // :98-101
 
 private:
     // reads past the sentinel (never observed for any input: the sentinel read already fails the grammar) are defined as 0
-    uint32_t at(size_t i) const { return i <= writeIdx_ ? indexes_[i] : 0u; }
+    // at/after writeIdx the reference reads its sentinel 0 = the document's first byte (BitIndexes.java:82-96)
+    uint32_t at(size_t i) const { return i < writeIdx_ ? indexes_[i] : sentinel_; }
     std::vector<uint32_t> indexes_;
-    size_t writeIdx_ = 0, readIdx_ = 0;
+    size_t writeIdx_ = 0, readIdx_ = 0, base_ = 0;
+    uint32_t sentinel_ = 0;
 };
 
 // Tape.java:5-98
@@ -128,6 +134,14 @@ public:
     // parser-owned memory and is invalidated by the next parse(), exactly like the reference.
     JsonValue parse(const uint8_t* buffer, size_t len);
 
+    // Batched parse: documents packed NDJSON-style at doc_offsets[k] (n+1 entries). One GPU pass for the batch,
+    // host stage 2 per document.  Fills batchTape()/batchTapeOffsets()/batchErrors(); throws only for a
+    // stage-1 (batch-level) error.
+    void parseBatch(const uint8_t* buffer, size_t totalLen, const uint64_t* docOffsets, size_t nDocs);
+    const std::vector<uint64_t>& batchTape() const { return batchTape_; }
+    const std::vector<uint64_t>& batchTapeOffsets() const { return batchTapeOffsets_; }
+    const std::vector<int32_t>& batchErrors() const { return batchErrors_; }
+
     const Tape& tape() const { return tape_; }
     const std::vector<uint8_t>& stringBuffer() const { return stringBuffer_; }
     size_t stringBufferLen() const { return stringBufferLen_; }
@@ -135,10 +149,11 @@ public:
 
 private:
     void stage1(const uint8_t* buffer, size_t len);   // :55-58 -> GPU
-    void walkDocument(size_t len);                    // JsonIterator.walkDocument, JsonIterator.java:26-200
+    void walkDocument(size_t endOffset);              // JsonIterator.walkDocument, JsonIterator.java:26-200
+    void unescapeStrings(size_t len, uint64_t count);
     void visitString(uint32_t idx, size_t indexPos);  // TapeBuilder.visitString :174-177 (record already on the GPU-made buffer)
     void visitPrimitive(uint32_t idx, size_t indexPos);
-    void visitRootPrimitive(uint32_t idx, size_t indexPos, size_t len);
+    void visitRootPrimitive(uint32_t idx, size_t indexPos, size_t endOffset);
     void parseNumber(const uint8_t* p);
     void emptyContainer(char start, char end);
 
@@ -148,11 +163,12 @@ private:
     Tape tape_;
     std::vector<uint8_t> stringBuffer_, paddedBuffer_;
     size_t stringBufferLen_ = 0, stringBufferIdx_ = 0;
-    uint64_t firstStringError_ = ~0ull;
-    uint32_t firstStringErrorCode_ = 0;
     struct OpenContainer { size_t tapeIndex; uint32_t count; };
     std::vector<OpenContainer> openContainers_;
     std::vector<uint8_t> isArray_;
+    std::vector<uint64_t> batchTape_, batchTapeOffsets_, indexOffsets_;
+    std::vector<int32_t> batchErrors_;
+    size_t docBase_ = 0;  // batch: byte offset of the current document (error positions are document-relative)
 };
 
 const char* errorMessage(int code);

@@ -29,6 +29,8 @@ struct sjmi_ctx {
     void* d_ws_str = nullptr;     // unescape workspace, grown on demand
     size_t ws_str_bytes = 0;
     sjmi_unescape_result* d_ures = nullptr;
+    unsigned long long* d_docoff = nullptr;  // batch: document offsets + index offsets, grown on demand
+    size_t docoff_bytes = 0;
     int forced_steps = 0;
     uint32_t dbg = 0;  // ablation flags (sjmi_debug_set_flags)
     bool profiling = false;  // bracket every stage-1 kernel with HIP events (bench.py roofline)
@@ -90,6 +92,7 @@ void sjmi_destroy(sjmi_ctx* c) {
     if (c->d_sb) (void)hipFree(c->d_sb);
     if (c->d_ws_str) (void)hipFree(c->d_ws_str);
     if (c->d_ures) (void)hipFree(c->d_ures);
+    if (c->d_docoff) (void)hipFree(c->d_docoff);
     if (c->h_res) (void)hipHostFree(c->h_res);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.first);
@@ -227,6 +230,7 @@ int sjmi_stage1_device(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_ind
     if (c->d_sb) (void)hipFree(c->d_sb);
     if (c->d_ws_str) (void)hipFree(c->d_ws_str);
     if (c->d_ures) (void)hipFree(c->d_ures);
+    if (c->d_docoff) (void)hipFree(c->d_docoff);
         c->d_ws_dev = nullptr;
         c->ws_dev_bytes = 0;
         if (fail(c, "hipMalloc(ws_dev)", hipMalloc(&c->d_ws_dev, need))) return SJMI_ERR_HIP;
@@ -251,6 +255,61 @@ int sjmi_stage1_device(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_ind
              hipMemcpyAsync(d_result, (uint8_t*)c->d_ws_dev + sjmi::WS_RESULT_OFFSET, sizeof(sjmi_stage1_result),
                             hipMemcpyDeviceToDevice, st)))
         return SJMI_ERR_HIP;
+    return SJMI_OK;
+}
+
+int sjmi_stage1_batch_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets,
+                             uint64_t n_docs, void* d_indexes, uint64_t index_capacity, void* d_index_offsets,
+                             void* d_result, void* stream) {
+    if (!c || !d_doc_offsets || !d_index_offsets) return SJMI_ERR_ARG;
+    int rc = sjmi_stage1_device(c, d_buf, total_len, d_indexes, index_capacity, d_result, stream);
+    if (rc != SJMI_OK) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (fail(c, "split launch",
+             sjmi::split_docs_launch((const uint32_t*)d_indexes, (const sjmi::Stage1Result*)d_result,
+                                     (const unsigned long long*)d_doc_offsets, n_docs,
+                                     (unsigned long long*)d_index_offsets, st)))
+        return SJMI_ERR_HIP;
+    return SJMI_OK;
+}
+
+int sjmi_stage1_batch(sjmi_ctx* c, const uint8_t* buf, uint64_t total_len, const uint64_t* doc_offsets, uint64_t n_docs,
+                      uint32_t* indexes, uint64_t index_capacity, uint64_t* index_offsets, uint64_t* count,
+                      uint32_t* status) {
+    if (!c || (!buf && total_len) || !doc_offsets || !indexes || !index_offsets || !count || !status) return SJMI_ERR_ARG;
+    if (total_len > c->capacity || total_len >= (1ull << 32)) {
+        c->err = "batch larger than the context capacity";
+        return SJMI_ERR_CAPACITY;
+    }
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    const size_t ob = (n_docs + 1) * sizeof(unsigned long long);
+    if (!grow(c, (void**)&c->d_docoff, &c->docoff_bytes, 2 * ob + 64, "hipMalloc(docoff)")) return SJMI_ERR_HIP;
+    unsigned long long* d_io = c->d_docoff + (n_docs + 1);
+    void* d_res = (uint8_t*)c->d_ws + sjmi::WS_RESULT_OFFSET;
+    if ((total_len && fail(c, "H2D", hipMemcpyAsync(c->d_in, buf, total_len, hipMemcpyHostToDevice, c->stream))) ||
+        fail(c, "H2D(offsets)", hipMemcpyAsync(c->d_docoff, doc_offsets, ob, hipMemcpyHostToDevice, c->stream)))
+        return SJMI_ERR_HIP;
+    const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(total_len);
+    const uint64_t dev_cap = c->capacity + 2 < index_capacity ? c->capacity + 2 : index_capacity;
+    if (fail(c, "launch", sjmi::stage1_launch(c->d_in, total_len, c->d_idx, dev_cap, c->d_ws, steps, c->stream, nullptr,
+                                              nullptr)) ||
+        fail(c, "split", sjmi::split_docs_launch(c->d_idx, (const sjmi::Stage1Result*)d_res, c->d_docoff, n_docs, d_io,
+                                                 c->stream)) ||
+        fail(c, "D2H(result)", hipMemcpyAsync(c->h_res, d_res, sizeof(sjmi_stage1_result), hipMemcpyDeviceToHost, c->stream)) ||
+        fail(c, "D2H(io)", hipMemcpyAsync(index_offsets, d_io, ob, hipMemcpyDeviceToHost, c->stream)) ||
+        fail(c, "sync", hipStreamSynchronize(c->stream)))
+        return SJMI_ERR_HIP;
+    *status = c->h_res->status & 0xFFu;
+    *count = c->h_res->count;
+    if (c->h_res->status & SJMI_ST_INTERNAL) return SJMI_ERR_INTERNAL;
+    if (c->h_res->status & SJMI_ST_CAPACITY) return SJMI_ERR_CAPACITY;
+    if (fail(c, "D2H(indexes)", hipMemcpyAsync(indexes, c->d_idx, (c->h_res->count + 1) * sizeof(uint32_t),
+                                               hipMemcpyDeviceToHost, c->stream)) ||
+        fail(c, "sync", hipStreamSynchronize(c->stream)))
+        return SJMI_ERR_HIP;
+    c->last_len = total_len;
+    c->last_count = c->h_res->count;
+    c->last_valid = true;
     return SJMI_OK;
 }
 

@@ -43,6 +43,8 @@ hipError_t stage1_launch(const uint8_t* d_buf, uint64_t len, uint32_t* d_out, ui
 size_t unescape_workspace_bytes(uint64_t count);
 hipError_t unescape_launch(const uint8_t* d_buf, uint64_t len, const uint32_t* d_idx, uint64_t count, uint8_t* d_sb,
                            uint64_t sb_cap, void* d_ws, UnescapeResult* d_res, hipStream_t stream);
+hipError_t split_docs_launch(const uint32_t* d_idx, const Stage1Result* d_res, const unsigned long long* d_doc_offsets,
+                             uint64_t n_docs, unsigned long long* d_index_offsets, hipStream_t stream);
 hipError_t transpose_selftest_launch(const uint32_t* d_words, uint32_t nblocks, uint32_t* d_mismatches,
                                      hipStream_t stream);
 

@@ -16,7 +16,8 @@
 //   k_str_write   : re-derives each lane's offset (LDS scan + workgroup base) and writes
 //                   [be32 length][unescaped bytes] -- bit-identical to the reference's stringBuffer.
 // Output parity domain: string_buffer[0, total).  With an erroneous string the reference throws at that
-// string; here every other string is still written and the failing one is reported by position + code.
+// string; here every other string is still written, the failing one becomes a 4-byte record FF FF FF <code>
+// (the host stage 2 throws when it reaches it) and the first one is also reported by position + code.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -247,13 +248,17 @@ k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __res
         const uint32_t open = idx[i];
         const uint32_t bound = (i + 1 < count) ? idx[i + 1] : len;
         const uint32_t close = find_close(buf, open, bound);
-        const uint32_t n = sz[k] - 4u;
+        uint32_t n = sz[k] - 4u;
         uint8_t* dst = sb + off;
+        if (n == 0) {  // empty or failed string: a failed one is marked FF FF FF <code> for the host stage 2
+            const int64_t r = close ? unescape_one<false>(buf, open, close, nullptr) : -(int64_t)SJMI_E_INTERNAL;
+            if (r < 0) n = 0xFFFFFF00u | (uint32_t)(-r);
+        }
         dst[0] = (uint8_t)(n >> 24);  // IntegerUtils.toBytes :12-17
         dst[1] = (uint8_t)(n >> 16);
         dst[2] = (uint8_t)(n >> 8);
         dst[3] = (uint8_t)n;
-        if (n && close) unescape_one<true>(buf, open, close, dst + 4);
+        if (n && n < 0xFFFFFF00u && close) unescape_one<true>(buf, open, close, dst + 4);
     }
 }
 
