@@ -67,7 +67,9 @@ SJ_HD void sj_mask_tail(sj_u64 p[8], uint32_t valid) {
     p[5] |= ~vm;  // 0x20
 }
 
-SJ_HD SjBlockMasks sj_block(const sj_u64 p[8], uint32_t e_in, uint32_t p_in, SjUtf8Carry uc) {
+// do_utf8 = false skips the UTF-8 algebra; only legal when the caller knows the block is pure ASCII and uc is
+// all zero (the kernel decides per wave with a ballot), in which case the result is identical.
+SJ_HD SjBlockMasks sj_block(const sj_u64 p[8], uint32_t e_in, uint32_t p_in, SjUtf8Carry uc, bool do_utf8 = true) {
     const sj_u64 p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4], p5 = p[5], p6 = p[6], p7 = p[7];
     const sj_u64 a = ~p7 & ~p6;  // 0x00..0x3F
     const sj_u64 b = ~p7 & p6;   // 0x40..0x7F
@@ -109,12 +111,14 @@ SJ_HD SjBlockMasks sj_block(const sj_u64 p[8], uint32_t e_in, uint32_t p_in, SjU
     const sj_u64 pot = op | (scalar & ~follows_nqs);
 
     // ---- UTF-8 (Utf8Validator.java:54-168 as plane algebra; == strict RFC 3629) ------------
+    sj_u64 err = 0;
+    if (do_utf8) {
     const sj_u64 cont = p7 & ~p6;
     const sj_u64 lead = p7 & p6;
     const sj_u64 L2 = lead & ~p5;
     const sj_u64 L3 = lead & p5 & ~p4;
     const sj_u64 L4 = lead & p5 & p4 & ~p3;
-    sj_u64 err = lead & p5 & p4 & p3;                      // 0xF8..0xFF
+    err = lead & p5 & p4 & p3;                             // 0xF8..0xFF
     const sj_u64 E1 = ((L2 | L3 | L4) << 1) | uc.c1;       // expected 1st continuation
     const sj_u64 E2 = ((L3 | L4) << 2) | uc.c2;            // expected 2nd
     const sj_u64 E3 = (L4 << 3) | uc.c3;                   // expected 3rd
@@ -129,6 +133,7 @@ SJ_HD SjBlockMasks sj_block(const sj_u64 p[8], uint32_t e_in, uint32_t p_in, SjU
     err |= sED & p5;                                       // ED A0..BF             (SURROGATE)
     err |= sF0 & ~p5 & ~p4;                                // F0 80..8F             (OVERLONG_4BYTE)
     err |= sF4 & (p5 | p4);                                // F4 90..BF             (TOO_LARGE)
+    }
 
     SjBlockMasks r;
     r.pot = pot;
@@ -141,61 +146,45 @@ SJ_HD SjBlockMasks sj_block(const sj_u64 p[8], uint32_t e_in, uint32_t p_in, SjU
 }
 
 // ---- carries from the bytes before the block -------------------------------------------------
-// halo = the 8 bytes preceding the block, little-endian (byte -1 is bits 56..63).
-
-SJ_HD uint32_t sj_lead_len(uint32_t b) { return b >= 0xF0 ? 4u : b >= 0xE0 ? 3u : b >= 0xC0 ? 2u : 0u; }
+// halo = the 8 bytes preceding the block, little-endian (byte -1 is bits 56..63).  Branch-free SWAR: this runs
+// once per block in every lane, so every instruction counts.
 
 SJ_HD SjUtf8Carry sj_utf8_carry(sj_u64 halo) {
-    const uint32_t h1 = (uint32_t)(halo >> 56) & 0xFF, h2 = (uint32_t)(halo >> 48) & 0xFF,
-                   h3 = (uint32_t)(halo >> 40) & 0xFF;
-    const uint32_t l1 = sj_lead_len(h1), l2 = sj_lead_len(h2), l3 = sj_lead_len(h3);
+    const uint32_t hh = (uint32_t)(halo >> 32);  // bytes -4..-1; only bit 7 of each byte is meaningful below
+    const uint32_t geC0 = hh & (hh << 1);        // byte >= 0xC0: a 2/3/4-byte lead
+    const uint32_t geE0 = geC0 & (hh << 2);      // byte >= 0xE0: a 3/4-byte lead
+    const uint32_t geF0 = geE0 & (hh << 3);      // byte >= 0xF0: a 4-byte lead
+    const uint32_t h1 = hh >> 24;
     SjUtf8Carry c;
-    c.c1 = l1 >= 2;
-    c.c2 = (uint32_t)(l2 >= 3) | ((uint32_t)(l1 >= 3) << 1);
-    c.c3 = (uint32_t)(l3 == 4) | ((uint32_t)(l2 == 4) << 1) | ((uint32_t)(l1 == 4) << 2);
+    c.c1 = geC0 >> 31;
+    c.c2 = ((geE0 >> 23) & 1u) | ((geE0 >> 30) & 2u);
+    c.c3 = ((geF0 >> 15) & 1u) | ((geF0 >> 22) & 2u) | ((geF0 >> 29) & 4u);
     c.sec = (uint32_t)(h1 == 0xE0) | ((uint32_t)(h1 == 0xED) << 1) | ((uint32_t)(h1 == 0xF0) << 2) |
             ((uint32_t)(h1 == 0xF4) << 3);
     return c;
 }
 
-// bit j-1 set iff byte -j is a backslash (j = 1..8)
-SJ_HD uint32_t sj_halo_bs_mask(sj_u64 halo) {
-    uint32_t m = 0;
-    for (int j = 1; j <= 8; ++j) m |= (uint32_t)(((halo >> (64 - 8 * j)) & 0xFF) == 0x5C) << (j - 1);
-    return m;
-}
-
-SJ_HD uint32_t sj_is_ws_or_op(uint32_t c) {
-    return c == 0x20 || c == 0x09 || c == 0x0A || c == 0x0D || c == ',' || c == ':' || c == '[' || c == ']' ||
-           c == '{' || c == '}' || c == 0x0C || c == 0x1A;
+SJ_HD uint32_t sj_is_ws_or_op(uint32_t c) {  // { 09 0A 0D 20 , : [ ] { } } and 0C, 1A (StructuralIndexer.java:23-28)
+    const sj_u64 LO = (1ull << 0x09) | (1ull << 0x0A) | (1ull << 0x0C) | (1ull << 0x0D) | (1ull << 0x1A) | (1ull << 0x20) |
+                      (1ull << 0x2C) | (1ull << 0x3A);
+    const sj_u64 HI = (1ull << (0x5B - 64)) | (1ull << (0x5D - 64)) | (1ull << (0x7B - 64)) | (1ull << (0x7D - 64));
+    const sj_u64 m = (c & 64u) ? HI : LO;
+    return (c < 128u) & (uint32_t)((m >> (c & 63u)) & 1ull);
 }
 
 // Resolve e_in / p_in from the 8-byte halo.  Returns false when the backslash run reaches past
-// the halo (then the caller counts the run from memory: sj_count_backslashes_before).
+// the halo (then the caller counts the run from memory: sj_carry_slow).
 //   e_in = (length of the backslash run ending at byte -1) is odd
 //   p_in = byte -1 is a scalar that is not an (unescaped) quote
 SJ_HD bool sj_carry_from_halo(sj_u64 halo, uint32_t* e_in, uint32_t* p_in) {
-    const uint32_t bm = sj_halo_bs_mask(halo);
-    const uint32_t h1 = (uint32_t)(halo >> 56) & 0xFF;
-    if (bm & 1u) {  // byte -1 is a backslash: scalar, never a quote
-        if (bm == 0xFFu) return false;
-        uint32_t run = 0;
-        while ((bm >> run) & 1u) ++run;
-        *e_in = run & 1u;
-        *p_in = 1;
-        return true;
-    }
-    *e_in = 0;
-    if (h1 == 0x22) {  // a quote: non-quote scalar only if it is escaped
-        const uint32_t bm2 = bm >> 1;
-        if (bm2 == 0x7Fu) return false;
-        uint32_t run = 0;
-        while ((bm2 >> run) & 1u) ++run;
-        *p_in = run & 1u;
-        return true;
-    }
-    *p_in = !sj_is_ws_or_op(h1);
-    return true;
+    const sj_u64 z = halo ^ 0x5C5C5C5C5C5C5C5Cull;                    // zero bytes = backslashes
+    const uint32_t h1 = (uint32_t)(halo >> 56);
+    const uint32_t run1 = z ? (uint32_t)__builtin_clzll(z) >> 3 : 8u;  // backslashes ending at byte -1
+    const uint32_t run2 = (uint32_t)__builtin_clzll((z << 8) | 0xFFull) >> 3;  // ... ending at byte -2 (0..7)
+    const bool is_q = h1 == 0x22;
+    *e_in = run1 & 1u;
+    *p_in = run1 ? 1u : (is_q ? (run2 & 1u) : (sj_is_ws_or_op(h1) ^ 1u));
+    return !((run1 == 8u) | (is_q & (run2 == 7u)));
 }
 
 // Slow path (backslash run longer than the halo): parity of the run of backslashes that ends
@@ -220,6 +209,59 @@ SJ_HD void sj_carry_slow(const uint8_t* buf, sj_u64 doc_lo, sj_u64 start, uint32
     } else {
         *e_in = 0;
         *p_in = !sj_is_ws_or_op(h1);
+    }
+}
+
+// ---- bit-plane transposition, butterfly form ------------------------------------------------------
+// 8 x (8x8 bit-matrix transpose of 8 consecutive bytes, Hacker's Delight 7-3, in 32-bit halves, VOP2 only)
+// + 4 x (4x4 byte transpose with v_perm_b32) to gather byte k of every group into plane k.
+// 312 issue units per block against 480 for the v_and/v_msad_u8 form (VOP3 ops cost double on gfx950).
+SJ_HD uint32_t sj_perm(uint32_t hi, uint32_t lo, uint32_t sel) {  // v_perm_b32 D = bytes of {hi:lo} picked by sel
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    const sj_u64 v = ((sj_u64)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) r |= (uint32_t)((v >> (8 * ((sel >> (8 * i)) & 7))) & 0xFF) << (8 * i);
+    return r;
+#endif
+}
+
+SJ_HD void sj_transpose8x8(uint32_t& lo, uint32_t& hi) {
+    uint32_t t;
+    t = (lo ^ (lo >> 7)) & 0x00AA00AAu;  lo = lo ^ t ^ (t << 7);
+    t = (hi ^ (hi >> 7)) & 0x00AA00AAu;  hi = hi ^ t ^ (t << 7);
+    t = (lo ^ (lo >> 14)) & 0x0000CCCCu; lo = lo ^ t ^ (t << 14);
+    t = (hi ^ (hi >> 14)) & 0x0000CCCCu; hi = hi ^ t ^ (t << 14);
+    t = (lo ^ ((lo >> 28) | (hi << 4))) & 0xF0F0F0F0u;
+    lo ^= t;
+    hi ^= t >> 4;
+}
+
+SJ_HD void sj_transpose4x4_bytes(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t b[4]) {
+    const uint32_t t0 = sj_perm(a1, a0, 0x05010400u), t1 = sj_perm(a1, a0, 0x07030602u);
+    const uint32_t t2 = sj_perm(a3, a2, 0x05010400u), t3 = sj_perm(a3, a2, 0x07030602u);
+    b[0] = sj_perm(t2, t0, 0x05040100u);
+    b[1] = sj_perm(t2, t0, 0x07060302u);
+    b[2] = sj_perm(t3, t1, 0x05040100u);
+    b[3] = sj_perm(t3, t1, 0x07060302u);
+}
+
+SJ_HD void sj_transpose_butterfly(const uint32_t w[16], sj_u64 p[8]) {
+    uint32_t lo[8], hi[8];
+    for (int g = 0; g < 8; ++g) {
+        lo[g] = w[2 * g];
+        hi[g] = w[2 * g + 1];
+        sj_transpose8x8(lo[g], hi[g]);  // byte k of lo/hi = plane k / k+4 of the group's 8 bytes
+    }
+    uint32_t a[4], b[4], c[4], d[4];
+    sj_transpose4x4_bytes(lo[0], lo[1], lo[2], lo[3], a);  // planes 0..3, bytes 0..31
+    sj_transpose4x4_bytes(lo[4], lo[5], lo[6], lo[7], b);  // planes 0..3, bytes 32..63
+    sj_transpose4x4_bytes(hi[0], hi[1], hi[2], hi[3], c);  // planes 4..7, bytes 0..31
+    sj_transpose4x4_bytes(hi[4], hi[5], hi[6], hi[7], d);
+    for (int k = 0; k < 4; ++k) {
+        p[k] = (sj_u64)a[k] | ((sj_u64)b[k] << 32);
+        p[k + 4] = (sj_u64)c[k] | ((sj_u64)d[k] << 32);
     }
 }
 

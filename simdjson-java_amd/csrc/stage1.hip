@@ -86,24 +86,33 @@ __global__ void k_transpose_selftest(const uint32_t* __restrict__ words, uint32_
     uint32_t w[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) w[i] = words[b * 16 + i];
-    sj_u64 pf[8], pr[8];
-    transpose_fast(w, pf);
+    sj_u64 pf[8], pb[8], pr[8];
+    transpose_fast(w, pf);       // v_and + v_msad_u8 form
+    sj_transpose_butterfly(w, pb);  // butterfly + v_perm_b32 form (the one the kernel uses)
     sj_transpose_ref(w, pr);
     uint32_t bad = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bad += pf[k] != pr[k];
+    for (int k = 0; k < 8; ++k) bad += (pf[k] != pr[k]) + (pb[k] != pr[k]);
     if (bad) atomicAdd(mismatches, bad);
 }
 
 // ---------------------------------------------------------------------------------------------
 // wave helpers (wave = 64 lanes)
 // ---------------------------------------------------------------------------------------------
+// Inclusive + scan over the 64 lanes with DPP (no LDS traffic): Kogge-Stone inside each row of 16 lanes
+// (row_shr 1/2/4/8, out-of-row reads give 0), then the row totals are carried across with row_bcast:15 / :31.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+}
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
+    (void)lane;
+    v = dpp_add<0x111, 0xF>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xF>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xF>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xF>(v);  // row_shr:8
+    v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 -> rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 -> rows 2 and 3
     return v;
 }
 
@@ -293,10 +302,12 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
                     unresolved = !sj_carry_from_halo(cur.halo, &e_in, &p_in);
                 }
                 sj_u64 p[8];
-                transpose_fast(w, p);
+                sj_transpose_butterfly(w, p);
                 const sj_u64 rem = len - start;
                 sj_mask_tail(p, rem < 64 ? (uint32_t)rem : 64u);
-                const SjBlockMasks bm = sj_block(p, e_in, p_in, uc);
+                // the UTF-8 algebra is skipped when no lane of the wave has a non-ASCII byte or a pending carry
+                const bool need_utf8 = __ballot((p[7] != 0) | ((uc.c1 | uc.c2 | uc.c3 | uc.sec) != 0)) != 0;
+                const SjBlockMasks bm = sj_block(p, e_in, p_in, uc, need_utf8);
                 pot[s] = bm.pot;
                 m0[s] = bm.sm0;
                 fl[s] = bm.qpar | (bm.ue0 << 1) | (bm.ue1 << 2) | (bm.utf8 << 3);
@@ -358,7 +369,7 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
         m0[s] = lpar[s] ? (pot[s] & m0[s]) : (pot[s] & ~m0[s]);  // StructuralIndexer.java:251
         const uint32_t c0 = (uint32_t)__popcll(m0[s]), cp = (uint32_t)__popcll(pot[s]);
         const uint32_t packed = wave_incl_scan(c0 | (cp << 16), lane);  // both <= 4096 per step: no carry
-        const uint32_t tot = __shfl(packed, 63);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)packed, 63);
         ex0[s] = W0 + (packed & 0xFFFFu) - c0;   // wave-relative exclusive offsets
         exp_[s] = WP + (packed >> 16) - cp;
         W0 += tot & 0xFFFFu;

@@ -18,7 +18,13 @@ extern "C" int sim_stage1(const uint8_t* buf, uint64_t len, uint32_t* idx, uint6
         memset(w, 0, sizeof w);
         memcpy(w, buf + start, valid);  // device loads all 64 and masks; garbage beyond valid is masked too
         sj_u64 p[8];
-        sj_transpose_ref(w, p);
+        sj_transpose_butterfly(w, p);
+        {
+            sj_u64 q[8];
+            sj_transpose_ref(w, q);
+            for (int k = 0; k < 8; ++k)
+                if (p[k] != q[k]) return -2;  // butterfly transposition disagrees with the bit loop
+        }
         sj_mask_tail(p, valid);
         uint32_t e_in = 0, p_in = 0;
         SjUtf8Carry uc = {0, 0, 0, 0};
