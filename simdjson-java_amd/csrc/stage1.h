@@ -28,7 +28,7 @@ static_assert(sizeof(UnescapeResult) == sizeof(sjmi_unescape_result), "ABI struc
 // ablation switches for performance experiments only (results are NOT valid with any of them set)
 constexpr uint32_t DBG_NO_WRITE = 1, DBG_NO_LOOKBACK = 2;
 
-constexpr uint32_t STAGE_CAP = 1024;  // indexes staged in LDS per wave and round (4 KiB)
+constexpr uint32_t STAGE_CAP = 2048;  // indexes staged in LDS per wave and round (8 KiB)
 
 // workspace layout (zeroed by one hipMemsetAsync per launch)
 constexpr size_t WS_RESULT_OFFSET = 0;        // Stage1Result

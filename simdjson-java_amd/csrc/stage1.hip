@@ -432,31 +432,45 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
         uint32_t* stage = sh.stage[wave];
         const uint32_t WT = par_in ? (WP - W0) : W0;                       // indexes of this wave
         uint32_t* dst0 = out + cnt_in + (par_in ? (basep - base0) : base0);  // its contiguous output run
-        for (uint32_t base = 0; base < WT; base += STAGE_CAP) {
-            const uint32_t lim = base + STAGE_CAP;
+        if (WT <= STAGE_CAP) {
+            // common case: everything fits in one round, so the per-bit loops need no window test
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const uint32_t bstart = (uint32_t)((blk0 + (sj_u64)s * 64 + lane) * 64);
-                uint32_t lo = (uint32_t)m0[s], hi = (uint32_t)(m0[s] >> 32);
-                uint32_t ps = pos[s];
-                while (lo && ps < lim) {
-                    stage[ps - base] = bstart + (uint32_t)__builtin_ctz(lo);
-                    lo &= lo - 1;
-                    ++ps;
-                }
-                while (!lo && hi && ps < lim) {
-                    stage[ps - base] = bstart + 32u + (uint32_t)__builtin_ctz(hi);
-                    hi &= hi - 1;
-                    ++ps;
-                }
-                m0[s] = (sj_u64)lo | ((sj_u64)hi << 32);
-                pos[s] = ps;
+                uint32_t* q = stage + pos[s];
+                for (uint32_t lo = (uint32_t)m0[s]; lo; lo &= lo - 1) *q++ = bstart | (uint32_t)__builtin_ctz(lo);
+                for (uint32_t hi = (uint32_t)(m0[s] >> 32); hi; hi &= hi - 1) *q++ = bstart | 32u | (uint32_t)__builtin_ctz(hi);
             }
             wave_lds_fence();
-            const uint32_t n = (WT - base) < STAGE_CAP ? (WT - base) : STAGE_CAP;
-            uint32_t* dst = dst0 + base;
-            for (uint32_t i = lane; i < n; i += 64) dst[i] = stage[i];
+            for (uint32_t i = lane; i < WT; i += 64) dst0[i] = stage[i];
             wave_lds_fence();
+        } else {
+            for (uint32_t base = 0; base < WT; base += STAGE_CAP) {
+                const uint32_t lim = base + STAGE_CAP;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const uint32_t bstart = (uint32_t)((blk0 + (sj_u64)s * 64 + lane) * 64);
+                    uint32_t lo = (uint32_t)m0[s], hi = (uint32_t)(m0[s] >> 32);
+                    uint32_t ps = pos[s];
+                    while (lo && ps < lim) {
+                        stage[ps - base] = bstart + (uint32_t)__builtin_ctz(lo);
+                        lo &= lo - 1;
+                        ++ps;
+                    }
+                    while (!lo && hi && ps < lim) {
+                        stage[ps - base] = bstart + 32u + (uint32_t)__builtin_ctz(hi);
+                        hi &= hi - 1;
+                        ++ps;
+                    }
+                    m0[s] = (sj_u64)lo | ((sj_u64)hi << 32);
+                    pos[s] = ps;
+                }
+                wave_lds_fence();
+                const uint32_t n = (WT - base) < STAGE_CAP ? (WT - base) : STAGE_CAP;
+                uint32_t* dst = dst0 + base;
+                for (uint32_t i = lane; i < n; i += 64) dst[i] = stage[i];
+                wave_lds_fence();
+            }
         }
     }
     // one status update per wave
