@@ -100,12 +100,16 @@ def main():
     if args.tile_steps:
         ctx.set_tile_steps(args.tile_steps)
     assert ctx.selftest() == 0
-    stream = torch.cuda.current_stream().cuda_stream
+    # one explicit (non-default) stream for kernels, copies and the collective, so that everything is ordered
+    work = torch.cuda.Stream(device=dev)
+    work.wait_stream(torch.cuda.current_stream())
+    stream = work.cuda_stream
 
     def step():
-        ctx.stage1_device(buf.data_ptr(), n, out.data_ptr(), cap, res.data_ptr(), stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, res)  # per-shard {count, status}: the only collective
+        with torch.cuda.stream(work):
+            ctx.stage1_device(buf.data_ptr(), n, out.data_ptr(), cap, res.data_ptr(), stream)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, res)  # per-shard {count, status}: the only collective
 
     for _ in range(max(args.warmup, 1)):
         step()

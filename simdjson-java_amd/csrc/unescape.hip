@@ -7,14 +7,18 @@
 // In a valid document the strings are visited in structural order, so record k starts at
 // sum_{j<k}(4 + len_j): that is an exclusive prefix sum, and every string is independent.
 //
-// Three launches over the structural indexes produced by stage 1:
+// Four launches over the structural indexes produced by stage 1:
 //   k_str_measure : one lane per structural; a lane whose byte is '"' finds the closing quote (the
 //                   last non-whitespace byte before the next structural -- stage 1 already proved it
-//                   exists), parses the escapes and stores 4 + unescaped length; the first failing
-//                   string (lowest structural position) is kept with an atomicMin;
-//   k_block_sums / k_scan_sums : reduce-then-scan of those sizes at 4096 structurals per workgroup;
-//   k_str_write   : re-derives each lane's offset (LDS scan + workgroup base) and writes
-//                   [be32 length][unescaped bytes] -- bit-identical to the reference's stringBuffer.
+//                   exists) and sweeps the string with aligned 16-byte loads for a backslash.  No
+//                   backslash (98 % of twitter.json's strings): length = raw length, done.  Otherwise
+//                   the lane parses the escapes byte by byte; the first failing string (lowest
+//                   structural position) is kept with an atomicMax of the complement;
+//   k_block_sums / k_scan_sums : reduce-then-scan of the 4+len sizes, 4096 structurals per workgroup;
+//   k_str_write   : re-derives each lane's offset (LDS scan + workgroup base); escape-free strings are
+//                   copied by the whole wave (coalesced byte lanes, one string after the other), strings
+//                   with escapes by their own lane -- [be32 length][bytes], bit-identical to the
+//                   reference's stringBuffer.
 // Output parity domain: string_buffer[0, total).  With an erroneous string the reference throws at that
 // string; here every other string is still written, the failing one becomes a 4-byte record FF FF FF <code>
 // (the host stage 2 throws when it reaches it) and the first one is also reported by position + code.
@@ -79,13 +83,22 @@ __device__ __forceinline__ int64_t unescape_one(const uint8_t* __restrict__ buf,
     uint32_t src = open + 1;
     uint32_t n = 0;
     while (src < close) {
-        const uint32_t c = buf[src];
-        if (c != '\\') {
-            if (WRITE) dst[n] = (uint8_t)c;
+        // plain run: one aligned 8-byte load per window instead of a dependent load per byte
+        const uint32_t a = src & ~7u;
+        const unsigned long long w = *reinterpret_cast<const unsigned long long*>(buf + a);
+        const uint32_t lo = src - a;
+        const uint32_t hi = (close - a) < 8u ? (close - a) : 8u;
+        const unsigned long long z = w ^ 0x5C5C5C5C5C5C5C5Cull;
+        unsigned long long f = ~(((z & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | z) & 0x8080808080808080ull;
+        f &= ~0ull << (8 * lo);  // backslashes at or after src
+        uint32_t stop = f ? (uint32_t)__builtin_ctzll(f) >> 3 : 8u;
+        if (stop > hi) stop = hi;
+        for (uint32_t b = lo; b < stop; ++b) {
+            if (WRITE) dst[n] = (uint8_t)(w >> (8 * b));
             ++n;
-            ++src;
-            continue;
         }
+        src = a + stop;
+        if (stop >= hi) continue;  // window (or string) exhausted without an escape
         const uint32_t e = buf[src + 1];
         if (e == 'u') {                                                   // :45-57
             int32_t cp = hex4(buf + src + 2);
@@ -136,7 +149,25 @@ __device__ __forceinline__ int64_t unescape_one(const uint8_t* __restrict__ buf,
     return (int64_t)n;
 }
 
-// sizes[i] = 4 + unescaped length if structural i opens a string, else 0
+// any backslash in the aligned 16-byte chunks covering [from, to)?  (May look at up to 15 bytes on either side:
+// a false positive only sends the string down the exact byte-wise path.)
+__device__ __forceinline__ bool has_backslash(const uint8_t* __restrict__ buf, uint32_t from, uint32_t to) {
+    uint32_t any = 0;
+    for (uint32_t p = from & ~15u; p < to; p += 16) {
+        const uint4 v = *reinterpret_cast<const uint4*>(buf + p);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t z = w[i] ^ 0x5C5C5C5Cu;
+            any |= ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;  // 0x80 where the byte is a backslash
+        }
+    }
+    return any != 0;
+}
+
+constexpr uint32_t SIZE_SLOW = 0x80000000u;  // sizes[] flag: the string has escapes (lane-serial path)
+
+// sizes[i] = 4 + unescaped length if structural i opens a string (| SIZE_SLOW if it has escapes), else 0
 __global__ void __launch_bounds__(UNESC_THREADS)
 k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __restrict__ idx, uint64_t count,
               uint32_t* __restrict__ sizes, UnescapeResult* res) {
@@ -147,14 +178,21 @@ k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __r
     if (buf[open] == '"') {
         const uint32_t bound = (i + 1 < count) ? idx[i + 1] : len;
         const uint32_t close = find_close(buf, open, bound);
-        int64_t r = close ? unescape_one<false>(buf, open, close, nullptr) : -(int64_t)SJMI_E_INTERNAL;
+        uint32_t slow = 0;
+        int64_t r;
+        if (!close) r = -(int64_t)SJMI_E_INTERNAL;
+        else if (!has_backslash(buf, open + 1, close)) r = (int64_t)(close - open - 1);
+        else {
+            slow = SIZE_SLOW;
+            r = unescape_one<false>(buf, open, close, nullptr);
+        }
         if (r < 0) {
             // first = lowest position: keep max of the complement so that the memset-to-zero state means "none"
             atomicMax(reinterpret_cast<unsigned long long*>(&res->first_error_inv),
                       ~(((unsigned long long)i << 8) | (unsigned long long)(-r)));
             r = 0;
         }
-        size = 4u + (uint32_t)r;
+        size = (4u + (uint32_t)r) | slow;
     }
     sizes[i] = size;
 }
@@ -167,7 +205,7 @@ k_block_sums(const uint32_t* __restrict__ sizes, uint64_t count, unsigned long l
 #pragma unroll
     for (int k = 0; k < UNESC_ITEMS; ++k) {
         const uint64_t i = base + (uint64_t)k * UNESC_THREADS + threadIdx.x;
-        if (i < count) sum += sizes[i];
+        if (i < count) sum += sizes[i] & ~SIZE_SLOW;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
@@ -210,14 +248,15 @@ k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __res
             const uint32_t* __restrict__ sizes, const unsigned long long* __restrict__ block_offsets,
             uint8_t* __restrict__ sb, uint64_t sb_cap, UnescapeResult* res) {
     __shared__ uint32_t s_wave[UNESC_ITEMS][UNESC_THREADS / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t base = (uint64_t)blockIdx.x * UNESC_TILE;
     uint32_t sz[UNESC_ITEMS], incl[UNESC_ITEMS];
 #pragma unroll
     for (int k = 0; k < UNESC_ITEMS; ++k) {
         const uint64_t i = base + (uint64_t)k * UNESC_THREADS + threadIdx.x;
         sz[k] = i < count ? sizes[i] : 0u;
-        uint32_t x = sz[k];
+        uint32_t x = sz[k] & ~SIZE_SLOW;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t t = __shfl_up(x, d);
@@ -228,7 +267,7 @@ k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __res
     }
     __syncthreads();
     unsigned long long row = block_offsets[blockIdx.x];
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < UNESC_ITEMS; ++k) {
         unsigned long long off = row;
         uint32_t rowsum = 0;
@@ -238,27 +277,68 @@ k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __res
             rowsum += s_wave[k][w];
         }
         row += rowsum;
-        if (sz[k] == 0) continue;
-        off += incl[k] - sz[k];
-        const uint64_t i = base + (uint64_t)k * UNESC_THREADS + threadIdx.x;
-        if (off + sz[k] > sb_cap) {
+        const uint32_t size = sz[k] & ~SIZE_SLOW;
+        const bool slow = (sz[k] & SIZE_SLOW) != 0;
+        off += incl[k] - size;
+        bool active = size != 0;
+        if (active && off + size > sb_cap) {
             atomicOr(&res->flags, 1u);  // string buffer too small
-            continue;
+            active = false;
         }
-        const uint32_t open = idx[i];
-        const uint32_t bound = (i + 1 < count) ? idx[i + 1] : len;
-        const uint32_t close = find_close(buf, open, bound);
-        uint32_t n = sz[k] - 4u;
-        uint8_t* dst = sb + off;
-        if (n == 0) {  // empty or failed string: a failed one is marked FF FF FF <code> for the host stage 2
-            const int64_t r = close ? unescape_one<false>(buf, open, close, nullptr) : -(int64_t)SJMI_E_INTERNAL;
-            if (r < 0) n = 0xFFFFFF00u | (uint32_t)(-r);
+        const uint64_t i = base + (uint64_t)k * UNESC_THREADS + threadIdx.x;
+        uint32_t open = 0, n = 0;
+        if (active) {
+            open = idx[i];
+            n = size - 4u;
+            uint8_t* dst = sb + off;
+            uint32_t hdr = n;
+            if (slow || n == 0) {  // escapes, empty or failed: the owning lane does everything
+                const uint32_t bound = (i + 1 < count) ? idx[i + 1] : len;
+                const uint32_t close = find_close(buf, open, bound);
+                if (n == 0) {  // empty or failed string: a failed one is marked FF FF FF <code> for the host stage 2
+                    const int64_t r = close ? unescape_one<false>(buf, open, close, nullptr) : -(int64_t)SJMI_E_INTERNAL;
+                    if (r < 0) hdr = 0xFFFFFF00u | (uint32_t)(-r);
+                } else if (close) {
+                    unescape_one<true>(buf, open, close, dst + 4);
+                }
+            }
+            dst[0] = (uint8_t)(hdr >> 24);  // IntegerUtils.toBytes :12-17
+            dst[1] = (uint8_t)(hdr >> 16);
+            dst[2] = (uint8_t)(hdr >> 8);
+            dst[3] = (uint8_t)hdr;
         }
-        dst[0] = (uint8_t)(n >> 24);  // IntegerUtils.toBytes :12-17
-        dst[1] = (uint8_t)(n >> 16);
-        dst[2] = (uint8_t)(n >> 8);
-        dst[3] = (uint8_t)n;
-        if (n && n < 0xFFFFFF00u && close) unescape_one<true>(buf, open, close, dst + 4);
+        // escape-free strings: the wave copies them, 64 consecutive bytes per instruction, EIGHT strings per
+        // round so that eight independent loads are in flight before the first store (a one-string-at-a-time
+        // loop pays a full memory round trip per string)
+        unsigned long long m = __ballot(active && !slow && n != 0);
+        const uint32_t off_lo = (uint32_t)off, off_hi = (uint32_t)(off >> 32);
+        while (m) {
+            uint32_t src[8], cnt[8];
+            unsigned long long d[8];
+            uint8_t v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                cnt[q] = 0;
+                src[q] = 0;
+                d[q] = 0;
+                if (m) {
+                    const int j = __builtin_ctzll(m);
+                    m &= m - 1;
+                    src[q] = (uint32_t)__builtin_amdgcn_readlane((int)open, j) + 1u;
+                    cnt[q] = (uint32_t)__builtin_amdgcn_readlane((int)n, j);
+                    d[q] = (((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)off_hi, j) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)off_lo, j)) + 4ull;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (uint32_t)lane < cnt[q] ? buf[src[q] + lane] : (uint8_t)0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if ((uint32_t)lane < cnt[q]) sb[d[q] + lane] = v[q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)  // rare: strings longer than 64 bytes
+                for (uint32_t t = 64 + lane; t < cnt[q]; t += 64) sb[d[q] + t] = buf[src[q] + t];
+        }
     }
 }
 
