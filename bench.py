@@ -144,6 +144,16 @@ def main():
     ctx.set_profiling(False)
 
     if rank == 0:
+        # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside
+        # the timed region): profiles/r1/pmc_summary.json, FETCH_SIZE doubled per the gfx950 note. null if absent
+        # or if the workload differs from the profiled one.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")) as f:
+                if reps == 1024:
+                    traffic = int(json.load(f)["hbm_traffic_bytes_per_launch"]["total"])
+        except (OSError, KeyError, ValueError):
+            traffic = None
         ms_per_step = elapsed / args.steps * 1e3
         value = n * world * args.steps / elapsed / 1e9
         avg_kernel_s = kern_ms / max(launches, 1) / 1e3
@@ -158,7 +168,7 @@ def main():
                        "bytes_per_gpu": n, "structurals_per_gpu": s_total, "tile_steps": args.tile_steps or "auto",
                        "sharding": "by document, RCCL all_gather of per-shard {count,status} only" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "k_stage1", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
                          "algorithmic_bytes_per_launch": n,
                          "achieved_incl_index_writes": round((n + 4 * (s_total + 1)) / avg_kernel_s / 1e9, 2)},
