@@ -8,8 +8,9 @@
 // Mapping to the hardware:
 //   * one lane  = one 64-byte block (the reference's loop step), loaded as 4 x dwordx4; loads are
 //     software-pipelined one step ahead of the ALU work;
-//   * the block is transposed to 8 bit planes with v_and + v_msad_u8 (4 mask bits per op), and all
-//     classification / escape / string / UTF-8 logic is 64-bit boolean algebra in VGPRs (sj_block.h);
+//   * the block is transposed to 8 bit planes (8x8 bit-matrix butterflies in VOP2 ops + v_perm_b32 byte
+//     transposes, sj_block.h; an earlier v_and + v_msad_u8 form is kept for the self-test) and all
+//     classification / escape / string / UTF-8 logic is 64-bit boolean algebra in VGPRs;
 //   * the three serial carries of the reference loop (prevEscaped, prevScalar, previous 4 UTF-8
 //     bytes) are LOCAL: each lane re-derives them from the 8 bytes before its block;
 //   * the two truly global carries -- in-string parity (XOR scan) and the output offset (+ scan of
@@ -24,7 +25,7 @@
 //   * indexes are expanded into a wave-private LDS slice and leave the CU as coalesced stores.
 // Measured cost model on gfx950 (tools/ubench/valu_rate.hip): VOP2 integer ops issue in 2 cycles per
 // wave, every VOP3 op (v_msad_u8, v_or3, v_lshl_or, v_bfi, v_bcnt, 64-bit shifts) in 4.  The kernel
-// is VALU-bound: ~300 of its ~900 instructions per block are the bit-plane transposition.
+// is VALU-bound (775 VALU instructions per 4 KiB wave-step after this round's reductions).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
