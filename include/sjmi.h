@@ -101,7 +101,7 @@ int sjmi_stage1(sjmi_ctx* ctx, const uint8_t* buf, uint64_t len, uint32_t* index
 
 /* Same path on DEVICE-resident data (roofline runs, pipelines that already hold the document in
  * HBM). d_buf must be 16-byte aligned with SJMI_PADDING readable bytes after len (contents
- * ignored); d_indexes holds index_capacity u32; d_result is a device sjmi_stage1_result.
+ * ignored); d_indexes (16-byte aligned) holds index_capacity u32; d_result is a device sjmi_stage1_result.
  * Asynchronous on `stream` (a hipStream_t, may be NULL = the context's stream). len < 2^32. */
 int sjmi_stage1_device(sjmi_ctx* ctx, const void* d_buf, uint64_t len, void* d_indexes, uint64_t index_capacity,
                        void* d_result, void* stream);

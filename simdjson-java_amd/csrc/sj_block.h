@@ -165,26 +165,29 @@ SJ_HD SjUtf8Carry sj_utf8_carry(sj_u64 halo) {
 }
 
 SJ_HD uint32_t sj_is_ws_or_op(uint32_t c) {  // { 09 0A 0D 20 , : [ ] { } } and 0C, 1A (StructuralIndexer.java:23-28)
-    const sj_u64 LO = (1ull << 0x09) | (1ull << 0x0A) | (1ull << 0x0C) | (1ull << 0x0D) | (1ull << 0x1A) | (1ull << 0x20) |
-                      (1ull << 0x2C) | (1ull << 0x3A);
-    const sj_u64 HI = (1ull << (0x5B - 64)) | (1ull << (0x5D - 64)) | (1ull << (0x7B - 64)) | (1ull << (0x7D - 64));
-    const sj_u64 m = (c & 64u) ? HI : LO;
-    return (c < 128u) & (uint32_t)((m >> (c & 63u)) & 1ull);
+    // 128-bit membership bitmap, looked up with 32-bit operations only (64-bit shifts are half rate on gfx950)
+    const uint32_t M0 = (1u << 0x09) | (1u << 0x0A) | (1u << 0x0C) | (1u << 0x0D) | (1u << 0x1A);  // 0x00..0x1F
+    const uint32_t M1 = (1u << (0x20 - 32)) | (1u << (0x2C - 32)) | (1u << (0x3A - 32));            // 0x20..0x3F
+    const uint32_t M2 = (1u << (0x5B - 64)) | (1u << (0x5D - 64));                                   // 0x40..0x5F
+    const uint32_t M3 = (1u << (0x7B - 96)) | (1u << (0x7D - 96));                                   // 0x60..0x7F
+    const uint32_t m = (c & 64u) ? ((c & 32u) ? M3 : M2) : ((c & 32u) ? M1 : M0);
+    return (c < 128u) & ((m >> (c & 31u)) & 1u);
 }
 
-// Resolve e_in / p_in from the 8-byte halo.  Returns false when the backslash run reaches past
-// the halo (then the caller counts the run from memory: sj_carry_slow).
+// Resolve e_in / p_in from the halo (only its top 4 bytes are used here).  Returns false when the backslash run
+// reaches past them (then the caller counts the run from memory: sj_carry_slow).
 //   e_in = (length of the backslash run ending at byte -1) is odd
 //   p_in = byte -1 is a scalar that is not an (unescaped) quote
 SJ_HD bool sj_carry_from_halo(sj_u64 halo, uint32_t* e_in, uint32_t* p_in) {
-    const sj_u64 z = halo ^ 0x5C5C5C5C5C5C5C5Cull;                    // zero bytes = backslashes
-    const uint32_t h1 = (uint32_t)(halo >> 56);
-    const uint32_t run1 = z ? (uint32_t)__builtin_clzll(z) >> 3 : 8u;  // backslashes ending at byte -1
-    const uint32_t run2 = (uint32_t)__builtin_clzll((z << 8) | 0xFFull) >> 3;  // ... ending at byte -2 (0..7)
+    const uint32_t hh = (uint32_t)(halo >> 32);                   // bytes -4..-1, byte -1 on top
+    const uint32_t z = hh ^ 0x5C5C5C5Cu;                          // zero bytes = backslashes
+    const uint32_t h1 = hh >> 24;
+    const uint32_t run1 = z ? (uint32_t)__builtin_clz(z) >> 3 : 4u;         // backslashes ending at byte -1 (0..4)
+    const uint32_t run2 = (uint32_t)__builtin_clz((z << 8) | 0xFFu) >> 3;   // ... ending at byte -2 (0..3)
     const bool is_q = h1 == 0x22;
     *e_in = run1 & 1u;
     *p_in = run1 ? 1u : (is_q ? (run2 & 1u) : (sj_is_ws_or_op(h1) ^ 1u));
-    return !((run1 == 8u) | (is_q & (run2 == 7u)));
+    return !((run1 == 4u) | (is_q & (run2 == 3u)));
 }
 
 // Slow path (backslash run longer than the halo): parity of the run of backslashes that ends

@@ -220,7 +220,7 @@ int sjmi_unescape(sjmi_ctx* c, uint8_t* string_buffer, uint64_t string_capacity,
 int sjmi_stage1_device(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_indexes, uint64_t index_capacity,
                        void* d_result, void* stream) {
     if (!c || !d_buf || !d_indexes || !d_result) return SJMI_ERR_ARG;
-    if (len >= (1ull << 32) || ((uintptr_t)d_buf & 15)) return SJMI_ERR_ARG;
+    if (len >= (1ull << 32) || ((uintptr_t)d_buf & 15) || ((uintptr_t)d_indexes & 15)) return SJMI_ERR_ARG;
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(len);

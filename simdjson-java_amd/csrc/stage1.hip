@@ -255,7 +255,7 @@ struct TileShared {
     uint32_t wpar[4], wc0[4], wcp[4];
     uint32_t par_in, tile;
     sj_u64 cnt_in;
-    uint32_t stage[4][STAGE_CAP];  // per-wave staging of indexes for coalesced stores
+    alignas(16) uint32_t stage[4][STAGE_CAP];  // per-wave staging of indexes for coalesced stores
 };
 
 template <int S>
@@ -433,17 +433,34 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
         uint32_t* stage = sh.stage[wave];
         const uint32_t WT = par_in ? (WP - W0) : W0;                       // indexes of this wave
         uint32_t* dst0 = out + cnt_in + (par_in ? (basep - base0) : base0);  // its contiguous output run
-        if (WT <= STAGE_CAP) {
-            // common case: everything fits in one round, so the per-bit loops need no window test
+        if (WT + 3 <= STAGE_CAP) {
+            // common case: everything fits in one round, so the per-bit loops need no window test.  Entries are
+            // staged at the same position modulo 4 as their final index, so that whole 16-byte quads of the LDS
+            // slice go out as global_store_dwordx4 (the index array is 16-byte aligned); only the two boundary
+            // quads of the wave's run need element-wise stores.
+            const uint32_t g0 = (uint32_t)((cnt_in + (par_in ? (basep - base0) : base0)) & 3ull);
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const uint32_t bstart = (uint32_t)((blk0 + (sj_u64)s * 64 + lane) * 64);
-                uint32_t* q = stage + pos[s];
+                uint32_t* q = stage + g0 + pos[s];
                 for (uint32_t lo = (uint32_t)m0[s]; lo; lo &= lo - 1) *q++ = bstart | (uint32_t)__builtin_ctz(lo);
                 for (uint32_t hi = (uint32_t)(m0[s] >> 32); hi; hi &= hi - 1) *q++ = bstart | 32u | (uint32_t)__builtin_ctz(hi);
             }
             wave_lds_fence();
-            for (uint32_t i = lane; i < WT; i += 64) dst0[i] = stage[i];
+            const uint32_t span = g0 + WT;
+            uint32_t* gbase = dst0 - g0;  // 16-byte aligned
+            for (uint32_t qi = lane; qi * 4 < span; qi += 64) {
+                const uint4 v = reinterpret_cast<const uint4*>(stage)[qi];
+                const uint32_t lo = qi * 4;
+                if (lo >= g0 && lo + 4 <= span) {
+                    reinterpret_cast<uint4*>(gbase)[qi] = v;
+                } else {
+                    if (lo + 0 >= g0 && lo + 0 < span) gbase[lo + 0] = v.x;
+                    if (lo + 1 >= g0 && lo + 1 < span) gbase[lo + 1] = v.y;
+                    if (lo + 2 >= g0 && lo + 2 < span) gbase[lo + 2] = v.z;
+                    if (lo + 3 >= g0 && lo + 3 < span) gbase[lo + 3] = v.w;
+                }
+            }
             wave_lds_fence();
         } else {
             for (uint32_t base = 0; base < WT; base += STAGE_CAP) {
