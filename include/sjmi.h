@@ -169,6 +169,13 @@ int sjmi_selftest(sjmi_ctx* ctx, uint32_t* mismatches);
 /* tuning knob for tests: force the tile size = steps x 16 KiB per workgroup (1, 2 or 4; 0 = automatic) */
 int sjmi_set_tile_steps(sjmi_ctx* ctx, int steps);
 
+/* Tile assignment inside the stage-1 kernel: 0 (default) = tile = workgroup index (fast; liveness assumes
+ * lower-numbered workgroups are dispatched no later than higher ones, results never depend on it), 1 = atomic
+ * ticket (no assumption at all, ~12 % slower).  A fast-mode launch whose bounded look-back spin trips reports
+ * SJMI_ST_INTERNAL: the host-buffer entry points then re-run in ticket mode and latch it; device-resident callers
+ * check d_result.status and call sjmi_set_tile_mode(ctx, 1).  Env SJMI_TILE_MODE=ticket starts in mode 1. */
+int sjmi_set_tile_mode(sjmi_ctx* ctx, int ticket);
+
 /* Measurement hooks for bench.py: when on, every sjmi_stage1_device launch is bracketed by HIP events
  * on the launch stream (kernel only); sjmi_kernel_time returns their summed duration and count. */
 int sjmi_set_profiling(sjmi_ctx* ctx, int on);

@@ -57,7 +57,7 @@ def build(force=False, verbose=False):
 _lib = None
 
 EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sjmi_stage1", "sjmi_stage1_device",
-           "sjmi_selftest", "sjmi_set_tile_steps", "sjmi_set_profiling", "sjmi_kernel_time", "sjmi_debug_set_flags",
+           "sjmi_selftest", "sjmi_set_tile_steps", "sjmi_set_profiling", "sjmi_kernel_time", "sjmi_debug_set_flags", "sjmi_set_tile_mode",
            "sjmi_unescape", "sjmi_unescape_device",
            "sjmi_parser_create", "sjmi_parser_destroy", "sjmi_parser_parse", "sjmi_parser_last_message",
            "sjmi_stage1_batch", "sjmi_stage1_batch_device", "sjmi_parser_parse_batch"]
@@ -118,6 +118,8 @@ def lib():
         L.sjmi_parser_parse_batch.restype = C.c_int
         L.sjmi_parser_parse_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sjmi_set_tile_mode.restype = C.c_int
+        L.sjmi_set_tile_mode.argtypes = [C.c_void_p, C.c_int]
         L.sjmi_kernel_time.restype = C.c_int
         L.sjmi_kernel_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -207,6 +209,9 @@ class Context:
         """Device-resident path; arguments are raw device pointers (ints) and a hipStream_t handle."""
         self._check(lib().sjmi_stage1_device(self._h, d_buf, length, d_indexes, index_capacity, d_result, stream),
                     "sjmi_stage1_device")
+
+    def set_tile_mode(self, ticket):
+        self._check(lib().sjmi_set_tile_mode(self._h, 1 if ticket else 0), "sjmi_set_tile_mode")
 
     def debug_set_flags(self, flags):
         self._check(lib().sjmi_debug_set_flags(self._h, flags), "sjmi_debug_set_flags")

@@ -33,6 +33,7 @@ struct sjmi_ctx {
     size_t docoff_bytes = 0;
     int forced_steps = 0;
     uint32_t dbg = 0;  // ablation flags (sjmi_debug_set_flags)
+    bool ticket_mode = false;  // safe tile assignment (latched on after a look-back timeout in fast mode)
     bool profiling = false;  // bracket every stage-1 kernel with HIP events (bench.py roofline)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
@@ -40,6 +41,8 @@ struct sjmi_ctx {
 };
 
 namespace {
+
+uint32_t launch_flags(const sjmi_ctx* c) { return c->dbg | (c->ticket_mode ? sjmi::FLAG_TICKET : 0u); }
 
 bool fail(sjmi_ctx* c, const char* what, hipError_t e) {
     if (e == hipSuccess) return false;
@@ -77,6 +80,8 @@ int sjmi_create(sjmi_ctx** out, int device, uint64_t capacity_bytes) {
         sjmi_destroy(c);
         return SJMI_ERR_HIP;
     }
+    const char* mode = getenv("SJMI_TILE_MODE");  // "ticket" = start in the safe tile-assignment mode
+    c->ticket_mode = mode && strcmp(mode, "ticket") == 0;
     *out = c;
     return SJMI_OK;
 }
@@ -123,13 +128,17 @@ int sjmi_stage1(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes
     if (len && fail(c, "H2D", hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
     const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(len);
     const uint64_t dev_cap = c->capacity + 2 < index_capacity ? c->capacity + 2 : index_capacity;
-    if (fail(c, "launch", sjmi::stage1_launch(c->d_in, len, c->d_idx, dev_cap, c->d_ws, steps, c->stream, nullptr, nullptr)))
-        return SJMI_ERR_HIP;
-    if (fail(c, "D2H(result)",
-             hipMemcpyAsync(c->h_res, (uint8_t*)c->d_ws + sjmi::WS_RESULT_OFFSET, sizeof(sjmi_stage1_result),
-                            hipMemcpyDeviceToHost, c->stream)) ||
-        fail(c, "sync", hipStreamSynchronize(c->stream)))
-        return SJMI_ERR_HIP;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (fail(c, "launch", sjmi::stage1_launch(c->d_in, len, c->d_idx, dev_cap, c->d_ws, steps, c->stream, nullptr,
+                                                  nullptr, launch_flags(c))) ||
+            fail(c, "D2H(result)",
+                 hipMemcpyAsync(c->h_res, (uint8_t*)c->d_ws + sjmi::WS_RESULT_OFFSET, sizeof(sjmi_stage1_result),
+                                hipMemcpyDeviceToHost, c->stream)) ||
+            fail(c, "sync", hipStreamSynchronize(c->stream)))
+            return SJMI_ERR_HIP;
+        if (!(c->h_res->status & SJMI_ST_INTERNAL) || c->ticket_mode) break;
+        c->ticket_mode = true;  // fast-mode liveness assumption failed: latch the safe mode and run again
+    }
     *status = c->h_res->status & 0xFFu;
     *count = c->h_res->count;
     if (c->h_res->status & SJMI_ST_INTERNAL) {
@@ -249,7 +258,7 @@ int sjmi_stage1_device(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_ind
         ++c->events_used;
     }
     if (fail(c, "launch", sjmi::stage1_launch((const uint8_t*)d_buf, len, (uint32_t*)d_indexes, index_capacity,
-                                              c->d_ws_dev, steps, st, ev0, ev1, c->dbg)))
+                                              c->d_ws_dev, steps, st, ev0, ev1, launch_flags(c))))
         return SJMI_ERR_HIP;
     if (fail(c, "D2D(result)",
              hipMemcpyAsync(d_result, (uint8_t*)c->d_ws_dev + sjmi::WS_RESULT_OFFSET, sizeof(sjmi_stage1_result),
@@ -292,7 +301,7 @@ int sjmi_stage1_batch(sjmi_ctx* c, const uint8_t* buf, uint64_t total_len, const
     const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(total_len);
     const uint64_t dev_cap = c->capacity + 2 < index_capacity ? c->capacity + 2 : index_capacity;
     if (fail(c, "launch", sjmi::stage1_launch(c->d_in, total_len, c->d_idx, dev_cap, c->d_ws, steps, c->stream, nullptr,
-                                              nullptr)) ||
+                                              nullptr, launch_flags(c))) ||
         fail(c, "split", sjmi::split_docs_launch(c->d_idx, (const sjmi::Stage1Result*)d_res, c->d_docoff, n_docs, d_io,
                                                  c->stream)) ||
         fail(c, "D2H(result)", hipMemcpyAsync(c->h_res, d_res, sizeof(sjmi_stage1_result), hipMemcpyDeviceToHost, c->stream)) ||
@@ -310,6 +319,12 @@ int sjmi_stage1_batch(sjmi_ctx* c, const uint8_t* buf, uint64_t total_len, const
     c->last_len = total_len;
     c->last_count = c->h_res->count;
     c->last_valid = true;
+    return SJMI_OK;
+}
+
+int sjmi_set_tile_mode(sjmi_ctx* c, int ticket) {
+    if (!c) return SJMI_ERR_ARG;
+    c->ticket_mode = ticket != 0;
     return SJMI_OK;
 }
 

@@ -27,6 +27,8 @@ static_assert(sizeof(UnescapeResult) == sizeof(sjmi_unescape_result), "ABI struc
 
 // ablation switches for performance experiments only (results are NOT valid with any of them set)
 constexpr uint32_t DBG_NO_WRITE = 1, DBG_NO_LOOKBACK = 2;
+// kernel flag (not an ablation): hand tiles out by atomic ticket instead of blockIdx (safe liveness mode)
+constexpr uint32_t FLAG_TICKET = 0x100;
 
 constexpr uint32_t STAGE_CAP = 2048;  // indexes staged in LDS per wave and round (8 KiB)
 

@@ -218,9 +218,7 @@ __device__ __forceinline__ void tile_lookback(sj_u64* tile_state, uint32_t tile,
 // the output and can be staged + stored without a workgroup barrier.  Three barriers per tile: the
 // parity table, the count table, the look-back broadcast.
 //
-// Tiles are handed out by ONE atomic ticket: a tile then only waits for tiles whose workgroups
-// already run, whatever the dispatch order or placement (HIP promises neither).  The ticket word
-// saturates at ~88 tickets/us = 5.8 TB/s at 64 KiB per ticket, above what the ALUs can deliver.
+// Tile assignment: tile = blockIdx (fast, default) or an atomic ticket (safe fallback) -- see the kernel.
 // Variants measured and dropped: 16 KiB workgroup tiles (ticket-bound), persistent
 // waves with static striding (phase-locked waves, VGPR growth from loop-invariant hoisting),
 // wave-autonomous 8-32 KiB tiles with per-wave look-back (chain rate ~100 tiles/us), a dedicated
@@ -265,9 +263,20 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
     __shared__ TileShared<S> sh;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform => scalar tile math
-    if (threadIdx.x == 0) sh.tile = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const uint32_t tile = sh.tile;
+    uint32_t tile;
+    if (dbg & FLAG_TICKET) {
+        // SAFE mode: tiles handed out by an atomic ticket, so a tile only waits for tiles whose workgroups already
+        // run, whatever the dispatch order.  Costs ~12 % (one exposed atomic round trip per workgroup).
+        if (threadIdx.x == 0) sh.tile = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        tile = sh.tile;
+    } else {
+        // FAST mode (default): tile = blockIdx.  RESULTS never depend on dispatch order; LIVENESS does: a tile
+        // spins on lower tiles, which is fine as long as lower-numbered workgroups are dispatched no later than
+        // higher ones (what gfx950 is observed to do for 1-D grids).  If that ever fails, the bounded spin in
+        // tile_lookback trips, the launch reports SJMI_ST_INTERNAL and the host re-runs it in SAFE mode.
+        tile = blockIdx.x;
+    }
     const sj_u64 nblocks = len / 64 + 1;  // the reference always processes one tail block (:255-294)
     const sj_u64 blk0 = (sj_u64)tile * (256 * S) + (sj_u64)wave * (64 * S);  // first block of this wave
     const sj_u64 lt_mask = (1ull << lane) - 1ull;

@@ -12,10 +12,12 @@ from tests.golden import vectors as V
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=["fast", "ticket"])
+def ctx(request):
+    """Both tile-assignment modes of the kernel: tile = workgroup index (default) and atomic ticket (safe)."""
     import simdjson_java_amd as S
     c = S.Context(device=0, capacity=96 * 1024 * 1024)
+    c.set_tile_mode(request.param == "ticket")
     yield c
     c.close()
 

@@ -26,7 +26,7 @@ print("torch copy: %.3f ms  read %.0f GB/s (r+w %.0f GB/s)" % (t * 1e3, n / t / 
 del dst
 for steps in (4,):
     ctx.set_tile_steps(steps)
-    for flags, name in [(0, "full"), (1, "no_write")]:
+    for flags, name in [(0, "full"), (0x100, "full, ticket mode"), (1, "no_write")]:
         ctx.debug_set_flags(flags)
         for _ in range(3):
             ctx.stage1_device(buf.data_ptr(), n, out.data_ptr(), out.numel(), res.data_ptr(), st)
