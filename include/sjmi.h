@@ -179,8 +179,8 @@ int sjmi_set_tile_mode(sjmi_ctx* ctx, int ticket);
 /* Measurement hooks for bench.py: when on, every sjmi_stage1_device launch is bracketed by HIP events
  * on the launch stream (kernel only); sjmi_kernel_time returns their summed duration and count. */
 int sjmi_set_profiling(sjmi_ctx* ctx, int on);
-/* performance-ablation switches for sjmi_stage1_device (1 = no index stores, 2 = no look-back);
- * results are INVALID while any is set. Experiments only. */
+/* performance-ablation switches for sjmi_stage1_device (1 = no index stores, 2 = no look-back): results are
+ * INVALID while any is set (experiments only); 16 = test hook: fast-mode launches report SJMI_ST_INTERNAL. */
 int sjmi_debug_set_flags(sjmi_ctx* ctx, uint32_t flags);
 int sjmi_kernel_time(sjmi_ctx* ctx, double* sum_ms, uint32_t* launches);
 

@@ -193,10 +193,17 @@ SJ_HD bool sj_carry_from_halo(sj_u64 halo, uint32_t* e_in, uint32_t* p_in) {
 // Slow path (backslash run longer than the halo): parity of the run of backslashes that ends
 // right before buf[pos] and does not extend below buf[lo].
 SJ_HD uint32_t sj_backslash_run_parity(const uint8_t* buf, sj_u64 lo, sj_u64 pos) {
+    // whole aligned 8-byte groups of backslashes do not change the parity: skip them with one load each
+    while (pos >= lo + 8 && (pos & 7) == 0 &&
+           *reinterpret_cast<const sj_u64*>(buf + pos - 8) == 0x5C5C5C5C5C5C5C5Cull)
+        pos -= 8;
     uint32_t par = 0;
     while (pos > lo && buf[pos - 1] == 0x5C) {
         par ^= 1u;
         --pos;
+        while (pos >= lo + 8 && (pos & 7) == 0 &&
+               *reinterpret_cast<const sj_u64*>(buf + pos - 8) == 0x5C5C5C5C5C5C5C5Cull)
+            pos -= 8;
     }
     return par;
 }

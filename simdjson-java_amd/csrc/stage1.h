@@ -27,6 +27,8 @@ static_assert(sizeof(UnescapeResult) == sizeof(sjmi_unescape_result), "ABI struc
 
 // ablation switches for performance experiments only (results are NOT valid with any of them set)
 constexpr uint32_t DBG_NO_WRITE = 1, DBG_NO_LOOKBACK = 2;
+// test hook: a fast-mode launch reports SJMI_ST_INTERNAL as if its look-back spin had tripped
+constexpr uint32_t DBG_FAKE_TIMEOUT = 16;
 // kernel flag (not an ablation): hand tiles out by atomic ticket instead of blockIdx (safe liveness mode)
 constexpr uint32_t FLAG_TICKET = 0x100;
 

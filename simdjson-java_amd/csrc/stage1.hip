@@ -276,6 +276,8 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
         // higher ones (what gfx950 is observed to do for 1-D grids).  If that ever fails, the bounded spin in
         // tile_lookback trips, the launch reports SJMI_ST_INTERNAL and the host re-runs it in SAFE mode.
         tile = blockIdx.x;
+        if ((dbg & DBG_FAKE_TIMEOUT) && blockIdx.x == 0 && threadIdx.x == 0)
+            __hip_atomic_fetch_or(&res->status, SJMI_ST_INTERNAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const sj_u64 nblocks = len / 64 + 1;  // the reference always processes one tail block (:255-294)
     const sj_u64 blk0 = (sj_u64)tile * (256 * S) + (sj_u64)wave * (64 * S);  // first block of this wave

@@ -154,7 +154,7 @@ def test_fuzz_tile_boundaries(ctx, steps):
 
 def test_adversarial_runs(ctx):
     n = 200 * 1024
-    for d in (b'"' * n, b"\\" * n, b"\\" * (n - 1) + b'"', b'"' + b"\\" * (n - 3) + b'"x', b"[" * n, b" " * n, b"a" * n,
+    for d in (b'"' * n, b"\\" * n, b"\\" * (4 * 1024 * 1024 + 3) + b'"x"', b"\\" * (n - 1) + b'"', b'"' + b"\\" * (n - 3) + b'"x', b"[" * n, b" " * n, b"a" * n,
               b'"' + b"\x01" * n + b'"', ("é" * (n // 2)).encode(), ("€" * (n // 3)).encode()[:-1], b"\xf0\x9f\x98" * 1000):
         _check(ctx, d)
 
@@ -175,6 +175,23 @@ def test_many_tiles_parity_chain(ctx):
     finally:
         ctx.set_tile_steps(0)
     _check(ctx, d)
+
+
+def test_fast_mode_timeout_falls_back_to_ticket_mode(twitter):
+    """If a fast-mode launch reports a look-back timeout, the host path must re-run it in ticket mode, return
+    correct results and stay in ticket mode."""
+    import simdjson_java_amd as S
+    c = S.Context(device=0, capacity=len(twitter) + 64)
+    try:
+        c.debug_set_flags(16)  # fake the timeout report of fast-mode launches
+        idx, st = c.stage1(twitter)
+        want, wst = O.stage1(twitter)
+        assert st == wst == 0 and np.array_equal(idx, want)
+        c.debug_set_flags(0)
+        idx, st = c.stage1(twitter)   # now latched in ticket mode
+        assert np.array_equal(idx, want)
+    finally:
+        c.close()
 
 
 def test_index_capacity_error(ctx):
