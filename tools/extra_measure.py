@@ -60,6 +60,80 @@ def device_run(reps, iters=10):
 device_run(1024)
 if len(sys.argv) > 1 and sys.argv[1] == "4g":
     device_run(6801, iters=5)
+def synth_run():
+    # BASELINE.json configs[2]: 4 GiB synthetic (50 % strings, 10 % escapes, non-ASCII), stage 1 + UTF-8 validation
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth
+    from oracle import oracle as O
+    tile = synth.synth_tile(target_bytes=4 << 20)
+    reps = (1 << 32) // len(tile) - 1
+    n = len(tile) * reps
+    idx0, st0 = O.stage1(tile)
+    assert st0 == 0
+    with torch.cuda.stream(work):
+        buf = torch.zeros(n + 128, dtype=torch.uint8, device="cuda")
+        buf[:n] = torch.frombuffer(bytearray(tile), dtype=torch.uint8).cuda().repeat(reps)
+        cap = idx0.size * reps + 1
+        out = torch.empty(cap, dtype=torch.int32, device="cuda")
+        res = torch.zeros(2, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx = S.Context(0, 1 << 20)
+    for _ in range(2):
+        ctx.stage1_device(buf.data_ptr(), n, out.data_ptr(), cap, res.data_ptr(), st)
+    torch.cuda.synchronize()
+    r = res.cpu().numpy()
+    assert int(r[0]) == idx0.size * reps and (int(r[1]) & 0xFFFFFFFF) == 0, r
+    h = O.fnv1a64_u32(out[:idx0.size].cpu().numpy().view(np.uint32))
+    assert h == O.fnv1a64_u32(idx0)
+    ctx.set_profiling(True)
+    for _ in range(5):
+        ctx.stage1_device(buf.data_ptr(), n, out.data_ptr(), cap, res.data_ptr(), st)
+    torch.cuda.synchronize()
+    ms, k = ctx.kernel_time()
+    print("config[2] synthetic %d B (%.1f structurals/KB): %.4f ms -> %.0f GB/s (%.1f%% of 8 TB/s)" % (n, idx0.size / len(tile) * 1024, ms / k, n / (ms / k) / 1e6, n / (ms / k) / 1e6 / 80))
+    ctx.close()
+    del buf, out
+
+
+def batch_run():
+    # BASELINE.json configs[3] on ONE GPU: 1M ~1 KB documents, one stage-1 launch + per-document split
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth
+    docs = synth.small_docs(n=4000)
+    unit = b"".join(d + b"\n" for d in docs)
+    lens = np.array([len(d) + 1 for d in docs], dtype=np.uint64)
+    reps = 250
+    n_docs = len(docs) * reps
+    n = len(unit) * reps
+    offs = np.concatenate([[0], np.cumsum(np.tile(lens, reps))]).astype(np.uint64)
+    with torch.cuda.stream(work):
+        buf = torch.zeros(n + 128, dtype=torch.uint8, device="cuda")
+        buf[:n] = torch.frombuffer(bytearray(unit), dtype=torch.uint8).cuda().repeat(reps)
+        d_offs = torch.from_numpy(offs.view(np.int64)).cuda()
+        d_io = torch.zeros(n_docs + 1, dtype=torch.int64, device="cuda")
+        cap = n // 4 + 1
+        out = torch.empty(cap, dtype=torch.int32, device="cuda")
+        res = torch.zeros(2, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx = S.Context(0, 1 << 20)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(work):
+        for it in range(6):
+            if it == 1:
+                e0.record()
+            ctx.stage1_batch_device(buf.data_ptr(), n, d_offs.data_ptr(), n_docs, out.data_ptr(), cap, d_io.data_ptr(), res.data_ptr(), st)
+        e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / 5
+    r = res.cpu().numpy()
+    assert (int(r[1]) & 0xFFFFFFFF) == 0 and int(d_io[-1].item()) == int(r[0])
+    print("config[3] batch on 1 GPU: %d documents (%d B): %.3f ms per batch (memset + stage 1 + split) -> %.1f M docs/s, %.0f GB/s" % (n_docs, n, t, n_docs / t / 1e3, n / t / 1e6))
+    ctx.close()
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "4g":
+    synth_run()
+batch_run()
 # host-buffer path (PCIe H2D + kernel + D2H of the indexes)
 reps = 64
 hdoc = doc * reps
