@@ -236,10 +236,6 @@ int sjmi_stage1_device(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_ind
     const size_t need = sjmi::stage1_workspace_bytes(len, steps);
     if (need > c->ws_dev_bytes) {  // grown outside any timed loop on first use of a given size
         if (c->d_ws_dev) (void)hipFree(c->d_ws_dev);
-    if (c->d_sb) (void)hipFree(c->d_sb);
-    if (c->d_ws_str) (void)hipFree(c->d_ws_str);
-    if (c->d_ures) (void)hipFree(c->d_ures);
-    if (c->d_docoff) (void)hipFree(c->d_docoff);
         c->d_ws_dev = nullptr;
         c->ws_dev_bytes = 0;
         if (fail(c, "hipMalloc(ws_dev)", hipMalloc(&c->d_ws_dev, need))) return SJMI_ERR_HIP;
