@@ -223,9 +223,12 @@ SJ_HD void sj_carry_slow(const uint8_t* buf, sj_u64 doc_lo, sj_u64 start, uint32
 }
 
 // ---- bit-plane transposition, butterfly form ------------------------------------------------------
-// 8 x (8x8 bit-matrix transpose of 8 consecutive bytes, Hacker's Delight 7-3, in 32-bit halves, VOP2 only)
-// + 4 x (4x4 byte transpose with v_perm_b32) to gather byte k of every group into plane k.
-// 312 issue units per block against 480 for the v_and/v_msad_u8 form (VOP3 ops cost double on gfx950).
+// Per 32-byte half: 2 x (4x4 byte transpose with v_perm_b32) gather byte 8c+r of the half into byte c of register r,
+// then ONE 8x8 bit-matrix transpose ACROSS the 8 registers (register index <-> bit index inside the byte, all four
+// bytes of a register at once): 3 butterfly stages x 4 register pairs x 6 VOP2 ops.  Register k then IS the half's
+// 32 bits of plane k.  176 instructions per block (32 VOP3 + 144 VOP2); the first butterfly version transposed
+// 8 bytes at a time inside register pairs (Hacker's Delight 7-3) and needed 256, the v_and/v_msad_u8 form 480 issue
+// units (VOP3 ops cost double on gfx950).
 SJ_HD uint32_t sj_perm(uint32_t hi, uint32_t lo, uint32_t sel) {  // v_perm_b32 D = bytes of {hi:lo} picked by sel
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_perm(hi, lo, sel);
@@ -237,15 +240,12 @@ SJ_HD uint32_t sj_perm(uint32_t hi, uint32_t lo, uint32_t sel) {  // v_perm_b32 
 #endif
 }
 
-SJ_HD void sj_transpose8x8(uint32_t& lo, uint32_t& hi) {
-    uint32_t t;
-    t = (lo ^ (lo >> 7)) & 0x00AA00AAu;  lo = lo ^ t ^ (t << 7);
-    t = (hi ^ (hi >> 7)) & 0x00AA00AAu;  hi = hi ^ t ^ (t << 7);
-    t = (lo ^ (lo >> 14)) & 0x0000CCCCu; lo = lo ^ t ^ (t << 14);
-    t = (hi ^ (hi >> 14)) & 0x0000CCCCu; hi = hi ^ t ^ (t << 14);
-    t = (lo ^ ((lo >> 28) | (hi << 4))) & 0xF0F0F0F0u;
-    lo ^= t;
-    hi ^= t >> 4;
+// one butterfly stage between two registers: x's bits at positions with (bit & D) set <-> y's bits with it clear
+template <int D, uint32_t LOW_MASK>
+SJ_HD void sj_bit_swap(uint32_t& x, uint32_t& y) {
+    const uint32_t t = ((x >> D) ^ y) & LOW_MASK;
+    y ^= t;
+    x ^= t << D;
 }
 
 SJ_HD void sj_transpose4x4_bytes(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t b[4]) {
@@ -258,21 +258,20 @@ SJ_HD void sj_transpose4x4_bytes(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t
 }
 
 SJ_HD void sj_transpose_butterfly(const uint32_t w[16], sj_u64 p[8]) {
-    uint32_t lo[8], hi[8];
-    for (int g = 0; g < 8; ++g) {
-        lo[g] = w[2 * g];
-        hi[g] = w[2 * g + 1];
-        sj_transpose8x8(lo[g], hi[g]);  // byte k of lo/hi = plane k / k+4 of the group's 8 bytes
+    uint32_t y[2][8];
+    for (int h = 0; h < 2; ++h) {
+        uint32_t* x = y[h];  // x[r] byte c = byte 8c + r of this half
+        sj_transpose4x4_bytes(w[8 * h + 0], w[8 * h + 2], w[8 * h + 4], w[8 * h + 6], x);
+        sj_transpose4x4_bytes(w[8 * h + 1], w[8 * h + 3], w[8 * h + 5], w[8 * h + 7], x + 4);
+        for (int r = 0; r < 4; ++r) sj_bit_swap<4, 0x0F0F0F0Fu>(x[r], x[r + 4]);
+        for (int r = 0; r < 8; r += 4) {
+            sj_bit_swap<2, 0x33333333u>(x[r], x[r + 2]);
+            sj_bit_swap<2, 0x33333333u>(x[r + 1], x[r + 3]);
+        }
+        for (int r = 0; r < 8; r += 2) sj_bit_swap<1, 0x55555555u>(x[r], x[r + 1]);
+        // now x[k] bit (8c + r) = bit k of byte 8c + r
     }
-    uint32_t a[4], b[4], c[4], d[4];
-    sj_transpose4x4_bytes(lo[0], lo[1], lo[2], lo[3], a);  // planes 0..3, bytes 0..31
-    sj_transpose4x4_bytes(lo[4], lo[5], lo[6], lo[7], b);  // planes 0..3, bytes 32..63
-    sj_transpose4x4_bytes(hi[0], hi[1], hi[2], hi[3], c);  // planes 4..7, bytes 0..31
-    sj_transpose4x4_bytes(hi[4], hi[5], hi[6], hi[7], d);
-    for (int k = 0; k < 4; ++k) {
-        p[k] = (sj_u64)a[k] | ((sj_u64)b[k] << 32);
-        p[k + 4] = (sj_u64)c[k] | ((sj_u64)d[k] << 32);
-    }
+    for (int k = 0; k < 8; ++k) p[k] = (sj_u64)y[0][k] | ((sj_u64)y[1][k] << 32);
 }
 
 // portable transposition (host + reference for the device fast path's self-test)
