@@ -8,8 +8,8 @@ batch is sharded by document (every rank scans its own 1024 copies: weak scaling
 only to all-gather the per-shard {count, status} records, as north_star prescribes.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel (k_stage1) vs the 8 TB/s HBM peak, timed with HIP events that
-                  bracket only the kernel on its launch stream (sjmi_set_profiling)
+  roofline     -- dominant kernel (k_stage1) vs the 8 TB/s HBM peak, timed with HIP events attached to
+                  the kernel's dispatch on its launch stream (sjmi_set_profiling)
   cpu_baseline -- the C oracle (a port of the reference's Java stage 1) on one host core, on a
                   bounded sample of the same workload
 """
@@ -56,10 +56,13 @@ def cpu_baseline(doc, seconds=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--preheat", type=int, default=400,
+                    help="untimed launches before the warmup steps: the GPU's clock governor needs ~100 back-to-back "
+                         "launches (25 ms) of this kernel to settle (per-launch times: tools/perlaunch.py)")
     ap.add_argument("--reps", type=int, default=1024, help="copies of twitter.json per GPU (1024 = configs[1])")
-    ap.add_argument("--tile-steps", type=int, default=0, help="force 16 KiB steps per tile (0 = auto)")
+    ap.add_argument("--tile-steps", type=int, default=0, help="force the chain granule = N x 4 KiB: 1, 2 or 4 (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -111,8 +114,7 @@ def main():
             if world > 1:
                 dist.all_gather_into_tensor(gathered, res)  # per-shard {count, status}: the only collective
 
-    for _ in range(max(args.warmup, 1)):
-        step()
+    step()
     torch.cuda.synchronize()
     # parity check outside the timed region: closed form index[k*S+j] = k*N0 + index0[j]
     r = res.cpu().numpy()
@@ -124,6 +126,8 @@ def main():
     assert int(out[s_total].item()) == 0
     del want, got
 
+    for _ in range(args.preheat + args.warmup):  # untimed
+        step()
     ctx.set_profiling(True)
     if world > 1:
         dist.barrier()
@@ -166,6 +170,7 @@ def main():
             "config": {"workload": "twitter.json x%d concatenated: stage-1 = UTF-8 validation + structural indexing + "
                                    "uint32 index compaction, one fused single-pass kernel, bit-exact index check" % reps,
                        "bytes_per_gpu": n, "structurals_per_gpu": s_total, "tile_steps": args.tile_steps or "auto",
+                       "preheat_launches": args.preheat,
                        "sharding": "by document, RCCL all_gather of per-shard {count,status} only" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -166,14 +166,17 @@ int sjmi_parser_parse_batch(sjmi_parser* p, const uint8_t* buf, uint64_t total_l
 /* Run the on-device self-test of the bit-plane transposition; *mismatches == 0 on success. */
 int sjmi_selftest(sjmi_ctx* ctx, uint32_t* mismatches);
 
-/* tuning knob for tests: force the tile size = steps x 16 KiB per workgroup (1, 2 or 4; 0 = automatic) */
+/* tuning knob for tests: force the chain granule = steps x 4 KiB per worker wave and iteration (1, 2 or 4;
+ * 0 = automatic: 1 for documents up to 4 MiB, else 4) */
 int sjmi_set_tile_steps(sjmi_ctx* ctx, int steps);
 
-/* Tile assignment inside the stage-1 kernel: 0 (default) = tile = workgroup index (fast; liveness assumes
- * lower-numbered workgroups are dispatched no later than higher ones, results never depend on it), 1 = atomic
- * ticket (no assumption at all, ~12 % slower).  A fast-mode launch whose bounded look-back spin trips reports
- * SJMI_ST_INTERNAL: the host-buffer entry points then re-run in ticket mode and latch it; device-resident callers
- * check d_result.status and call sjmi_set_tile_mode(ctx, 1).  Env SJMI_TILE_MODE=ticket starts in mode 1. */
+/* Liveness mode of the stage-1 kernel (results never depend on it): 0 (default) = FAST: persistent worker waves plus
+ * one scanner workgroup that turns the workers' per-granule aggregates into prefixes; assumes that the whole grid
+ * (sized with the occupancy API) is resident at the same time.  1 = SAFE: no scanner, granules by one atomic ticket,
+ * every worker resolves its prefix by a decoupled look-back; no residency assumption at all, ~2.5x slower.
+ * A FAST launch whose bounded spins trip reports SJMI_ST_INTERNAL: the host-buffer entry points then latch SAFE mode
+ * and re-run the launch; the *_device entry points return the status bit to the caller.
+ * Environment: SJMI_TILE_MODE=ticket selects SAFE mode at context creation. */
 int sjmi_set_tile_mode(sjmi_ctx* ctx, int ticket);
 
 /* Measurement hooks for bench.py: when on, every sjmi_stage1_device launch is bracketed by HIP events

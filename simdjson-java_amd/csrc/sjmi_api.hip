@@ -42,7 +42,7 @@ struct sjmi_ctx {
 
 namespace {
 
-uint32_t launch_flags(const sjmi_ctx* c) { return c->dbg | (c->ticket_mode ? sjmi::FLAG_TICKET : 0u); }
+uint32_t launch_flags(const sjmi_ctx* c) { return c->dbg | (c->ticket_mode ? sjmi::FLAG_SAFE : 0u); }
 
 bool fail(sjmi_ctx* c, const char* what, hipError_t e) {
     if (e == hipSuccess) return false;
@@ -108,6 +108,14 @@ void sjmi_destroy(sjmi_ctx* c) {
 }
 
 const char* sjmi_last_error(const sjmi_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+#ifdef SJMI_TRACE
+extern "C" int sjmi_debug_read_ws(sjmi_ctx* c, void* dst, uint64_t offset, uint64_t bytes) {
+    if (!c || !c->d_ws_dev || offset + bytes > c->ws_dev_bytes) return SJMI_ERR_ARG;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(dst, (uint8_t*)c->d_ws_dev + offset, bytes, hipMemcpyDeviceToHost) == hipSuccess ? SJMI_OK : SJMI_ERR_HIP;
+}
+#endif
 
 int sjmi_set_tile_steps(sjmi_ctx* c, int steps) {
     if (!c || !(steps == 0 || steps == 1 || steps == 2 || steps == 4)) return SJMI_ERR_ARG;

@@ -29,15 +29,16 @@ static_assert(sizeof(UnescapeResult) == sizeof(sjmi_unescape_result), "ABI struc
 constexpr uint32_t DBG_NO_WRITE = 1, DBG_NO_LOOKBACK = 2;
 // test hook: a fast-mode launch reports SJMI_ST_INTERNAL as if its look-back spin had tripped
 constexpr uint32_t DBG_FAKE_TIMEOUT = 16;
-// kernel flag (not an ablation): hand tiles out by atomic ticket instead of blockIdx (safe liveness mode)
-constexpr uint32_t FLAG_TICKET = 0x100;
-
-constexpr uint32_t STAGE_CAP = 2048;  // indexes staged in LDS per wave and round (8 KiB)
+// kernel flag (not an ablation): SAFE liveness mode -- no scanner workgroup, every worker looks back itself
+constexpr uint32_t FLAG_SAFE = 0x100;
+// experiments: static tile striding instead of the atomic ticket
+constexpr uint32_t FLAG_STATIC = 0x400;
 
 // workspace layout (zeroed by one hipMemsetAsync per launch)
-constexpr size_t WS_RESULT_OFFSET = 0;        // Stage1Result
-constexpr size_t WS_TICKET_OFFSET = 64;       // u32 tile ticket, alone in its 64-byte line
-constexpr size_t WS_TILE_STATE_OFFSET = 128;  // u64 per tile
+constexpr size_t WS_RESULT_OFFSET = 0;        // Stage1Result (16 bytes)
+constexpr uint32_t WS_SCANNER_CU_WORD = 8;    // u32 index from the workspace start: id of the scanner's CU
+constexpr size_t WS_TICKET_OFFSET = 64;       // 8 u32 granule tickets, each alone in its 64-byte line
+constexpr size_t WS_TILE_STATE_OFFSET = 640;  // u64 aggregates[granules], then u64 prefixes[granules]
 
 size_t stage1_workspace_bytes(uint64_t len, int steps);
 int stage1_pick_steps(uint64_t len);

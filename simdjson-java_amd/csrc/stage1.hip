@@ -14,19 +14,20 @@
 //   * the three serial carries of the reference loop (prevEscaped, prevScalar, previous 4 UTF-8
 //     bytes) are LOCAL: each lane re-derives them from the 8 bytes before its block;
 //   * the two truly global carries -- in-string parity (XOR scan) and the output offset (+ scan of
-//     popcounts) -- are resolved inside the wave by ballot/shuffle, inside the workgroup through
-//     LDS, and across workgroups by a single-pass DECOUPLED LOOK-BACK over 8-byte {state,payload}
-//     granules (agent-scope relaxed atomics, one granule per 64 KiB tile), so the input is read
-//     from HBM exactly once.  Tiles are handed out by an atomic ticket so that a tile only ever
-//     waits for tiles whose workgroups have already started (no dependence on dispatch order);
+//     popcounts) -- are resolved inside the wave by ballot / DPP scans and across waves by a single-pass chain
+//     over 8-byte {state,payload} granules (agent-scope relaxed atomics, one granule per 16 KiB of input): every
+//     worker wave publishes its granule's AGGREGATE, a scanner workgroup turns aggregates into PREFIXes, and the
+//     worker picks its prefix up one classification later (software pipeline), so the input is read from HBM
+//     exactly once and nobody waits for the chain;
 //   * structurals depend on the incoming parity only through a complement
 //     (structurals(p) = p ? pot & sm : pot & ~sm), so each tile publishes counts for BOTH parities
 //     and the look-back composes functions {0,1} -> (parity, count);
 //   * indexes are expanded into a wave-private LDS slice and leave the CU as coalesced stores.
 // Measured cost model on gfx950 (tools/ubench/valu_rate.hip): VOP2 integer ops issue in 2 cycles per
-// wave, every VOP3 op (v_msad_u8, v_or3, v_lshl_or, v_bfi, v_bcnt, 64-bit shifts) in 4.  The kernel
-// is VALU-bound (775 VALU instructions per 4 KiB wave-step after this round's reductions).
+// wave, every VOP3 op (v_msad_u8, v_or3, v_lshl_or, v_bfi, v_bcnt, 64-bit shifts) in 4; ~680 VALU instructions
+// per 4 KiB wave-step.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "sj_block.h"
@@ -142,34 +143,45 @@ __device__ __forceinline__ sj_u64 ts_load(const sj_u64* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Executed by all 64 lanes of wave 0.  Returns the parity / structural count entering `tile`.
-__device__ __forceinline__ void tile_lookback(sj_u64* tile_state, uint32_t tile, int lane, uint32_t T0,
-                                              uint32_t T1, uint32_t tpar, uint32_t* par_in, sj_u64* cnt_in,
-                                              Stage1Result* res) {
-    if (tile == 0) {
-        *par_in = 0;
-        *cnt_in = 0;
-        if (lane == 0) ts_store(&tile_state[0], TS_PFX | ((sj_u64)tpar << 40) | (sj_u64)T0);
-        return;
-    }
-    if (lane == 0) ts_store(&tile_state[tile], TS_AGG | ((sj_u64)tpar << 40) | ((sj_u64)T1 << 20) | (sj_u64)T0);
+__device__ __forceinline__ void publish_aggregate(sj_u64* tile_state, uint32_t tile, uint32_t T0, uint32_t T1,
+                                                  uint32_t tpar) {
+    ts_store(&tile_state[tile], TS_AGG | ((sj_u64)tpar << 40) | ((sj_u64)T1 << 20) | (sj_u64)T0);
+}
+__device__ __forceinline__ void publish_prefix(sj_u64* tile_state, uint32_t tile, uint32_t par_after, sj_u64 cnt_after) {
+    ts_store(&tile_state[tile], TS_PFX | ((sj_u64)par_after << 40) | cnt_after);
+}
 
+// Executed by all 64 lanes of a wave.  Returns the parity / structural count entering `tile` (> 0).  Reads only.
+// The window is 64 * K tiles wide (lane i looks at the K tiles tile-1-i*K-j, j < K): the prefix frontier can
+// only advance by one window per store-visibility + load round trip (~1.2 us under load), so the window width
+// over that latency has to stay well above the rate at which tiles are produced (40-90 per us).
+template <int K>
+__device__ __forceinline__ void tile_lookback(const sj_u64* tile_state, uint32_t tile, int lane, uint32_t* par_in,
+                                              sj_u64* cnt_in, Stage1Result* res) {
     sj_u64 g0 = 0, g1 = 0;  // structurals in the tiles already folded, if entered with parity 0 / 1
     uint32_t gpar = 0;      // their combined quote parity
-    long long k = (long long)tile;  // lane i looks at tile k-1-i
+    long long k = (long long)tile;
     uint32_t P = 0;
     sj_u64 C = 0;
     for (;;) {
-        const long long t = k - 1 - lane;
-        sj_u64 v = 0;
-        int J = 64;
+        const long long hi = k - 1 - (long long)lane * K;  // this lane's newest tile
+        sj_u64 v[K];
+        int jp = K;  // this lane's newest PREFIX (K = none)
+        int J = 64;  // first lane that holds a PREFIX
         for (uint32_t spins = 0;; ++spins) {
-            if (t >= 0) v = ts_load(&tile_state[t]);
-            const bool is_pfx = (t < 0) || ((v >> 62) == 2);
-            const bool ready = (t < 0) || (v != 0);
-            const sj_u64 pm = __ballot(is_pfx);
+#pragma unroll
+            for (int j = 0; j < K; ++j) v[j] = (hi - j >= 0) ? ts_load(&tile_state[hi - j]) : TS_PFX;  // "before tile 0": prefix (0, 0)
+            jp = K;
+#pragma unroll
+            for (int j = K - 1; j >= 0; --j)
+                if ((v[j] >> 62) == 2) jp = j;
+            bool ready = true;
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                if (j < jp && v[j] == 0) ready = false;
+            const sj_u64 pm = __ballot(jp < K);
             J = pm ? __builtin_ctzll(pm) : 64;
-            const sj_u64 need = J >= 64 ? ~0ull : ((1ull << J) - 1ull);
+            const sj_u64 need = J >= 63 ? ~0ull : ((2ull << J) - 1ull);  // lanes 0..J
             if ((__ballot(ready) & need) == need) break;
             if (spins > SPIN_LIMIT) {  // never expected: a predecessor tile did not publish
                 if (lane == 0)
@@ -178,51 +190,175 @@ __device__ __forceinline__ void tile_lookback(sj_u64* tile_state, uint32_t tile,
             }
             __builtin_amdgcn_s_sleep(1);
         }
-        const bool in_win = lane < J;  // AGGREGATE tiles newer than the nearest PREFIX
-        const uint32_t apar = in_win ? (uint32_t)(v >> 40) & 1u : 0u;
-        const sj_u64 pb = __ballot(apar);
-        // parity accumulated by the window's tiles OLDER than this lane's tile (higher lanes)
+        // fold this lane's AGGREGATE tiles newer than the nearest PREFIX, oldest first
+        const int nin = lane < J ? K : (lane == J ? jp : 0);
+        uint32_t c0 = 0, c1 = 0, lpar = 0;
+        sj_u64 pfxv = 0;
+#pragma unroll
+        for (int j = K - 1; j >= 0; --j) {
+            if (j == jp) pfxv = v[j];
+            if (j < nin) {
+                const uint32_t a0 = (uint32_t)v[j] & 0xFFFFFu, a1 = (uint32_t)(v[j] >> 20) & 0xFFFFFu;
+                const uint32_t n0 = c0 + (lpar ? a1 : a0), n1 = c1 + (lpar ? a0 : a1);
+                c0 = n0;
+                c1 = n1;
+                lpar ^= (uint32_t)(v[j] >> 40) & 1u;
+            }
+        }
+        const sj_u64 pb = __ballot(lpar);
+        // parity accumulated by the window's tiles OLDER than this lane's tiles (higher lanes)
         const uint32_t q = (lane < 63) ? (uint32_t)__popcll(pb >> (lane + 1)) & 1u : 0u;
-        const uint32_t a0 = (uint32_t)v & 0xFFFFFu, a1 = (uint32_t)(v >> 20) & 0xFFFFFu;
-        const uint32_t w0 = wave_sum(in_win ? (q ? a1 : a0) : 0u);  // window entered with parity 0
-        const uint32_t w1 = wave_sum(in_win ? (q ? a0 : a1) : 0u);  // ... with parity 1
+        const uint32_t w0 = wave_sum(q ? c1 : c0);  // window entered with parity 0
+        const uint32_t w1 = wave_sum(q ? c0 : c1);  // ... with parity 1
         const uint32_t wpar = (uint32_t)__popcll(pb) & 1u;
         if (J < 64) {
-            const long long tj = k - 1 - J;
-            const sj_u64 pv = __shfl(v, J);  // 64-bit shuffle of lane J's granule
-            P = tj < 0 ? 0u : (uint32_t)(pv >> 40) & 1u;
-            C = tj < 0 ? 0ull : (pv & ((1ull << 40) - 1ull));
+            const sj_u64 pv = __shfl(pfxv, J);  // 64-bit shuffle of the PREFIX granule
+            P = (uint32_t)(pv >> 40) & 1u;
+            C = pv & ((1ull << 40) - 1ull);
             C += P ? w1 : w0;
             P ^= wpar;
             C += P ? g1 : g0;
             P ^= gpar;
             break;
         }
-        // no prefix among these 64 tiles: fold the window in front of the suffix and keep walking
+        // no prefix among these tiles: fold the window in front of the suffix and keep walking
         const sj_u64 n0 = (sj_u64)w0 + (wpar ? g1 : g0);
         const sj_u64 n1 = (sj_u64)w1 + (wpar ? g0 : g1);
         g0 = n0;
         g1 = n1;
         gpar ^= wpar;
-        k -= 64;
+        k -= 64 * K;
     }
     *par_in = P;
     *cnt_in = C;
-    if (lane == 0)
-        ts_store(&tile_state[tile], TS_PFX | ((sj_u64)(P ^ tpar) << 40) | (C + (P ? T1 : T0)));
+}
+
+// The SCANNER: workgroup 0 does nothing but turn the workers' per-granule AGGREGATEs, in order, into per-granule
+// inclusive PREFIXes in a second array.  Every granule crosses the chip exactly twice (aggregate: worker ->
+// scanner, prefix: scanner -> worker).  Measured alternative: every worker polling a 64..256-granule window of
+// uncached granules itself, whose traffic and round trips (one per window of distance to the nearest prefix)
+// were the bottleneck.  The workers need a granule's prefix one whole classification after they published its
+// aggregate, so the scanner's latency (load + store visibility, ~3 us) is off the critical path; its THROUGHPUT
+// is not (200+ granules per us): a single wave managed ~250/us, so the four waves take the windows of 256 granules
+// round-robin, do everything that does not depend on the running state (polling, folding 4 granules per lane,
+// cross-lane scans for both entry parities) in parallel, and pass the running (parity, count) from window to
+// window through LDS, which is the only serial step.
+constexpr int SCAN_K = 4;  // granules per lane
+struct ScanHandoff {
+    uint32_t seq;  // window whose entry state is in P / C; 0xFFFFFFFF = a scanner wave gave up
+    uint32_t P;    // in-string parity after the windows scanned so far
+    sj_u64 C;      // structurals in them
+};
+
+__device__ __forceinline__ void scanner_wave(ScanHandoff* hand, int wave, const sj_u64* agg, sj_u64* pfx, uint32_t n,
+                                             int lane, uint32_t* out, sj_u64 out_cap, Stage1Result* res) {
+    __builtin_amdgcn_s_setprio(3);  // everybody waits for these four waves
+    constexpr uint32_t WIN = 64 * SCAN_K;
+    for (sj_u64 win = (sj_u64)wave; win * WIN < n; win += 4) {
+        const sj_u64 first = win * WIN + (sj_u64)lane * SCAN_K;  // this lane's granules
+        sj_u64 v[SCAN_K];
+        for (uint32_t spins = 0;; ++spins) {
+            bool ready = true;
+#pragma unroll
+            for (int j = 0; j < SCAN_K; ++j) {
+                v[j] = first + j < n ? ts_load(&agg[first + j]) : TS_AGG;  // past the end: empty aggregates
+                ready &= v[j] != 0;
+            }
+            if (__ballot(ready) == ~0ull) break;
+            if (spins > SPIN_LIMIT || __hip_atomic_load(&hand->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0xFFFFFFFFu) {
+                // never expected: a worker did not publish
+                if (lane == 0) {
+                    __hip_atomic_fetch_or(&res->status, SJMI_ST_INTERNAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&hand->seq, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                return;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        // the lane's granules as one function {entered outside, inside a string} -> (count, parity)
+        uint32_t c0 = 0, c1 = 0, lp = 0;
+#pragma unroll
+        for (int j = 0; j < SCAN_K; ++j) {
+            const uint32_t a0 = (uint32_t)v[j] & 0xFFFFFu, a1 = (uint32_t)(v[j] >> 20) & 0xFFFFFu;
+            const uint32_t n0 = c0 + (lp ? a1 : a0), n1 = c1 + (lp ? a0 : a1);
+            c0 = n0;
+            c1 = n1;
+            lp ^= (uint32_t)(v[j] >> 40) & 1u;
+        }
+        const sj_u64 pb = __ballot(lp);
+        const uint32_t qrel = (uint32_t)__popcll(pb & ((1ull << lane) - 1ull)) & 1u;  // parity of the lanes in front
+        const uint32_t mine0 = qrel ? c1 : c0, mine1 = qrel ? c0 : c1;                // window entered outside / inside
+        const uint32_t incl0 = wave_incl_scan(mine0, lane), incl1 = wave_incl_scan(mine1, lane);
+        const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)incl0, 63);
+        const uint32_t tot1 = (uint32_t)__builtin_amdgcn_readlane((int)incl1, 63);
+        const uint32_t wpar = (uint32_t)__popcll(pb) & 1u;
+        // ---- the serial step: take the running state from the previous window's wave, pass it on ----
+        uint32_t seq;
+        for (uint32_t spins = 0;; ++spins) {
+            seq = __hip_atomic_load(&hand->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (seq == (uint32_t)win || seq == 0xFFFFFFFFu) break;
+            __builtin_amdgcn_s_sleep(0);
+        }
+        if (seq == 0xFFFFFFFFu) return;
+        const uint32_t P = hand->P;
+        const sj_u64 C = hand->C;
+        const uint32_t P2 = P ^ wpar;
+        const sj_u64 C2 = C + (P ? tot1 : tot0);
+        if (lane == 0) {
+            hand->P = P2;
+            hand->C = C2;
+            __hip_atomic_store(&hand->seq, (uint32_t)win + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        // ---- publish the window's prefixes ----
+        uint32_t q = P ^ qrel;                                          // parity entering the lane's first granule
+        sj_u64 run = C + (P ? incl1 - mine1 : incl0 - mine0);            // structurals before it
+#pragma unroll
+        for (int j = 0; j < SCAN_K; ++j) {
+            run += q ? (uint32_t)(v[j] >> 20) & 0xFFFFFu : (uint32_t)v[j] & 0xFFFFFu;
+            q ^= (uint32_t)(v[j] >> 40) & 1u;
+            if (first + j < n) publish_prefix(pfx, (uint32_t)(first + j), q, run);
+        }
+        if ((win + 1) * WIN >= n && lane == 0) {
+            // that was the last window: count, sentinel, unclosed string
+            res->count = C2;
+            uint32_t e = 0;
+            if (P2) e |= SJMI_ST_UNCLOSED;   // StructuralIndexer.java:297-299
+            if (C2 < out_cap) out[C2] = 0;   // BitIndexes.finish :82-96
+            else e |= SJMI_ST_CAPACITY;
+            if (e) __hip_atomic_fetch_or(&res->status, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// the stage-1 kernel.  One workgroup (4 waves) = one tile of 4 * S * 4 KiB; wave w owns the w-th
-// contiguous quarter of it (S steps of 64 blocks), so every wave's indexes are one contiguous run of
-// the output and can be staged + stored without a workgroup barrier.  Three barriers per tile: the
-// parity table, the count table, the look-back broadcast.
+// the stage-1 kernel: PERSISTENT, WAVE-AUTONOMOUS workers, software-pipelined across granules.
 //
-// Tile assignment: tile = blockIdx (fast, default) or an atomic ticket (safe fallback) -- see the kernel.
-// Variants measured and dropped: 16 KiB workgroup tiles (ticket-bound), persistent
-// waves with static striding (phase-locked waves, VGPR growth from loop-invariant hoisting),
-// wave-autonomous 8-32 KiB tiles with per-wave look-back (chain rate ~100 tiles/us), a dedicated
-// scanner wave (one cross-chip round trip per 256-1024 tiles, still ~100 tiles/us).
+// A worker wave owns one granule of S * 4 KiB at a time (S steps of 64 blocks); its indexes are one contiguous run
+// of the output.  Waves never synchronise with each other: no barrier, no workgroup-level table -- a workgroup is
+// just four waves sharing an LDS allocation.  A per-tile timeline of the earlier one-tile-per-workgroup kernel
+// (tools/trace.py) showed ~8 of every workgroup's ~20 us spent in two bubbles: the first load of a fresh
+// workgroup (~2.7 us) and the wait between "aggregate published" and "prefix known" (~2 us for the slowest
+// predecessor + ~3 us of cross-XCD visibility and load latency); that kernel's time followed
+// T = 0.15 ms + 7 ns * tiles -- the bubbles over the ~1000 resident workgroups.  Here both are overlapped:
+//
+//   iteration k of a wave:   C(k)    classify granule k (its first step was loaded during E(k-2)), publish its
+//                                    AGGREGATE; before the last step, request the PREFIX in front of granule k-1
+//                            E(k-1)  expand granule k-1's masks (parked in LDS) and store its indexes
+//                            park granule k's masks / offsets in the wave's LDS slice (20 bytes per block)
+//
+// so a granule's prefix is needed one whole classification after its aggregate went out, and it comes from the
+// scanner wave (above), not from a look-back by the worker.
+//
+// Granule assignment, FAST mode (default): static striding, granule = k * workers + worker.  RESULTS never depend
+// on scheduling; LIVENESS does: the workers spin on prefixes, so every worker wave and the scanner have to be
+// resident (the host sizes the grid with the occupancy API; the scanner is workgroup 0).  If that ever fails, the
+// bounded spins trip, the launch reports SJMI_ST_INTERNAL and the host re-runs it in SAFE mode: granules by
+// atomic ticket and a decoupled look-back by the worker itself (a granule then only waits for granules some
+// running wave already holds), slower (one exposed atomic per granule) but free of residency assumptions.
+// Variants measured and dropped: one tile per workgroup with the look-back on the critical
+// path (2.8 TB/s), two chain granules per workgroup with a late look-back, persistent workgroups with a barrier
+// per tile and look-back windows of 64..256 granules (uncached polling traffic), 16 KiB workgroup tiles
+// (ticket-bound), wave-autonomous tiles with per-wave look-back (chain rate ~100 tiles/us).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS accesses of one wave execute in order; this only stops the compiler from reordering them
@@ -248,318 +384,479 @@ __device__ __forceinline__ void load_step(StepData& d, const uint8_t* __restrict
     d.halo = *reinterpret_cast<const sj_u64*>(buf + (b > 0 ? b * 64 - 8 : 0));  // unused for block 0
 }
 
+#ifdef SJMI_TRACE  // experiments only (tools/trace.py): per-granule timestamps behind the granule states
+#define SJMI_TRACE_SLOTS 6
+#define SJMI_TSTAMP(g_, k_)                                                                                    \
+    do {                                                                                                       \
+        if (lane == 0) (gstate + 2 * (sj_u64)ngran + (sj_u64)(g_) * SJMI_TRACE_SLOTS)[k_] = wall_clock64();     \
+    } while (0)
+#else
+#define SJMI_TRACE_SLOTS 0
+#define SJMI_TSTAMP(g_, k_) do { } while (0)
+#endif
+
+constexpr uint32_t NO_TILE = 0xFFFFFFFFu;
+constexpr uint32_t TICKET_CLASSES = 8;
+constexpr int LB_K = 1;  // SAFE mode's look-back window = 64 * LB_K granules
+
+// S = 4 KiB steps per granule, LDSW = bytes of LDS per wave
 template <int S>
-struct TileShared {
-    uint32_t wpar[4], wc0[4], wcp[4];
-    uint32_t par_in, tile;
-    sj_u64 cnt_in;
-    alignas(16) uint32_t stage[4][STAGE_CAP];  // per-wave staging of indexes for coalesced stores
+struct Parked {
+    // per-block state of the granule awaiting its prefix, [step][lane]: every lane reads back exactly what it wrote
+    // (LDS as a register file extension); lane 0's meta doubles as the step's base offset
+    sj_u64 pot[S][64];     // potential structurals (StructuralIndexer.java:245-250 before the string mask)
+    sj_u64 m0[S][64];      // structurals if the granule is entered outside a string; inside: pot ^ m0
+    uint32_t meta[S][64];  // [13:0] granule-relative offset of m0's indexes, [27:14] of pot's, [28]/[29] unescaped-
+                           // character error if the granule is entered outside / inside a string
+};
+template <int S, int LDSW>
+union WaveShared {
+    Parked<S> park;
+    // staging of indexes for coalesced stores: overlays the parked state, which is dead from the moment the
+    // expansion has read it into registers until the next granule is parked
+    alignas(16) uint32_t stage[LDSW / 4];
+    static_assert(sizeof(Parked<S>) <= LDSW, "LDS slice too small");
 };
 
-template <int S>
+template <int S, int LDSW, bool SAFE>
 __global__ void __launch_bounds__(256)
 k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out, sj_u64 out_cap,
-         sj_u64* tile_state, uint32_t* ticket, Stage1Result* res, uint32_t dbg) {
-    __shared__ TileShared<S> sh;
+         sj_u64* gstate, uint32_t* ticket, Stage1Result* res, uint32_t ngran, uint32_t dbg) {
+    constexpr int E = S, CAP = LDSW / 4;
+    static_assert(S <= 4, "meta packs 14-bit offsets: at most 4 steps per granule");
+    __shared__ WaveShared<S, LDSW> sh[4];
+    __shared__ ScanHandoff hand;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform => scalar tile math
-    uint32_t tile;
-    if (dbg & FLAG_TICKET) {
-        // SAFE mode: tiles handed out by an atomic ticket, so a tile only waits for tiles whose workgroups already
-        // run, whatever the dispatch order.  Costs ~12 % (one exposed atomic round trip per workgroup).
-        if (threadIdx.x == 0) sh.tile = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        tile = sh.tile;
-    } else {
-        // FAST mode (default): tile = blockIdx.  RESULTS never depend on dispatch order; LIVENESS does: a tile
-        // spins on lower tiles, which is fine as long as lower-numbered workgroups are dispatched no later than
-        // higher ones (what gfx950 is observed to do for 1-D grids).  If that ever fails, the bounded spin in
-        // tile_lookback trips, the launch reports SJMI_ST_INTERNAL and the host re-runs it in SAFE mode.
-        tile = blockIdx.x;
-        if ((dbg & DBG_FAKE_TIMEOUT) && blockIdx.x == 0 && threadIdx.x == 0)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr bool safe = SAFE;  // a separate instantiation: the look-back code costs the fast kernel 8+ VGPRs
+    sj_u64* const agg = gstate;         // AGGREGATE per granule (SAFE mode: overwritten by its PREFIX)
+    sj_u64* const pfx = gstate + ngran;  // the scanner's prefixes (FAST mode)
+    // (xcc, se, sh, cu) of the CU this workgroup runs on, never 0
+    const uint32_t my_cu = (((uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 8) & 0xFFu) |
+                           (((uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) << 8) | 0x80000000u;
+    uint32_t* const scanner_cu = reinterpret_cast<uint32_t*>(res) + WS_SCANNER_CU_WORD;
+    if (!safe && blockIdx.x == 0) {
+        if (threadIdx.x == 0) __hip_atomic_store(scanner_cu, my_cu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((dbg & DBG_FAKE_TIMEOUT) && threadIdx.x == 0)
             __hip_atomic_fetch_or(&res->status, SJMI_ST_INTERNAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            hand.seq = 0;
+            hand.P = 0;
+            hand.C = 0;
+        }
+        __syncthreads();
+        if (!(dbg & DBG_NO_LOOKBACK)) scanner_wave(&hand, wave, agg, pfx, ngran, lane, out, out_cap, res);
+        return;
     }
+    const uint32_t nworkers = (gridDim.x - (safe ? 0u : 1u)) * 4u;
+    const uint32_t worker = (blockIdx.x - (safe ? 0u : 1u)) * 4u + (uint32_t)wave;
+    WaveShared<S, LDSW>& ws = sh[wave];
     const sj_u64 nblocks = len / 64 + 1;  // the reference always processes one tail block (:255-294)
-    const sj_u64 blk0 = (sj_u64)tile * (256 * S) + (sj_u64)wave * (64 * S);  // first block of this wave
     const sj_u64 lt_mask = (1ull << lane) - 1ull;
+    const uint32_t last = ngran - 1;
 
-    sj_u64 pot[S], m0[S];
-    uint32_t fl[S];  // bit0 quote parity, bit1 ue0, bit2 ue1, bit3 utf8 error
+    // Granule assignment.  FAST: dynamic, so that a wave that is slowed down (three neighbours on its SIMD in their
+    // ALU-heavy phase) simply takes fewer granules instead of holding up the chain for everybody (static striding
+    // made every iteration a chip-wide barrier in effect).  One atomic counter saturates at ~88 tickets/us on
+    // gfx950 and 200+ granules/us are needed, so the waves are split into NC classes by worker index, class c
+    // owning the granules == c (mod NC) and its own counter (64 bytes apart); the classes are statistically
+    // identical and the chain's back-pressure keeps them together.  The first granule is static (= worker index),
+    // tickets start behind those.
+    // SAFE: one counter, ticket taken when needed (any running wave can take any granule).
+    const uint32_t NC = safe ? 1u : (nworkers < TICKET_CLASSES ? nworkers : TICKET_CLASSES);
+    const uint32_t cls = worker % NC;
+    uint32_t* const my_ticket = ticket + cls * 16u;                 // one counter per 64-byte line
+    const uint32_t ticket_base = (nworkers - cls + NC - 1u) / NC;  // waves of this class = its static first granules
+    // The scanner's high-priority waves slow the workers that share its CU to ~2/3 speed, and a slow worker holds
+    // up the whole chain (per-CU timeline: tools/trace.py), so those workers retire after their first granule.
+    uint32_t retire = 0;
+    if (!safe && gridDim.x >= 64)
+        retire = __hip_atomic_load(scanner_cu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ^ my_cu;  // 0 = same CU (used a granule later)
+    else
+        retire = 1;
+    uint32_t cur = worker;
+    if (safe) {
+        uint32_t t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    }
+    uint32_t prev = NO_TILE, prev_par = 0, prev_c0 = 0, prev_c1 = 0;  // the parked granule and its aggregate
+    uint32_t err = 0;
+    StepData d;  // the step being loaded / classified (single buffer: re-used as soon as it has been transposed)
+    load_step(d, buf, (sj_u64)cur * (64 * S) + lane, nblocks);
 
-    // ---- phase 1: load, transpose, classify (everything that needs no cross-lane data) ----
-    {
-        StepData d[2];
-        uint32_t slow = 0;  // steps whose carries the 8-byte halo could not resolve (backslash run > 7)
-        load_step(d[0], buf, blk0 + lane, nblocks);
+    for (;;) {
+        const bool have = cur < ngran;  // wave-uniform
+        uint32_t tk = 0;  // FAST mode: the ticket of the next iteration, requested before the last step below
+        sj_u64 pot[S], m[S];
+        uint32_t meta[S];
+        uint32_t wpar = 0, W0 = 0, WP = 0;
+        sj_u64 pf = 0;  // FAST mode: the prefix in front of `prev`, requested before the last step below
+
+        // =================== C: classify granule `cur`, publish its aggregate ===================
+        if (have) {
+            // a granule that is not classified yet holds up every granule behind it; one that is being expanded holds
+            // up nobody: classification gets the SIMD first (equal priorities go oldest wave first, for ever the same
+            // wave last in a persistent kernel: classifications of 25 us instead of 9 in the timeline)
+            __builtin_amdgcn_s_setprio(2);
+            SJMI_TSTAMP(cur, 0);
+            const sj_u64 blk0 = (sj_u64)cur * (64 * S);
+            sj_u64 sm[S];
+            uint32_t fl[S];     // bit0 quote parity, bit1 ue0, bit2 ue1, bit3 utf8 error
+            uint32_t slow = 0;  // steps whose carries the halo could not resolve (long backslash run)
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            // software pipeline, depth 1, ping-pong buffers with compile-time indices; the compiler barrier
-            // keeps hipcc from hoisting every step's loads to the top (16 VGPRs per step in flight)
-            if (s + 1 < S) load_step(d[(s + 1) & 1], buf, blk0 + (sj_u64)(s + 1) * 64 + lane, nblocks);
-            asm volatile("" ::: "memory");
-            const StepData& cur = d[s & 1];
-            const sj_u64 blk = blk0 + (sj_u64)s * 64 + lane;
-            pot[s] = 0;
-            m0[s] = 0;
-            fl[s] = 0;
-            bool unresolved = false;
-            if (blk < nblocks) {
-                const sj_u64 start = blk * 64;
-                const uint32_t w[16] = {cur.q0.x, cur.q0.y, cur.q0.z, cur.q0.w, cur.q1.x, cur.q1.y, cur.q1.z, cur.q1.w,
-                                        cur.q2.x, cur.q2.y, cur.q2.z, cur.q2.w, cur.q3.x, cur.q3.y, cur.q3.z, cur.q3.w};
-                uint32_t e_in = 0, p_in = 0;
-                SjUtf8Carry uc = {0, 0, 0, 0};
-                if (blk > 0) {
-                    uc = sj_utf8_carry(cur.halo);
-                    unresolved = !sj_carry_from_halo(cur.halo, &e_in, &p_in);
-                }
+            for (int s = 0; s < S; ++s) {
+                // software pipeline with ONE buffer: step s was loaded during the algebra of step s-1 (step 0 before
+                // the previous granule's expansion); as soon as it is transposed into planes, its registers take the
+                // loads of step s+1.  (Ping-pong buffers cost 18 more VGPRs = one wave per SIMD at S = 4.)
+                const sj_u64 blk = blk0 + (sj_u64)s * 64 + lane;
+                const uint32_t w[16] = {d.q0.x, d.q0.y, d.q0.z, d.q0.w, d.q1.x, d.q1.y, d.q1.z, d.q1.w,
+                                        d.q2.x, d.q2.y, d.q2.z, d.q2.w, d.q3.x, d.q3.y, d.q3.z, d.q3.w};
+                const sj_u64 halo = d.halo;
                 sj_u64 p[8];
                 sj_transpose_butterfly(w, p);
-                const sj_u64 rem = len - start;
-                sj_mask_tail(p, rem < 64 ? (uint32_t)rem : 64u);
-                // the UTF-8 algebra is skipped when no lane of the wave has a non-ASCII byte or a pending carry
-                const bool need_utf8 = __ballot((p[7] != 0) | ((uc.c1 | uc.c2 | uc.c3 | uc.sec) != 0)) != 0;
-                const SjBlockMasks bm = sj_block(p, e_in, p_in, uc, need_utf8);
-                pot[s] = bm.pot;
-                m0[s] = bm.sm0;
-                fl[s] = bm.qpar | (bm.ue0 << 1) | (bm.ue1 << 2) | (bm.utf8 << 3);
-            }
-            slow |= unresolved ? (1u << s) : 0u;
-        }
-        // Rare: a backslash run longer than the halo reaches a block boundary.  Kept out of the streaming
-        // loop (its dependent byte loads would make hipcc drain the load queue there): redo those blocks.
-        if (__ballot(slow != 0)) {
-            for (int s = 0; s < S; ++s) {
-                if (!((slow >> s) & 1u)) continue;
-                const sj_u64 blk = blk0 + (sj_u64)s * 64 + lane;
-                const sj_u64 start = blk * 64;
-                uint32_t w[16];
-                for (int i = 0; i < 16; ++i) w[i] = reinterpret_cast<const uint32_t*>(buf + start)[i];
-                const sj_u64 halo = *reinterpret_cast<const sj_u64*>(buf + start - 8);
-                uint32_t e_in = 0, p_in = 0;
-                sj_carry_slow(buf, 0, start, &e_in, &p_in);
-                sj_u64 p[8];
-                sj_transpose_ref(w, p);
-                const sj_u64 rem = len - start;
-                sj_mask_tail(p, rem < 64 ? (uint32_t)rem : 64u);
-                const SjBlockMasks bm = sj_block(p, e_in, p_in, sj_utf8_carry(halo));
-                pot[s] = bm.pot;
-                m0[s] = bm.sm0;
-                fl[s] = bm.qpar | (bm.ue0 << 1) | (bm.ue1 << 2) | (bm.utf8 << 3);
-            }
-        }
-    }
-
-    // ---- phase 2: in-string parity prefix inside the tile (order: wave, step, lane) ----
-    uint32_t lpar[S];
-    uint32_t wpar = 0;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const sj_u64 bal = __ballot(fl[s] & 1u);
-        lpar[s] = ((uint32_t)__popcll(bal & lt_mask) & 1u) ^ wpar;
-        wpar ^= (uint32_t)__popcll(bal) & 1u;
-    }
-    if (lane == 0) sh.wpar[wave] = wpar;
-    __syncthreads();
-    uint32_t tpar = 0;
-    {
-        uint32_t before = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (j == wave) before = tpar;  // parity of the waves in front of this one
-            tpar ^= sh.wpar[j];
-        }
-#pragma unroll
-        for (int s = 0; s < S; ++s) lpar[s] ^= before;
-    }
-
-    // ---- phase 3: structurals for tile-entry parity 0, counts for both parities, offsets ----
-    uint32_t ex0[S], exp_[S];
-    uint32_t W0 = 0, WP = 0;  // wave totals
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        m0[s] = lpar[s] ? (pot[s] & m0[s]) : (pot[s] & ~m0[s]);  // StructuralIndexer.java:251
-        const uint32_t c0 = (uint32_t)__popcll(m0[s]), cp = (uint32_t)__popcll(pot[s]);
-        const uint32_t packed = wave_incl_scan(c0 | (cp << 16), lane);  // both <= 4096 per step: no carry
-        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)packed, 63);
-        ex0[s] = W0 + (packed & 0xFFFFu) - c0;   // wave-relative exclusive offsets
-        exp_[s] = WP + (packed >> 16) - cp;
-        W0 += tot & 0xFFFFu;
-        WP += tot >> 16;
-    }
-    if (lane == 0) {
-        sh.wc0[wave] = W0;
-        sh.wcp[wave] = WP;
-    }
-    __syncthreads();
-    uint32_t T0 = 0, TP = 0, base0 = 0, basep = 0;  // tile totals; offsets of this wave inside the tile
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (j == wave) {
-            base0 = T0;
-            basep = TP;
-        }
-        T0 += sh.wc0[j];
-        TP += sh.wcp[j];
-    }
-    const uint32_t T1 = TP - T0;
-
-    // ---- phase 4: decoupled look-back (wave 0), broadcast through LDS ----
-    if (wave == 0) {
-        uint32_t P;
-        sj_u64 C;
-        if (dbg & DBG_NO_LOOKBACK) {  // ablation: no inter-tile chain (indexes land at fake offsets)
-            P = 0;
-            C = ((sj_u64)tile * 5700ull * S) % (out_cap / 2);
-        } else {
-            tile_lookback(tile_state, tile, lane, T0, T1, tpar, &P, &C, res);
-        }
-        if (lane == 0) {
-            sh.par_in = P;
-            sh.cnt_in = C;
-        }
-    }
-    __syncthreads();
-    const uint32_t par_in = sh.par_in;
-    const sj_u64 cnt_in = sh.cnt_in;
-    const uint32_t T = par_in ? T1 : T0;
-
-    // ---- phase 5: final masks + error flags ----
-    uint32_t err = 0;
-    uint32_t pos[S];  // wave-relative position of the lane's next index
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const uint32_t in_par = lpar[s] ^ par_in;  // parity entering this block
-        if (in_par ? (fl[s] & 4u) : (fl[s] & 2u)) err |= SJMI_ST_UNESCAPED;  // :252,:300-302
-        if (fl[s] & 8u) err |= SJMI_ST_UTF8;
-        m0[s] = par_in ? (pot[s] ^ m0[s]) : m0[s];
-        pos[s] = par_in ? (exp_[s] - ex0[s]) : ex0[s];
-    }
-    const bool fits = cnt_in + T < out_cap;  // strict: keeps room for the sentinel
-    if (!fits && T) err |= SJMI_ST_CAPACITY;
-
-    // ---- phase 6: index emission (BitIndexes.write :14-41): expand the wave's masks into its LDS
-    //      slice at their wave-relative positions, then store them with coalesced 4-byte stores ----
-    if (fits && !(dbg & DBG_NO_WRITE)) {
-        uint32_t* stage = sh.stage[wave];
-        const uint32_t WT = par_in ? (WP - W0) : W0;                       // indexes of this wave
-        uint32_t* dst0 = out + cnt_in + (par_in ? (basep - base0) : base0);  // its contiguous output run
-        if (WT + 3 <= STAGE_CAP) {
-            // common case: everything fits in one round, so the per-bit loops need no window test.  Entries are
-            // staged at the same position modulo 4 as their final index, so that whole 16-byte quads of the LDS
-            // slice go out as global_store_dwordx4 (the index array is 16-byte aligned); only the two boundary
-            // quads of the wave's run need element-wise stores.
-            const uint32_t g0 = (uint32_t)((cnt_in + (par_in ? (basep - base0) : base0)) & 3ull);
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const uint32_t bstart = (uint32_t)((blk0 + (sj_u64)s * 64 + lane) * 64);
-                uint32_t* q = stage + g0 + pos[s];
-                for (uint32_t lo = (uint32_t)m0[s]; lo; lo &= lo - 1) *q++ = bstart | (uint32_t)__builtin_ctz(lo);
-                for (uint32_t hi = (uint32_t)(m0[s] >> 32); hi; hi &= hi - 1) *q++ = bstart | 32u | (uint32_t)__builtin_ctz(hi);
-            }
-            wave_lds_fence();
-            const uint32_t span = g0 + WT;
-            uint32_t* gbase = dst0 - g0;  // 16-byte aligned
-            for (uint32_t qi = lane; qi * 4 < span; qi += 64) {
-                const uint4 v = reinterpret_cast<const uint4*>(stage)[qi];
-                const uint32_t lo = qi * 4;
-                if (lo >= g0 && lo + 4 <= span) {
-                    reinterpret_cast<uint4*>(gbase)[qi] = v;
-                } else {
-                    if (lo + 0 >= g0 && lo + 0 < span) gbase[lo + 0] = v.x;
-                    if (lo + 1 >= g0 && lo + 1 < span) gbase[lo + 1] = v.y;
-                    if (lo + 2 >= g0 && lo + 2 < span) gbase[lo + 2] = v.z;
-                    if (lo + 3 >= g0 && lo + 3 < span) gbase[lo + 3] = v.w;
+                asm volatile("" ::: "memory");
+                if (s + 1 < S) load_step(d, buf, blk0 + (sj_u64)(s + 1) * 64 + lane, nblocks);
+                if (s == S - 1 && !safe) {
+                    // requested one step ahead of their use: late enough that granules are started in ticket order
+                    // (a ticket held through a whole slow iteration delays every granule behind it), early enough to
+                    // hide the round trips
+                    if (lane == 0 && retire != 0) tk = __hip_atomic_fetch_add(my_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (prev != NO_TILE && prev != 0) pf = ts_load(&pfx[prev - 1]);
                 }
+                asm volatile("" ::: "memory");
+                pot[s] = 0;
+                sm[s] = 0;
+                fl[s] = 0;
+                bool unresolved = false;
+                if (blk < nblocks) {
+                    const sj_u64 start = blk * 64;
+                    uint32_t e_in = 0, p_in = 0;
+                    SjUtf8Carry uc = {0, 0, 0, 0};
+                    if (blk > 0) {
+                        uc = sj_utf8_carry(halo);
+                        unresolved = !sj_carry_from_halo(halo, &e_in, &p_in);
+                    }
+                    const sj_u64 rem = len - start;
+                    sj_mask_tail(p, rem < 64 ? (uint32_t)rem : 64u);
+                    // the UTF-8 algebra is skipped when no lane of the wave has a non-ASCII byte or a pending carry
+                    const bool need_utf8 = __ballot((p[7] != 0) | ((uc.c1 | uc.c2 | uc.c3 | uc.sec) != 0)) != 0;
+                    const SjBlockMasks bm = sj_block(p, e_in, p_in, uc, need_utf8);
+                    pot[s] = bm.pot;
+                    sm[s] = bm.sm0;
+                    fl[s] = bm.qpar | (bm.ue0 << 1) | (bm.ue1 << 2) | (bm.utf8 << 3);
+                }
+                slow |= unresolved ? (1u << s) : 0u;
             }
-            wave_lds_fence();
-        } else {
-            for (uint32_t base = 0; base < WT; base += STAGE_CAP) {
-                const uint32_t lim = base + STAGE_CAP;
-#pragma unroll
+            // Rare: a backslash run longer than the halo reaches a block boundary.  Kept out of the streaming
+            // loop (its dependent byte loads would make hipcc drain the load queue there): redo those blocks.
+            if (__ballot(slow != 0)) {
                 for (int s = 0; s < S; ++s) {
-                    const uint32_t bstart = (uint32_t)((blk0 + (sj_u64)s * 64 + lane) * 64);
-                    uint32_t lo = (uint32_t)m0[s], hi = (uint32_t)(m0[s] >> 32);
-                    uint32_t ps = pos[s];
-                    while (lo && ps < lim) {
-                        stage[ps - base] = bstart + (uint32_t)__builtin_ctz(lo);
-                        lo &= lo - 1;
-                        ++ps;
-                    }
-                    while (!lo && hi && ps < lim) {
-                        stage[ps - base] = bstart + 32u + (uint32_t)__builtin_ctz(hi);
-                        hi &= hi - 1;
-                        ++ps;
-                    }
-                    m0[s] = (sj_u64)lo | ((sj_u64)hi << 32);
-                    pos[s] = ps;
+                    if (!((slow >> s) & 1u)) continue;
+                    const sj_u64 blk = blk0 + (sj_u64)s * 64 + lane;
+                    const sj_u64 start = blk * 64;
+                    uint32_t w[16];
+                    for (int i = 0; i < 16; ++i) w[i] = reinterpret_cast<const uint32_t*>(buf + start)[i];
+                    const sj_u64 halo = *reinterpret_cast<const sj_u64*>(buf + start - 8);
+                    uint32_t e_in = 0, p_in = 0;
+                    sj_carry_slow(buf, 0, start, &e_in, &p_in);
+                    sj_u64 p[8];
+                    sj_transpose_ref(w, p);
+                    const sj_u64 rem = len - start;
+                    sj_mask_tail(p, rem < 64 ? (uint32_t)rem : 64u);
+                    const SjBlockMasks bm = sj_block(p, e_in, p_in, sj_utf8_carry(halo));
+                    pot[s] = bm.pot;
+                    sm[s] = bm.sm0;
+                    fl[s] = bm.qpar | (bm.ue0 << 1) | (bm.ue1 << 2) | (bm.utf8 << 3);
                 }
-                wave_lds_fence();
-                const uint32_t n = (WT - base) < STAGE_CAP ? (WT - base) : STAGE_CAP;
-                uint32_t* dst = dst0 + base;
-                for (uint32_t i = lane; i < n; i += 64) dst[i] = stage[i];
-                wave_lds_fence();
+            }
+            // in-string parity, structurals and their offsets, all RELATIVE TO THE GRANULE being entered outside a
+            // string (order inside the granule: step, lane)
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const sj_u64 bal = __ballot(fl[s] & 1u);
+                const uint32_t lp = ((uint32_t)__popcll(bal & lt_mask) & 1u) ^ wpar;  // parity entering the block
+                wpar ^= (uint32_t)__popcll(bal) & 1u;
+                m[s] = lp ? (pot[s] & sm[s]) : (pot[s] & ~sm[s]);  // StructuralIndexer.java:251
+                const uint32_t c0 = (uint32_t)__popcll(m[s]), cp = (uint32_t)__popcll(pot[s]);
+                const uint32_t packed = wave_incl_scan(c0 | (cp << 16), lane);  // both <= 4096 per step: no carry
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)packed, 63);
+                const uint32_t ex0 = W0 + (packed & 0xFFFFu) - c0;  // granule-relative exclusive offsets
+                const uint32_t exp_ = WP + (packed >> 16) - cp;
+                W0 += tot & 0xFFFFu;
+                WP += tot >> 16;
+                const uint32_t ue0 = (fl[s] >> 1) & 1u, ue1 = (fl[s] >> 2) & 1u;  // :252 for entry parity 0 / 1
+                if (fl[s] & 8u) err |= SJMI_ST_UTF8;
+                meta[s] = ex0 | (exp_ << 14) | ((lp ? ue1 : ue0) << 28) | ((lp ? ue0 : ue1) << 29);
+            }
+            if (lane == 0 && !(dbg & DBG_NO_LOOKBACK)) {
+                if (safe && cur == 0) publish_prefix(agg, 0, wpar, (sj_u64)W0);  // nothing to look back at
+                else publish_aggregate(agg, cur, W0, WP - W0, wpar);
+            }
+            SJMI_TSTAMP(cur, 1);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        uint32_t nxt = NO_TILE;
+        if (have) {
+            if (safe) {
+                uint32_t t = 0;
+                if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            } else {
+                nxt = retire != 0 ? ((uint32_t)__builtin_amdgcn_readfirstlane((int)tk) + ticket_base) * NC + cls : NO_TILE;
             }
         }
+        // first step of the next granule: in flight during the expansion below (clamped, so harmless without one)
+        load_step(d, buf, (sj_u64)nxt * (64 * S) + lane, nblocks);
+
+        // =================== E: resolve granule `prev`'s prefix, expand and store its indexes ===================
+        if (prev != NO_TILE) {
+            uint32_t pe = 0;  // parity entering the granule
+            sj_u64 cnt_in = 0;
+            SJMI_TSTAMP(prev, 2);
+            if (dbg & DBG_NO_LOOKBACK) {  // ablation: no chain (indexes land at fake offsets)
+                cnt_in = (sj_u64)prev * 512ull * S;  // 1 index slot per 8 input bytes (ablation buffers are sized for it)
+            } else if (prev != 0) {
+                if constexpr (safe) {
+                    tile_lookback<LB_K>(agg, prev, lane, &pe, &cnt_in, res);
+                } else {
+                    for (uint32_t spins = 0; (pf >> 62) != 2; ++spins) {
+                        if (spins > SPIN_LIMIT) {  // never expected: the scanner is not running
+                            if (lane == 0)
+                                __hip_atomic_fetch_or(&res->status, SJMI_ST_INTERNAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                        if (spins) __builtin_amdgcn_s_sleep(1);
+                        pf = ts_load(&pfx[prev - 1]);
+                    }
+                    pe = (uint32_t)(pf >> 40) & 1u;
+                    cnt_in = pf & ((1ull << 40) - 1ull);
+                }
+            }
+            SJMI_TSTAMP(prev, 3);
+            const uint32_t WT_all = pe ? prev_c1 : prev_c0;  // indexes of the granule
+            if (safe && lane == 0 && !(dbg & DBG_NO_LOOKBACK)) {
+                if (prev != 0) publish_prefix(agg, prev, pe ^ prev_par, cnt_in + WT_all);
+                if (prev == last) {
+                    // the granule that holds the final (tail) block finishes the job: count, sentinel, unclosed string
+                    const sj_u64 total = cnt_in + WT_all;
+                    res->count = total;
+                    uint32_t e = 0;
+                    if (pe ^ prev_par) e |= SJMI_ST_UNCLOSED;  // StructuralIndexer.java:297-299
+                    if (total < out_cap) out[total] = 0;       // BitIndexes.finish :82-96
+                    else e |= SJMI_ST_CAPACITY;
+                    if (e) __hip_atomic_fetch_or(&res->status, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            const bool fits = cnt_in + WT_all < out_cap;  // strict: keeps room for the sentinel
+            if (!fits && WT_all) err |= SJMI_ST_CAPACITY;
+            const sj_u64 pblk0 = (sj_u64)prev * (64 * S);
+            uint32_t* stage = ws.stage;
+#pragma unroll
+            for (int g = 0; g < S / E; ++g) {
+                // ---- final masks + error flags of E steps ----
+                sj_u64 mk[E];
+                uint32_t pos[E];  // group-relative position of the lane's next index
+                const uint32_t mb = ws.park.meta[g * E][0];
+                const uint32_t gbase = pe ? ((mb >> 14) & 0x3FFFu) - (mb & 0x3FFFu) : (mb & 0x3FFFu);
+                uint32_t gend = WT_all;
+                if (g + 1 < S / E) {
+                    const uint32_t me = ws.park.meta[(g + 1) * E][0];
+                    gend = pe ? ((me >> 14) & 0x3FFFu) - (me & 0x3FFFu) : (me & 0x3FFFu);
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int s = g * E + e;
+                    const sj_u64 pt = ws.park.pot[s][lane], mm = ws.park.m0[s][lane];
+                    const uint32_t mt = ws.park.meta[s][lane];
+                    mk[e] = pe ? (pt ^ mm) : mm;
+                    const uint32_t o0 = mt & 0x3FFFu, op = (mt >> 14) & 0x3FFFu;
+                    pos[e] = (pe ? op - o0 : o0) - gbase;
+                    if ((mt >> (28 + pe)) & 1u) err |= SJMI_ST_UNESCAPED;  // :252,:300-302
+                }
+                wave_lds_fence();  // the parked state is in registers now: its LDS becomes the staging buffer
+                // ---- index emission (BitIndexes.write :14-41): expand the masks into the wave's LDS slice at
+                //      their relative positions, then store them with coalesced stores ----
+                if (fits && !(dbg & DBG_NO_WRITE)) {
+                    const uint32_t WT = gend - gbase;
+                    uint32_t* dst0 = out + cnt_in + gbase;
+                    if (WT + 3 <= (uint32_t)CAP) {
+                        // common case: everything fits in one round, so the per-bit loops need no window test.  Entries
+                        // are staged at the same position modulo 4 as their final index, so that whole 16-byte quads of
+                        // the LDS slice go out as global_store_dwordx4 (the index array is 16-byte aligned); only the
+                        // two boundary quads of the run need element-wise stores.
+                        const uint32_t g0 = (uint32_t)((cnt_in + gbase) & 3ull);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const uint32_t bstart = (uint32_t)((pblk0 + (sj_u64)(g * E + e) * 64 + lane) * 64);
+                            uint32_t* q = stage + g0 + pos[e];
+                            for (uint32_t lo = (uint32_t)mk[e]; lo; lo &= lo - 1) *q++ = bstart | (uint32_t)__builtin_ctz(lo);
+                            for (uint32_t hi = (uint32_t)(mk[e] >> 32); hi; hi &= hi - 1)
+                                *q++ = bstart | 32u | (uint32_t)__builtin_ctz(hi);
+                        }
+                        wave_lds_fence();
+                        const uint32_t span = g0 + WT;
+                        uint32_t* gbp = dst0 - g0;  // 16-byte aligned
+                        for (uint32_t qi = lane; qi * 4 < span; qi += 64) {
+                            const uint4 v = reinterpret_cast<const uint4*>(stage)[qi];
+                            const uint32_t lo = qi * 4;
+                            if (lo >= g0 && lo + 4 <= span) {
+                                reinterpret_cast<uint4*>(gbp)[qi] = v;
+                            } else {
+                                if (lo + 0 >= g0 && lo + 0 < span) gbp[lo + 0] = v.x;
+                                if (lo + 1 >= g0 && lo + 1 < span) gbp[lo + 1] = v.y;
+                                if (lo + 2 >= g0 && lo + 2 < span) gbp[lo + 2] = v.z;
+                                if (lo + 3 >= g0 && lo + 3 < span) gbp[lo + 3] = v.w;
+                            }
+                        }
+                        wave_lds_fence();
+                    } else {
+                        for (uint32_t base = 0; base < WT; base += CAP) {
+                            const uint32_t lim = base + CAP;
+#pragma unroll
+                            for (int e = 0; e < E; ++e) {
+                                const uint32_t bstart = (uint32_t)((pblk0 + (sj_u64)(g * E + e) * 64 + lane) * 64);
+                                uint32_t lo = (uint32_t)mk[e], hi = (uint32_t)(mk[e] >> 32);
+                                uint32_t p2 = pos[e];
+                                while (lo && p2 < lim) {
+                                    stage[p2 - base] = bstart + (uint32_t)__builtin_ctz(lo);
+                                    lo &= lo - 1;
+                                    ++p2;
+                                }
+                                while (!lo && hi && p2 < lim) {
+                                    stage[p2 - base] = bstart + 32u + (uint32_t)__builtin_ctz(hi);
+                                    hi &= hi - 1;
+                                    ++p2;
+                                }
+                                mk[e] = (sj_u64)lo | ((sj_u64)hi << 32);
+                                pos[e] = p2;
+                            }
+                            wave_lds_fence();
+                            const uint32_t nn = (WT - base) < (uint32_t)CAP ? (WT - base) : (uint32_t)CAP;
+                            uint32_t* dst = dst0 + base;
+                            for (uint32_t i = lane; i < nn; i += 64) dst[i] = stage[i];
+                            wave_lds_fence();
+                        }
+                    }
+                }
+            }
+            SJMI_TSTAMP(prev, 4);
+#ifdef SJMI_TRACE
+            if (lane == 0)
+                (gstate + 2 * (sj_u64)ngran + (sj_u64)prev * SJMI_TRACE_SLOTS)[5] =
+                    (sj_u64)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((sj_u64)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+#endif
+        }
+        if (!have) break;
+        // park granule `cur` until its prefix is known (next iteration)
+        wave_lds_fence();
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            ws.park.pot[s][lane] = pot[s];
+            ws.park.m0[s][lane] = m[s];
+            ws.park.meta[s][lane] = meta[s];
+        }
+        wave_lds_fence();
+        prev = cur;
+        prev_par = wpar;
+        prev_c0 = W0;
+        prev_c1 = WP - W0;
+        cur = nxt;
     }
     // one status update per wave
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) err |= __shfl_xor(err, d);
-    if (lane == 0 && err) __hip_atomic_fetch_or(&res->status, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // the tile that holds the final (tail) block finishes the job: count, sentinel, unclosed string
-    if (threadIdx.x == 0 && tile == (uint32_t)((nblocks - 1) / (256 * S))) {
-        const sj_u64 total = cnt_in + T;
-        res->count = total;
-        uint32_t e = 0;
-        if (par_in ^ tpar) e |= SJMI_ST_UNCLOSED;  // StructuralIndexer.java:297-299
-        if (total < out_cap) out[total] = 0;       // BitIndexes.finish :82-96
-        else e |= SJMI_ST_CAPACITY;
-        if (e) __hip_atomic_fetch_or(&res->status, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    for (int dd = 32; dd >= 1; dd >>= 1) err |= __shfl_xor(err, dd);
+    if (lane == 0 && err && !(dbg & DBG_NO_LOOKBACK))  // (with fake prefixes every granule would report errors)
+        __hip_atomic_fetch_or(&res->status, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
-static uint64_t tiles_for(uint64_t len, int steps) {
+// granules of steps x 4 KiB (one per worker wave and iteration)
+static uint64_t granules_for(uint64_t len, int steps) {
     const uint64_t nblocks = len / 64 + 1;
-    return (nblocks + 256ull * steps - 1) / (256ull * steps);
+    return (nblocks + 64ull * steps - 1) / (64ull * steps);
 }
 
 size_t stage1_workspace_bytes(uint64_t len, int steps) {
-    return WS_TILE_STATE_OFFSET + (size_t)tiles_for(len, steps) * sizeof(sj_u64);
+    return WS_TILE_STATE_OFFSET + (2 + SJMI_TRACE_SLOTS) * (size_t)granules_for(len, steps) * sizeof(sj_u64);
 }
 
 int stage1_pick_steps(uint64_t len) {
-    // small documents: small tiles so that more CUs get work; large: 64 KiB tiles (fewer tickets / granules)
+    // small documents: small granules so that more CUs get work; large: 16 KiB granules
     return len <= (4u << 20) ? 1 : 4;
+}
+
+// workgroups of k_stage1<...> that are resident at the same time on the current device (fast mode's grid)
+template <int S, int LDSW, bool SAFE>
+static hipError_t resident_workgroups(unsigned* out) {
+    static unsigned cached[16] = {0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 16 || !cached[dev]) {
+        int per_cu = 0, cus = 0;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stage1<S, LDSW, SAFE>, 256, 0)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        const unsigned n = (unsigned)(per_cu > 0 ? per_cu : 1) * (unsigned)(cus > 0 ? cus : 1);
+        if (dev < 0 || dev >= 16) {
+            *out = n;
+            return hipSuccess;
+        }
+        cached[dev] = n;
+    }
+    *out = cached[dev];
+    return hipSuccess;
+}
+
+template <int S, int LDSW, bool SAFE>
+static hipError_t launch_mode(const uint8_t* d_buf, uint64_t len, uint32_t* d_out, uint64_t out_cap, sj_u64* gs,
+                                 uint32_t* ticket, Stage1Result* res, uint64_t ngran, hipStream_t stream,
+                                 hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg) {
+    unsigned resident = 0;
+    hipError_t e = resident_workgroups<S, LDSW, SAFE>(&resident);
+    if (e != hipSuccess) return e;
+    const uint64_t want = (ngran + 3) / 4 + (SAFE ? 0 : 1);  // 4 worker waves each + the scanner workgroup
+    const dim3 grid((unsigned)(want < resident ? want : resident)), block(256);
+    if (ev_start && ev_stop) {
+        // the events are attached to the dispatch itself (its start / end timestamps), not recorded around it:
+        // hipEventRecord pairs added 10-25 us of queue latency to a 200 us kernel
+        hipExtLaunchKernelGGL((k_stage1<S, LDSW, SAFE>), grid, block, 0, stream, ev_start, ev_stop, 0, d_buf, (sj_u64)len,
+                              d_out, (sj_u64)out_cap, gs, ticket, res, (uint32_t)ngran, dbg);
+    } else {
+        hipLaunchKernelGGL((k_stage1<S, LDSW, SAFE>), grid, block, 0, stream, d_buf, (sj_u64)len, d_out, (sj_u64)out_cap,
+                           gs, ticket, res, (uint32_t)ngran, dbg);
+    }
+    return hipGetLastError();
+}
+
+template <int S, int LDSW>
+static hipError_t launch_variant(const uint8_t* d_buf, uint64_t len, uint32_t* d_out, uint64_t out_cap, sj_u64* gs,
+                                 uint32_t* ticket, Stage1Result* res, uint64_t ngran, hipStream_t stream,
+                                 hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg) {
+    return (dbg & FLAG_SAFE)
+               ? launch_mode<S, LDSW, true>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg)
+               : launch_mode<S, LDSW, false>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg);
 }
 
 hipError_t stage1_launch(const uint8_t* d_buf, uint64_t len, uint32_t* d_out, uint64_t out_cap, void* d_ws,
                          int steps, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg) {
-    const uint64_t tiles = tiles_for(len, steps);
-    const size_t ws_bytes = WS_TILE_STATE_OFFSET + (size_t)tiles * sizeof(sj_u64);
+    const uint64_t ngran = granules_for(len, steps);
+    const size_t ws_bytes = WS_TILE_STATE_OFFSET + (2 + SJMI_TRACE_SLOTS) * (size_t)ngran * sizeof(sj_u64);
     hipError_t e = hipMemsetAsync(d_ws, 0, ws_bytes, stream);
     if (e != hipSuccess) return e;
     uint8_t* ws = static_cast<uint8_t*>(d_ws);
     uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + WS_TICKET_OFFSET);
     Stage1Result* res = reinterpret_cast<Stage1Result*>(ws + WS_RESULT_OFFSET);
-    sj_u64* ts = reinterpret_cast<sj_u64*>(ws + WS_TILE_STATE_OFFSET);
-    const dim3 grid((unsigned)tiles), block(256);
-    if (ev_start && (e = hipEventRecord(ev_start, stream)) != hipSuccess) return e;
-#define SJMI_LAUNCH(S_)                                                                                           \
-    hipLaunchKernelGGL((k_stage1<S_>), grid, block, 0, stream, d_buf, (sj_u64)len, d_out, (sj_u64)out_cap, ts, ticket, \
-                       res, dbg)
-    switch (steps) {
-    case 1: SJMI_LAUNCH(1); break;
-    case 2: SJMI_LAUNCH(2); break;
-    case 4: SJMI_LAUNCH(4); break;
+    sj_u64* gs = reinterpret_cast<sj_u64*>(ws + WS_TILE_STATE_OFFSET);
+    switch (steps) {  // granule = steps x 4 KiB
+    case 1: e = launch_variant<1, 6144>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg); break;
+    case 2: e = launch_variant<2, 9216>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg); break;
+    case 4: e = launch_variant<4, 9216>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg); break;
     default: return hipErrorInvalidValue;
     }
-#undef SJMI_LAUNCH
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (ev_stop) return hipEventRecord(ev_stop, stream);
-    return hipSuccess;
+    return e;
 }
 
 hipError_t transpose_selftest_launch(const uint32_t* d_words, uint32_t nblocks, uint32_t* d_mismatches,
