@@ -183,7 +183,8 @@ int sjmi_set_tile_mode(sjmi_ctx* ctx, int ticket);
  * on the launch stream (kernel only); sjmi_kernel_time returns their summed duration and count. */
 int sjmi_set_profiling(sjmi_ctx* ctx, int on);
 /* performance-ablation switches for sjmi_stage1_device (1 = no index stores, 2 = no look-back): results are
- * INVALID while any is set (experiments only); 16 = test hook: fast-mode launches report SJMI_ST_INTERNAL. */
+ * INVALID while any is set (experiments only); test hooks with valid results: 16 = fast-mode launches report
+ * SJMI_ST_INTERNAL, 32 = launch only 8 worker workgroups (as if most of the GPU were busy with other work). */
 int sjmi_debug_set_flags(sjmi_ctx* ctx, uint32_t flags);
 int sjmi_kernel_time(sjmi_ctx* ctx, double* sum_ms, uint32_t* launches);
 

@@ -29,6 +29,8 @@ static_assert(sizeof(UnescapeResult) == sizeof(sjmi_unescape_result), "ABI struc
 constexpr uint32_t DBG_NO_WRITE = 1, DBG_NO_LOOKBACK = 2;
 // test hook: a fast-mode launch reports SJMI_ST_INTERNAL as if its look-back spin had tripped
 constexpr uint32_t DBG_FAKE_TIMEOUT = 16;
+// test hook: launch only 8 worker workgroups (as if the GPU were shared with other work)
+constexpr uint32_t DBG_SMALL_GRID = 32;
 // kernel flag (not an ablation): SAFE liveness mode -- no scanner workgroup, every worker looks back itself
 constexpr uint32_t FLAG_SAFE = 0x100;
 // experiments: static tile striding instead of the atomic ticket
@@ -38,7 +40,7 @@ constexpr uint32_t FLAG_STATIC = 0x400;
 constexpr size_t WS_RESULT_OFFSET = 0;        // Stage1Result (16 bytes)
 constexpr uint32_t WS_SCANNER_CU_WORD = 8;    // u32 index from the workspace start: id of the scanner's CU
 constexpr size_t WS_TICKET_OFFSET = 64;       // 8 u32 granule tickets, each alone in its 64-byte line
-constexpr size_t WS_TILE_STATE_OFFSET = 640;  // u64 aggregates[granules], then u64 prefixes[granules]
+constexpr size_t WS_TILE_STATE_OFFSET = 640;   // u64 aggregates[granules], then u64 prefixes[granules]
 
 size_t stage1_workspace_bytes(uint64_t len, int steps);
 int stage1_pick_steps(uint64_t len);

@@ -250,73 +250,141 @@ struct ScanHandoff {
     sj_u64 C;      // structurals in them
 };
 
+__device__ __forceinline__ void scanner_load(sj_u64 v[SCAN_K], const sj_u64* agg, sj_u64 first, uint32_t n) {
+#pragma unroll
+    for (int j = 0; j < SCAN_K; ++j) v[j] = first + j < n ? ts_load(&agg[first + j]) : TS_AGG;  // past the end: empty aggregates
+}
+__device__ __forceinline__ bool scanner_ready(const sj_u64 v[SCAN_K]) {
+    bool ready = true;
+#pragma unroll
+    for (int j = 0; j < SCAN_K; ++j) ready &= v[j] != 0;
+    return ready;
+}
+// the lane's granules as one function {entered outside, inside a string} -> (count, parity)
+__device__ __forceinline__ void scanner_fold(const sj_u64 v[SCAN_K], uint32_t* c0, uint32_t* c1, uint32_t* par) {
+    uint32_t a = 0, b = 0, lp = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_K; ++j) {
+        const uint32_t a0 = (uint32_t)v[j] & 0xFFFFFu, a1 = (uint32_t)(v[j] >> 20) & 0xFFFFFu;
+        const uint32_t n0 = a + (lp ? a1 : a0), n1 = b + (lp ? a0 : a1);
+        a = n0;
+        b = n1;
+        lp ^= (uint32_t)(v[j] >> 40) & 1u;
+    }
+    *c0 = a;
+    *c1 = b;
+    *par = lp;
+}
+// prefixes of the lane's granules, given the parity entering the first one and the structurals before it
+__device__ __forceinline__ void scanner_publish(const sj_u64 v[SCAN_K], sj_u64* pfx, sj_u64 first, uint32_t n, uint32_t q,
+                                                sj_u64 run) {
+#pragma unroll
+    for (int j = 0; j < SCAN_K; ++j) {
+        run += q ? (uint32_t)(v[j] >> 20) & 0xFFFFFu : (uint32_t)v[j] & 0xFFFFFu;
+        q ^= (uint32_t)(v[j] >> 40) & 1u;
+        if (first + j < n) publish_prefix(pfx, (uint32_t)(first + j), q, run);
+    }
+}
+
 __device__ __forceinline__ void scanner_wave(ScanHandoff* hand, int wave, const sj_u64* agg, sj_u64* pfx, uint32_t n,
                                              int lane, uint32_t* out, sj_u64 out_cap, Stage1Result* res) {
     __builtin_amdgcn_s_setprio(3);  // everybody waits for these four waves
     constexpr uint32_t WIN = 64 * SCAN_K;
+    const sj_u64 lt_mask = (1ull << lane) - 1ull;
     for (sj_u64 win = (sj_u64)wave; win * WIN < n; win += 4) {
         const sj_u64 first = win * WIN + (sj_u64)lane * SCAN_K;  // this lane's granules
         sj_u64 v[SCAN_K];
-        for (uint32_t spins = 0;; ++spins) {
-            bool ready = true;
-#pragma unroll
-            for (int j = 0; j < SCAN_K; ++j) {
-                v[j] = first + j < n ? ts_load(&agg[first + j]) : TS_AGG;  // past the end: empty aggregates
-                ready &= v[j] != 0;
-            }
-            if (__ballot(ready) == ~0ull) break;
-            if (spins > SPIN_LIMIT || __hip_atomic_load(&hand->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0xFFFFFFFFu) {
-                // never expected: a worker did not publish
-                if (lane == 0) {
-                    __hip_atomic_fetch_or(&res->status, SJMI_ST_INTERNAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&hand->seq, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                return;
-            }
+        uint32_t P2;
+        sj_u64 C2;
+        // poll the window until it is complete (then most of the work can be done before the running state arrives) or
+        // until the running state has arrived (then the ready part cannot wait for the rest)
+        bool full;
+        for (;;) {
+            scanner_load(v, agg, first, n);
+            full = __ballot(scanner_ready(v)) == ~0ull;
+            if (full) break;
+            const uint32_t seq = __hip_atomic_load(&hand->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (seq == (uint32_t)win || seq == 0xFFFFFFFFu) break;
             __builtin_amdgcn_s_sleep(1);
         }
-        // the lane's granules as one function {entered outside, inside a string} -> (count, parity)
-        uint32_t c0 = 0, c1 = 0, lp = 0;
+        if (full) {
+            // ---- the scanner is behind the workers: the window is complete at the first look.  Everything that does
+            //      not depend on the running state is done before waiting for it ----
+            uint32_t c0, c1, lp;
+            scanner_fold(v, &c0, &c1, &lp);
+            const sj_u64 pb = __ballot(lp);
+            const uint32_t qrel = (uint32_t)__popcll(pb & lt_mask) & 1u;      // parity of the lanes in front
+            const uint32_t mine0 = qrel ? c1 : c0, mine1 = qrel ? c0 : c1;  // window entered outside / inside
+            const uint32_t incl0 = wave_incl_scan(mine0, lane), incl1 = wave_incl_scan(mine1, lane);
+            const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)incl0, 63);
+            const uint32_t tot1 = (uint32_t)__builtin_amdgcn_readlane((int)incl1, 63);
+            // the serial step: take the running state from the previous window's wave, pass it on
+            uint32_t seq;
+            do {
+                seq = __hip_atomic_load(&hand->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } while (seq != (uint32_t)win && seq != 0xFFFFFFFFu);
+            if (seq == 0xFFFFFFFFu) return;
+            const uint32_t P = hand->P;
+            const sj_u64 C = hand->C;
+            P2 = P ^ ((uint32_t)__popcll(pb) & 1u);
+            C2 = C + (P ? tot1 : tot0);
+            if (lane == 0) {
+                hand->P = P2;
+                hand->C = C2;
+                __hip_atomic_store(&hand->seq, (uint32_t)win + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            scanner_publish(v, pfx, first, n, P ^ qrel, C + (P ? incl1 - mine1 : incl0 - mine0));
+        } else {
+            // ---- the scanner is at the workers' frontier: take the running state first, then publish whatever
+            //      becomes ready, lane by lane in order (a worker may be waiting for a prefix in the front part of this
+            //      window while the back part has not even been handed out) ----
+            uint32_t seq;
+            do {
+                seq = __hip_atomic_load(&hand->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } while (seq != (uint32_t)win && seq != 0xFFFFFFFFu);
+            if (seq == 0xFFFFFFFFu) return;
+            uint32_t P = hand->P;
+            sj_u64 C = hand->C;
+            int done = 0;  // lanes already turned into prefixes
+            for (uint32_t spins = 0;; ++spins) {
+                const sj_u64 rb = __ballot(scanner_ready(v));
+                const int nr = ~rb ? __builtin_ctzll(~rb) : 64;  // lanes ready in a row from lane 0
+                if (nr > done) {
+                    const bool act = lane >= done && lane < nr;
+                    uint32_t c0, c1, lp;
+                    scanner_fold(v, &c0, &c1, &lp);
+                    const sj_u64 pb = __ballot(act && lp);
+                    const uint32_t q = P ^ ((uint32_t)__popcll(pb & lt_mask) & 1u);
+                    const uint32_t mine = act ? (q ? c1 : c0) : 0u;
+                    const uint32_t incl = wave_incl_scan(mine, lane);
+                    if (act) scanner_publish(v, pfx, first, n, q, C + (incl - mine));
+                    C += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    P ^= (uint32_t)__popcll(pb) & 1u;
+                    done = nr;
+                    spins = 0;
+                }
+                if (done == 64) break;
+                if (spins > SPIN_LIMIT) {  // never expected: a worker did not publish
+                    if (lane == 0) {
+                        __hip_atomic_fetch_or(&res->status, SJMI_ST_INTERNAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&hand->seq, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                sj_u64 nv[SCAN_K];
+                scanner_load(nv, agg, first, n);
 #pragma unroll
-        for (int j = 0; j < SCAN_K; ++j) {
-            const uint32_t a0 = (uint32_t)v[j] & 0xFFFFFu, a1 = (uint32_t)(v[j] >> 20) & 0xFFFFFu;
-            const uint32_t n0 = c0 + (lp ? a1 : a0), n1 = c1 + (lp ? a0 : a1);
-            c0 = n0;
-            c1 = n1;
-            lp ^= (uint32_t)(v[j] >> 40) & 1u;
-        }
-        const sj_u64 pb = __ballot(lp);
-        const uint32_t qrel = (uint32_t)__popcll(pb & ((1ull << lane) - 1ull)) & 1u;  // parity of the lanes in front
-        const uint32_t mine0 = qrel ? c1 : c0, mine1 = qrel ? c0 : c1;                // window entered outside / inside
-        const uint32_t incl0 = wave_incl_scan(mine0, lane), incl1 = wave_incl_scan(mine1, lane);
-        const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)incl0, 63);
-        const uint32_t tot1 = (uint32_t)__builtin_amdgcn_readlane((int)incl1, 63);
-        const uint32_t wpar = (uint32_t)__popcll(pb) & 1u;
-        // ---- the serial step: take the running state from the previous window's wave, pass it on ----
-        uint32_t seq;
-        for (uint32_t spins = 0;; ++spins) {
-            seq = __hip_atomic_load(&hand->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (seq == (uint32_t)win || seq == 0xFFFFFFFFu) break;
-            __builtin_amdgcn_s_sleep(0);
-        }
-        if (seq == 0xFFFFFFFFu) return;
-        const uint32_t P = hand->P;
-        const sj_u64 C = hand->C;
-        const uint32_t P2 = P ^ wpar;
-        const sj_u64 C2 = C + (P ? tot1 : tot0);
-        if (lane == 0) {
-            hand->P = P2;
-            hand->C = C2;
-            __hip_atomic_store(&hand->seq, (uint32_t)win + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        // ---- publish the window's prefixes ----
-        uint32_t q = P ^ qrel;                                          // parity entering the lane's first granule
-        sj_u64 run = C + (P ? incl1 - mine1 : incl0 - mine0);            // structurals before it
-#pragma unroll
-        for (int j = 0; j < SCAN_K; ++j) {
-            run += q ? (uint32_t)(v[j] >> 20) & 0xFFFFFu : (uint32_t)v[j] & 0xFFFFFu;
-            q ^= (uint32_t)(v[j] >> 40) & 1u;
-            if (first + j < n) publish_prefix(pfx, (uint32_t)(first + j), q, run);
+                for (int j = 0; j < SCAN_K; ++j)
+                    if (lane >= done) v[j] = nv[j];  // (finished lanes keep what their prefixes were computed from)
+            }
+            P2 = P;
+            C2 = C;
+            if (lane == 0) {
+                hand->P = P2;
+                hand->C = C2;
+                __hip_atomic_store(&hand->seq, (uint32_t)win + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
         if ((win + 1) * WIN >= n && lane == 0) {
             // that was the last window: count, sentinel, unclosed string
@@ -460,13 +528,14 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
     // made every iteration a chip-wide barrier in effect).  One atomic counter saturates at ~88 tickets/us on
     // gfx950 and 200+ granules/us are needed, so the waves are split into NC classes by worker index, class c
     // owning the granules == c (mod NC) and its own counter (64 bytes apart); the classes are statistically
-    // identical and the chain's back-pressure keeps them together.  The first granule is static (= worker index),
-    // tickets start behind those.
-    // SAFE: one counter, ticket taken when needed (any running wave can take any granule).
+    // identical and the chain's back-pressure keeps them together (measured: 6 or 8 classes are equally fast, 4
+    // are ticket-bound, 32 drift apart: +2 %).  Only the FIRST granule of every wave is static (= its worker index,
+    // the counters start behind those): taking it by ticket as well would make a launch whose workgroups are not all
+    // resident degrade gracefully instead of timing out into SAFE mode, but costs 6 % (A/B: tools/abtest.sh).
+    // SAFE: one counter, every granule by ticket, taken when needed (any running wave can take any granule).
     const uint32_t NC = safe ? 1u : (nworkers < TICKET_CLASSES ? nworkers : TICKET_CLASSES);
     const uint32_t cls = worker % NC;
     uint32_t* const my_ticket = ticket + cls * 16u;                 // one counter per 64-byte line
-    const uint32_t ticket_base = (nworkers - cls + NC - 1u) / NC;  // waves of this class = its static first granules
     // The scanner's high-priority waves slow the workers that share its CU to ~2/3 speed, and a slow worker holds
     // up the whole chain (per-CU timeline: tools/trace.py), so those workers retire after their first granule.
     uint32_t retire = 0;
@@ -474,12 +543,13 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
         retire = __hip_atomic_load(scanner_cu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ^ my_cu;  // 0 = same CU (used a granule later)
     else
         retire = 1;
-    uint32_t cur = worker;
+    uint32_t cur;
+    const uint32_t ticket_base = safe ? 0u : (nworkers - cls + NC - 1u) / NC;
     if (safe) {
         uint32_t t = 0;
-        if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-    }
+        if (lane == 0) t = __hip_atomic_fetch_add(my_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) * NC + cls;
+    } else cur = worker;
     uint32_t prev = NO_TILE, prev_par = 0, prev_c0 = 0, prev_c1 = 0;  // the parked granule and its aggregate
     uint32_t err = 0;
     StepData d;  // the step being loaded / classified (single buffer: re-used as soon as it has been transposed)
@@ -600,7 +670,7 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
         if (have) {
             if (safe) {
                 uint32_t t = 0;
-                if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) t = __hip_atomic_fetch_add(my_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
             } else {
                 nxt = retire != 0 ? ((uint32_t)__builtin_amdgcn_readfirstlane((int)tk) + ticket_base) * NC + cls : NO_TILE;
@@ -818,6 +888,7 @@ static hipError_t launch_mode(const uint8_t* d_buf, uint64_t len, uint32_t* d_ou
     hipError_t e = resident_workgroups<S, LDSW, SAFE>(&resident);
     if (e != hipSuccess) return e;
     const uint64_t want = (ngran + 3) / 4 + (SAFE ? 0 : 1);  // 4 worker waves each + the scanner workgroup
+    if (dbg & DBG_SMALL_GRID) resident = SAFE ? 8 : 9;  // test hook: far fewer granules in flight than a scanner window
     const dim3 grid((unsigned)(want < resident ? want : resident)), block(256);
     if (ev_start && ev_stop) {
         // the events are attached to the dispatch itself (its start / end timestamps), not recorded around it:

@@ -194,6 +194,26 @@ def test_fast_mode_timeout_falls_back_to_ticket_mode(twitter):
         c.close()
 
 
+def test_few_resident_workgroups(twitter):
+    """Far fewer granules in flight (8 worker workgroups = 64) than one scanner window holds (256): the scanner has to
+    publish prefixes for the front part of a window whose back part has not been handed out yet, in both granule
+    sizes, and the safe mode has to cope as well."""
+    import simdjson_java_amd as S
+    doc = twitter * 8  # 5 MB: 16 KiB granules
+    want, wst = O.stage1(doc)
+    for mode in (0, 1):
+        c = S.Context(device=0, capacity=len(doc) + 64)
+        try:
+            c.set_tile_mode(mode)
+            c.debug_set_flags(32)
+            for steps in (0, 1, 2):
+                c.set_tile_steps(steps)
+                idx, st = c.stage1(doc)
+                assert st == wst == 0 and np.array_equal(idx, want), (mode, steps)
+        finally:
+            c.close()
+
+
 def test_index_capacity_error(ctx):
     import simdjson_java_amd as S
     with pytest.raises(S.SjmiError):

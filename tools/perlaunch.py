@@ -5,6 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import simdjson_java_amd as S
+import simdjson_java_amd.binding as B
+if os.environ.get('SJMI_LIB'):
+    B._LIB = os.environ['SJMI_LIB']
 doc = gzip.open(os.path.join(ROOT, "tests/golden/data/twitter.json.gz")).read()
 reps = 1024
 n = len(doc) * reps
