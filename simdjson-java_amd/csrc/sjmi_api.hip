@@ -184,7 +184,7 @@ int sjmi_unescape_device(sjmi_ctx* c, const void* d_buf, uint64_t len, const voi
                          void* d_string_buffer, uint64_t string_capacity, void* d_result, void* stream) {
     if (!c || !d_buf || !d_indexes || !d_string_buffer || !d_result || len >= (1ull << 32)) return SJMI_ERR_ARG;
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
-    if (!grow(c, &c->d_ws_str, &c->ws_str_bytes, sjmi::unescape_workspace_bytes(count), "hipMalloc(ws_str)"))
+    if (!grow(c, &c->d_ws_str, &c->ws_str_bytes, sjmi::unescape_workspace_bytes(count, len), "hipMalloc(ws_str)"))
         return SJMI_ERR_HIP;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     if (fail(c, "unescape launch",

@@ -15,10 +15,10 @@
 //                   the lane parses the escapes byte by byte; the first failing string (lowest
 //                   structural position) is kept with an atomicMax of the complement;
 //   k_block_sums / k_scan_sums : reduce-then-scan of the 4+len sizes, 4096 structurals per workgroup;
-//   k_str_write   : re-derives each lane's offset (LDS scan + workgroup base); escape-free strings are
-//                   copied by the whole wave (coalesced byte lanes, one string after the other), strings
-//                   with escapes by their own lane -- [be32 length][bytes], bit-identical to the
-//                   reference's stringBuffer.
+//   k_str_write   : re-derives each lane's offset (LDS scan + workgroup base); every lane writes its own
+//                   record: escape-free strings with 16-byte copies at byte granularity, strings with
+//                   escapes byte by byte -- [be32 length][bytes], bit-identical to the reference's
+//                   stringBuffer.
 // Output parity domain: string_buffer[0, total).  With an erroneous string the reference throws at that
 // string; here every other string is still written, the failing one becomes a 4-byte record FF FF FF <code>
 // (the host stage 2 throws when it reaches it) and the first one is also reported by position + code.
@@ -50,12 +50,55 @@ __device__ __forceinline__ uint32_t escape_map(uint32_t e) {
     }
 }
 
+// Where the serial escape parser reads from: the document in global memory, or -- for positions [lo, hi) -- a copy
+// of it in LDS.  A lane parsing a string with escapes does one dependent access per 8-byte window and per escape;
+// against global memory that is a ~1 us round trip each, and the whole wave waits for its slowest lane (a third of
+// twitter.json's waves hold at least one such string), so the string is first pulled into LDS with a few independent
+// wide loads.
+constexpr uint32_t SCR_BYTES = 128;  // per slot: mirrored source bytes / staged output bytes
+constexpr int SCR_SLOTS = 8;         // slots per wave (further strings with escapes in the same wave read global memory)
+struct ByteSrc {
+    const uint8_t* __restrict__ buf;
+    const uint8_t* lds;
+    uint32_t lo, hi;  // lo is 8-byte aligned
+    __device__ __forceinline__ uint32_t byte(uint32_t pos) const {
+        return (pos >= lo && pos < hi) ? lds[pos - lo] : buf[pos];
+    }
+    __device__ __forceinline__ unsigned long long word8(uint32_t a) const {  // a is 8-byte aligned
+        return (a >= lo && a + 8 <= hi) ? *reinterpret_cast<const unsigned long long*>(lds + (a - lo))
+                                        : *reinterpret_cast<const unsigned long long*>(buf + a);
+    }
+};
+// mirror [from & ~7, ...) of the document, up to SCR_BYTES (never reading past `limit`, the padded end of the input)
+__device__ __forceinline__ ByteSrc mirror_string(const uint8_t* __restrict__ buf, uint32_t from, uint32_t to, uint32_t limit,
+                                                 uint8_t* scr) {
+    ByteSrc s;
+    s.buf = buf;
+    s.lds = scr;
+    s.lo = from & ~7u;
+    uint32_t hi = (to + 7u) & ~7u;
+    if (hi > s.lo + SCR_BYTES) hi = s.lo + SCR_BYTES;
+    if (hi > (limit & ~7u)) hi = limit & ~7u;
+    if (hi < s.lo) hi = s.lo;
+    s.hi = hi;
+    for (uint32_t p = s.lo; p < hi; p += 8)
+        *reinterpret_cast<unsigned long long*>(scr + (p - s.lo)) = *reinterpret_cast<const unsigned long long*>(buf + p);
+    return s;
+}
+__device__ __forceinline__ ByteSrc global_source(const uint8_t* __restrict__ buf) {
+    ByteSrc s;
+    s.buf = buf;
+    s.lds = nullptr;
+    s.lo = s.hi = 0;
+    return s;
+}
+
 // CharacterUtils.hexToInt (CharacterUtils.java:241-247): negative if any of the 4 digits is bad
-__device__ __forceinline__ int32_t hex4(const uint8_t* p) {
+__device__ __forceinline__ int32_t hex4(const ByteSrc& in, uint32_t p) {
     int32_t v = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const uint32_t c = p[i];
+        const uint32_t c = in.byte(p + i);
         int32_t d;
         if (c - '0' <= 9u) d = (int32_t)(c - '0');
         else if ((c | 0x20u) - 'a' <= 5u) d = (int32_t)((c | 0x20u) - 'a' + 10);
@@ -75,17 +118,27 @@ __device__ __forceinline__ uint32_t find_close(const uint8_t* __restrict__ buf, 
     return p - 1;
 }
 
+// Output of the serial parser: the first OCAP bytes are staged in LDS and leave with wide stores (flush), the rest
+// (strings whose unescaped form is longer than a slot) goes to global memory byte by byte.
+struct ByteSink {
+    uint8_t* __restrict__ dst;  // final position of the string's bytes
+    uint8_t* lds;               // staging slot or nullptr
+    __device__ __forceinline__ void put(uint32_t n, uint32_t v) const {
+        if (lds != nullptr && n < SCR_BYTES) lds[n] = (uint8_t)v;
+        else dst[n] = (uint8_t)v;
+    }
+};
+
 // One pass of StringParser.doParseString (StringParser.java:29-68) over [open+1, close).
 // WRITE = false: only count.  Returns the unescaped length or -(error code).
 template <bool WRITE>
-__device__ __forceinline__ int64_t unescape_one(const uint8_t* __restrict__ buf, uint32_t open, uint32_t close,
-                                                uint8_t* __restrict__ dst) {
+__device__ __forceinline__ int64_t unescape_one(const ByteSrc& in, uint32_t open, uint32_t close, const ByteSink& out) {
     uint32_t src = open + 1;
     uint32_t n = 0;
     while (src < close) {
         // plain run: one aligned 8-byte load per window instead of a dependent load per byte
         const uint32_t a = src & ~7u;
-        const unsigned long long w = *reinterpret_cast<const unsigned long long*>(buf + a);
+        const unsigned long long w = in.word8(a);
         const uint32_t lo = src - a;
         const uint32_t hi = (close - a) < 8u ? (close - a) : 8u;
         const unsigned long long z = w ^ 0x5C5C5C5C5C5C5C5Cull;
@@ -94,18 +147,18 @@ __device__ __forceinline__ int64_t unescape_one(const uint8_t* __restrict__ buf,
         uint32_t stop = f ? (uint32_t)__builtin_ctzll(f) >> 3 : 8u;
         if (stop > hi) stop = hi;
         for (uint32_t b = lo; b < stop; ++b) {
-            if (WRITE) dst[n] = (uint8_t)(w >> (8 * b));
+            if (WRITE) out.put(n, (uint32_t)(w >> (8 * b)) & 0xFFu);
             ++n;
         }
         src = a + stop;
         if (stop >= hi) continue;  // window (or string) exhausted without an escape
-        const uint32_t e = buf[src + 1];
+        const uint32_t e = in.byte(src + 1);
         if (e == 'u') {                                                   // :45-57
-            int32_t cp = hex4(buf + src + 2);
+            int32_t cp = hex4(in, src + 2);
             src += 6;
             if (cp >= 0xD800 && cp <= 0xDBFF) {                           // parseLowSurrogate :112-124
-                if (!(buf[src] == '\\' && buf[src + 1] == 'u')) return -(int64_t)SJMI_E_LOW_SURROGATE_NO_U;
-                const int32_t low = hex4(buf + src + 2) - 0xDC00;
+                if (!(in.byte(src) == '\\' && in.byte(src + 1) == 'u')) return -(int64_t)SJMI_E_LOW_SURROGATE_NO_U;
+                const int32_t low = hex4(in, src + 2) - 0xDC00;
                 if ((low >> 10) != 0) return -(int64_t)SJMI_E_LOW_SURROGATE_RANGE;
                 cp = (((cp - 0xD800) << 10) | low) + 0x10000;
                 src += 6;
@@ -114,37 +167,175 @@ __device__ __forceinline__ int64_t unescape_one(const uint8_t* __restrict__ buf,
             }
             if (cp < 0) return -(int64_t)SJMI_E_INVALID_UNICODE_ESCAPE;   // storeCodePointInStringBuffer :127-129
             if (cp <= 0x7F) {
-                if (WRITE) dst[n] = (uint8_t)cp;
+                if (WRITE) out.put(n, (uint32_t)cp);
                 n += 1;
             } else if (cp <= 0x7FF) {
                 if (WRITE) {
-                    dst[n] = (uint8_t)((cp >> 6) + 192);
-                    dst[n + 1] = (uint8_t)((cp & 63) + 128);
+                    out.put(n, (uint32_t)((cp >> 6) + 192));
+                    out.put(n + 1, (uint32_t)((cp & 63) + 128));
                 }
                 n += 2;
             } else if (cp <= 0xFFFF) {
                 if (WRITE) {
-                    dst[n] = (uint8_t)((cp >> 12) + 224);
-                    dst[n + 1] = (uint8_t)(((cp >> 6) & 63) + 128);
-                    dst[n + 2] = (uint8_t)((cp & 63) + 128);
+                    out.put(n, (uint32_t)((cp >> 12) + 224));
+                    out.put(n + 1, (uint32_t)(((cp >> 6) & 63) + 128));
+                    out.put(n + 2, (uint32_t)((cp & 63) + 128));
                 }
                 n += 3;
             } else {
                 if (WRITE) {
-                    dst[n] = (uint8_t)((cp >> 18) + 240);
-                    dst[n + 1] = (uint8_t)(((cp >> 12) & 63) + 128);
-                    dst[n + 2] = (uint8_t)(((cp >> 6) & 63) + 128);
-                    dst[n + 3] = (uint8_t)((cp & 63) + 128);
+                    out.put(n, (uint32_t)((cp >> 18) + 240));
+                    out.put(n + 1, (uint32_t)(((cp >> 12) & 63) + 128));
+                    out.put(n + 2, (uint32_t)(((cp >> 6) & 63) + 128));
+                    out.put(n + 3, (uint32_t)((cp & 63) + 128));
                 }
                 n += 4;
             }
         } else {                                                          // :58-61
             const uint32_t r = (e & 0x80u) ? 0u : escape_map(e);
             if (r == 0) return -(int64_t)SJMI_E_ESCAPE_UNEXPECTED;
-            if (WRITE) dst[n] = (uint8_t)r;
+            if (WRITE) out.put(n, r);
             ++n;
             src += 2;
         }
+    }
+    return (int64_t)n;
+}
+
+// byte-granular wide accesses: gfx950 global memory runs in unaligned-access mode, hipcc turns these into
+// global_load/store_dword[x2|x4] at any byte address
+struct __attribute__((packed, aligned(1))) U16B { uint32_t a, b, c, d; };
+struct __attribute__((packed, aligned(1))) U8B { uint32_t a, b; };
+struct __attribute__((packed, aligned(1))) U4B { uint32_t a; };
+struct __attribute__((packed, aligned(1))) U2B { uint16_t a; };
+
+// ---- wave-cooperative unescape ------------------------------------------------------------------
+// One string with escapes, all 64 lanes: lane j owns source byte (window start + j), 64 bytes per step.  The escape
+// structure is bit algebra on ballot masks (the same odd/even backslash-run carry as stage 1,
+// StructuralIndexer.java:211-229): every byte knows whether it is a backslash that starts an escape (emits nothing),
+// an escaped character (emits its translation; a 'u' decodes its four hex digits, a high surrogate also the
+// following \uXXXX), a hex digit consumed by a preceding \u (nothing), or plain (itself).  Output positions are a
+// DPP prefix sum of the per-byte output lengths.  Errors are found by the byte that would raise them in
+// StringParser.doParseString (:45-61, :112-129); the lowest position wins, which is the sequential parser's first
+// error because everything in front of it parsed cleanly.
+// (The lane-serial parser above costs ~15 instructions per source byte with the whole wave waiting for one lane:
+// on twitter.json it was more than half of all instructions of the unescape kernels.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t udpp_add(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v = udpp_add<0x111, 0xF>(v);  // row_shr:1
+    v = udpp_add<0x112, 0xF>(v);  // row_shr:2
+    v = udpp_add<0x114, 0xF>(v);  // row_shr:4
+    v = udpp_add<0x118, 0xF>(v);  // row_shr:8
+    v = udpp_add<0x142, 0xA>(v);  // row_bcast:15 -> rows 1 and 3
+    v = udpp_add<0x143, 0xC>(v);  // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+// four hex digits packed little endian in w (first digit in the low byte): value, or negative (CharacterUtils.java:241-247)
+__device__ __forceinline__ int32_t hex4_word(uint32_t w) {
+    uint32_t v = 0, bad = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t c = (w >> (8 * i)) & 0xFFu;
+        const uint32_t dec = c - '0', alpha = (c | 0x20u) - 'a';
+        const uint32_t d = dec <= 9u ? dec : alpha + 10u;
+        bad |= (dec > 9u) & (alpha > 5u);
+        v = (v << 4) | (d & 15u);
+    }
+    return bad ? -1 : (int32_t)v;
+}
+
+// Must be called by all 64 lanes.  [s, e) = the string's bytes (e = its closing quote).  Returns the unescaped
+// length or -(SJMI_E_* code); the bytes go to dst[0, length).
+__device__ __forceinline__ int64_t unescape_wave(const uint8_t* __restrict__ buf, uint32_t s, uint32_t e,
+                                                 uint8_t* __restrict__ dst, int lane) {
+    const unsigned long long EVEN = 0x5555555555555555ull;
+    unsigned long long prev_U = 0;  // \u escapes ('u' positions) of the previous window
+    uint32_t carry = 0;             // the window's first byte is escaped
+    uint32_t n = 0;
+    for (uint32_t wb = s; wb < e; wb += 64) {
+        const uint32_t pos = wb + (uint32_t)lane;
+        const bool valid = pos < e;
+        const uint32_t c = valid ? (uint32_t)buf[pos] : 0u;
+        const unsigned long long B = __ballot(valid && c == '\\');
+        const unsigned long long bs = B & ~(unsigned long long)carry;
+        const unsigned long long follows = (bs << 1) | carry;
+        const unsigned long long odd_starts = bs & ~EVEN & ~follows;
+        const unsigned long long seq_even = odd_starts + bs;
+        const uint32_t carry_out = seq_even < bs ? 1u : 0u;
+        const unsigned long long escaped = (EVEN ^ (seq_even << 1)) & follows;
+        const bool is_esc = valid && ((escaped >> lane) & 1ull);
+        const bool is_start = ((B & ~escaped) >> lane) & 1ull;  // a backslash that starts an escape
+        const unsigned long long U = __ballot(is_esc && c == 'u');
+        const unsigned long long digits = (U << 1) | (U << 2) | (U << 3) | (U << 4) | (prev_U >> 63) | (prev_U >> 62) |
+                                          (prev_U >> 61) | (prev_U >> 60);
+        uint32_t outlen = 1, out = c, err = 0;  // out: up to 4 output bytes, first in the low byte
+        if (!valid || is_start || ((digits >> lane) & 1ull)) {
+            outlen = 0;
+        } else if (is_esc) {
+            if (c == 'u') {                                                      // StringParser.java:45-57
+                int32_t cp = hex4_word(reinterpret_cast<const U4B*>(buf + pos + 1)->a);
+                if (cp >= 0xD800 && cp <= 0xDBFF) {                              // parseLowSurrogate :112-124
+                    const U8B t = *reinterpret_cast<const U8B*>(buf + pos + 5);  // \ u X X X X
+                    if ((t.a & 0xFFFFu) != (uint32_t)('\\' | ('u' << 8))) {
+                        err = SJMI_E_LOW_SURROGATE_NO_U;
+                    } else {
+                        const int32_t low = hex4_word((t.a >> 16) | (t.b << 16)) - 0xDC00;
+                        if ((low >> 10) != 0) err = SJMI_E_LOW_SURROGATE_RANGE;
+                        else cp = (((cp - 0xD800) << 10) | low) + 0x10000;
+                    }
+                } else if (cp >= 0xDC00 && cp <= 0xDFFF) {
+                    // the second half of a pair (its first half emitted all four bytes), or a lone low surrogate (:53-55)
+                    bool paired = false;
+                    if (pos >= s + 6) {
+                        const bool prev_is_u = lane >= 6 ? ((U >> (lane - 6)) & 1ull) : ((prev_U >> (58 + lane)) & 1ull);
+                        if (prev_is_u) {
+                            const int32_t hi = hex4_word(reinterpret_cast<const U4B*>(buf + pos - 5)->a);
+                            paired = hi >= 0xD800 && hi <= 0xDBFF;
+                        }
+                    }
+                    if (paired) cp = -2;  // emits nothing
+                    else err = SJMI_E_LOW_SURROGATE_RESERVED;
+                }
+                if (!err) {
+                    if (cp == -2) {
+                        outlen = 0;
+                    } else if (cp < 0) {
+                        err = SJMI_E_INVALID_UNICODE_ESCAPE;                     // storeCodePointInStringBuffer :127-129
+                    } else if (cp <= 0x7F) {
+                        out = (uint32_t)cp;
+                    } else if (cp <= 0x7FF) {
+                        outlen = 2;
+                        out = (uint32_t)((cp >> 6) + 192) | ((uint32_t)((cp & 63) + 128) << 8);
+                    } else if (cp <= 0xFFFF) {
+                        outlen = 3;
+                        out = (uint32_t)((cp >> 12) + 224) | ((uint32_t)(((cp >> 6) & 63) + 128) << 8) |
+                              ((uint32_t)((cp & 63) + 128) << 16);
+                    } else {
+                        outlen = 4;
+                        out = (uint32_t)((cp >> 18) + 240) | ((uint32_t)(((cp >> 12) & 63) + 128) << 8) |
+                              ((uint32_t)(((cp >> 6) & 63) + 128) << 16) | ((uint32_t)((cp & 63) + 128) << 24);
+                    }
+                }
+            } else {                                                             // :58-61
+                const uint32_t r = (c & 0x80u) ? 0u : escape_map(c);
+                if (r == 0) err = SJMI_E_ESCAPE_UNEXPECTED;
+                out = r;
+            }
+        }
+        const unsigned long long errs = __ballot(err != 0);
+        if (errs) return -(int64_t)(uint32_t)__builtin_amdgcn_readlane((int)err, __builtin_ctzll(errs));
+        const uint32_t incl = wave_incl_scan_u32(outlen);
+        uint8_t* q = dst + n + (incl - outlen);
+        if (outlen >= 1) q[0] = (uint8_t)out;
+        if (outlen >= 2) q[1] = (uint8_t)(out >> 8);
+        if (outlen >= 3) q[2] = (uint8_t)(out >> 16);
+        if (outlen >= 4) q[3] = (uint8_t)(out >> 24);
+        n += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        prev_U = U;
+        carry = carry_out;
     }
     return (int64_t)n;
 }
@@ -165,36 +356,81 @@ __device__ __forceinline__ bool has_backslash(const uint8_t* __restrict__ buf, u
     return any != 0;
 }
 
+// copy n > 0 bytes between arbitrary byte addresses with the widest accesses that stay INSIDE [0, n) on both sides
+// (tails are done with an overlapping access, so neither a byte before nor after the string is touched)
+__device__ __forceinline__ void copy_bytes(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n) {
+    if (n >= 16) {
+        for (uint32_t t = 0; t + 16 <= n; t += 16) *reinterpret_cast<U16B*>(dst + t) = *reinterpret_cast<const U16B*>(src + t);
+        if (n & 15u) *reinterpret_cast<U16B*>(dst + n - 16) = *reinterpret_cast<const U16B*>(src + n - 16);
+    } else if (n >= 8) {
+        const U8B a = *reinterpret_cast<const U8B*>(src), b = *reinterpret_cast<const U8B*>(src + n - 8);
+        *reinterpret_cast<U8B*>(dst) = a;
+        *reinterpret_cast<U8B*>(dst + n - 8) = b;
+    } else if (n >= 4) {
+        const U4B a = *reinterpret_cast<const U4B*>(src), b = *reinterpret_cast<const U4B*>(src + n - 4);
+        *reinterpret_cast<U4B*>(dst) = a;
+        *reinterpret_cast<U4B*>(dst + n - 4) = b;
+    } else if (n >= 2) {
+        const U2B a = *reinterpret_cast<const U2B*>(src), b = *reinterpret_cast<const U2B*>(src + n - 2);
+        *reinterpret_cast<U2B*>(dst) = a;
+        *reinterpret_cast<U2B*>(dst + n - 2) = b;
+    } else {
+        dst[0] = src[0];
+    }
+}
+
 constexpr uint32_t SIZE_SLOW = 0x80000000u;  // sizes[] flag: the string has escapes (lane-serial path)
 
-// sizes[i] = 4 + unescaped length if structural i opens a string (| SIZE_SLOW if it has escapes), else 0
+// sizes[i] = 4 + unescaped length if structural i opens a string (| SIZE_SLOW if it has escapes), else 0.
+// A string with escapes is unescaped HERE, once: its bytes go to scratch[open + 1 ...] (a buffer as long as the
+// document -- an unescaped string is never longer than its source), so that the write pass copies it like any other
+// string, only from a different base.  A failed string has size 4 | SIZE_SLOW and its SJMI_E_* code in scratch[open].
 __global__ void __launch_bounds__(UNESC_THREADS)
 k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __restrict__ idx, uint64_t count,
-              uint32_t* __restrict__ sizes, UnescapeResult* res) {
+              uint32_t* __restrict__ sizes, uint8_t* __restrict__ scratch, UnescapeResult* res) {
+    const int lane = threadIdx.x & 63;
     const uint64_t i = (uint64_t)blockIdx.x * UNESC_THREADS + threadIdx.x;
-    if (i >= count) return;
-    const uint32_t open = idx[i];
-    uint32_t size = 0;
-    if (buf[open] == '"') {
-        const uint32_t bound = (i + 1 < count) ? idx[i + 1] : len;
-        const uint32_t close = find_close(buf, open, bound);
-        uint32_t slow = 0;
-        int64_t r;
-        if (!close) r = -(int64_t)SJMI_E_INTERNAL;
-        else if (!has_backslash(buf, open + 1, close)) r = (int64_t)(close - open - 1);
-        else {
-            slow = SIZE_SLOW;
-            r = unescape_one<false>(buf, open, close, nullptr);
+    const bool in_range = i < count;  // (no early return: the cooperative path needs whole waves)
+    uint32_t open = 0, close = 0;
+    bool is_str = false, esc = false;
+    if (in_range) {
+        open = idx[i];
+        is_str = buf[open] == '"';
+        if (is_str) {
+            const uint32_t bound = (i + 1 < count) ? idx[i + 1] : len;
+            close = find_close(buf, open, bound);
+            esc = close && has_backslash(buf, open + 1, close);
         }
+    }
+    int64_t r = 0;
+    uint32_t slow = 0;
+    if (is_str) {
+        if (!close) r = -(int64_t)SJMI_E_INTERNAL;
+        else if (!esc) r = (int64_t)(close - open - 1);
+        else slow = SIZE_SLOW;
+    }
+    // strings with escapes: the whole wave unescapes them one after the other
+    for (unsigned long long todo = __ballot(esc); todo; todo &= todo - 1) {
+        const int j = __builtin_ctzll(todo);
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)open, j) + 1u;
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)close, j);
+        const int64_t rj = unescape_wave(buf, s0, e0, scratch + s0, lane);
+        if (lane == j) r = rj;
+    }
+    if (is_str) {
+        if (r == 0) slow = 0;  // (the backslash sweep may be a false positive of a neighbour: an empty string stays empty)
         if (r < 0) {
             // first = lowest position: keep max of the complement so that the memset-to-zero state means "none"
             atomicMax(reinterpret_cast<unsigned long long*>(&res->first_error_inv),
                       ~(((unsigned long long)i << 8) | (unsigned long long)(-r)));
+            scratch[open] = (uint8_t)(-r);  // for the record FF FF FF <code> (the host stage 2 throws when it reaches it)
+            slow = SIZE_SLOW;
             r = 0;
         }
-        size = (4u + (uint32_t)r) | slow;
+        sizes[i] = (4u + (uint32_t)r) | slow;
+    } else if (in_range) {
+        sizes[i] = 0;
     }
-    sizes[i] = size;
 }
 
 __global__ void __launch_bounds__(UNESC_THREADS)
@@ -243,13 +479,50 @@ k_scan_sums(unsigned long long* __restrict__ block_sums, uint32_t nblocks, Unesc
     if (threadIdx.x == 0) res->total_bytes = s_carry;
 }
 
+// ---- k_str_write ------------------------------------------------------------------------------
+// OUTPUT-driven: the string buffer is produced in aligned 16-byte chunks, one lane per chunk, so every store is a
+// full global_store_dwordx4 and the control flow does not depend on the string lengths.  A lane finds the record its
+// chunk starts in (binary search over the pass's record table in LDS), then walks the records that overlap the
+// chunk -- typically "rest of one string, next header, start of the next string" -- and shifts each piece (one
+// byte-granular 16-byte load from the document, or from the scratch copy for a string that had escapes, or the
+// big-endian length) into place.
+// The lane-per-string versions before it were instruction-bound by divergence (8e8 VALU instructions and 5.7e7 store
+// instructions per twitter x1024 launch: every length class, every 16-byte piece of a long string and every string
+// with escapes was a separate pass of the whole wave).
+constexpr int WSUB_ROWS = 4;
+constexpr int WSUB = WSUB_ROWS * UNESC_THREADS;  // records of 1024 structurals per pass
+constexpr uint32_t REC_SCRATCH = 0x80000000u;    // rec_len flag: the bytes are in the scratch copy
+constexpr uint32_t REC_FAILED = 0x40000000u;     // rec_len flag: failed string, low byte = SJMI_E_* code
+
+// overwrite bytes [p, 16) of the 16-byte value (v0, v1) with (w0, w1) shifted up by p bytes; p in [-3, 15],
+// negative p drops the first -p bytes of w
+__device__ __forceinline__ void insert_at(unsigned long long& v0, unsigned long long& v1, unsigned long long w0,
+                                          unsigned long long w1, int p) {
+    if (p < 0) {  // (only the 4-byte header starts before the chunk: w1 == 0)
+        w0 >>= 8 * (-p);
+        p = 0;
+    }
+    const uint32_t s = 8u * ((uint32_t)p & 7u);
+    const unsigned long long keep = (1ull << s) - 1ull;      // s == 0: nothing kept
+    const unsigned long long spill = s ? (w0 >> (64u - s)) : 0ull;
+    if (p < 8) {
+        v0 = (v0 & keep) | (w0 << s);
+        v1 = (w1 << s) | spill;
+    } else {
+        v1 = (v1 & keep) | (w0 << s);
+    }
+}
+
 __global__ void __launch_bounds__(UNESC_THREADS)
 k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __restrict__ idx, uint64_t count,
             const uint32_t* __restrict__ sizes, const unsigned long long* __restrict__ block_offsets,
-            uint8_t* __restrict__ sb, uint64_t sb_cap, UnescapeResult* res) {
-    __shared__ uint32_t s_wave[UNESC_ITEMS][UNESC_THREADS / 64];
+            const uint8_t* __restrict__ scratch, uint8_t* __restrict__ sb, uint64_t sb_cap, UnescapeResult* res) {
+    __shared__ uint32_t s_wave[UNESC_ITEMS][UNESC_THREADS / 64];  // bytes per (row, wave)
+    __shared__ uint32_t s_cnt[UNESC_ITEMS][UNESC_THREADS / 64];   // strings per (row, wave)
+    __shared__ uint32_t rec_d[WSUB], rec_src[WSUB], rec_len[WSUB];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint64_t base = (uint64_t)blockIdx.x * UNESC_TILE;
     uint32_t sz[UNESC_ITEMS], incl[UNESC_ITEMS];
 #pragma unroll
@@ -257,112 +530,123 @@ k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __res
         const uint64_t i = base + (uint64_t)k * UNESC_THREADS + threadIdx.x;
         sz[k] = i < count ? sizes[i] : 0u;
         uint32_t x = sz[k] & ~SIZE_SLOW;
+        const unsigned long long sm = __ballot(x != 0);
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t t = __shfl_up(x, d);
             if (lane >= d) x += t;
         }
         incl[k] = x;
-        if (lane == 63) s_wave[k][wave] = x;
+        if (lane == 63) {
+            s_wave[k][wave] = x;
+            s_cnt[k][wave] = (uint32_t)__popcll(sm);
+        }
     }
     __syncthreads();
     unsigned long long row = block_offsets[blockIdx.x];
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) {  // (string buffer too small: reported once, by the last tile)
+        unsigned long long end = row;
+        for (int k = 0; k < UNESC_ITEMS; ++k)
+            for (int w = 0; w < UNESC_THREADS / 64; ++w) end += s_wave[k][w];
+        if (end > sb_cap) atomicOr(&res->flags, 1u);
+    }
 #pragma unroll 1
-    for (int k = 0; k < UNESC_ITEMS; ++k) {
-        unsigned long long off = row;
-        uint32_t rowsum = 0;
+    for (int k0 = 0; k0 < UNESC_ITEMS; k0 += WSUB_ROWS) {
+        // ---- the records of this pass, in order, as a table in LDS ----
+        const unsigned long long D0 = row;  // where this pass's records start in the string buffer
+        uint32_t nrec = 0;
 #pragma unroll
-        for (int w = 0; w < UNESC_THREADS / 64; ++w) {
-            if (w < wave) off += s_wave[k][w];
-            rowsum += s_wave[k][w];
+        for (int kk = 0; kk < WSUB_ROWS; ++kk) {
+            const int k = k0 + kk;
+            unsigned long long off = row;
+            uint32_t rowsum = 0, r = nrec;
+#pragma unroll
+            for (int w = 0; w < UNESC_THREADS / 64; ++w) {
+                if (w < wave) {
+                    off += s_wave[k][w];
+                    r += s_cnt[k][w];
+                }
+                rowsum += s_wave[k][w];
+                nrec += s_cnt[k][w];
+            }
+            row += rowsum;
+            const uint32_t size = sz[k] & ~SIZE_SLOW;
+            const bool slow = (sz[k] & SIZE_SLOW) != 0;
+            off += incl[k] - size;
+            const bool isrec = size != 0;
+            r += (uint32_t)__popcll(__ballot(isrec) & lt_mask);
+            if (isrec) {
+                const uint32_t open = idx[base + (uint64_t)k * UNESC_THREADS + threadIdx.x];
+                const uint32_t n = size - 4u;
+                rec_d[r] = (uint32_t)(off - D0);
+                rec_src[r] = open + 1u;
+                rec_len[r] = (slow && n == 0) ? (REC_FAILED | scratch[open]) : (n | (slow ? REC_SCRATCH : 0u));
+            }
         }
-        row += rowsum;
-        const uint32_t size = sz[k] & ~SIZE_SLOW;
-        const bool slow = (sz[k] & SIZE_SLOW) != 0;
-        off += incl[k] - size;
-        bool active = size != 0;
-        if (active && off + size > sb_cap) {
-            atomicOr(&res->flags, 1u);  // string buffer too small
-            active = false;
-        }
-        const uint64_t i = base + (uint64_t)k * UNESC_THREADS + threadIdx.x;
-        uint32_t open = 0, n = 0;
-        if (active) {
-            open = idx[i];
-            n = size - 4u;
-            uint8_t* dst = sb + off;
-            uint32_t hdr = n;
-            if (slow || n == 0) {  // escapes, empty or failed: the owning lane does everything
-                const uint32_t bound = (i + 1 < count) ? idx[i + 1] : len;
-                const uint32_t close = find_close(buf, open, bound);
-                if (n == 0) {  // empty or failed string: a failed one is marked FF FF FF <code> for the host stage 2
-                    const int64_t r = close ? unescape_one<false>(buf, open, close, nullptr) : -(int64_t)SJMI_E_INTERNAL;
-                    if (r < 0) hdr = 0xFFFFFF00u | (uint32_t)(-r);
-                } else if (close) {
-                    unescape_one<true>(buf, open, close, dst + 4);
+        __syncthreads();
+        // ---- the pass's part of the string buffer, [D0, D1), in aligned 16-byte chunks ----
+        const unsigned long long D1 = row < sb_cap ? row : sb_cap;
+        for (unsigned long long glo = (D0 & ~15ull) + 16ull * threadIdx.x; glo < D1 && nrec != 0; glo += 16ull * UNESC_THREADS) {
+            const unsigned long long lo = glo > D0 ? glo : D0;
+            const unsigned long long hi = glo + 16 < D1 ? glo + 16 : D1;
+            const uint32_t rel = (uint32_t)(lo - D0);
+            uint32_t r = 0, span = nrec;
+            while (span > 1) {  // last record that starts at or before `lo` (uniform trip count)
+                const uint32_t half = span >> 1;
+                if (rec_d[r + half] <= rel) r += half;
+                span -= half;
+            }
+            unsigned long long v0 = 0, v1 = 0;
+            for (; r < nrec; ++r) {
+                const unsigned long long rd = D0 + rec_d[r];
+                if (rd >= hi) break;
+                const uint32_t L = rec_len[r];
+                const uint32_t n = (L & REC_FAILED) ? 0u : (L & ~REC_SCRATCH);
+                const uint32_t hdr = (L & REC_FAILED) ? (0xFFFFFF00u | (L & 0xFFu)) : n;  // IntegerUtils.toBytes :12-17: big endian
+                if (rd + 4 > lo) insert_at(v0, v1, (unsigned long long)__builtin_bswap32(hdr), 0ull, (int)((long long)rd - (long long)glo));
+                const unsigned long long g0 = rd + 4 > lo ? rd + 4 : lo, g1 = rd + 4 + n < hi ? rd + 4 + n : hi;
+                if (g0 < g1) {
+                    const uint8_t* from = ((L & REC_SCRATCH) ? scratch : buf) + rec_src[r] + (uint32_t)(g0 - (rd + 4));
+                    const U16B w = *reinterpret_cast<const U16B*>(from);
+                    insert_at(v0, v1, (unsigned long long)w.a | ((unsigned long long)w.b << 32),
+                              (unsigned long long)w.c | ((unsigned long long)w.d << 32), (int)(g0 - glo));
                 }
             }
-            dst[0] = (uint8_t)(hdr >> 24);  // IntegerUtils.toBytes :12-17
-            dst[1] = (uint8_t)(hdr >> 16);
-            dst[2] = (uint8_t)(hdr >> 8);
-            dst[3] = (uint8_t)hdr;
-        }
-        // escape-free strings: the wave copies them, 64 consecutive bytes per instruction, EIGHT strings per
-        // round so that eight independent loads are in flight before the first store (a one-string-at-a-time
-        // loop pays a full memory round trip per string)
-        unsigned long long m = __ballot(active && !slow && n != 0);
-        const uint32_t off_lo = (uint32_t)off, off_hi = (uint32_t)(off >> 32);
-        while (m) {
-            uint32_t src[8], cnt[8];
-            unsigned long long d[8];
-            uint8_t v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                cnt[q] = 0;
-                src[q] = 0;
-                d[q] = 0;
-                if (m) {
-                    const int j = __builtin_ctzll(m);
-                    m &= m - 1;
-                    src[q] = (uint32_t)__builtin_amdgcn_readlane((int)open, j) + 1u;
-                    cnt[q] = (uint32_t)__builtin_amdgcn_readlane((int)n, j);
-                    d[q] = (((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)off_hi, j) << 32) |
-                            (uint32_t)__builtin_amdgcn_readlane((int)off_lo, j)) + 4ull;
-                }
+            if (lo == glo && hi == glo + 16) {
+                *reinterpret_cast<uint4*>(sb + glo) = make_uint4((uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32));
+            } else {  // chunk shared with another pass / workgroup (or cut by the capacity): byte stores
+                for (uint32_t j = (uint32_t)(lo - glo); j < (uint32_t)(hi - glo); ++j)
+                    sb[glo + j] = (uint8_t)((j < 8 ? v0 >> (8 * j) : v1 >> (8 * (j - 8))));
             }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = (uint32_t)lane < cnt[q] ? buf[src[q] + lane] : (uint8_t)0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if ((uint32_t)lane < cnt[q]) sb[d[q] + lane] = v[q];
-#pragma unroll
-            for (int q = 0; q < 8; ++q)  // rare: strings longer than 64 bytes
-                for (uint32_t t = 64 + lane; t < cnt[q]; t += 64) sb[d[q] + t] = buf[src[q] + t];
         }
+        __syncthreads();  // the record table is rebuilt by the next pass
     }
 }
 
-size_t unescape_workspace_bytes(uint64_t count) {
+// layout: sizes[count] | block sums | scratch[len + 128] (unescaped copies of the strings that had escapes)
+static size_t ws_sums_offset(uint64_t count) { return (((size_t)count * sizeof(uint32_t) + 63) / 64) * 64 + 64; }
+static size_t ws_scratch_offset(uint64_t count) {
     const uint64_t nblocks = (count + UNESC_TILE - 1) / UNESC_TILE;
-    return 64 + (size_t)count * sizeof(uint32_t) + 64 + (size_t)(nblocks + 1) * sizeof(unsigned long long);
+    return ws_sums_offset(count) + (((size_t)(nblocks + 1) * sizeof(unsigned long long) + 63) / 64) * 64 + 64;
 }
+size_t unescape_workspace_bytes(uint64_t count, uint64_t len) { return ws_scratch_offset(count) + (size_t)len + 128; }
 
 hipError_t unescape_launch(const uint8_t* d_buf, uint64_t len, const uint32_t* d_idx, uint64_t count, uint8_t* d_sb,
                            uint64_t sb_cap, void* d_ws, UnescapeResult* d_res, hipStream_t stream) {
     const uint64_t nblocks = (count + UNESC_TILE - 1) / UNESC_TILE;
     uint8_t* ws = static_cast<uint8_t*>(d_ws);
     uint32_t* sizes = reinterpret_cast<uint32_t*>(ws);
-    unsigned long long* sums =
-        reinterpret_cast<unsigned long long*>(ws + (((size_t)count * sizeof(uint32_t) + 63) / 64) * 64 + 64);
+    unsigned long long* sums = reinterpret_cast<unsigned long long*>(ws + ws_sums_offset(count));
+    uint8_t* scratch = ws + ws_scratch_offset(count);
     hipError_t e = hipMemsetAsync(d_res, 0, sizeof(UnescapeResult), stream);
     if (e != hipSuccess) return e;
     if (count == 0) return hipSuccess;
     hipLaunchKernelGGL(k_str_measure, dim3((unsigned)((count + UNESC_THREADS - 1) / UNESC_THREADS)), dim3(UNESC_THREADS), 0,
-                       stream, d_buf, (uint32_t)len, d_idx, count, sizes, d_res);
+                       stream, d_buf, (uint32_t)len, d_idx, count, sizes, scratch, d_res);
     hipLaunchKernelGGL(k_block_sums, dim3((unsigned)nblocks), dim3(UNESC_THREADS), 0, stream, sizes, count, sums);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, (uint32_t)nblocks, d_res);
     hipLaunchKernelGGL(k_str_write, dim3((unsigned)nblocks), dim3(UNESC_THREADS), 0, stream, d_buf, (uint32_t)len, d_idx,
-                       count, sizes, sums, d_sb, sb_cap, d_res);
+                       count, sizes, sums, scratch, d_sb, sb_cap, d_res);
     return hipGetLastError();
 }
 
