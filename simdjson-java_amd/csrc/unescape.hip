@@ -7,18 +7,17 @@
 // In a valid document the strings are visited in structural order, so record k starts at
 // sum_{j<k}(4 + len_j): that is an exclusive prefix sum, and every string is independent.
 //
-// Four launches over the structural indexes produced by stage 1:
-//   k_str_measure : one lane per structural; a lane whose byte is '"' finds the closing quote (the
-//                   last non-whitespace byte before the next structural -- stage 1 already proved it
-//                   exists) and sweeps the string with aligned 16-byte loads for a backslash.  No
-//                   backslash (98 % of twitter.json's strings): length = raw length, done.  Otherwise
-//                   the lane parses the escapes byte by byte; the first failing string (lowest
-//                   structural position) is kept with an atomicMax of the complement;
-//   k_block_sums / k_scan_sums : reduce-then-scan of the 4+len sizes, 4096 structurals per workgroup;
-//   k_str_write   : re-derives each lane's offset (LDS scan + workgroup base); every lane writes its own
-//                   record: escape-free strings with 16-byte copies at byte granularity, strings with
-//                   escapes byte by byte -- [be32 length][bytes], bit-identical to the reference's
-//                   stringBuffer.
+// Three launches over the structural indexes produced by stage 1:
+//   k_str_measure : one workgroup per 4096 structurals.  A lane whose structural is '"' finds the closing quote
+//                   (the last byte > 0x20 before the next structural -- stage 1 already proved it exists) and looks
+//                   for a backslash.  No backslash (98 % of twitter.json's strings): length = raw length, done.
+//                   Otherwise the WAVE unescapes the string, 64 bytes per step, into a scratch copy; the first
+//                   failing string (lowest structural position) is kept with an atomicMax of the complement.
+//                   Also the tile's byte total;
+//   k_scan_sums   : exclusive scan of the tile totals;
+//   k_str_write   : re-derives every record's offset (LDS scan + tile base) and produces the string buffer in
+//                   aligned 16-byte chunks, one lane per chunk, gathering from the document or the scratch copy --
+//                   [be32 length][bytes], bit-identical to the reference's stringBuffer.
 // Output parity domain: string_buffer[0, total).  With an erroneous string the reference throws at that
 // string; here every other string is still written, the failing one becomes a 4-byte record FF FF FF <code>
 // (the host stage 2 throws when it reaches it) and the first one is also reported by position + code.
@@ -255,10 +254,21 @@ __device__ __forceinline__ int64_t unescape_wave(const uint8_t* __restrict__ buf
     unsigned long long prev_U = 0;  // \u escapes ('u' positions) of the previous window
     uint32_t carry = 0;             // the window's first byte is escaped
     uint32_t n = 0;
-    for (uint32_t wb = s; wb < e; wb += 64) {
+    for (uint32_t wb0 = s; wb0 < e; wb0 += 256) {
+    // (the bytes of four windows are requested together: one memory round trip per 256 source bytes, not per 64)
+    uint32_t cw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t pp = wb0 + 64u * u + (uint32_t)lane;
+        cw[u] = pp < e ? (uint32_t)buf[pp] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t wb = wb0 + 64u * u;
+        if (wb >= e) break;
         const uint32_t pos = wb + (uint32_t)lane;
         const bool valid = pos < e;
-        const uint32_t c = valid ? (uint32_t)buf[pos] : 0u;
+        const uint32_t c = cw[u];
         const unsigned long long B = __ballot(valid && c == '\\');
         const unsigned long long bs = B & ~(unsigned long long)carry;
         const unsigned long long follows = (bs << 1) | carry;
@@ -337,6 +347,7 @@ __device__ __forceinline__ int64_t unescape_wave(const uint8_t* __restrict__ buf
         prev_U = U;
         carry = carry_out;
     }
+    }
     return (int64_t)n;
 }
 
@@ -381,71 +392,181 @@ __device__ __forceinline__ void copy_bytes(uint8_t* __restrict__ dst, const uint
 
 constexpr uint32_t SIZE_SLOW = 0x80000000u;  // sizes[] flag: the string has escapes (lane-serial path)
 
-// sizes[i] = 4 + unescaped length if structural i opens a string (| SIZE_SLOW if it has escapes), else 0.
+// sizes[i] = 4 + unescaped length if structural i opens a string (| SIZE_SLOW if it has escapes), else 0;
+// block_sums[tile] = the tile's bytes.
 // A string with escapes is unescaped HERE, once: its bytes go to scratch[open + 1 ...] (a buffer as long as the
 // document -- an unescaped string is never longer than its source), so that the write pass copies it like any other
 // string, only from a different base.  A failed string has size 4 | SIZE_SLOW and its SJMI_E_* code in scratch[open].
-__global__ void __launch_bounds__(UNESC_THREADS)
-k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __restrict__ idx, uint64_t count,
-              uint32_t* __restrict__ sizes, uint8_t* __restrict__ scratch, UnescapeResult* res) {
-    const int lane = threadIdx.x & 63;
-    const uint64_t i = (uint64_t)blockIdx.x * UNESC_THREADS + threadIdx.x;
-    const bool in_range = i < count;  // (no early return: the cooperative path needs whole waves)
-    uint32_t open = 0, close = 0;
-    bool is_str = false, esc = false;
-    if (in_range) {
-        open = idx[i];
-        is_str = buf[open] == '"';
-        if (is_str) {
-            const uint32_t bound = (i + 1 < count) ? idx[i + 1] : len;
-            close = find_close(buf, open, bound);
-            esc = close && has_backslash(buf, open + 1, close);
+//
+// One workgroup per tile of 4096 structurals, 16 per lane, handled four at a time with all their loads in flight
+// together: the first version (one structural per lane, one wave per 64) was bound by the workgroup dispatcher and by
+// five dependent round trips per structural.  Now two: the structural and its successor, then the 16 bytes at the
+// structural (is it a quote? backslashes in the head of the string) together with the 16 bytes in front of the
+// successor (the closing quote is the last byte > 0x20 there: between it and the next structural there is only
+// whitespace, or that byte would be a structural itself).
+constexpr int MEAS_GROUP = 4;
+constexpr int SPAN_W = 2;  // 64-chunk words of the per-row backslash map: rows spanning up to SPAN_W KiB use it
+
+struct MeasuredString {
+    uint32_t close;  // position of the closing quote (0: not found)
+    bool esc;        // may contain a backslash
+};
+// span_bs: one bit per aligned 16-byte chunk of the document from span_lo on (64 * SPAN_W chunks), set if the chunk
+// holds a backslash; valid if span_ok (the wave's 64 structurals span no more than that)
+__device__ __forceinline__ MeasuredString measure_string(const uint8_t* __restrict__ buf, uint32_t open, uint32_t bound,
+                                                        uint32_t tpos, const U16B& hw, const U16B& tw, uint32_t span_lo,
+                                                        bool span_ok, const unsigned long long span_bs[SPAN_W]) {
+    MeasuredString m;
+    const unsigned long long t0 = (unsigned long long)tw.a | ((unsigned long long)tw.b << 32);
+    const unsigned long long t1 = (unsigned long long)tw.c | ((unsigned long long)tw.d << 32);
+    const unsigned long long H = 0x8080808080808080ull, L = 0x7F7F7F7F7F7F7F7Full;
+    const unsigned long long g0 = (((t0 & L) + 0x5F5F5F5F5F5F5F5Full) | t0) & H;  // 0x80 where the byte is > 0x20
+    const unsigned long long g1 = (((t1 & L) + 0x5F5F5F5F5F5F5F5Full) | t1) & H;
+    uint32_t last = 16;  // index of the last byte > 0x20 in the tail window (16 = none)
+    if (g1) last = 15u - ((uint32_t)__builtin_clzll(g1) >> 3);
+    else if (g0) last = 7u - ((uint32_t)__builtin_clzll(g0) >> 3);
+    const uint32_t cpos = tpos + last;
+    const uint32_t cbyte = last < 16 ? (uint32_t)((last < 8 ? t0 >> (8 * last) : t1 >> (8 * (last - 8))) & 0xFFu) : 0u;
+    if (bound >= 16u && last < 16 && cbyte == '"' && cpos > open) {
+        m.close = cpos;
+        // backslashes: head and tail windows cover strings up to 30 bytes; the middle of longer ones is swept
+        // with byte-granular 16-byte loads (false positives of neighbouring bytes only cost the exact path)
+        const unsigned long long h0 = (unsigned long long)hw.a | ((unsigned long long)hw.b << 32);
+        const unsigned long long h1 = (unsigned long long)hw.c | ((unsigned long long)hw.d << 32);
+        unsigned long long any = 0;
+        const unsigned long long z[4] = {h0 ^ 0x5C5C5C5C5C5C5C5Cull, h1 ^ 0x5C5C5C5C5C5C5C5Cull,
+                                         t0 ^ 0x5C5C5C5C5C5C5C5Cull, t1 ^ 0x5C5C5C5C5C5C5C5Cull};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) any |= ~(((z[q] & L) + L) | z[q]) & H;
+        if (open + 16 < tpos) {  // the string has a middle: bytes [open + 16, tpos)
+            if (span_ok) {
+                // the wave swept the whole stretch of the document its 64 structurals cover (one coalesced load per
+                // KiB, requested together with the head / tail windows): look the middle up in that map
+                const uint32_t ca = (open + 16 - span_lo) >> 4, cb = (tpos - 1 - span_lo) >> 4;  // chunk range, inclusive
+#pragma unroll
+                for (int w = 0; w < SPAN_W; ++w) {
+                    const uint32_t la = ca > 64u * w ? ca - 64u * w : 0u;
+                    const uint32_t lb = cb < 64u * w + 63u ? cb - 64u * w : 63u;
+                    if (ca <= 64u * w + 63u && cb >= 64u * w) any |= span_bs[w] & (~0ull >> (63u - lb)) & (~0ull << la);
+                }
+            } else {
+                // (a wave whose structurals span more than that: four loads in flight per trip; a one-load loop costs a
+                //  long string one memory round trip per 16 bytes, and the whole wave waits for its longest string)
+                for (uint32_t p = open + 16; p < tpos; p += 64) {
+                    U16B w[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const U16B*>(buf + (p + 16u * u < tpos ? p + 16u * u : tpos));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned long long m0 = ((unsigned long long)w[u].a | ((unsigned long long)w[u].b << 32)) ^ 0x5C5C5C5C5C5C5C5Cull;
+                        const unsigned long long m1 = ((unsigned long long)w[u].c | ((unsigned long long)w[u].d << 32)) ^ 0x5C5C5C5C5C5C5C5Cull;
+                        any |= (~(((m0 & L) + L) | m0) & H) | (~(((m1 & L) + L) | m1) & H);
+                    }
+                }
+            }
         }
+        m.esc = any != 0;
+    } else {  // more than 15 bytes of whitespace after the string, or the very beginning of the document
+        m.close = find_close(buf, open, bound);
+        m.esc = m.close && has_backslash(buf, open + 1, m.close);
     }
-    int64_t r = 0;
-    uint32_t slow = 0;
-    if (is_str) {
-        if (!close) r = -(int64_t)SJMI_E_INTERNAL;
-        else if (!esc) r = (int64_t)(close - open - 1);
-        else slow = SIZE_SLOW;
-    }
-    // strings with escapes: the whole wave unescapes them one after the other
-    for (unsigned long long todo = __ballot(esc); todo; todo &= todo - 1) {
-        const int j = __builtin_ctzll(todo);
-        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)open, j) + 1u;
-        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)close, j);
-        const int64_t rj = unescape_wave(buf, s0, e0, scratch + s0, lane);
-        if (lane == j) r = rj;
-    }
-    if (is_str) {
-        if (r == 0) slow = 0;  // (the backslash sweep may be a false positive of a neighbour: an empty string stays empty)
-        if (r < 0) {
-            // first = lowest position: keep max of the complement so that the memset-to-zero state means "none"
-            atomicMax(reinterpret_cast<unsigned long long*>(&res->first_error_inv),
-                      ~(((unsigned long long)i << 8) | (unsigned long long)(-r)));
-            scratch[open] = (uint8_t)(-r);  // for the record FF FF FF <code> (the host stage 2 throws when it reaches it)
-            slow = SIZE_SLOW;
-            r = 0;
-        }
-        sizes[i] = (4u + (uint32_t)r) | slow;
-    } else if (in_range) {
-        sizes[i] = 0;
-    }
+    return m;
 }
 
 __global__ void __launch_bounds__(UNESC_THREADS)
-k_block_sums(const uint32_t* __restrict__ sizes, uint64_t count, unsigned long long* __restrict__ block_sums) {
+k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __restrict__ idx, uint64_t count,
+              uint32_t* __restrict__ sizes, unsigned long long* __restrict__ block_sums, uint8_t* __restrict__ scratch,
+              UnescapeResult* res) {
     __shared__ unsigned long long s_part[UNESC_THREADS / 64];
+    const int lane = threadIdx.x & 63;
     const uint64_t base = (uint64_t)blockIdx.x * UNESC_TILE;
     unsigned long long sum = 0;
+#pragma unroll 1
+    for (int g = 0; g < UNESC_ITEMS; g += MEAS_GROUP) {
+        uint32_t open[MEAS_GROUP], bound[MEAS_GROUP], tpos[MEAS_GROUP];
+        bool in_range[MEAS_GROUP];
 #pragma unroll
-    for (int k = 0; k < UNESC_ITEMS; ++k) {
-        const uint64_t i = base + (uint64_t)k * UNESC_THREADS + threadIdx.x;
-        if (i < count) sum += sizes[i] & ~SIZE_SLOW;
+        for (int q = 0; q < MEAS_GROUP; ++q) {
+            const uint64_t i = base + (uint64_t)(g + q) * UNESC_THREADS + threadIdx.x;
+            in_range[q] = i < count;
+            open[q] = in_range[q] ? idx[i] : 0u;
+            bound[q] = (i + 1 < count) ? idx[i + 1] : len;
+        }
+        U16B hw[MEAS_GROUP], tw[MEAS_GROUP];
+        uint4 sp[MEAS_GROUP][SPAN_W];
+        uint32_t span_lo[MEAS_GROUP];
+        bool span_ok[MEAS_GROUP];
+#pragma unroll
+        for (int q = 0; q < MEAS_GROUP; ++q) {
+            tpos[q] = bound[q] >= 16u ? bound[q] - 16u : 0u;  // (bound < 16: garbage below, fixed up by the slow path)
+            hw[q] = *reinterpret_cast<const U16B*>(buf + open[q]);
+            tw[q] = *reinterpret_cast<const U16B*>(buf + tpos[q]);
+            // the stretch of the document this wave's 64 structurals cover (they are sorted): swept for backslashes
+            // in aligned 16-byte chunks, lane j taking chunks j, j + 64, ... -- if it is no longer than SPAN_W KiB
+            const unsigned long long rm = __ballot(in_range[q]);
+            const int last_lane = rm ? 63 - __builtin_clzll(rm) : 0;
+            span_lo[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)open[q]) & ~15u;
+            const uint32_t span_hi = (uint32_t)__builtin_amdgcn_readlane((int)bound[q], last_lane);
+            span_ok[q] = rm != 0 && span_hi - span_lo[q] <= 1024u * SPAN_W;
+#pragma unroll
+            for (int w = 0; w < SPAN_W; ++w) {
+                const uint32_t p = span_lo[q] + 16u * (64u * w + (uint32_t)lane);
+                sp[q][w] = (span_ok[q] && p < span_hi) ? *reinterpret_cast<const uint4*>(buf + p) : make_uint4(0, 0, 0, 0);
+            }
+        }
+        unsigned long long span_bs[MEAS_GROUP][SPAN_W];
+#pragma unroll
+        for (int q = 0; q < MEAS_GROUP; ++q)
+#pragma unroll
+            for (int w = 0; w < SPAN_W; ++w) {
+                const uint32_t x[4] = {sp[q][w].x ^ 0x5C5C5C5Cu, sp[q][w].y ^ 0x5C5C5C5Cu, sp[q][w].z ^ 0x5C5C5C5Cu,
+                                       sp[q][w].w ^ 0x5C5C5C5Cu};
+                uint32_t hit = 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) hit |= ~(((x[t] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x[t]) & 0x80808080u;
+                span_bs[q][w] = __ballot(hit != 0);
+            }
+#pragma unroll
+        for (int q = 0; q < MEAS_GROUP; ++q) {
+            const uint64_t i = base + (uint64_t)(g + q) * UNESC_THREADS + threadIdx.x;
+            const bool is_str = in_range[q] && (hw[q].a & 0xFFu) == '"';
+            MeasuredString m = {0u, false};
+            if (is_str) m = measure_string(buf, open[q], bound[q], tpos[q], hw[q], tw[q], span_lo[q], span_ok[q], span_bs[q]);
+            int64_t r = 0;
+            uint32_t slow = 0;
+            if (is_str) {
+                if (!m.close) r = -(int64_t)SJMI_E_INTERNAL;
+                else if (!m.esc) r = (int64_t)(m.close - open[q] - 1);
+                else slow = SIZE_SLOW;
+            }
+            // strings with escapes: the whole wave unescapes them one after the other
+            for (unsigned long long todo = __ballot(m.esc); todo; todo &= todo - 1) {
+                const int j = __builtin_ctzll(todo);
+                const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)open[q], j) + 1u;
+                const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)m.close, j);
+                const int64_t rj = unescape_wave(buf, s0, e0, scratch + s0, lane);
+                if (lane == j) r = rj;
+            }
+            if (is_str) {
+                if (r == 0) slow = 0;  // (the backslash sweep may be a false positive of a neighbour: an empty string stays empty)
+                if (r < 0) {
+                    // first = lowest position: keep max of the complement so that the memset-to-zero state means "none"
+                    atomicMax(reinterpret_cast<unsigned long long*>(&res->first_error_inv),
+                              ~(((unsigned long long)i << 8) | (unsigned long long)(-r)));
+                    scratch[open[q]] = (uint8_t)(-r);  // for the record FF FF FF <code> (the host stage 2 throws when it reaches it)
+                    slow = SIZE_SLOW;
+                    r = 0;
+                }
+                sizes[i] = (4u + (uint32_t)r) | slow;
+                sum += 4u + (uint32_t)r;
+            } else if (in_range[q]) {
+                sizes[i] = 0;
+            }
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
+    if (lane == 0) s_part[threadIdx.x >> 6] = sum;
     __syncthreads();
     if (threadIdx.x == 0) block_sums[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
 }
@@ -641,9 +762,8 @@ hipError_t unescape_launch(const uint8_t* d_buf, uint64_t len, const uint32_t* d
     hipError_t e = hipMemsetAsync(d_res, 0, sizeof(UnescapeResult), stream);
     if (e != hipSuccess) return e;
     if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_str_measure, dim3((unsigned)((count + UNESC_THREADS - 1) / UNESC_THREADS)), dim3(UNESC_THREADS), 0,
-                       stream, d_buf, (uint32_t)len, d_idx, count, sizes, scratch, d_res);
-    hipLaunchKernelGGL(k_block_sums, dim3((unsigned)nblocks), dim3(UNESC_THREADS), 0, stream, sizes, count, sums);
+    hipLaunchKernelGGL(k_str_measure, dim3((unsigned)nblocks), dim3(UNESC_THREADS), 0, stream, d_buf, (uint32_t)len, d_idx,
+                       count, sizes, sums, scratch, d_res);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, (uint32_t)nblocks, d_res);
     hipLaunchKernelGGL(k_str_write, dim3((unsigned)nblocks), dim3(UNESC_THREADS), 0, stream, d_buf, (uint32_t)len, d_idx,
                        count, sizes, sums, scratch, d_sb, sb_cap, d_res);

@@ -5,6 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import simdjson_java_amd as S
+import simdjson_java_amd.binding as B
+if os.environ.get('SJMI_LIB'):
+    B._LIB = os.environ['SJMI_LIB']
 doc = gzip.open(os.path.join(ROOT, "tests/golden/data/twitter.json.gz")).read()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n = len(doc) * reps
@@ -23,4 +26,9 @@ ures = torch.zeros(3, dtype=torch.int64, device="cuda")
 for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
     ctx.unescape_device(buf.data_ptr(), n, out.data_ptr(), 55263 * reps, sb.data_ptr(), sb_cap, ures.data_ptr(), st)
 torch.cuda.synchronize()
-print(ures.cpu().numpy())
+import time
+t0 = time.perf_counter()
+for _ in range(20):
+    ctx.unescape_device(buf.data_ptr(), n, out.data_ptr(), 55263 * reps, sb.data_ptr(), sb_cap, ures.data_ptr(), st)
+torch.cuda.synchronize()
+print('unescape total %.3f ms' % ((time.perf_counter() - t0) / 20 * 1e3), ures.cpu().numpy())

@@ -1,12 +1,12 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
+for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY"; do
   tag=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --kernel-trace --output-format csv --pmc $grp -d $R/gpurun_out/upmc_$tag -o p -- python $R/tools/unescape_prof.py 1024 2 > $R/gpurun_out/upmc_$tag.log 2>&1
 done
 python - <<PY
 import csv,glob,collections
-for f in sorted(glob.glob("$R/gpurun_out/upmc_*/**/*counter_collection.csv", recursive=True)):
+for f in sorted(glob.glob("$R/gpurun_out/upmc_SQ_WAVES/**/*counter_collection.csv", recursive=True)):
     agg=collections.defaultdict(lambda:[0.0,0])
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"]
