@@ -645,19 +645,15 @@ k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __res
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint64_t base = (uint64_t)blockIdx.x * UNESC_TILE;
-    uint32_t sz[UNESC_ITEMS], incl[UNESC_ITEMS];
+    // bytes and strings per (row, wave) of the whole tile; the sizes themselves are read again pass by pass (they
+    // would cost 32 VGPRs if kept)
 #pragma unroll
     for (int k = 0; k < UNESC_ITEMS; ++k) {
         const uint64_t i = base + (uint64_t)k * UNESC_THREADS + threadIdx.x;
-        sz[k] = i < count ? sizes[i] : 0u;
-        uint32_t x = sz[k] & ~SIZE_SLOW;
+        uint32_t x = (i < count ? sizes[i] : 0u) & ~SIZE_SLOW;
         const unsigned long long sm = __ballot(x != 0);
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(x, d);
-            if (lane >= d) x += t;
-        }
-        incl[k] = x;
+        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
         if (lane == 63) {
             s_wave[k][wave] = x;
             s_cnt[k][wave] = (uint32_t)__popcll(sm);
@@ -676,6 +672,13 @@ k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __res
         // ---- the records of this pass, in order, as a table in LDS ----
         const unsigned long long D0 = row;  // where this pass's records start in the string buffer
         uint32_t nrec = 0;
+        uint32_t opens[WSUB_ROWS], sz[WSUB_ROWS];  // (requested together: one memory round trip per pass, not per row)
+#pragma unroll
+        for (int kk = 0; kk < WSUB_ROWS; ++kk) {
+            const uint64_t i = base + (uint64_t)(k0 + kk) * UNESC_THREADS + threadIdx.x;
+            opens[kk] = i < count ? idx[i] : 0u;
+            sz[kk] = i < count ? sizes[i] : 0u;
+        }
 #pragma unroll
         for (int kk = 0; kk < WSUB_ROWS; ++kk) {
             const int k = k0 + kk;
@@ -691,13 +694,21 @@ k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __res
                 nrec += s_cnt[k][w];
             }
             row += rowsum;
-            const uint32_t size = sz[k] & ~SIZE_SLOW;
-            const bool slow = (sz[k] & SIZE_SLOW) != 0;
-            off += incl[k] - size;
+            const uint32_t size = sz[kk] & ~SIZE_SLOW;
+            const bool slow = (sz[kk] & SIZE_SLOW) != 0;
+            {
+                uint32_t x = size;  // inclusive scan inside the wave
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t t = __shfl_up(x, d);
+                    if (lane >= d) x += t;
+                }
+                off += x - size;
+            }
             const bool isrec = size != 0;
             r += (uint32_t)__popcll(__ballot(isrec) & lt_mask);
             if (isrec) {
-                const uint32_t open = idx[base + (uint64_t)k * UNESC_THREADS + threadIdx.x];
+                const uint32_t open = opens[kk];
                 const uint32_t n = size - 4u;
                 rec_d[r] = (uint32_t)(off - D0);
                 rec_src[r] = open + 1u;
@@ -717,21 +728,37 @@ k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __res
                 if (rec_d[r + half] <= rel) r += half;
                 span -= half;
             }
-            unsigned long long v0 = 0, v1 = 0;
-            for (; r < nrec; ++r) {
-                const unsigned long long rd = D0 + rec_d[r];
-                if (rd >= hi) break;
-                const uint32_t L = rec_len[r];
+            // A 16-byte chunk overlaps at most 5 records (a record has at least 4 bytes).  First all of them are
+            // looked up and their source bytes requested, then everything is shifted into place: a loop that loads and
+            // inserts record by record pays one memory round trip per record.
+            constexpr int MAXREC = 5;
+            bool hdr_on[MAXREC], dat_on[MAXREC];
+            int hdr_p[MAXREC], dat_p[MAXREC];
+            uint32_t hdr_v[MAXREC];
+            U16B w[MAXREC];
+#pragma unroll
+            for (int j = 0; j < MAXREC; ++j) {
+                const uint32_t rr = r + j < nrec ? r + j : nrec - 1;
+                const unsigned long long rd = D0 + rec_d[rr];
+                const bool on = r + j < nrec && rd < hi;
+                const uint32_t L = rec_len[rr];
                 const uint32_t n = (L & REC_FAILED) ? 0u : (L & ~REC_SCRATCH);
-                const uint32_t hdr = (L & REC_FAILED) ? (0xFFFFFF00u | (L & 0xFFu)) : n;  // IntegerUtils.toBytes :12-17: big endian
-                if (rd + 4 > lo) insert_at(v0, v1, (unsigned long long)__builtin_bswap32(hdr), 0ull, (int)((long long)rd - (long long)glo));
+                hdr_v[j] = __builtin_bswap32((L & REC_FAILED) ? (0xFFFFFF00u | (L & 0xFFu)) : n);  // IntegerUtils.toBytes :12-17: big endian
+                hdr_on[j] = on && rd + 4 > lo;
+                hdr_p[j] = (int)((long long)rd - (long long)glo);
                 const unsigned long long g0 = rd + 4 > lo ? rd + 4 : lo, g1 = rd + 4 + n < hi ? rd + 4 + n : hi;
-                if (g0 < g1) {
-                    const uint8_t* from = ((L & REC_SCRATCH) ? scratch : buf) + rec_src[r] + (uint32_t)(g0 - (rd + 4));
-                    const U16B w = *reinterpret_cast<const U16B*>(from);
-                    insert_at(v0, v1, (unsigned long long)w.a | ((unsigned long long)w.b << 32),
-                              (unsigned long long)w.c | ((unsigned long long)w.d << 32), (int)(g0 - glo));
-                }
+                dat_on[j] = on && g0 < g1;
+                dat_p[j] = (int)(g0 - glo);
+                const uint8_t* from = ((L & REC_SCRATCH) ? scratch : buf) + rec_src[rr] + (uint32_t)(g0 - (rd + 4));
+                if (dat_on[j]) w[j] = *reinterpret_cast<const U16B*>(from);
+            }
+            unsigned long long v0 = 0, v1 = 0;
+#pragma unroll
+            for (int j = 0; j < MAXREC; ++j) {
+                if (hdr_on[j]) insert_at(v0, v1, (unsigned long long)hdr_v[j], 0ull, hdr_p[j]);
+                if (dat_on[j])
+                    insert_at(v0, v1, (unsigned long long)w[j].a | ((unsigned long long)w[j].b << 32),
+                              (unsigned long long)w[j].c | ((unsigned long long)w[j].d << 32), dat_p[j]);
             }
             if (lo == glo && hi == glo + 16) {
                 *reinterpret_cast<uint4*>(sb + glo) = make_uint4((uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32));
