@@ -144,6 +144,22 @@ int sjmi_stage1_batch(sjmi_ctx* ctx, const uint8_t* buf, uint64_t total_len, con
                       uint32_t* indexes, uint64_t index_capacity, uint64_t* index_offsets, uint64_t* count,
                       uint32_t* status);
 
+/* ISOLATED batch: exact per document whatever the other documents contain.  One wave per document, every carry
+ * (in-string parity, escape run, previous scalar, UTF-8 continuation) starts from zero at the document's first byte.
+ * doc_status[k] = the SJMI_ST_* bits document k would get from sjmi_stage1 on its own; a document with a non-zero
+ * status contributes NO indexes (index_offsets[k+1] == index_offsets[k], as the reference throws before its stage 2);
+ * the others get exactly their own indexes (absolute byte offsets).  result.status = OR of the document statuses
+ * (| SJMI_ST_CAPACITY), result.count = indexes written.  The plain batch above is ~3x faster but cannot attribute an
+ * error to a document, and two documents with an unclosed string each cancel in its verdict.
+ * Device form, asynchronous on `stream`; d_doc_status: n_docs uint32. */
+int sjmi_stage1_batch_isolated_device(sjmi_ctx* ctx, const void* d_buf, uint64_t total_len, const void* d_doc_offsets,
+                                      uint64_t n_docs, void* d_indexes, uint64_t index_capacity, void* d_index_offsets,
+                                      void* d_doc_status, void* d_result, void* stream);
+/* Host form. */
+int sjmi_stage1_batch_isolated(sjmi_ctx* ctx, const uint8_t* buf, uint64_t total_len, const uint64_t* doc_offsets,
+                               uint64_t n_docs, uint32_t* indexes, uint64_t index_capacity, uint64_t* index_offsets,
+                               uint32_t* doc_status, uint64_t* count, uint32_t* status);
+
 /* ---- whole parse: SimdJsonParser.parse(byte[], int) (SimdJsonParser.java:35-40) ----------------------------
  * GPU stage 1 + GPU string unescape + the host stage-2 tree builder (C++ mirror of JsonIterator / TapeBuilder /
  * Tape: simdjson-java_amd/csrc/host/simdjson_parser.h).  The tape (Tape.java:5-47 word layout) and string
@@ -157,8 +173,8 @@ int sjmi_parser_parse(sjmi_parser* p, const uint8_t* buf, uint64_t len, const ui
 const char* sjmi_parser_last_message(const sjmi_parser* p);
 /* Batched parse (BASELINE.json configs[4]): one GPU stage-1 + unescape pass over the whole batch, then the host
  * stage 2 per document.  Document k's tape is tape[tape_offsets[k] .. tape_offsets[k+1]) (its STRING payloads are
- * offsets into the shared `strings` buffer) and errors[k] is 0 or its SJMI_E_* grammar error.  A stage-1 error
- * anywhere in the batch is returned as the call's result (> 0) -- see sjmi_stage1_batch. */
+ * offsets into the shared `strings` buffer) and errors[k] is 0 or document k's own SJMI_E_* error -- stage-1 errors
+ * included (isolated batch mode: one broken document never affects another). */
 int sjmi_parser_parse_batch(sjmi_parser* p, const uint8_t* buf, uint64_t total_len, const uint64_t* doc_offsets,
                             uint64_t n_docs, const uint64_t** tape, const uint64_t** tape_offsets,
                             const uint8_t** strings, uint64_t* strings_len, const int32_t** errors);

@@ -60,7 +60,8 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_selftest", "sjmi_set_tile_steps", "sjmi_set_profiling", "sjmi_kernel_time", "sjmi_debug_set_flags", "sjmi_set_tile_mode",
            "sjmi_unescape", "sjmi_unescape_device",
            "sjmi_parser_create", "sjmi_parser_destroy", "sjmi_parser_parse", "sjmi_parser_last_message",
-           "sjmi_stage1_batch", "sjmi_stage1_batch_device", "sjmi_parser_parse_batch"]
+           "sjmi_stage1_batch", "sjmi_stage1_batch_device", "sjmi_parser_parse_batch",
+           "sjmi_stage1_batch_isolated", "sjmi_stage1_batch_isolated_device"]
 
 
 def lib():
@@ -115,6 +116,12 @@ def lib():
         L.sjmi_stage1_batch_device.restype = C.c_int
         L.sjmi_stage1_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                                C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sjmi_stage1_batch_isolated.restype = C.c_int
+        L.sjmi_stage1_batch_isolated.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                                 C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sjmi_stage1_batch_isolated_device.restype = C.c_int
+        L.sjmi_stage1_batch_isolated_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                                        C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sjmi_parser_parse_batch.restype = C.c_int
         L.sjmi_parser_parse_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p]
@@ -188,6 +195,23 @@ class Context:
                                             idx.ctypes.data, cap, io.ctypes.data, C.addressof(cnt), C.addressof(st)),
                     "sjmi_stage1_batch")
         return idx[:cnt.value].copy(), io, st.value
+
+    def stage1_batch_isolated(self, data, doc_offsets):
+        """Isolated batched host path: -> (indexes, index_offsets[np.uint64 n+1], doc_status[np.uint32 n], status)."""
+        a = np.frombuffer(bytes(data), dtype=np.uint8)
+        offs = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+        n = offs.size - 1
+        cap = a.size + 2
+        idx = np.empty(max(cap, 1), dtype=np.uint32)
+        io = np.zeros(n + 1, dtype=np.uint64)
+        ds = np.zeros(max(n, 1), dtype=np.uint32)
+        cnt = C.c_uint64(0)
+        st = C.c_uint32(0)
+        self._check(lib().sjmi_stage1_batch_isolated(self._h, a.ctypes.data if a.size else None, a.size, offs.ctypes.data, n,
+                                                     idx.ctypes.data, cap, io.ctypes.data, ds.ctypes.data, C.addressof(cnt),
+                                                     C.addressof(st)), "sjmi_stage1_batch_isolated")
+        assert idx[cnt.value] == 0, "sentinel missing"
+        return idx[:cnt.value].copy(), io, ds[:n], st.value
 
     def unescape(self, string_capacity):
         """Unescape every string of the document of the last stage1() call.

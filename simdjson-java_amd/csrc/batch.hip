@@ -8,11 +8,14 @@
 // Why one launch is exact for well-formed batches: stage 1 is alignment invariant (SURVEY.md 8(a) a3'), a closed
 // document leaves the in-string parity at 0, and the whitespace separator clears the prevScalar / escape
 // carries, so the structural indexes of the concatenation are the union of the documents' own indexes shifted by
-// their offsets.  A document with an unclosed string or broken UTF-8 poisons the BATCH verdict (status is per
-// launch); isolating it needs segmented carries -- listed as next in DESIGN.md.
+// their offsets.  That launch cannot tell WHICH document is broken, though, and two documents with an unclosed
+// string each even cancel in the batch verdict.  The ISOLATED mode below is exact per document whatever the
+// others contain: one wave per document, every carry starts from zero at the document's first byte, a document
+// that fails stage 1 gets its own SJMI_ST_* bits and contributes no indexes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "sj_block.h"
 #include "stage1.h"
 
 namespace sjmi {
@@ -38,6 +41,174 @@ hipError_t split_docs_launch(const uint32_t* d_idx, const Stage1Result* d_res, c
                              uint64_t n_docs, unsigned long long* d_index_offsets, hipStream_t stream) {
     hipLaunchKernelGGL(k_split_docs, dim3((unsigned)((n_docs + 1 + 255) / 256)), dim3(256), 0, stream, d_idx, d_res,
                        d_doc_offsets, n_docs, d_index_offsets);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// isolated mode: one wave per document (documents of a batch are small; a long one is walked 4 KiB at a time)
+// ---------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(1))) DocU16 { uint32_t a, b, c, d; };
+struct __attribute__((packed, aligned(1))) DocU8 { unsigned long long v; };
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t bdpp_add(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+}
+__device__ __forceinline__ uint32_t doc_incl_scan(uint32_t v) {
+    v = bdpp_add<0x111, 0xF>(v);
+    v = bdpp_add<0x112, 0xF>(v);
+    v = bdpp_add<0x114, 0xF>(v);
+    v = bdpp_add<0x118, 0xF>(v);
+    v = bdpp_add<0x142, 0xA>(v);
+    v = bdpp_add<0x143, 0xC>(v);
+    return v;
+}
+
+// WRITE = false: doc_status[k] and counts[k] (0 for a failing document); WRITE = true: the indexes of the passing
+// documents at index_offsets[k].  Same per-block algebra as the single-document kernel (sj_block.h); blocks are counted
+// from the document's first byte, so the loads are byte-granular.
+template <bool WRITE>
+__global__ void __launch_bounds__(256)
+k_doc_pass(const uint8_t* __restrict__ buf, const unsigned long long* __restrict__ doc_offsets, uint64_t n_docs,
+           uint32_t* __restrict__ counts, uint32_t* __restrict__ doc_status,
+           const unsigned long long* __restrict__ index_offsets, uint32_t* __restrict__ out, uint64_t out_cap) {
+    const int lane = threadIdx.x & 63;
+    const sj_u64 lt_mask = (1ull << lane) - 1ull;
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t k = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < n_docs; k += nwaves) {
+        const sj_u64 s = doc_offsets[k], e = doc_offsets[k + 1];
+        const sj_u64 len = e - s;
+        sj_u64 base = 0;
+        if (WRITE) {
+            if (doc_status[k] != 0) continue;
+            base = index_offsets[k];
+        }
+        const sj_u64 nblocks = len / 64 + 1;  // the reference always processes one tail block (StructuralIndexer.java:255-294)
+        uint32_t parity = 0, err = 0;
+        sj_u64 cnt = 0;
+        for (sj_u64 b0 = 0; b0 < nblocks; b0 += 64) {
+            const sj_u64 blk = b0 + lane;
+            const bool active = blk < nblocks;
+            const sj_u64 start = s + (active ? blk : nblocks - 1) * 64;
+            uint32_t w[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const DocU16 v = *reinterpret_cast<const DocU16*>(buf + start + 16 * q);
+                w[4 * q] = v.a;
+                w[4 * q + 1] = v.b;
+                w[4 * q + 2] = v.c;
+                w[4 * q + 3] = v.d;
+            }
+            uint32_t e_in = 0, p_in = 0;
+            SjUtf8Carry uc = {0, 0, 0, 0};
+            if (active && blk > 0) {
+                const sj_u64 halo = reinterpret_cast<const DocU8*>(buf + start - 8)->v;
+                uc = sj_utf8_carry(halo);
+                if (!sj_carry_from_halo(halo, &e_in, &p_in)) sj_carry_slow(buf, s, start, &e_in, &p_in);
+            }
+            sj_u64 p[8];
+            sj_transpose_butterfly(w, p);
+            const sj_u64 rem = len - (active ? blk : nblocks - 1) * 64;
+            sj_mask_tail(p, rem < 64 ? (uint32_t)rem : 64u);
+            SjBlockMasks bm = sj_block(p, e_in, p_in, uc);
+            if (!active) {
+                bm.pot = 0;
+                bm.sm0 = 0;
+                bm.qpar = bm.ue0 = bm.ue1 = bm.utf8 = 0;
+            }
+            const sj_u64 bal = __ballot(bm.qpar != 0);
+            const uint32_t lp = ((uint32_t)__popcll(bal & lt_mask) & 1u) ^ parity;  // in-string parity entering the block
+            parity ^= (uint32_t)__popcll(bal) & 1u;
+            const sj_u64 m = lp ? (bm.pot & bm.sm0) : (bm.pot & ~bm.sm0);  // StructuralIndexer.java:251
+            if (lp ? bm.ue1 : bm.ue0) err |= SJMI_ST_UNESCAPED;            // :252
+            if (bm.utf8) err |= SJMI_ST_UTF8;
+            const uint32_t c = (uint32_t)__popcll(m);
+            const uint32_t incl = doc_incl_scan(c);
+            if (WRITE) {
+                sj_u64 pos = base + cnt + (incl - c);
+                const uint32_t bstart = (uint32_t)start;
+                for (sj_u64 bits = m; bits; bits &= bits - 1, ++pos)
+                    if (pos < out_cap) out[pos] = bstart + (uint32_t)__builtin_ctzll(bits);  // BitIndexes.write :14-41
+            }
+            cnt += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (!WRITE) {
+            uint32_t all = err;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) all |= __shfl_xor(all, d);
+            if (parity) all |= SJMI_ST_UNCLOSED;  // :297-299
+            if (lane == 0) {
+                doc_status[k] = all;
+                counts[k] = all ? 0u : (uint32_t)cnt;
+            }
+        }
+    }
+}
+
+// index_offsets = exclusive scan of counts (one workgroup); total, sentinel and the OR of the document statuses
+__global__ void __launch_bounds__(1024)
+k_doc_scan(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ doc_status, uint64_t n_docs,
+           unsigned long long* __restrict__ index_offsets, uint32_t* __restrict__ out, uint64_t out_cap, Stage1Result* res) {
+    __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned long long s_carry;
+    __shared__ uint32_t s_status;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        s_carry = 0;
+        s_status = 0;
+    }
+    __syncthreads();
+    uint32_t st = 0;
+    for (uint64_t b = 0; b < n_docs; b += 1024) {
+        const uint64_t i = b + threadIdx.x;
+        const unsigned long long v = i < n_docs ? counts[i] : 0ull;
+        if (i < n_docs) st |= doc_status[i];
+        unsigned long long x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long t = __shfl_up(x, d);
+            if (lane >= d) x += t;
+        }
+        if (lane == 63) s_wave[wave] = x;
+        __syncthreads();
+        unsigned long long off = s_carry;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (i < n_docs) index_offsets[i] = off + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = off + x;
+        __syncthreads();
+    }
+    if (st) atomicOr(&s_status, st);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long total = s_carry;
+        index_offsets[n_docs] = total;
+        res->count = total;
+        uint32_t e = s_status & 0xFFu;
+        if (total < out_cap) out[total] = 0;  // BitIndexes.finish :82-96
+        else e |= SJMI_ST_CAPACITY;
+        res->status = e;
+    }
+}
+
+size_t batch_isolated_workspace_bytes(uint64_t n_docs) { return (size_t)(n_docs + 16) * sizeof(uint32_t); }
+
+hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs,
+                                 uint32_t* d_out, uint64_t out_cap, unsigned long long* d_index_offsets,
+                                 uint32_t* d_doc_status, uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream) {
+    if (n_docs == 0) {
+        hipLaunchKernelGGL(k_doc_scan, dim3(1), dim3(1024), 0, stream, d_counts, d_doc_status, n_docs, d_index_offsets,
+                           d_out, out_cap, d_res);
+        return hipGetLastError();
+    }
+    const uint64_t want = (n_docs + 3) / 4;
+    const unsigned grid = (unsigned)(want < 8192 ? want : 8192);  // grid-stride over the documents
+    hipLaunchKernelGGL(k_doc_pass<false>, dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_counts,
+                       d_doc_status, (const unsigned long long*)nullptr, (uint32_t*)nullptr, (uint64_t)0);
+    hipLaunchKernelGGL(k_doc_scan, dim3(1), dim3(1024), 0, stream, d_counts, d_doc_status, n_docs, d_index_offsets, d_out,
+                       out_cap, d_res);
+    hipLaunchKernelGGL(k_doc_pass<true>, dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_counts,
+                       d_doc_status, (const unsigned long long*)d_index_offsets, d_out, out_cap);
     return hipGetLastError();
 }
 

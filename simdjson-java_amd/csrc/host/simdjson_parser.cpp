@@ -166,12 +166,12 @@ void SimdJsonParser::parseBatch(const uint8_t* buffer, size_t totalLen, const ui
     indexOffsets_.assign(nDocs + 1, 0);
     uint64_t count = 0;
     uint32_t status = 0;
-    const int rc = sjmi_stage1_batch(ctx_, paddedBuffer_.data(), totalLen, docOffsets, nDocs, bitIndexes_.array(),
-                                     bitIndexes_.capacity(), indexOffsets_.data(), &count, &status);
-    if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_stage1_batch: ") + sjmi_last_error(ctx_));
-    if (status & SJMI_ST_UTF8) throw fail(E_UTF8);
-    if (status & SJMI_ST_UNCLOSED) throw fail(E_UNCLOSED_STRING);
-    if (status & SJMI_ST_UNESCAPED) throw fail(E_UNESCAPED_CHARS);
+    // isolated mode: a document that fails stage 1 gets its own verdict and contributes no indexes, so the strings
+    // and trees of all other documents are exactly what they would be alone
+    docStatus_.assign(nDocs ? nDocs : 1, 0);
+    const int rc = sjmi_stage1_batch_isolated(ctx_, paddedBuffer_.data(), totalLen, docOffsets, nDocs, bitIndexes_.array(),
+                                              bitIndexes_.capacity(), indexOffsets_.data(), docStatus_.data(), &count, &status);
+    if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_stage1_batch_isolated: ") + sjmi_last_error(ctx_));
     unescapeStrings(totalLen, count);
     batchTape_.clear();
     batchTapeOffsets_.assign(1, 0);
@@ -187,6 +187,10 @@ void SimdJsonParser::parseBatch(const uint8_t* buffer, size_t totalLen, const ui
         bitIndexes_.window(from, to, (uint32_t)docBase_);
         stringBufferIdx_ = cursor;
         try {
+            // SimdJsonParser.stage1 order: Utf8Validator.validate (:165-167), then StructuralIndexer.index (:297-302)
+            if (docStatus_[k] & SJMI_ST_UTF8) throw fail(E_UTF8);
+            if (docStatus_[k] & SJMI_ST_UNCLOSED) throw fail(E_UNCLOSED_STRING);
+            if (docStatus_[k] & SJMI_ST_UNESCAPED) throw fail(E_UNESCAPED_CHARS);
             walkDocument((size_t)docOffsets[k + 1]);
             batchTape_.insert(batchTape_.end(), tape_.data(), tape_.data() + tape_.getCurrentIdx());
         } catch (const JsonParsingException& e) {

@@ -167,6 +167,7 @@ private:
     std::vector<OpenContainer> openContainers_;
     std::vector<uint8_t> isArray_;
     std::vector<uint64_t> batchTape_, batchTapeOffsets_, indexOffsets_;
+    std::vector<uint32_t> docStatus_;
     std::vector<int32_t> batchErrors_;
     size_t docBase_ = 0;  // batch: byte offset of the current document (error positions are document-relative)
 };

@@ -29,7 +29,9 @@ struct sjmi_ctx {
     void* d_ws_str = nullptr;     // unescape workspace, grown on demand
     size_t ws_str_bytes = 0;
     sjmi_unescape_result* d_ures = nullptr;
-    unsigned long long* d_docoff = nullptr;  // batch: document offsets + index offsets, grown on demand
+    unsigned long long* d_docoff = nullptr;  // batch: document offsets + index offsets (+ statuses), grown on demand
+    uint32_t* d_doccnt = nullptr;            // isolated batch: per-document index counts
+    size_t doccnt_bytes = 0;
     size_t docoff_bytes = 0;
     int forced_steps = 0;
     uint32_t dbg = 0;  // ablation flags (sjmi_debug_set_flags)
@@ -98,6 +100,7 @@ void sjmi_destroy(sjmi_ctx* c) {
     if (c->d_ws_str) (void)hipFree(c->d_ws_str);
     if (c->d_ures) (void)hipFree(c->d_ures);
     if (c->d_docoff) (void)hipFree(c->d_docoff);
+    if (c->d_doccnt) (void)hipFree(c->d_doccnt);
     if (c->h_res) (void)hipHostFree(c->h_res);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.first);
@@ -315,6 +318,65 @@ int sjmi_stage1_batch(sjmi_ctx* c, const uint8_t* buf, uint64_t total_len, const
     *status = c->h_res->status & 0xFFu;
     *count = c->h_res->count;
     if (c->h_res->status & SJMI_ST_INTERNAL) return SJMI_ERR_INTERNAL;
+    if (c->h_res->status & SJMI_ST_CAPACITY) return SJMI_ERR_CAPACITY;
+    if (fail(c, "D2H(indexes)", hipMemcpyAsync(indexes, c->d_idx, (c->h_res->count + 1) * sizeof(uint32_t),
+                                               hipMemcpyDeviceToHost, c->stream)) ||
+        fail(c, "sync", hipStreamSynchronize(c->stream)))
+        return SJMI_ERR_HIP;
+    c->last_len = total_len;
+    c->last_count = c->h_res->count;
+    c->last_valid = true;
+    return SJMI_OK;
+}
+
+int sjmi_stage1_batch_isolated_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets,
+                                      uint64_t n_docs, void* d_indexes, uint64_t index_capacity, void* d_index_offsets,
+                                      void* d_doc_status, void* d_result, void* stream) {
+    if (!c || !d_buf || !d_doc_offsets || !d_indexes || !d_index_offsets || !d_doc_status || !d_result) return SJMI_ERR_ARG;
+    if (total_len >= (1ull << 32)) return SJMI_ERR_ARG;
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    if (!grow(c, (void**)&c->d_doccnt, &c->doccnt_bytes, sjmi::batch_isolated_workspace_bytes(n_docs), "hipMalloc(doccnt)"))
+        return SJMI_ERR_HIP;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (fail(c, "isolated batch launch",
+             sjmi::batch_isolated_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs,
+                                         (uint32_t*)d_indexes, index_capacity, (unsigned long long*)d_index_offsets,
+                                         (uint32_t*)d_doc_status, c->d_doccnt, (sjmi::Stage1Result*)d_result, st)))
+        return SJMI_ERR_HIP;
+    return SJMI_OK;
+}
+
+int sjmi_stage1_batch_isolated(sjmi_ctx* c, const uint8_t* buf, uint64_t total_len, const uint64_t* doc_offsets,
+                               uint64_t n_docs, uint32_t* indexes, uint64_t index_capacity, uint64_t* index_offsets,
+                               uint32_t* doc_status, uint64_t* count, uint32_t* status) {
+    if (!c || (!buf && total_len) || !doc_offsets || !indexes || !index_offsets || !doc_status || !count || !status)
+        return SJMI_ERR_ARG;
+    if (total_len > c->capacity || total_len >= (1ull << 32)) {
+        c->err = "batch larger than the context capacity";
+        return SJMI_ERR_CAPACITY;
+    }
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    const size_t ob = (n_docs + 1) * sizeof(unsigned long long);
+    // document offsets | index offsets | document statuses
+    if (!grow(c, (void**)&c->d_docoff, &c->docoff_bytes, 2 * ob + (n_docs + 16) * sizeof(uint32_t) + 64, "hipMalloc(docoff)"))
+        return SJMI_ERR_HIP;
+    unsigned long long* d_io = c->d_docoff + (n_docs + 1);
+    uint32_t* d_st = reinterpret_cast<uint32_t*>(c->d_docoff + 2 * (n_docs + 1));
+    void* d_res = (uint8_t*)c->d_ws + sjmi::WS_RESULT_OFFSET;
+    if ((total_len && fail(c, "H2D", hipMemcpyAsync(c->d_in, buf, total_len, hipMemcpyHostToDevice, c->stream))) ||
+        fail(c, "H2D(offsets)", hipMemcpyAsync(c->d_docoff, doc_offsets, ob, hipMemcpyHostToDevice, c->stream)))
+        return SJMI_ERR_HIP;
+    const uint64_t dev_cap = c->capacity + 2 < index_capacity ? c->capacity + 2 : index_capacity;
+    const int rc = sjmi_stage1_batch_isolated_device(c, c->d_in, total_len, c->d_docoff, n_docs, c->d_idx, dev_cap, d_io, d_st,
+                                                     d_res, c->stream);
+    if (rc != SJMI_OK) return rc;
+    if (fail(c, "D2H(result)", hipMemcpyAsync(c->h_res, d_res, sizeof(sjmi_stage1_result), hipMemcpyDeviceToHost, c->stream)) ||
+        fail(c, "D2H(io)", hipMemcpyAsync(index_offsets, d_io, ob, hipMemcpyDeviceToHost, c->stream)) ||
+        (n_docs && fail(c, "D2H(status)", hipMemcpyAsync(doc_status, d_st, n_docs * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream))) ||
+        fail(c, "sync", hipStreamSynchronize(c->stream)))
+        return SJMI_ERR_HIP;
+    *status = c->h_res->status & 0xFFu;
+    *count = c->h_res->count;
     if (c->h_res->status & SJMI_ST_CAPACITY) return SJMI_ERR_CAPACITY;
     if (fail(c, "D2H(indexes)", hipMemcpyAsync(indexes, c->d_idx, (c->h_res->count + 1) * sizeof(uint32_t),
                                                hipMemcpyDeviceToHost, c->stream)) ||

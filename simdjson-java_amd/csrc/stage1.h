@@ -52,6 +52,10 @@ hipError_t unescape_launch(const uint8_t* d_buf, uint64_t len, const uint32_t* d
                            uint64_t sb_cap, void* d_ws, UnescapeResult* d_res, hipStream_t stream);
 hipError_t split_docs_launch(const uint32_t* d_idx, const Stage1Result* d_res, const unsigned long long* d_doc_offsets,
                              uint64_t n_docs, unsigned long long* d_index_offsets, hipStream_t stream);
+size_t batch_isolated_workspace_bytes(uint64_t n_docs);
+hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint32_t* d_out,
+                                 uint64_t out_cap, unsigned long long* d_index_offsets, uint32_t* d_doc_status,
+                                 uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream);
 hipError_t transpose_selftest_launch(const uint32_t* d_words, uint32_t nblocks, uint32_t* d_mismatches,
                                      hipStream_t stream);
 

@@ -49,12 +49,53 @@ def test_stage1_batch_matches_per_document_oracle():
         ctx.close()
 
 
+def test_stage1_batch_isolated_attributes_errors_to_documents():
+    """Isolated mode: every document gets the status it would get alone and failing documents do not disturb their
+    neighbours -- including two unclosed strings that would cancel in a whole-batch parity, broken UTF-8 next to good
+    documents, a long document (several 4 KiB steps), backslash runs across block boundaries, and an empty document."""
+    import simdjson_java_amd as S
+    rng = random.Random(79)
+    docs = _small_docs(rng, 2000)
+    bad = [b'["abc', b'{"k": "v}', b'"', b'["' + b"\\" * 101 + b'"]', b'["x' + b"\\" * 70 + b'"',
+           bytes([0x5B, 0x22, 0xC3, 0x22, 0x5D]), bytes([0x22, 0x80, 0x22]), b'["a\nb"]', b'["tab\there"]',
+           b'["' + b"\xe2\x82" + b'"]', b'["abc']
+    for b in bad:
+        docs.insert(rng.randrange(len(docs)), b)
+    docs.insert(100, load_fixture("github_events.json").rstrip())
+    docs.insert(1000, b'["' + b"x" * 9000 + b'", "unclosed')
+    docs.insert(1500, b"")
+    docs.insert(1600, b'["' + b"y" * 5000 + b'\\\\' * 40 + b'", 1, 2]')
+    buf, offs = _pack(docs)
+    ctx = S.Context(0, len(buf) + 64)
+    try:
+        idx, io, ds, st = ctx.stage1_batch_isolated(buf, offs)
+        want_or = 0
+        nbad = 0
+        for k, d in enumerate(docs):
+            want, wst = O.stage1(d + b"\n")  # the document's range includes its separator
+            assert int(ds[k]) == wst, (k, d[:40], int(ds[k]), wst)
+            got = idx[int(io[k]):int(io[k + 1])].astype(np.int64) - int(offs[k])
+            if wst:
+                assert got.size == 0
+                nbad += 1
+            else:
+                assert np.array_equal(got, want.astype(np.int64)), k
+            want_or |= wst
+        assert st == want_or and nbad >= 10
+        assert int(io[-1]) == idx.size
+    finally:
+        ctx.close()
+
+
 def test_parse_batch_trees_and_errors():
     import simdjson_java_amd as S
     rng = random.Random(78)
     docs = _small_docs(rng, 1500)
     # grammar-invalid (but stage-1-valid) documents must fail alone, with the oracle's own error
     bad = [b"[1 1]", b"[1,,1]", b'{"a" 1}', b"[1,2", b'{"a":1,}', b"tru", b"[01]", b'["\\q"]', b'["\\uD800"]', b"1 2", b"[-]"]
+    # stage-1-invalid documents too: unclosed strings (two of them: they cancel in a whole-batch parity), broken UTF-8,
+    # an unescaped control character -- each must fail alone with the reference's stage-1 message
+    bad += [b'["abc', b'{"k": "v', bytes([0x5B, 0x22, 0xC3, 0x22, 0x5D]), b'["a\x01b"]']
     for b in bad:
         docs.insert(rng.randrange(len(docs)), b)
     buf, offs = _pack(docs)
