@@ -235,6 +235,12 @@ class Context:
                                                    index_capacity, d_index_offsets, d_result, stream),
                     "sjmi_stage1_batch_device")
 
+    def stage1_batch_isolated_device(self, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity,
+                                     d_index_offsets, d_doc_status, d_result, stream=0):
+        self._check(lib().sjmi_stage1_batch_isolated_device(self._h, d_buf, total_len, d_doc_offsets, n_docs, d_indexes,
+                                                            index_capacity, d_index_offsets, d_doc_status, d_result,
+                                                            stream), "sjmi_stage1_batch_isolated_device")
+
     def stage1_device(self, d_buf, length, d_indexes, index_capacity, d_result, stream=0):
         """Device-resident path; arguments are raw device pointers (ints) and a hipStream_t handle."""
         self._check(lib().sjmi_stage1_device(self._h, d_buf, length, d_indexes, index_capacity, d_result, stream),

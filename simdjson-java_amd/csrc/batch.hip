@@ -10,7 +10,7 @@
 // carries, so the structural indexes of the concatenation are the union of the documents' own indexes shifted by
 // their offsets.  That launch cannot tell WHICH document is broken, though, and two documents with an unclosed
 // string each even cancel in the batch verdict.  The ISOLATED mode below is exact per document whatever the
-// others contain: one wave per document, every carry starts from zero at the document's first byte, a document
+// others contain: 16 lanes per document, every carry starts from zero at the document's first byte, a document
 // that fails stage 1 gets its own SJMI_ST_* bits and contributes no indexes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -45,7 +45,7 @@ hipError_t split_docs_launch(const uint32_t* d_idx, const Stage1Result* d_res, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// isolated mode: one wave per document (documents of a batch are small; a long one is walked 4 KiB at a time)
+// isolated mode: one row of 16 lanes per document (documents of a batch are small; a long one is walked 1 KiB at a time)
 // ---------------------------------------------------------------------------------------------
 struct __attribute__((packed, aligned(1))) DocU16 { uint32_t a, b, c, d; };
 struct __attribute__((packed, aligned(1))) DocU8 { unsigned long long v; };
@@ -54,42 +54,42 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t bdpp_add(uint32_t v) {
     return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
 }
-__device__ __forceinline__ uint32_t doc_incl_scan(uint32_t v) {
-    v = bdpp_add<0x111, 0xF>(v);
-    v = bdpp_add<0x112, 0xF>(v);
-    v = bdpp_add<0x114, 0xF>(v);
-    v = bdpp_add<0x118, 0xF>(v);
-    v = bdpp_add<0x142, 0xA>(v);
-    v = bdpp_add<0x143, 0xC>(v);
-    return v;
-}
-
 // WRITE = false: doc_status[k] and counts[k] (0 for a failing document); WRITE = true: the indexes of the passing
 // documents at index_offsets[k].  Same per-block algebra as the single-document kernel (sj_block.h); blocks are counted
 // from the document's first byte, so the loads are byte-granular.
+// One document per ROW of 16 lanes (four documents per wave), 1 KiB per step: the documents of a batch are small (a
+// whole wave per ~1 KB document left 3/4 of the lanes idle), the DPP row scans are exactly 16 lanes wide, and the four
+// rows only share the trip count of the longest document.
 template <bool WRITE>
 __global__ void __launch_bounds__(256)
 k_doc_pass(const uint8_t* __restrict__ buf, const unsigned long long* __restrict__ doc_offsets, uint64_t n_docs,
            uint32_t* __restrict__ counts, uint32_t* __restrict__ doc_status,
            const unsigned long long* __restrict__ index_offsets, uint32_t* __restrict__ out, uint64_t out_cap) {
     const int lane = threadIdx.x & 63;
-    const sj_u64 lt_mask = (1ull << lane) - 1ull;
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
-    for (uint64_t k = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < n_docs; k += nwaves) {
-        const sj_u64 s = doc_offsets[k], e = doc_offsets[k + 1];
-        const sj_u64 len = e - s;
-        sj_u64 base = 0;
-        if (WRITE) {
-            if (doc_status[k] != 0) continue;
-            base = index_offsets[k];
+    const int rl = lane & 15;         // lane inside the row
+    const int rshift = lane & ~15;    // first lane of the row
+    const uint32_t row_lt = (1u << rl) - 1u;
+    const uint64_t nrows = (uint64_t)gridDim.x * 16;
+    for (uint64_t k0 = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 6) * 4; k0 < n_docs; k0 += nrows) {
+        const uint64_t k = k0 + (uint64_t)(lane >> 4);
+        bool live = k < n_docs;
+        sj_u64 s = 0, len = 0, base = 0;
+        if (live) {
+            s = doc_offsets[k];
+            len = doc_offsets[k + 1] - s;
+            if (WRITE) {
+                live = doc_status[k] == 0;
+                base = index_offsets[k];
+            }
         }
-        const sj_u64 nblocks = len / 64 + 1;  // the reference always processes one tail block (StructuralIndexer.java:255-294)
+        const sj_u64 nblocks = live ? len / 64 + 1 : 0;  // the reference always processes one tail block (StructuralIndexer.java:255-294)
         uint32_t parity = 0, err = 0;
         sj_u64 cnt = 0;
-        for (sj_u64 b0 = 0; b0 < nblocks; b0 += 64) {
-            const sj_u64 blk = b0 + lane;
+        for (sj_u64 b0 = 0; __ballot(b0 < nblocks); b0 += 16) {
+            const sj_u64 blk = b0 + rl;
             const bool active = blk < nblocks;
-            const sj_u64 start = s + (active ? blk : nblocks - 1) * 64;
+            const sj_u64 cblk = active ? blk : (nblocks ? nblocks - 1 : 0);
+            const sj_u64 start = s + cblk * 64;
             uint32_t w[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -108,7 +108,7 @@ k_doc_pass(const uint8_t* __restrict__ buf, const unsigned long long* __restrict
             }
             sj_u64 p[8];
             sj_transpose_butterfly(w, p);
-            const sj_u64 rem = len - (active ? blk : nblocks - 1) * 64;
+            const sj_u64 rem = len - cblk * 64;
             sj_mask_tail(p, rem < 64 ? (uint32_t)rem : 64u);
             SjBlockMasks bm = sj_block(p, e_in, p_in, uc);
             if (!active) {
@@ -116,28 +116,32 @@ k_doc_pass(const uint8_t* __restrict__ buf, const unsigned long long* __restrict
                 bm.sm0 = 0;
                 bm.qpar = bm.ue0 = bm.ue1 = bm.utf8 = 0;
             }
-            const sj_u64 bal = __ballot(bm.qpar != 0);
-            const uint32_t lp = ((uint32_t)__popcll(bal & lt_mask) & 1u) ^ parity;  // in-string parity entering the block
-            parity ^= (uint32_t)__popcll(bal) & 1u;
+            const uint32_t bal = (uint32_t)(__ballot(bm.qpar != 0) >> rshift) & 0xFFFFu;  // this row's quote parities
+            const uint32_t lp = ((uint32_t)__popc(bal & row_lt) & 1u) ^ parity;          // in-string parity entering the block
+            parity ^= (uint32_t)__popc(bal) & 1u;
             const sj_u64 m = lp ? (bm.pot & bm.sm0) : (bm.pot & ~bm.sm0);  // StructuralIndexer.java:251
             if (lp ? bm.ue1 : bm.ue0) err |= SJMI_ST_UNESCAPED;            // :252
             if (bm.utf8) err |= SJMI_ST_UTF8;
             const uint32_t c = (uint32_t)__popcll(m);
-            const uint32_t incl = doc_incl_scan(c);
+            uint32_t incl = c;  // inclusive scan inside the row of 16 lanes
+            incl = bdpp_add<0x111, 0xF>(incl);
+            incl = bdpp_add<0x112, 0xF>(incl);
+            incl = bdpp_add<0x114, 0xF>(incl);
+            incl = bdpp_add<0x118, 0xF>(incl);
             if (WRITE) {
                 sj_u64 pos = base + cnt + (incl - c);
                 const uint32_t bstart = (uint32_t)start;
                 for (sj_u64 bits = m; bits; bits &= bits - 1, ++pos)
                     if (pos < out_cap) out[pos] = bstart + (uint32_t)__builtin_ctzll(bits);  // BitIndexes.write :14-41
             }
-            cnt += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            cnt += (uint32_t)__shfl((int)incl, rshift + 15);
         }
         if (!WRITE) {
             uint32_t all = err;
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) all |= __shfl_xor(all, d);
+            for (int d = 8; d >= 1; d >>= 1) all |= __shfl_xor(all, d);  // (stays inside the row)
             if (parity) all |= SJMI_ST_UNCLOSED;  // :297-299
-            if (lane == 0) {
+            if (rl == 0 && k < n_docs) {
                 doc_status[k] = all;
                 counts[k] = all ? 0u : (uint32_t)cnt;
             }
@@ -145,70 +149,134 @@ k_doc_pass(const uint8_t* __restrict__ buf, const unsigned long long* __restrict
     }
 }
 
-// index_offsets = exclusive scan of counts (one workgroup); total, sentinel and the OR of the document statuses
-__global__ void __launch_bounds__(1024)
-k_doc_scan(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ doc_status, uint64_t n_docs,
-           unsigned long long* __restrict__ index_offsets, uint32_t* __restrict__ out, uint64_t out_cap, Stage1Result* res) {
-    __shared__ unsigned long long s_wave[16];
-    __shared__ unsigned long long s_carry;
-    __shared__ uint32_t s_status;
+// ---- index_offsets = exclusive scan of counts: chunk sums, scan of the chunk sums (one workgroup), chunk scans ----
+constexpr int SCAN_CHUNK = 16384;  // documents per workgroup of 1024 lanes
+
+__device__ __forceinline__ unsigned long long block_excl_scan_1024(unsigned long long v, unsigned long long* s_wave,
+                                                                    unsigned long long* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) {
-        s_carry = 0;
-        s_status = 0;
-    }
-    __syncthreads();
-    uint32_t st = 0;
-    for (uint64_t b = 0; b < n_docs; b += 1024) {
-        const uint64_t i = b + threadIdx.x;
-        const unsigned long long v = i < n_docs ? counts[i] : 0ull;
-        if (i < n_docs) st |= doc_status[i];
-        unsigned long long x = v;
+    unsigned long long x = v;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned long long t = __shfl_up(x, d);
-            if (lane >= d) x += t;
-        }
-        if (lane == 63) s_wave[wave] = x;
-        __syncthreads();
-        unsigned long long off = s_carry;
-        for (int w = 0; w < wave; ++w) off += s_wave[w];
-        if (i < n_docs) index_offsets[i] = off + x - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = off + x;
-        __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long t = __shfl_up(x, d);
+        if (lane >= d) x += t;
     }
-    if (st) atomicOr(&s_status, st);
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    unsigned long long off = 0, all = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) off += s_wave[w];
+        all += s_wave[w];
+    }
+    __syncthreads();
+    *total = all;
+    return off + x - v;
+}
+
+__global__ void __launch_bounds__(1024)
+k_doc_chunk_sums(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ doc_status, uint64_t n_docs,
+                 unsigned long long* __restrict__ chunk_sums, uint32_t* __restrict__ status_or) {
+    __shared__ unsigned long long s_wave[16];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK;
+    unsigned long long sum = 0;
+    uint32_t st = 0;
+    for (int j = 0; j < SCAN_CHUNK / 1024; ++j) {
+        const uint64_t i = base + (uint64_t)j * 1024 + threadIdx.x;
+        if (i < n_docs) {
+            sum += counts[i];
+            st |= doc_status[i];
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        sum += __shfl_xor(sum, d);
+        st |= __shfl_xor(st, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_wave[threadIdx.x >> 6] = sum;
+        if (st) atomicOr(status_or, st);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long total = s_carry;
-        index_offsets[n_docs] = total;
-        res->count = total;
-        uint32_t e = s_status & 0xFFu;
-        if (total < out_cap) out[total] = 0;  // BitIndexes.finish :82-96
+        unsigned long long t = 0;
+        for (int w = 0; w < 16; ++w) t += s_wave[w];
+        chunk_sums[blockIdx.x] = t;
+    }
+}
+
+// exclusive scan of the chunk sums in place (one workgroup); total, sentinel and the OR of the document statuses
+__global__ void __launch_bounds__(1024)
+k_doc_scan(unsigned long long* __restrict__ chunk_sums, uint64_t nchunks, const uint32_t* __restrict__ status_or,
+           uint64_t n_docs, unsigned long long* __restrict__ index_offsets, uint32_t* __restrict__ out, uint64_t out_cap,
+           Stage1Result* res) {
+    __shared__ unsigned long long s_wave[16];
+    unsigned long long carry = 0;
+    for (uint64_t b = 0; b < nchunks; b += 1024) {
+        const uint64_t i = b + threadIdx.x;
+        const unsigned long long v = i < nchunks ? chunk_sums[i] : 0ull;
+        unsigned long long total;
+        const unsigned long long ex = block_excl_scan_1024(v, s_wave, &total);
+        if (i < nchunks) chunk_sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        index_offsets[n_docs] = carry;
+        res->count = carry;
+        uint32_t e = *status_or & 0xFFu;
+        if (carry < out_cap) out[carry] = 0;  // BitIndexes.finish :82-96
         else e |= SJMI_ST_CAPACITY;
         res->status = e;
     }
 }
 
-size_t batch_isolated_workspace_bytes(uint64_t n_docs) { return (size_t)(n_docs + 16) * sizeof(uint32_t); }
+__global__ void __launch_bounds__(1024)
+k_doc_offsets(const uint32_t* __restrict__ counts, uint64_t n_docs, const unsigned long long* __restrict__ chunk_base,
+              unsigned long long* __restrict__ index_offsets) {
+    __shared__ unsigned long long s_wave[16];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK;
+    unsigned long long carry = chunk_base[blockIdx.x];
+    for (int j = 0; j < SCAN_CHUNK / 1024; ++j) {
+        const uint64_t i = base + (uint64_t)j * 1024 + threadIdx.x;
+        const unsigned long long v = i < n_docs ? counts[i] : 0ull;
+        unsigned long long total;
+        const unsigned long long ex = block_excl_scan_1024(v, s_wave, &total);
+        if (i < n_docs) index_offsets[i] = carry + ex;
+        carry += total;
+    }
+}
+
+// workspace: counts[n_docs] | status word | chunk sums
+static size_t iso_status_offset(uint64_t n_docs) { return (((size_t)n_docs * sizeof(uint32_t) + 63) / 64) * 64; }
+static size_t iso_chunks_offset(uint64_t n_docs) { return iso_status_offset(n_docs) + 64; }
+size_t batch_isolated_workspace_bytes(uint64_t n_docs) {
+    return iso_chunks_offset(n_docs) + ((size_t)(n_docs / SCAN_CHUNK) + 2) * sizeof(unsigned long long);
+}
 
 hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs,
                                  uint32_t* d_out, uint64_t out_cap, unsigned long long* d_index_offsets,
                                  uint32_t* d_doc_status, uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream) {
-    if (n_docs == 0) {
-        hipLaunchKernelGGL(k_doc_scan, dim3(1), dim3(1024), 0, stream, d_counts, d_doc_status, n_docs, d_index_offsets,
-                           d_out, out_cap, d_res);
-        return hipGetLastError();
-    }
-    const uint64_t want = (n_docs + 3) / 4;
+    uint8_t* ws = reinterpret_cast<uint8_t*>(d_counts);
+    uint32_t* status_or = reinterpret_cast<uint32_t*>(ws + iso_status_offset(n_docs));
+    unsigned long long* chunk_sums = reinterpret_cast<unsigned long long*>(ws + iso_chunks_offset(n_docs));
+    const uint64_t nchunks = (n_docs + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    hipError_t e = hipMemsetAsync(status_or, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const uint64_t want = (n_docs + 15) / 16;  // 16 documents per workgroup and trip
     const unsigned grid = (unsigned)(want < 8192 ? want : 8192);  // grid-stride over the documents
-    hipLaunchKernelGGL(k_doc_pass<false>, dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_counts,
-                       d_doc_status, (const unsigned long long*)nullptr, (uint32_t*)nullptr, (uint64_t)0);
-    hipLaunchKernelGGL(k_doc_scan, dim3(1), dim3(1024), 0, stream, d_counts, d_doc_status, n_docs, d_index_offsets, d_out,
-                       out_cap, d_res);
-    hipLaunchKernelGGL(k_doc_pass<true>, dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_counts,
-                       d_doc_status, (const unsigned long long*)d_index_offsets, d_out, out_cap);
+    if (n_docs) {
+        hipLaunchKernelGGL(k_doc_pass<false>, dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_counts,
+                           d_doc_status, (const unsigned long long*)nullptr, (uint32_t*)nullptr, (uint64_t)0);
+        hipLaunchKernelGGL(k_doc_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, d_counts, d_doc_status, n_docs,
+                           chunk_sums, status_or);
+    }
+    hipLaunchKernelGGL(k_doc_scan, dim3(1), dim3(1024), 0, stream, chunk_sums, nchunks, status_or, n_docs, d_index_offsets,
+                       d_out, out_cap, d_res);
+    if (n_docs) {
+        hipLaunchKernelGGL(k_doc_offsets, dim3((unsigned)nchunks), dim3(1024), 0, stream, d_counts, n_docs, chunk_sums,
+                           d_index_offsets);
+        hipLaunchKernelGGL(k_doc_pass<true>, dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_counts,
+                           d_doc_status, (const unsigned long long*)d_index_offsets, d_out, out_cap);
+    }
     return hipGetLastError();
 }
 

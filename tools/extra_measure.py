@@ -132,6 +132,19 @@ def batch_run():
     r = res.cpu().numpy()
     assert (int(r[1]) & 0xFFFFFFFF) == 0 and int(d_io[-1].item()) == int(r[0])
     print("config[3] batch on 1 GPU: %d documents (%d B): %.3f ms per batch (memset + stage 1 + split) -> %.1f M docs/s, %.0f GB/s" % (n_docs, n, t, n_docs / t / 1e3, n / t / 1e6))
+    count_fast = int(r[0])
+    d_st = torch.zeros(n_docs, dtype=torch.int32, device="cuda")
+    with torch.cuda.stream(work):
+        for it in range(30):
+            if it == 10:
+                e0.record()
+            ctx.stage1_batch_isolated_device(buf.data_ptr(), n, d_offs.data_ptr(), n_docs, out.data_ptr(), cap, d_io.data_ptr(), d_st.data_ptr(), res.data_ptr(), st)
+        e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / 20
+    r = res.cpu().numpy()
+    assert (int(r[1]) & 0xFFFFFFFF) == 0 and int(r[0]) == count_fast and int(d_io[-1].item()) == count_fast and not bool(d_st.any().item())
+    print("config[3] ISOLATED batch (16 lanes per document, per-document status): %.3f ms per batch -> %.1f M docs/s, %.0f GB/s" % (t, n_docs / t / 1e3, n / t / 1e6))
     ctx.close()
 
 
