@@ -307,14 +307,18 @@ int sjmi_stage1_batch(sjmi_ctx* c, const uint8_t* buf, uint64_t total_len, const
         return SJMI_ERR_HIP;
     const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(total_len);
     const uint64_t dev_cap = c->capacity + 2 < index_capacity ? c->capacity + 2 : index_capacity;
-    if (fail(c, "launch", sjmi::stage1_launch(c->d_in, total_len, c->d_idx, dev_cap, c->d_ws, steps, c->stream, nullptr,
-                                              nullptr, launch_flags(c))) ||
-        fail(c, "split", sjmi::split_docs_launch(c->d_idx, (const sjmi::Stage1Result*)d_res, c->d_docoff, n_docs, d_io,
-                                                 c->stream)) ||
-        fail(c, "D2H(result)", hipMemcpyAsync(c->h_res, d_res, sizeof(sjmi_stage1_result), hipMemcpyDeviceToHost, c->stream)) ||
-        fail(c, "D2H(io)", hipMemcpyAsync(index_offsets, d_io, ob, hipMemcpyDeviceToHost, c->stream)) ||
-        fail(c, "sync", hipStreamSynchronize(c->stream)))
-        return SJMI_ERR_HIP;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (fail(c, "launch", sjmi::stage1_launch(c->d_in, total_len, c->d_idx, dev_cap, c->d_ws, steps, c->stream, nullptr,
+                                                  nullptr, launch_flags(c))) ||
+            fail(c, "split", sjmi::split_docs_launch(c->d_idx, (const sjmi::Stage1Result*)d_res, c->d_docoff, n_docs, d_io,
+                                                     c->stream)) ||
+            fail(c, "D2H(result)", hipMemcpyAsync(c->h_res, d_res, sizeof(sjmi_stage1_result), hipMemcpyDeviceToHost, c->stream)) ||
+            fail(c, "D2H(io)", hipMemcpyAsync(index_offsets, d_io, ob, hipMemcpyDeviceToHost, c->stream)) ||
+            fail(c, "sync", hipStreamSynchronize(c->stream)))
+            return SJMI_ERR_HIP;
+        if (!(c->h_res->status & SJMI_ST_INTERNAL) || c->ticket_mode) break;
+        c->ticket_mode = true;  // fast-mode liveness assumption failed: latch the safe mode and run again
+    }
     *status = c->h_res->status & 0xFFu;
     *count = c->h_res->count;
     if (c->h_res->status & SJMI_ST_INTERNAL) return SJMI_ERR_INTERNAL;
