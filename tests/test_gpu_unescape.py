@@ -91,3 +91,33 @@ def test_first_error_is_the_lowest_position(ctx):
     _check(ctx, doc)
     for s in ['"\\uDC00"', '"\\uD800\\u0041"', '"\\u12G4"', '"\\x"']:
         _check(ctx, ("[" + ",".join([good] * 100 + [s] + [good] * 100) + "]").encode())
+
+
+def test_window_boundaries_of_the_cooperative_path(ctx):
+    """The wave-cooperative parser walks a string in windows of 64 bytes (256 per memory round trip): every kind of
+    escape, backslash runs, surrogate pairs and every error placed so that it straddles those boundaries; also the
+    paths around it (closing quote followed by more than 15 bytes of whitespace, rows spanning more than 2 KiB,
+    documents shorter than the 16-byte windows)."""
+    pieces = ["\\n", "\\\\", "\\\"", "\\u00e9", "\\u20AC", "\\uD83D\\uDE00", "\\\\\\\\\\\\", "\\/"]
+    docs = []
+    for boundary in (64, 128, 256, 512):
+        for back in range(0, 13):
+            for pc in pieces:
+                s = "a" * (boundary - back) + pc + "tail"
+                docs.append('"' + s + '"')
+    good = "[" + ",\n".join(docs) + "]"
+    _check(ctx, good.encode())
+    # errors straddling a boundary: the first one (lowest structural) must win, with the reference's code
+    for bad in ["\\uD83Dx", "\\uD83D\\u0041", "\\uDE00", "\\u12G4", "\\q", "\\uD83D\\uD83D", "\\u"]:
+        for back in (0, 1, 2, 3, 5, 6, 7, 11):
+            s = '"' + "b" * (64 - back) + bad + ' rest"'
+            _check(ctx, ("[" + ",".join(['"ok\\t"'] * 3 + [s] + ['"\\q"']) + "]").encode())
+    # whitespace runs after the closing quote (pretty-printed, deeper than the 16-byte tail window), long strings that
+    # make a row of 64 structurals span more than the 2 KiB backslash map, tiny documents
+    deep = '[\n' + ",\n".join('"v%d\\t"%s' % (i, " " * (i % 40)) for i in range(300)) + "\n" + " " * 37 + "]"
+    _check(ctx, deep.encode())
+    long_row = "[" + ",".join('"%s\\n%s"' % ("x" * (50 * (i % 9)), "y" * 300) for i in range(200)) + "]"
+    _check(ctx, long_row.encode())
+    for tiny in [b'""', b'"a"', b'"\\n"', b'["",""]', b'"\\u0041"', b' "x" ', b'"0123456789abc"', b'"0123456789abcd"',
+                 b'"0123456789abcde"']:
+        _check(ctx, tiny)
