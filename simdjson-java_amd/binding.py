@@ -61,7 +61,8 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_unescape", "sjmi_unescape_device",
            "sjmi_parser_create", "sjmi_parser_destroy", "sjmi_parser_parse", "sjmi_parser_last_message",
            "sjmi_stage1_batch", "sjmi_stage1_batch_device", "sjmi_parser_parse_batch",
-           "sjmi_stage1_batch_isolated", "sjmi_stage1_batch_isolated_device"]
+           "sjmi_stage1_batch_isolated", "sjmi_stage1_batch_isolated_device", "sjmi_host_register",
+           "sjmi_host_unregister"]
 
 
 def lib():

@@ -114,9 +114,18 @@ SimdJsonParser::SimdJsonParser(int capacity, int maxDepth, int device)
       paddedBuffer_((size_t)capacity + PADDING), openContainers_((size_t)maxDepth), isArray_((size_t)maxDepth) {
     const int rc = sjmi_create(&ctx_, device, (uint64_t)capacity);
     if (rc != SJMI_OK) throw std::runtime_error("SimdJsonParser: no usable MI355X device (sjmi_create rc=" + std::to_string(rc) + "); there is no CPU fallback");
+    // parser-owned buffers that cross PCIe on every parse are page-locked (a hint: failures are ignored)
+    stringBuffer_.resize((size_t)capacity + 4 * ((size_t)capacity / 2 + 2) + 64);
+    pinned_[0] = sjmi_host_register(ctx_, paddedBuffer_.data(), paddedBuffer_.size()) == SJMI_OK ? paddedBuffer_.data() : nullptr;
+    pinned_[1] = sjmi_host_register(ctx_, bitIndexes_.array(), bitIndexes_.capacity() * sizeof(uint32_t)) == SJMI_OK ? (void*)bitIndexes_.array() : nullptr;
+    pinned_[2] = sjmi_host_register(ctx_, stringBuffer_.data(), stringBuffer_.size()) == SJMI_OK ? stringBuffer_.data() : nullptr;
 }
 
-SimdJsonParser::~SimdJsonParser() { sjmi_destroy(ctx_); }
+SimdJsonParser::~SimdJsonParser() {
+    for (void* p : pinned_)
+        if (p) (void)sjmi_host_unregister(ctx_, p);
+    sjmi_destroy(ctx_);
+}
 
 // SimdJsonParser.stage1 (SimdJsonParser.java:55-58) on the GPU + the string records stage 2 will need
 void SimdJsonParser::stage1(const uint8_t* buffer, size_t len) {
@@ -134,7 +143,11 @@ void SimdJsonParser::stage1(const uint8_t* buffer, size_t len) {
 // every string of the document(s) just indexed, unescaped on the GPU into stringBuffer_[0, stringBufferLen_)
 void SimdJsonParser::unescapeStrings(size_t len, uint64_t count) {
     const size_t need = len + 4 * (size_t)count + 64;
-    if (stringBuffer_.size() < need) stringBuffer_.resize(need);
+    if (stringBuffer_.size() < need) {  // (never for a document within the capacity: every string takes >= 2 source bytes)
+        if (pinned_[2]) (void)sjmi_host_unregister(ctx_, pinned_[2]);
+        pinned_[2] = nullptr;
+        stringBuffer_.resize(need);
+    }
     uint64_t total = 0, fei = 0;
     uint32_t fec = 0;
     const int rc = sjmi_unescape(ctx_, stringBuffer_.data(), stringBuffer_.size(), &total, &fei, &fec);

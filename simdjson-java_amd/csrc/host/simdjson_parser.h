@@ -168,6 +168,7 @@ private:
     std::vector<uint8_t> isArray_;
     std::vector<uint64_t> batchTape_, batchTapeOffsets_, indexOffsets_;
     std::vector<uint32_t> docStatus_;
+    void* pinned_[3] = {nullptr, nullptr, nullptr};  // page-locked parser buffers (sjmi_host_register)
     std::vector<int32_t> batchErrors_;
     size_t docBase_ = 0;  // batch: byte offset of the current document (error positions are document-relative)
 };

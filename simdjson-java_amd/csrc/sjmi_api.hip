@@ -392,6 +392,19 @@ int sjmi_stage1_batch_isolated(sjmi_ctx* c, const uint8_t* buf, uint64_t total_l
     return SJMI_OK;
 }
 
+int sjmi_host_register(sjmi_ctx* c, void* ptr, uint64_t bytes) {
+    if (!c || !ptr || !bytes) return SJMI_ERR_ARG;
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    if (fail(c, "hipHostRegister", hipHostRegister(ptr, bytes, hipHostRegisterDefault))) return SJMI_ERR_HIP;
+    return SJMI_OK;
+}
+
+int sjmi_host_unregister(sjmi_ctx* c, void* ptr) {
+    if (!c || !ptr) return SJMI_ERR_ARG;
+    if (fail(c, "hipHostUnregister", hipHostUnregister(ptr))) return SJMI_ERR_HIP;
+    return SJMI_OK;
+}
+
 int sjmi_set_tile_mode(sjmi_ctx* c, int ticket) {
     if (!c) return SJMI_ERR_ARG;
     c->ticket_mode = ticket != 0;

@@ -29,8 +29,9 @@
 namespace sjmi {
 
 constexpr int UNESC_THREADS = 256;
-constexpr int UNESC_ITEMS = 16;                               // structurals per lane
-constexpr int UNESC_TILE = UNESC_THREADS * UNESC_ITEMS;       // 4096 structurals per workgroup
+// structurals per lane = tile / 256: 16 (4096 per workgroup) for big inputs; a single document of a few hundred KB has
+// only tens of thousands of structurals, so small inputs use 1 (256 per workgroup) to have work for every CU
+constexpr int UNESC_ITEMS_MAX = 16;
 
 __device__ __forceinline__ bool is_json_ws(uint32_t c) { return c == 0x20 || c == 0x09 || c == 0x0A || c == 0x0D; }
 
@@ -404,7 +405,7 @@ constexpr uint32_t SIZE_SLOW = 0x80000000u;  // sizes[] flag: the string has esc
 // structural (is it a quote? backslashes in the head of the string) together with the 16 bytes in front of the
 // successor (the closing quote is the last byte > 0x20 there: between it and the next structural there is only
 // whitespace, or that byte would be a structural itself).
-constexpr int MEAS_GROUP = 4;
+constexpr int MEAS_GROUP_MAX = 4;
 constexpr int SPAN_W = 2;  // 64-chunk words of the per-row backslash map: rows spanning up to SPAN_W KiB use it
 
 struct MeasuredString {
@@ -473,16 +474,18 @@ __device__ __forceinline__ MeasuredString measure_string(const uint8_t* __restri
     return m;
 }
 
+template <int ITEMS>
 __global__ void __launch_bounds__(UNESC_THREADS)
 k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __restrict__ idx, uint64_t count,
               uint32_t* __restrict__ sizes, unsigned long long* __restrict__ block_sums, uint8_t* __restrict__ scratch,
               UnescapeResult* res) {
     __shared__ unsigned long long s_part[UNESC_THREADS / 64];
     const int lane = threadIdx.x & 63;
-    const uint64_t base = (uint64_t)blockIdx.x * UNESC_TILE;
+    constexpr int MEAS_GROUP = ITEMS < MEAS_GROUP_MAX ? ITEMS : MEAS_GROUP_MAX;
+    const uint64_t base = (uint64_t)blockIdx.x * (UNESC_THREADS * ITEMS);
     unsigned long long sum = 0;
 #pragma unroll 1
-    for (int g = 0; g < UNESC_ITEMS; g += MEAS_GROUP) {
+    for (int g = 0; g < ITEMS; g += MEAS_GROUP) {
         uint32_t open[MEAS_GROUP], bound[MEAS_GROUP], tpos[MEAS_GROUP];
         bool in_range[MEAS_GROUP];
 #pragma unroll
@@ -610,8 +613,7 @@ k_scan_sums(unsigned long long* __restrict__ block_sums, uint32_t nblocks, Unesc
 // The lane-per-string versions before it were instruction-bound by divergence (8e8 VALU instructions and 5.7e7 store
 // instructions per twitter x1024 launch: every length class, every 16-byte piece of a long string and every string
 // with escapes was a separate pass of the whole wave).
-constexpr int WSUB_ROWS = 4;
-constexpr int WSUB = WSUB_ROWS * UNESC_THREADS;  // records of 1024 structurals per pass
+constexpr int WSUB_ROWS_MAX = 8;  // records of up to 2048 structurals per pass
 constexpr uint32_t REC_SCRATCH = 0x80000000u;    // rec_len flag: the bytes are in the scratch copy
 constexpr uint32_t REC_FAILED = 0x40000000u;     // rec_len flag: failed string, low byte = SJMI_E_* code
 
@@ -634,21 +636,24 @@ __device__ __forceinline__ void insert_at(unsigned long long& v0, unsigned long 
     }
 }
 
+template <int ITEMS>
 __global__ void __launch_bounds__(UNESC_THREADS)
 k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __restrict__ idx, uint64_t count,
             const uint32_t* __restrict__ sizes, const unsigned long long* __restrict__ block_offsets,
             const uint8_t* __restrict__ scratch, uint8_t* __restrict__ sb, uint64_t sb_cap, UnescapeResult* res) {
-    __shared__ uint32_t s_wave[UNESC_ITEMS][UNESC_THREADS / 64];  // bytes per (row, wave)
-    __shared__ uint32_t s_cnt[UNESC_ITEMS][UNESC_THREADS / 64];   // strings per (row, wave)
+    constexpr int WSUB_ROWS = ITEMS < WSUB_ROWS_MAX ? ITEMS : WSUB_ROWS_MAX;
+    constexpr int WSUB = WSUB_ROWS * UNESC_THREADS;
+    __shared__ uint32_t s_wave[ITEMS][UNESC_THREADS / 64];  // bytes per (row, wave)
+    __shared__ uint32_t s_cnt[ITEMS][UNESC_THREADS / 64];   // strings per (row, wave)
     __shared__ uint32_t rec_d[WSUB], rec_src[WSUB], rec_len[WSUB];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint64_t base = (uint64_t)blockIdx.x * UNESC_TILE;
+    const uint64_t base = (uint64_t)blockIdx.x * (UNESC_THREADS * ITEMS);
     // bytes and strings per (row, wave) of the whole tile; the sizes themselves are read again pass by pass (they
     // would cost 32 VGPRs if kept)
 #pragma unroll
-    for (int k = 0; k < UNESC_ITEMS; ++k) {
+    for (int k = 0; k < ITEMS; ++k) {
         const uint64_t i = base + (uint64_t)k * UNESC_THREADS + threadIdx.x;
         uint32_t x = (i < count ? sizes[i] : 0u) & ~SIZE_SLOW;
         const unsigned long long sm = __ballot(x != 0);
@@ -663,12 +668,12 @@ k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __res
     unsigned long long row = block_offsets[blockIdx.x];
     if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) {  // (string buffer too small: reported once, by the last tile)
         unsigned long long end = row;
-        for (int k = 0; k < UNESC_ITEMS; ++k)
+        for (int k = 0; k < ITEMS; ++k)
             for (int w = 0; w < UNESC_THREADS / 64; ++w) end += s_wave[k][w];
         if (end > sb_cap) atomicOr(&res->flags, 1u);
     }
 #pragma unroll 1
-    for (int k0 = 0; k0 < UNESC_ITEMS; k0 += WSUB_ROWS) {
+    for (int k0 = 0; k0 < ITEMS; k0 += WSUB_ROWS) {
         // ---- the records of this pass, in order, as a table in LDS ----
         const unsigned long long D0 = row;  // where this pass's records start in the string buffer
         uint32_t nrec = 0;
@@ -771,17 +776,31 @@ k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __res
     }
 }
 
-// layout: sizes[count] | block sums | scratch[len + 128] (unescaped copies of the strings that had escapes)
+// layout: sizes[count] | block sums (sized for the smallest tile) | scratch[len + 128]
+static int unescape_items(uint64_t count) { return count >= (1u << 20) ? UNESC_ITEMS_MAX : (count >= (1u << 17) ? 4 : 1); }
 static size_t ws_sums_offset(uint64_t count) { return (((size_t)count * sizeof(uint32_t) + 63) / 64) * 64 + 64; }
 static size_t ws_scratch_offset(uint64_t count) {
-    const uint64_t nblocks = (count + UNESC_TILE - 1) / UNESC_TILE;
+    const uint64_t nblocks = (count + UNESC_THREADS - 1) / UNESC_THREADS;
     return ws_sums_offset(count) + (((size_t)(nblocks + 1) * sizeof(unsigned long long) + 63) / 64) * 64 + 64;
 }
 size_t unescape_workspace_bytes(uint64_t count, uint64_t len) { return ws_scratch_offset(count) + (size_t)len + 128; }
 
+template <int ITEMS>
+static hipError_t unescape_launch_items(const uint8_t* d_buf, uint64_t len, const uint32_t* d_idx, uint64_t count,
+                                        uint8_t* d_sb, uint64_t sb_cap, uint32_t* sizes, unsigned long long* sums,
+                                        uint8_t* scratch, UnescapeResult* d_res, hipStream_t stream) {
+    const uint64_t tile = (uint64_t)UNESC_THREADS * ITEMS;
+    const uint64_t nblocks = (count + tile - 1) / tile;
+    hipLaunchKernelGGL((k_str_measure<ITEMS>), dim3((unsigned)nblocks), dim3(UNESC_THREADS), 0, stream, d_buf, (uint32_t)len,
+                       d_idx, count, sizes, sums, scratch, d_res);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, (uint32_t)nblocks, d_res);
+    hipLaunchKernelGGL((k_str_write<ITEMS>), dim3((unsigned)nblocks), dim3(UNESC_THREADS), 0, stream, d_buf, (uint32_t)len,
+                       d_idx, count, sizes, sums, scratch, d_sb, sb_cap, d_res);
+    return hipGetLastError();
+}
+
 hipError_t unescape_launch(const uint8_t* d_buf, uint64_t len, const uint32_t* d_idx, uint64_t count, uint8_t* d_sb,
                            uint64_t sb_cap, void* d_ws, UnescapeResult* d_res, hipStream_t stream) {
-    const uint64_t nblocks = (count + UNESC_TILE - 1) / UNESC_TILE;
     uint8_t* ws = static_cast<uint8_t*>(d_ws);
     uint32_t* sizes = reinterpret_cast<uint32_t*>(ws);
     unsigned long long* sums = reinterpret_cast<unsigned long long*>(ws + ws_sums_offset(count));
@@ -789,12 +808,11 @@ hipError_t unescape_launch(const uint8_t* d_buf, uint64_t len, const uint32_t* d
     hipError_t e = hipMemsetAsync(d_res, 0, sizeof(UnescapeResult), stream);
     if (e != hipSuccess) return e;
     if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_str_measure, dim3((unsigned)nblocks), dim3(UNESC_THREADS), 0, stream, d_buf, (uint32_t)len, d_idx,
-                       count, sizes, sums, scratch, d_res);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, (uint32_t)nblocks, d_res);
-    hipLaunchKernelGGL(k_str_write, dim3((unsigned)nblocks), dim3(UNESC_THREADS), 0, stream, d_buf, (uint32_t)len, d_idx,
-                       count, sizes, sums, scratch, d_sb, sb_cap, d_res);
-    return hipGetLastError();
+    switch (unescape_items(count)) {
+    case 1: return unescape_launch_items<1>(d_buf, len, d_idx, count, d_sb, sb_cap, sizes, sums, scratch, d_res, stream);
+    case 4: return unescape_launch_items<4>(d_buf, len, d_idx, count, d_sb, sb_cap, sizes, sums, scratch, d_res, stream);
+    default: return unescape_launch_items<UNESC_ITEMS_MAX>(d_buf, len, d_idx, count, d_sb, sb_cap, sizes, sums, scratch, d_res, stream);
+    }
 }
 
 }  // namespace sjmi
