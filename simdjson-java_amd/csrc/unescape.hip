@@ -8,7 +8,7 @@
 // sum_{j<k}(4 + len_j): that is an exclusive prefix sum, and every string is independent.
 //
 // Three launches over the structural indexes produced by stage 1:
-//   k_str_measure : one workgroup per 4096 structurals.  A lane whose structural is '"' finds the closing quote
+//   k_str_measure : one workgroup per 256..4096 structurals.  A lane whose structural is '"' finds the closing quote
 //                   (the last byte > 0x20 before the next structural -- stage 1 already proved it exists) and looks
 //                   for a backslash.  No backslash (98 % of twitter.json's strings): length = raw length, done.
 //                   Otherwise the WAVE unescapes the string, 64 bytes per step, into a scratch copy; the first
@@ -50,64 +50,6 @@ __device__ __forceinline__ uint32_t escape_map(uint32_t e) {
     }
 }
 
-// Where the serial escape parser reads from: the document in global memory, or -- for positions [lo, hi) -- a copy
-// of it in LDS.  A lane parsing a string with escapes does one dependent access per 8-byte window and per escape;
-// against global memory that is a ~1 us round trip each, and the whole wave waits for its slowest lane (a third of
-// twitter.json's waves hold at least one such string), so the string is first pulled into LDS with a few independent
-// wide loads.
-constexpr uint32_t SCR_BYTES = 128;  // per slot: mirrored source bytes / staged output bytes
-constexpr int SCR_SLOTS = 8;         // slots per wave (further strings with escapes in the same wave read global memory)
-struct ByteSrc {
-    const uint8_t* __restrict__ buf;
-    const uint8_t* lds;
-    uint32_t lo, hi;  // lo is 8-byte aligned
-    __device__ __forceinline__ uint32_t byte(uint32_t pos) const {
-        return (pos >= lo && pos < hi) ? lds[pos - lo] : buf[pos];
-    }
-    __device__ __forceinline__ unsigned long long word8(uint32_t a) const {  // a is 8-byte aligned
-        return (a >= lo && a + 8 <= hi) ? *reinterpret_cast<const unsigned long long*>(lds + (a - lo))
-                                        : *reinterpret_cast<const unsigned long long*>(buf + a);
-    }
-};
-// mirror [from & ~7, ...) of the document, up to SCR_BYTES (never reading past `limit`, the padded end of the input)
-__device__ __forceinline__ ByteSrc mirror_string(const uint8_t* __restrict__ buf, uint32_t from, uint32_t to, uint32_t limit,
-                                                 uint8_t* scr) {
-    ByteSrc s;
-    s.buf = buf;
-    s.lds = scr;
-    s.lo = from & ~7u;
-    uint32_t hi = (to + 7u) & ~7u;
-    if (hi > s.lo + SCR_BYTES) hi = s.lo + SCR_BYTES;
-    if (hi > (limit & ~7u)) hi = limit & ~7u;
-    if (hi < s.lo) hi = s.lo;
-    s.hi = hi;
-    for (uint32_t p = s.lo; p < hi; p += 8)
-        *reinterpret_cast<unsigned long long*>(scr + (p - s.lo)) = *reinterpret_cast<const unsigned long long*>(buf + p);
-    return s;
-}
-__device__ __forceinline__ ByteSrc global_source(const uint8_t* __restrict__ buf) {
-    ByteSrc s;
-    s.buf = buf;
-    s.lds = nullptr;
-    s.lo = s.hi = 0;
-    return s;
-}
-
-// CharacterUtils.hexToInt (CharacterUtils.java:241-247): negative if any of the 4 digits is bad
-__device__ __forceinline__ int32_t hex4(const ByteSrc& in, uint32_t p) {
-    int32_t v = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t c = in.byte(p + i);
-        int32_t d;
-        if (c - '0' <= 9u) d = (int32_t)(c - '0');
-        else if ((c | 0x20u) - 'a' <= 5u) d = (int32_t)((c | 0x20u) - 'a' + 10);
-        else return -1;
-        v = (v << 4) | d;
-    }
-    return v;
-}
-
 // position of the closing quote of the string opened at `open`: the last non-whitespace byte before
 // the next structural (or before len for the last structural).  Returns 0 if that byte is not a quote
 // after `open` (cannot happen when stage 1 reported status 0).
@@ -116,90 +58,6 @@ __device__ __forceinline__ uint32_t find_close(const uint8_t* __restrict__ buf, 
     while (p > open + 1 && is_json_ws(buf[p - 1])) --p;
     if (p <= open + 1 || buf[p - 1] != '"') return 0;
     return p - 1;
-}
-
-// Output of the serial parser: the first OCAP bytes are staged in LDS and leave with wide stores (flush), the rest
-// (strings whose unescaped form is longer than a slot) goes to global memory byte by byte.
-struct ByteSink {
-    uint8_t* __restrict__ dst;  // final position of the string's bytes
-    uint8_t* lds;               // staging slot or nullptr
-    __device__ __forceinline__ void put(uint32_t n, uint32_t v) const {
-        if (lds != nullptr && n < SCR_BYTES) lds[n] = (uint8_t)v;
-        else dst[n] = (uint8_t)v;
-    }
-};
-
-// One pass of StringParser.doParseString (StringParser.java:29-68) over [open+1, close).
-// WRITE = false: only count.  Returns the unescaped length or -(error code).
-template <bool WRITE>
-__device__ __forceinline__ int64_t unescape_one(const ByteSrc& in, uint32_t open, uint32_t close, const ByteSink& out) {
-    uint32_t src = open + 1;
-    uint32_t n = 0;
-    while (src < close) {
-        // plain run: one aligned 8-byte load per window instead of a dependent load per byte
-        const uint32_t a = src & ~7u;
-        const unsigned long long w = in.word8(a);
-        const uint32_t lo = src - a;
-        const uint32_t hi = (close - a) < 8u ? (close - a) : 8u;
-        const unsigned long long z = w ^ 0x5C5C5C5C5C5C5C5Cull;
-        unsigned long long f = ~(((z & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | z) & 0x8080808080808080ull;
-        f &= ~0ull << (8 * lo);  // backslashes at or after src
-        uint32_t stop = f ? (uint32_t)__builtin_ctzll(f) >> 3 : 8u;
-        if (stop > hi) stop = hi;
-        for (uint32_t b = lo; b < stop; ++b) {
-            if (WRITE) out.put(n, (uint32_t)(w >> (8 * b)) & 0xFFu);
-            ++n;
-        }
-        src = a + stop;
-        if (stop >= hi) continue;  // window (or string) exhausted without an escape
-        const uint32_t e = in.byte(src + 1);
-        if (e == 'u') {                                                   // :45-57
-            int32_t cp = hex4(in, src + 2);
-            src += 6;
-            if (cp >= 0xD800 && cp <= 0xDBFF) {                           // parseLowSurrogate :112-124
-                if (!(in.byte(src) == '\\' && in.byte(src + 1) == 'u')) return -(int64_t)SJMI_E_LOW_SURROGATE_NO_U;
-                const int32_t low = hex4(in, src + 2) - 0xDC00;
-                if ((low >> 10) != 0) return -(int64_t)SJMI_E_LOW_SURROGATE_RANGE;
-                cp = (((cp - 0xD800) << 10) | low) + 0x10000;
-                src += 6;
-            } else if (cp >= 0xDC00 && cp <= 0xDFFF) {
-                return -(int64_t)SJMI_E_LOW_SURROGATE_RESERVED;           // :53-55
-            }
-            if (cp < 0) return -(int64_t)SJMI_E_INVALID_UNICODE_ESCAPE;   // storeCodePointInStringBuffer :127-129
-            if (cp <= 0x7F) {
-                if (WRITE) out.put(n, (uint32_t)cp);
-                n += 1;
-            } else if (cp <= 0x7FF) {
-                if (WRITE) {
-                    out.put(n, (uint32_t)((cp >> 6) + 192));
-                    out.put(n + 1, (uint32_t)((cp & 63) + 128));
-                }
-                n += 2;
-            } else if (cp <= 0xFFFF) {
-                if (WRITE) {
-                    out.put(n, (uint32_t)((cp >> 12) + 224));
-                    out.put(n + 1, (uint32_t)(((cp >> 6) & 63) + 128));
-                    out.put(n + 2, (uint32_t)((cp & 63) + 128));
-                }
-                n += 3;
-            } else {
-                if (WRITE) {
-                    out.put(n, (uint32_t)((cp >> 18) + 240));
-                    out.put(n + 1, (uint32_t)(((cp >> 12) & 63) + 128));
-                    out.put(n + 2, (uint32_t)(((cp >> 6) & 63) + 128));
-                    out.put(n + 3, (uint32_t)((cp & 63) + 128));
-                }
-                n += 4;
-            }
-        } else {                                                          // :58-61
-            const uint32_t r = (e & 0x80u) ? 0u : escape_map(e);
-            if (r == 0) return -(int64_t)SJMI_E_ESCAPE_UNEXPECTED;
-            if (WRITE) out.put(n, r);
-            ++n;
-            src += 2;
-        }
-    }
-    return (int64_t)n;
 }
 
 // byte-granular wide accesses: gfx950 global memory runs in unaligned-access mode, hipcc turns these into
@@ -218,8 +76,8 @@ struct __attribute__((packed, aligned(1))) U2B { uint16_t a; };
 // DPP prefix sum of the per-byte output lengths.  Errors are found by the byte that would raise them in
 // StringParser.doParseString (:45-61, :112-129); the lowest position wins, which is the sequential parser's first
 // error because everything in front of it parsed cleanly.
-// (The lane-serial parser above costs ~15 instructions per source byte with the whole wave waiting for one lane:
-// on twitter.json it was more than half of all instructions of the unescape kernels.)
+// (The lane-serial parser it replaced cost ~15 instructions per source byte with the whole wave waiting for one lane:
+// on twitter.json more than half of all instructions of the unescape kernels.)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t udpp_add(uint32_t v) {
     return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
@@ -366,29 +224,6 @@ __device__ __forceinline__ bool has_backslash(const uint8_t* __restrict__ buf, u
         }
     }
     return any != 0;
-}
-
-// copy n > 0 bytes between arbitrary byte addresses with the widest accesses that stay INSIDE [0, n) on both sides
-// (tails are done with an overlapping access, so neither a byte before nor after the string is touched)
-__device__ __forceinline__ void copy_bytes(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n) {
-    if (n >= 16) {
-        for (uint32_t t = 0; t + 16 <= n; t += 16) *reinterpret_cast<U16B*>(dst + t) = *reinterpret_cast<const U16B*>(src + t);
-        if (n & 15u) *reinterpret_cast<U16B*>(dst + n - 16) = *reinterpret_cast<const U16B*>(src + n - 16);
-    } else if (n >= 8) {
-        const U8B a = *reinterpret_cast<const U8B*>(src), b = *reinterpret_cast<const U8B*>(src + n - 8);
-        *reinterpret_cast<U8B*>(dst) = a;
-        *reinterpret_cast<U8B*>(dst + n - 8) = b;
-    } else if (n >= 4) {
-        const U4B a = *reinterpret_cast<const U4B*>(src), b = *reinterpret_cast<const U4B*>(src + n - 4);
-        *reinterpret_cast<U4B*>(dst) = a;
-        *reinterpret_cast<U4B*>(dst + n - 4) = b;
-    } else if (n >= 2) {
-        const U2B a = *reinterpret_cast<const U2B*>(src), b = *reinterpret_cast<const U2B*>(src + n - 2);
-        *reinterpret_cast<U2B*>(dst) = a;
-        *reinterpret_cast<U2B*>(dst + n - 2) = b;
-    } else {
-        dst[0] = src[0];
-    }
 }
 
 constexpr uint32_t SIZE_SLOW = 0x80000000u;  // sizes[] flag: the string has escapes (lane-serial path)
