@@ -33,8 +33,6 @@ constexpr uint32_t DBG_FAKE_TIMEOUT = 16;
 constexpr uint32_t DBG_SMALL_GRID = 32;
 // kernel flag (not an ablation): SAFE liveness mode -- no scanner workgroup, every worker looks back itself
 constexpr uint32_t FLAG_SAFE = 0x100;
-// experiments: static tile striding instead of the atomic ticket
-constexpr uint32_t FLAG_STATIC = 0x400;
 
 // workspace layout (zeroed by one hipMemsetAsync per launch)
 constexpr size_t WS_RESULT_OFFSET = 0;        // Stage1Result (16 bytes)

@@ -415,14 +415,16 @@ __device__ __forceinline__ void scanner_wave(ScanHandoff* hand, int wave, const 
 //                            park granule k's masks / offsets in the wave's LDS slice (20 bytes per block)
 //
 // so a granule's prefix is needed one whole classification after its aggregate went out, and it comes from the
-// scanner wave (above), not from a look-back by the worker.
+// scanner workgroup (above), not from a look-back by the worker.
 //
-// Granule assignment, FAST mode (default): static striding, granule = k * workers + worker.  RESULTS never depend
-// on scheduling; LIVENESS does: the workers spin on prefixes, so every worker wave and the scanner have to be
-// resident (the host sizes the grid with the occupancy API; the scanner is workgroup 0).  If that ever fails, the
-// bounded spins trip, the launch reports SJMI_ST_INTERNAL and the host re-runs it in SAFE mode: granules by
-// atomic ticket and a decoupled look-back by the worker itself (a granule then only waits for granules some
-// running wave already holds), slower (one exposed atomic per granule) but free of residency assumptions.
+// Granule assignment, FAST mode (default): the first granule of a wave is its worker index, all further ones come
+// from atomic tickets (8 counters, requested one step ahead; see the kernel).  Classification runs at raised wave
+// priority, workers that share the scanner's CU retire after one granule.  RESULTS never depend on scheduling;
+// LIVENESS does: the workers spin on prefixes, so every worker wave and the scanner have to be resident (the host
+// sizes the grid with the occupancy API; the scanner is workgroup 0).  If that ever fails, the bounded spins trip,
+// the launch reports SJMI_ST_INTERNAL and the host re-runs it in SAFE mode: a separate instantiation, every granule
+// by one atomic ticket and a decoupled look-back by the worker itself (a granule then only waits for granules some
+// running wave already holds), ~2.5x slower but free of residency assumptions.
 // Variants measured and dropped: one tile per workgroup with the look-back on the critical
 // path (2.8 TB/s), two chain granules per workgroup with a late look-back, persistent workgroups with a barrier
 // per tile and look-back windows of 64..256 granules (uncached polling traffic), 16 KiB workgroup tiles
