@@ -190,7 +190,7 @@ int sjmi_host_unregister(sjmi_ctx* ctx, void* ptr);
 int sjmi_selftest(sjmi_ctx* ctx, uint32_t* mismatches);
 
 /* tuning knob for tests: force the chain granule = steps x 4 KiB per worker wave and iteration (1, 2 or 4;
- * 0 = automatic: 1 for documents up to 4 MiB, else 4) */
+ * 0 = automatic: 1 for documents up to 4 MiB, 2 up to 16 MiB, else 4) */
 int sjmi_set_tile_steps(sjmi_ctx* ctx, int steps);
 
 /* Liveness mode of the stage-1 kernel (results never depend on it): 0 (default) = FAST: persistent worker waves plus

@@ -856,8 +856,9 @@ size_t stage1_workspace_bytes(uint64_t len, int steps) {
 }
 
 int stage1_pick_steps(uint64_t len) {
-    // small documents: small granules so that more CUs get work; large: 16 KiB granules
-    return len <= (4u << 20) ? 1 : 4;
+    // small documents: small granules so that more waves get work (tools/size_sweep.py: 0.6 MB 8.9 us with 4 KiB
+    // granules against 13.9 us with 16 KiB; 10 MB 14.5 us with 8 KiB; from ~20 MB on 16 KiB granules win)
+    return len <= (4u << 20) ? 1 : (len <= (16u << 20) ? 2 : 4);
 }
 
 // workgroups of k_stage1<...> that are resident at the same time on the current device (fast mode's grid)
