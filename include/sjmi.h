@@ -129,6 +129,13 @@ int sjmi_unescape_device(sjmi_ctx* ctx, const void* d_buf, uint64_t len, const v
 int sjmi_unescape(sjmi_ctx* ctx, uint8_t* string_buffer, uint64_t string_capacity, uint64_t* total_bytes,
                   uint64_t* first_error_index, uint32_t* first_error_code);
 
+/* SimdJsonParser.parse's GPU part in ONE call: sjmi_stage1 followed by sjmi_unescape of the same document, with two
+ * host synchronisations instead of four (the unescape kernels read the structural count from the stage-1 result on
+ * the device).  Outputs as in the two separate calls; the string outputs are meaningful only if *status == 0. */
+int sjmi_stage1_unescape(sjmi_ctx* ctx, const uint8_t* buf, uint64_t len, uint32_t* indexes, uint64_t index_capacity,
+                         uint64_t* count, uint32_t* status, uint8_t* string_buffer, uint64_t string_capacity,
+                         uint64_t* total_bytes, uint64_t* first_error_index, uint32_t* first_error_code);
+
 /* ---- batched documents ---------------------------------------------------------------------------------
  * n_docs documents packed in one buffer, document k at [doc_offsets[k], doc_offsets[k+1]), each followed by at
  * least one JSON whitespace byte inside its range (NDJSON style; doc_offsets[n_docs] = total length).

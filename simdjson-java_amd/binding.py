@@ -62,7 +62,7 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_parser_create", "sjmi_parser_destroy", "sjmi_parser_parse", "sjmi_parser_last_message",
            "sjmi_stage1_batch", "sjmi_stage1_batch_device", "sjmi_parser_parse_batch",
            "sjmi_stage1_batch_isolated", "sjmi_stage1_batch_isolated_device", "sjmi_host_register",
-           "sjmi_host_unregister"]
+           "sjmi_host_unregister", "sjmi_stage1_unescape"]
 
 
 def lib():
@@ -123,6 +123,9 @@ def lib():
         L.sjmi_stage1_batch_isolated_device.restype = C.c_int
         L.sjmi_stage1_batch_isolated_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                                         C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sjmi_stage1_unescape.restype = C.c_int
+        L.sjmi_stage1_unescape.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sjmi_parser_parse_batch.restype = C.c_int
         L.sjmi_parser_parse_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p]
@@ -181,6 +184,21 @@ class Context:
                     "sjmi_stage1")
         assert idx[cnt.value] == 0, "sentinel missing"
         return idx[:cnt.value].copy(), st.value
+
+    def stage1_unescape(self, data, idx=None, sb=None):
+        """Fused host path (sjmi_stage1_unescape): -> (indexes, status, string_buffer bytes, first_error_index, code)."""
+        a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        n = a.size
+        if idx is None:
+            idx = np.empty(n + 2, dtype=np.uint32)
+        if sb is None:
+            sb = np.empty(n + 4 * (n // 2 + 2) + 64, dtype=np.uint8)
+        cnt, total, fei = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        st, fec = C.c_uint32(0), C.c_uint32(0)
+        self._check(lib().sjmi_stage1_unescape(self._h, a.ctypes.data if n else None, n, idx.ctypes.data, idx.size,
+                                               C.addressof(cnt), C.addressof(st), sb.ctypes.data, sb.size, C.addressof(total),
+                                               C.addressof(fei), C.addressof(fec)), "sjmi_stage1_unescape")
+        return idx[:cnt.value], st.value, sb[:total.value], (None if fei.value == 2**64 - 1 else fei.value), fec.value
 
     def stage1_batch(self, data, doc_offsets):
         """Batched host path: -> (indexes, index_offsets[np.uint64 n+1], status)."""

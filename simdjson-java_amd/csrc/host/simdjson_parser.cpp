@@ -129,15 +129,23 @@ SimdJsonParser::~SimdJsonParser() {
 
 // SimdJsonParser.stage1 (SimdJsonParser.java:55-58) on the GPU + the string records stage 2 will need
 void SimdJsonParser::stage1(const uint8_t* buffer, size_t len) {
-    uint64_t count = 0;
-    uint32_t status = 0;
-    int rc = sjmi_stage1(ctx_, buffer, len, bitIndexes_.array(), bitIndexes_.capacity(), &count, &status);
-    if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_stage1: ") + sjmi_last_error(ctx_));
+    uint64_t count = 0, total = 0, fei = 0;
+    uint32_t status = 0, fec = 0;
+    const size_t need = len + 4 * (len / 2 + 2) + 64;  // every string takes >= 2 source bytes
+    if (stringBuffer_.size() < need) {
+        if (pinned_[2]) (void)sjmi_host_unregister(ctx_, pinned_[2]);
+        pinned_[2] = nullptr;
+        stringBuffer_.resize(need);
+    }
+    // stage 1 and the string records stage 2 will need, queued together (two synchronisations instead of four)
+    int rc = sjmi_stage1_unescape(ctx_, buffer, len, bitIndexes_.array(), bitIndexes_.capacity(), &count, &status,
+                                  stringBuffer_.data(), stringBuffer_.size(), &total, &fei, &fec);
+    if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_stage1_unescape: ") + sjmi_last_error(ctx_));
     bitIndexes_.setWriteIdx((size_t)count);
     if (status & SJMI_ST_UTF8) throw fail(E_UTF8);                 // Utf8Validator.java:165-167 (checked first)
     if (status & SJMI_ST_UNCLOSED) throw fail(E_UNCLOSED_STRING);  // StructuralIndexer.java:297-299
     if (status & SJMI_ST_UNESCAPED) throw fail(E_UNESCAPED_CHARS); // :300-302
-    unescapeStrings(len, count);
+    stringBufferLen_ = (size_t)total;
 }
 
 // every string of the document(s) just indexed, unescaped on the GPU into stringBuffer_[0, stringBufferLen_)

@@ -191,7 +191,7 @@ int sjmi_unescape_device(sjmi_ctx* c, const void* d_buf, uint64_t len, const voi
         return SJMI_ERR_HIP;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     if (fail(c, "unescape launch",
-             sjmi::unescape_launch((const uint8_t*)d_buf, len, (const uint32_t*)d_indexes, count,
+             sjmi::unescape_launch((const uint8_t*)d_buf, len, (const uint32_t*)d_indexes, count, nullptr,
                                    (uint8_t*)d_string_buffer, string_capacity, c->d_ws_str,
                                    (sjmi::UnescapeResult*)d_result, st)))
         return SJMI_ERR_HIP;
@@ -233,6 +233,83 @@ int sjmi_unescape(sjmi_ctx* c, uint8_t* string_buffer, uint64_t string_capacity,
     if (r.total_bytes &&
         (fail(c, "D2H(sb)", hipMemcpyAsync(string_buffer, c->d_sb, r.total_bytes, hipMemcpyDeviceToHost, c->stream)) ||
          fail(c, "sync", hipStreamSynchronize(c->stream))))
+        return SJMI_ERR_HIP;
+    return SJMI_OK;
+}
+
+int sjmi_stage1_unescape(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes, uint64_t index_capacity,
+                         uint64_t* count, uint32_t* status, uint8_t* string_buffer, uint64_t string_capacity,
+                         uint64_t* total_bytes, uint64_t* first_error_index, uint32_t* first_error_code) {
+    if (!c || (!buf && len) || !indexes || !count || !status || !string_buffer || !total_bytes || !first_error_index ||
+        !first_error_code)
+        return SJMI_ERR_ARG;
+    if (len > c->capacity || len >= (1ull << 32)) {
+        c->err = "document larger than the context capacity";
+        return SJMI_ERR_CAPACITY;
+    }
+    if (index_capacity < 1) return SJMI_ERR_CAPACITY;
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    // everything is queued before the first synchronisation: the unescape kernels take the structural count from the
+    // stage-1 result on the device; grids and workspace are sized for the bound "one structural per byte"
+    const uint64_t bound = len + 1;
+    const size_t need_sb = (size_t)len + 4 * ((size_t)len / 2 + 2) + 64;  // sum(4+len_k): every string takes >= 2 source bytes
+    if (!grow(c, (void**)&c->d_sb, &c->sb_bytes, need_sb, "hipMalloc(sb)") ||
+        !grow(c, &c->d_ws_str, &c->ws_str_bytes, sjmi::unescape_workspace_bytes(bound, len), "hipMalloc(ws_str)"))
+        return SJMI_ERR_HIP;
+    if (!c->d_ures && fail(c, "hipMalloc(ures)", hipMalloc((void**)&c->d_ures, sizeof(sjmi_unescape_result))))
+        return SJMI_ERR_HIP;
+    if (len && fail(c, "H2D", hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
+    const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(len);
+    const uint64_t dev_cap = c->capacity + 2 < index_capacity ? c->capacity + 2 : index_capacity;
+    const sjmi::Stage1Result* d_res1 = (const sjmi::Stage1Result*)((uint8_t*)c->d_ws + sjmi::WS_RESULT_OFFSET);
+    sjmi_unescape_result r;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (fail(c, "launch", sjmi::stage1_launch(c->d_in, len, c->d_idx, dev_cap, c->d_ws, steps, c->stream, nullptr,
+                                                  nullptr, launch_flags(c))) ||
+            fail(c, "unescape launch",
+                 sjmi::unescape_launch(c->d_in, len, c->d_idx, bound, d_res1, c->d_sb, c->sb_bytes, c->d_ws_str,
+                                       (sjmi::UnescapeResult*)c->d_ures, c->stream)) ||
+            fail(c, "D2H(result)", hipMemcpyAsync(c->h_res, d_res1, sizeof(sjmi_stage1_result), hipMemcpyDeviceToHost, c->stream)) ||
+            fail(c, "D2H(ures)", hipMemcpyAsync(&r, c->d_ures, sizeof r, hipMemcpyDeviceToHost, c->stream)) ||
+            fail(c, "sync", hipStreamSynchronize(c->stream)))
+            return SJMI_ERR_HIP;
+        if (!(c->h_res->status & SJMI_ST_INTERNAL) || c->ticket_mode) break;
+        c->ticket_mode = true;  // fast-mode liveness assumption failed: latch the safe mode and run again
+    }
+    *status = c->h_res->status & 0xFFu;
+    *count = c->h_res->count;
+    *total_bytes = 0;
+    *first_error_index = ~0ull;
+    *first_error_code = 0;
+    if (c->h_res->status & SJMI_ST_INTERNAL) {
+        c->err = "look-back timeout";
+        return SJMI_ERR_INTERNAL;
+    }
+    if (c->h_res->status & SJMI_ST_CAPACITY) {
+        c->err = "index_capacity too small";
+        return SJMI_ERR_CAPACITY;
+    }
+    c->last_len = len;
+    c->last_count = c->h_res->count;
+    c->last_valid = true;
+    const bool strings_ok = *status == 0;  // (a document that fails stage 1 has no meaningful strings: the caller throws)
+    if (strings_ok) {
+        *total_bytes = r.total_bytes;
+        if (r.first_error_inv) {
+            const uint64_t v = ~r.first_error_inv;
+            *first_error_index = v >> 8;
+            *first_error_code = (uint32_t)(v & 0xFF);
+        }
+        if (r.total_bytes > string_capacity || (r.flags & 1u)) {
+            c->err = "string_capacity too small";
+            return SJMI_ERR_CAPACITY;
+        }
+    }
+    if (fail(c, "D2H(indexes)",
+             hipMemcpyAsync(indexes, c->d_idx, (c->h_res->count + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)) ||
+        (strings_ok && r.total_bytes &&
+         fail(c, "D2H(sb)", hipMemcpyAsync(string_buffer, c->d_sb, r.total_bytes, hipMemcpyDeviceToHost, c->stream))) ||
+        fail(c, "sync", hipStreamSynchronize(c->stream)))
         return SJMI_ERR_HIP;
     return SJMI_OK;
 }

@@ -46,8 +46,9 @@ int stage1_pick_steps(uint64_t len);
 hipError_t stage1_launch(const uint8_t* d_buf, uint64_t len, uint32_t* d_out, uint64_t out_cap, void* d_ws, int steps,
                          hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg = 0);
 size_t unescape_workspace_bytes(uint64_t count, uint64_t len);
-hipError_t unescape_launch(const uint8_t* d_buf, uint64_t len, const uint32_t* d_idx, uint64_t count, uint8_t* d_sb,
-                           uint64_t sb_cap, void* d_ws, UnescapeResult* d_res, hipStream_t stream);
+hipError_t unescape_launch(const uint8_t* d_buf, uint64_t len, const uint32_t* d_idx, uint64_t count_bound,
+                           const Stage1Result* dev_count, uint8_t* d_sb, uint64_t sb_cap, void* d_ws, UnescapeResult* d_res,
+                           hipStream_t stream);
 hipError_t split_docs_launch(const uint32_t* d_idx, const Stage1Result* d_res, const unsigned long long* d_doc_offsets,
                              uint64_t n_docs, unsigned long long* d_index_offsets, hipStream_t stream);
 size_t batch_isolated_workspace_bytes(uint64_t n_docs);

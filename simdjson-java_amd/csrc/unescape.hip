@@ -312,8 +312,12 @@ __device__ __forceinline__ MeasuredString measure_string(const uint8_t* __restri
 template <int ITEMS>
 __global__ void __launch_bounds__(UNESC_THREADS)
 k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __restrict__ idx, uint64_t count,
-              uint32_t* __restrict__ sizes, unsigned long long* __restrict__ block_sums, uint8_t* __restrict__ scratch,
-              UnescapeResult* res) {
+              const Stage1Result* __restrict__ dev_count, uint32_t* __restrict__ sizes,
+              unsigned long long* __restrict__ block_sums, uint8_t* __restrict__ scratch, UnescapeResult* res) {
+    // dev_count != nullptr: the structural count is still on the device (stage 1 of the same document is queued right
+    // in front); the grid was sized for an upper bound, surplus workgroups leave at once
+    if (dev_count) count = dev_count->count;
+    if ((uint64_t)blockIdx.x * (UNESC_THREADS * ITEMS) >= count) return;
     __shared__ unsigned long long s_part[UNESC_THREADS / 64];
     const int lane = threadIdx.x & 63;
     constexpr int MEAS_GROUP = ITEMS < MEAS_GROUP_MAX ? ITEMS : MEAS_GROUP_MAX;
@@ -411,7 +415,9 @@ k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __r
 
 // exclusive scan of the workgroup sums by ONE workgroup (there are count/4096 of them); also the total
 __global__ void __launch_bounds__(1024)
-k_scan_sums(unsigned long long* __restrict__ block_sums, uint32_t nblocks, UnescapeResult* res) {
+k_scan_sums(unsigned long long* __restrict__ block_sums, uint32_t nblocks, const Stage1Result* __restrict__ dev_count,
+            uint32_t tile, UnescapeResult* res) {
+    if (dev_count) nblocks = (uint32_t)((dev_count->count + tile - 1) / tile);
     __shared__ unsigned long long s_wave[16];
     __shared__ unsigned long long s_carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -474,13 +480,16 @@ __device__ __forceinline__ void insert_at(unsigned long long& v0, unsigned long 
 template <int ITEMS>
 __global__ void __launch_bounds__(UNESC_THREADS)
 k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __restrict__ idx, uint64_t count,
-            const uint32_t* __restrict__ sizes, const unsigned long long* __restrict__ block_offsets,
+            const Stage1Result* __restrict__ dev_count, const uint32_t* __restrict__ sizes, const unsigned long long* __restrict__ block_offsets,
             const uint8_t* __restrict__ scratch, uint8_t* __restrict__ sb, uint64_t sb_cap, UnescapeResult* res) {
     constexpr int WSUB_ROWS = ITEMS < WSUB_ROWS_MAX ? ITEMS : WSUB_ROWS_MAX;
     constexpr int WSUB = WSUB_ROWS * UNESC_THREADS;
     __shared__ uint32_t s_wave[ITEMS][UNESC_THREADS / 64];  // bytes per (row, wave)
     __shared__ uint32_t s_cnt[ITEMS][UNESC_THREADS / 64];   // strings per (row, wave)
     __shared__ uint32_t rec_d[WSUB], rec_src[WSUB], rec_len[WSUB];
+    if (dev_count) count = dev_count->count;
+    const uint32_t nblocks_w = (uint32_t)((count + (uint64_t)UNESC_THREADS * ITEMS - 1) / ((uint64_t)UNESC_THREADS * ITEMS));
+    if (blockIdx.x >= nblocks_w) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -501,7 +510,7 @@ k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __res
     }
     __syncthreads();
     unsigned long long row = block_offsets[blockIdx.x];
-    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) {  // (string buffer too small: reported once, by the last tile)
+    if (threadIdx.x == 0 && blockIdx.x == nblocks_w - 1) {  // (string buffer too small: reported once, by the last tile)
         unsigned long long end = row;
         for (int k = 0; k < ITEMS; ++k)
             for (int w = 0; w < UNESC_THREADS / 64; ++w) end += s_wave[k][w];
@@ -622,31 +631,36 @@ size_t unescape_workspace_bytes(uint64_t count, uint64_t len) { return ws_scratc
 
 template <int ITEMS>
 static hipError_t unescape_launch_items(const uint8_t* d_buf, uint64_t len, const uint32_t* d_idx, uint64_t count,
-                                        uint8_t* d_sb, uint64_t sb_cap, uint32_t* sizes, unsigned long long* sums,
-                                        uint8_t* scratch, UnescapeResult* d_res, hipStream_t stream) {
+                                        const Stage1Result* dev_count, uint8_t* d_sb, uint64_t sb_cap, uint32_t* sizes,
+                                        unsigned long long* sums, uint8_t* scratch, UnescapeResult* d_res,
+                                        hipStream_t stream) {
     const uint64_t tile = (uint64_t)UNESC_THREADS * ITEMS;
-    const uint64_t nblocks = (count + tile - 1) / tile;
+    const uint64_t nblocks = (count + tile - 1) / tile;  // (an upper bound if the count is still on the device)
     hipLaunchKernelGGL((k_str_measure<ITEMS>), dim3((unsigned)nblocks), dim3(UNESC_THREADS), 0, stream, d_buf, (uint32_t)len,
-                       d_idx, count, sizes, sums, scratch, d_res);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, (uint32_t)nblocks, d_res);
+                       d_idx, count, dev_count, sizes, sums, scratch, d_res);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, (uint32_t)nblocks, dev_count, (uint32_t)tile, d_res);
     hipLaunchKernelGGL((k_str_write<ITEMS>), dim3((unsigned)nblocks), dim3(UNESC_THREADS), 0, stream, d_buf, (uint32_t)len,
-                       d_idx, count, sizes, sums, scratch, d_sb, sb_cap, d_res);
+                       d_idx, count, dev_count, sizes, sums, scratch, d_sb, sb_cap, d_res);
     return hipGetLastError();
 }
 
-hipError_t unescape_launch(const uint8_t* d_buf, uint64_t len, const uint32_t* d_idx, uint64_t count, uint8_t* d_sb,
-                           uint64_t sb_cap, void* d_ws, UnescapeResult* d_res, hipStream_t stream) {
+// count_bound = the structural count, or -- with dev_count -- an upper bound of it (the workspace and the grids are
+// sized for the bound; the kernels take the real count from *dev_count)
+hipError_t unescape_launch(const uint8_t* d_buf, uint64_t len, const uint32_t* d_idx, uint64_t count_bound,
+                           const Stage1Result* dev_count, uint8_t* d_sb, uint64_t sb_cap, void* d_ws, UnescapeResult* d_res,
+                           hipStream_t stream) {
     uint8_t* ws = static_cast<uint8_t*>(d_ws);
     uint32_t* sizes = reinterpret_cast<uint32_t*>(ws);
-    unsigned long long* sums = reinterpret_cast<unsigned long long*>(ws + ws_sums_offset(count));
-    uint8_t* scratch = ws + ws_scratch_offset(count);
+    unsigned long long* sums = reinterpret_cast<unsigned long long*>(ws + ws_sums_offset(count_bound));
+    uint8_t* scratch = ws + ws_scratch_offset(count_bound);
     hipError_t e = hipMemsetAsync(d_res, 0, sizeof(UnescapeResult), stream);
     if (e != hipSuccess) return e;
-    if (count == 0) return hipSuccess;
-    switch (unescape_items(count)) {
-    case 1: return unescape_launch_items<1>(d_buf, len, d_idx, count, d_sb, sb_cap, sizes, sums, scratch, d_res, stream);
-    case 4: return unescape_launch_items<4>(d_buf, len, d_idx, count, d_sb, sb_cap, sizes, sums, scratch, d_res, stream);
-    default: return unescape_launch_items<UNESC_ITEMS_MAX>(d_buf, len, d_idx, count, d_sb, sb_cap, sizes, sums, scratch, d_res, stream);
+    if (count_bound == 0) return hipSuccess;
+    // (with a bound, judge the size by the document: ~one structural per 8-11 bytes)
+    switch (unescape_items(dev_count ? len / 8 : count_bound)) {
+    case 1: return unescape_launch_items<1>(d_buf, len, d_idx, count_bound, dev_count, d_sb, sb_cap, sizes, sums, scratch, d_res, stream);
+    case 4: return unescape_launch_items<4>(d_buf, len, d_idx, count_bound, dev_count, d_sb, sb_cap, sizes, sums, scratch, d_res, stream);
+    default: return unescape_launch_items<UNESC_ITEMS_MAX>(d_buf, len, d_idx, count_bound, dev_count, d_sb, sb_cap, sizes, sums, scratch, d_res, stream);
     }
 }
 

@@ -16,6 +16,8 @@ def t(f, n=200):
 idx, st = ctx.stage1(doc)
 print("sjmi_stage1 (H2D + memset + kernel + D2H result + D2H indexes, incl. python/numpy overhead): %.1f us" % t(lambda: ctx.stage1(doc)))
 print("sjmi_unescape (3 kernels + D2H strings): %.1f us" % t(lambda: ctx.unescape(len(doc) + 4 * idx.size + 64)))
+a = np.frombuffer(doc, dtype=np.uint8); ix = np.empty(a.size + 2, dtype=np.uint32); sbuf = np.empty(a.size * 3 + 64, dtype=np.uint8)
+print("sjmi_stage1_unescape (fused: H2D, 4 kernels, 2 syncs, D2H indexes + strings; pageable numpy buffers): %.1f us" % t(lambda: ctx.stage1_unescape(a, ix, sbuf)))
 p = S.SimdJsonParser(capacity=len(doc) + 64)
 print("parse end to end: %.1f us" % t(lambda: p.parse(doc)))
 # device-side only
