@@ -152,6 +152,27 @@ def test_fuzz_tile_boundaries(ctx, steps):
         ctx.set_tile_steps(0)
 
 
+@pytest.mark.parametrize("steps", [1, 2, 4])
+def test_scanner_window_boundaries(ctx, steps):
+    """Granule counts around the scanner's windows of 256 granules (and the four-wave round of 1024): the last window
+    may be full, one granule long, or shared; hazards planted on the granule boundaries next to them."""
+    ctx.set_tile_steps(steps)
+    try:
+        rng = random.Random(70 + steps)
+        g = steps * 4096
+        counts = [255, 256, 257, 1024, 1025] if steps == 1 else [256, 257]
+        for ngran in counts:
+            for delta in (0, 1):
+                n = ngran * g - delta
+                d = bytearray(_json_like(rng, n))
+                for b in (255 * g, 256 * g, 257 * g, 512 * g, 1024 * g, n - g):
+                    if 8 <= b and b + 8 < len(d):
+                        d[b - 1:b + 1] = rng.choice([b'\\"', b'""', b'",'])
+                _check(ctx, bytes(d))
+    finally:
+        ctx.set_tile_steps(0)
+
+
 def test_adversarial_runs(ctx):
     n = 200 * 1024
     for d in (b'"' * n, b"\\" * n, b"\\" * (4 * 1024 * 1024 + 3) + b'"x"', b"\\" * (n - 1) + b'"', b'"' + b"\\" * (n - 3) + b'"x', b"[" * n, b" " * n, b"a" * n,
