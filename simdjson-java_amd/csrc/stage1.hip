@@ -6,11 +6,11 @@
 //  StructuralIndexer.java:196-303, BitIndexes.java:14-41,82-96).
 //
 // Mapping to the hardware:
-//   * one lane  = one 64-byte block (the reference's loop step), loaded as 4 x dwordx4; loads are
-//     software-pipelined one step ahead of the ALU work;
-//   * the block is transposed to 8 bit planes (8x8 bit-matrix butterflies in VOP2 ops + v_perm_b32 byte
-//     transposes, sj_block.h; an earlier v_and + v_msad_u8 form is kept for the self-test) and all
-//     classification / escape / string / UTF-8 logic is 64-bit boolean algebra in VGPRs;
+//   * one lane  = one 64-byte block (the reference's loop step), loaded as 4 x dwordx4; the loads of a step are
+//     requested as soon as the previous step has been transposed out of the registers they land in;
+//   * the block is transposed to 8 bit planes (v_perm_b32 byte transposes + one 8x8 bit-matrix butterfly across
+//     8 registers per 32-byte half, sj_block.h; an earlier v_and + v_msad_u8 form is kept for the self-test) and
+//     all classification / escape / string / UTF-8 logic is 64-bit boolean algebra in VGPRs;
 //   * the three serial carries of the reference loop (prevEscaped, prevScalar, previous 4 UTF-8
 //     bytes) are LOCAL: each lane re-derives them from the 8 bytes before its block;
 //   * the two truly global carries -- in-string parity (XOR scan) and the output offset (+ scan of
@@ -20,12 +20,12 @@
 //     worker picks its prefix up one classification later (software pipeline), so the input is read from HBM
 //     exactly once and nobody waits for the chain;
 //   * structurals depend on the incoming parity only through a complement
-//     (structurals(p) = p ? pot & sm : pot & ~sm), so each tile publishes counts for BOTH parities
-//     and the look-back composes functions {0,1} -> (parity, count);
-//   * indexes are expanded into a wave-private LDS slice and leave the CU as coalesced stores.
+//     (structurals(p) = p ? pot & sm : pot & ~sm), so each granule publishes counts for BOTH parities
+//     and the chain composes functions {0,1} -> (parity, count);
+//   * indexes are expanded into a wave-private LDS slice and leave the CU as aligned 16-byte stores.
 // Measured cost model on gfx950 (tools/ubench/valu_rate.hip): VOP2 integer ops issue in 2 cycles per
-// wave, every VOP3 op (v_msad_u8, v_or3, v_lshl_or, v_bfi, v_bcnt, 64-bit shifts) in 4; ~680 VALU instructions
-// per 4 KiB wave-step.
+// wave, every VOP3 op (v_msad_u8, v_or3, v_lshl_or, v_bfi, v_bcnt, 64-bit shifts) in 4; ~650 VALU instructions
+// per 4 KiB wave-step (SQ_INSTS_VALU, profiles/r1).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -125,11 +125,12 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// tile-state granules (one u64 per tile; zeroed by hipMemsetAsync before every launch)
+// chain granules (u64; one AGGREGATE and one PREFIX array entry per granule of input, zeroed by hipMemsetAsync
+// before every launch)
 //   bits 63..62 : 0 = nothing yet, 1 = AGGREGATE, 2 = INCLUSIVE PREFIX
-//   AGGREGATE   : [19:0] structurals if the tile is entered with parity 0, [39:20] with parity 1,
-//                 [40] quote parity of the tile
-//   PREFIX      : [39:0] structurals in tiles 0..t, [40] in-string parity after tile t
+//   AGGREGATE   : [19:0] structurals if the granule is entered with parity 0, [39:20] with parity 1,
+//                 [40] quote parity of the granule
+//   PREFIX      : [39:0] structurals in granules 0..t, [40] in-string parity after granule t
 // A granule is one naturally aligned 8-byte relaxed agent-scope store/load: the data is the flag
 // (cdna_hip_programming.md Guideline 16, form R2), so no fences are needed.
 // ---------------------------------------------------------------------------------------------
