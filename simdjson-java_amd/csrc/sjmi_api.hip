@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <new>
 #include <string>
 #include <utility>
@@ -44,7 +45,13 @@ struct sjmi_ctx {
 
 namespace {
 
-uint32_t launch_flags(const sjmi_ctx* c) { return c->dbg | (c->ticket_mode ? sjmi::FLAG_SAFE : 0u); }
+// contexts alive in this process: with more than one, two persistent stage-1 kernels may be resident at the same
+// time, each with only part of its grid -- the kernels then take every granule by ticket (FLAG_ALL_TICKETS), so that
+// a workgroup that has not started holds nothing the others could wait for (costs ~6 % on a GPU it has to itself)
+std::atomic<int> g_live_contexts{0};
+uint32_t launch_flags(const sjmi_ctx* c) {
+    return c->dbg | (c->ticket_mode ? sjmi::FLAG_SAFE : 0u) | (g_live_contexts.load() > 1 ? sjmi::FLAG_ALL_TICKETS : 0u);
+}
 
 bool fail(sjmi_ctx* c, const char* what, hipError_t e) {
     if (e == hipSuccess) return false;
@@ -68,6 +75,7 @@ int sjmi_create(sjmi_ctx** out, int device, uint64_t capacity_bytes) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return SJMI_ERR_NO_DEVICE;
     sjmi_ctx* c = new (std::nothrow) sjmi_ctx();
     if (!c) return SJMI_ERR_ARG;
+    g_live_contexts.fetch_add(1);  // (sjmi_destroy, also on the failure paths below, takes it back)
     c->device = device;
     c->capacity = capacity_bytes;
     const size_t in_bytes = ((capacity_bytes + 63) / 64) * 64 + 2 * SJMI_PADDING;
@@ -108,6 +116,7 @@ void sjmi_destroy(sjmi_ctx* c) {
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    g_live_contexts.fetch_sub(1);
 }
 
 const char* sjmi_last_error(const sjmi_ctx* c) { return c ? c->err.c_str() : "null context"; }

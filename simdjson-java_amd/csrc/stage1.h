@@ -33,6 +33,8 @@ constexpr uint32_t DBG_FAKE_TIMEOUT = 16;
 constexpr uint32_t DBG_SMALL_GRID = 32;
 // kernel flag (not an ablation): SAFE liveness mode -- no scanner workgroup, every worker looks back itself
 constexpr uint32_t FLAG_SAFE = 0x100;
+// kernel flag: FAST mode without static first granules (several contexts may be launching concurrently)
+constexpr uint32_t FLAG_ALL_TICKETS = 0x800;
 
 // workspace layout (zeroed by one hipMemsetAsync per launch)
 constexpr size_t WS_RESULT_OFFSET = 0;        // Stage1Result (16 bytes)

@@ -546,9 +546,12 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
         retire = __hip_atomic_load(scanner_cu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ^ my_cu;  // 0 = same CU (used a granule later)
     else
         retire = 1;
+    // FLAG_ALL_TICKETS (set by the host when several contexts may launch at the same time): the first granule comes
+    // from a ticket as well, so that a workgroup that is not resident yet holds nothing anybody could wait for
+    const bool first_by_ticket = safe || (dbg & FLAG_ALL_TICKETS) != 0;
     uint32_t cur;
-    const uint32_t ticket_base = safe ? 0u : (nworkers - cls + NC - 1u) / NC;
-    if (safe) {
+    const uint32_t ticket_base = first_by_ticket ? 0u : (nworkers - cls + NC - 1u) / NC;
+    if (first_by_ticket) {
         uint32_t t = 0;
         if (lane == 0) t = __hip_atomic_fetch_add(my_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) * NC + cls;
