@@ -20,8 +20,11 @@ struct sjmi_ctx {
     uint32_t* d_idx = nullptr;    // capacity + 1 entries (host-buffer path)
     void* d_ws = nullptr;         // tile-state workspace
     size_t ws_bytes = 0;
-    void* d_ws_dev = nullptr;     // workspace for the device-resident path (grown on demand)
-    size_t ws_dev_bytes = 0;
+    void* d_ws_dev = nullptr;     // workspace for the device-resident path: TWO halves used alternately (every launch
+    size_t ws_dev_bytes = 0;      // zeroes the half the next one will use), grown on demand
+    size_t ws_dev_clean[2] = {0, 0};  // bytes of each half known to be zero
+    int ws_dev_next = 0;              // half the next launch uses
+    void* ws_dev_last = nullptr;      // half the last launch used (debug read-back)
     sjmi_stage1_result* h_res = nullptr;  // pinned
     uint64_t last_len = 0, last_count = 0;  // document of the last sjmi_stage1 call (still on the device)
     bool last_valid = false;
@@ -123,9 +126,9 @@ const char* sjmi_last_error(const sjmi_ctx* c) { return c ? c->err.c_str() : "nu
 
 #ifdef SJMI_TRACE
 extern "C" int sjmi_debug_read_ws(sjmi_ctx* c, void* dst, uint64_t offset, uint64_t bytes) {
-    if (!c || !c->d_ws_dev || offset + bytes > c->ws_dev_bytes) return SJMI_ERR_ARG;
+    if (!c || !c->ws_dev_last || offset + bytes > c->ws_dev_bytes / 2) return SJMI_ERR_ARG;
     (void)hipDeviceSynchronize();
-    return hipMemcpy(dst, (uint8_t*)c->d_ws_dev + offset, bytes, hipMemcpyDeviceToHost) == hipSuccess ? SJMI_OK : SJMI_ERR_HIP;
+    return hipMemcpy(dst, (uint8_t*)c->ws_dev_last + offset, bytes, hipMemcpyDeviceToHost) == hipSuccess ? SJMI_OK : SJMI_ERR_HIP;
 }
 #endif
 
@@ -330,14 +333,27 @@ int sjmi_stage1_device(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_ind
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(len);
-    const size_t need = sjmi::stage1_workspace_bytes(len, steps);
-    if (need > c->ws_dev_bytes) {  // grown outside any timed loop on first use of a given size
+    const size_t need = (sjmi::stage1_workspace_bytes(len, steps) + 255) & ~(size_t)255;
+    if (2 * need > c->ws_dev_bytes) {  // grown outside any timed loop on first use of a given size
         if (c->d_ws_dev) (void)hipFree(c->d_ws_dev);
         c->d_ws_dev = nullptr;
         c->ws_dev_bytes = 0;
-        if (fail(c, "hipMalloc(ws_dev)", hipMalloc(&c->d_ws_dev, need))) return SJMI_ERR_HIP;
-        c->ws_dev_bytes = need;
+        if (fail(c, "hipMalloc(ws_dev)", hipMalloc(&c->d_ws_dev, 2 * need))) return SJMI_ERR_HIP;
+        c->ws_dev_bytes = 2 * need;
+        c->ws_dev_clean[0] = c->ws_dev_clean[1] = 0;
     }
+    // Nothing but the kernel is queued once the context is warm: this launch finds its half of the workspace zeroed
+    // by the previous one, zeroes the other half for the next one, and its last wave writes *d_result.
+    // (One launch stream per context at a time: the halves are handed over in stream order.)
+    const size_t half = c->ws_dev_bytes / 2;
+    const int h = c->ws_dev_next;
+    uint8_t* ws = (uint8_t*)c->d_ws_dev + (size_t)h * half;
+    const bool fast = !(launch_flags(c) & (sjmi::FLAG_SAFE | sjmi::DBG_NO_LOOKBACK));  // (the scanner writes the result)
+    sjmi::Stage1Extras ex;
+    ex.workspace_is_zero = c->ws_dev_clean[h] >= need;
+    ex.zero_next = (uint8_t*)c->d_ws_dev + (size_t)(1 - h) * half;
+    ex.zero_bytes = need;
+    ex.result_out = fast ? d_result : nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->profiling) {
         if (c->events_used == c->events.size()) {
@@ -350,13 +366,16 @@ int sjmi_stage1_device(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_ind
         ev1 = c->events[c->events_used].second;
         ++c->events_used;
     }
-    if (fail(c, "launch", sjmi::stage1_launch((const uint8_t*)d_buf, len, (uint32_t*)d_indexes, index_capacity,
-                                              c->d_ws_dev, steps, st, ev0, ev1, launch_flags(c))))
+    if (fail(c, "launch", sjmi::stage1_launch((const uint8_t*)d_buf, len, (uint32_t*)d_indexes, index_capacity, ws, steps,
+                                              st, ev0, ev1, launch_flags(c), ex)))
         return SJMI_ERR_HIP;
-    if (fail(c, "D2D(result)",
-             hipMemcpyAsync(d_result, (uint8_t*)c->d_ws_dev + sjmi::WS_RESULT_OFFSET, sizeof(sjmi_stage1_result),
-                            hipMemcpyDeviceToDevice, st)))
+    if (!fast && fail(c, "D2D(result)", hipMemcpyAsync(d_result, ws + sjmi::WS_RESULT_OFFSET, sizeof(sjmi_stage1_result),
+                                                       hipMemcpyDeviceToDevice, st)))
         return SJMI_ERR_HIP;
+    c->ws_dev_clean[h] = 0;
+    c->ws_dev_clean[1 - h] = need;
+    c->ws_dev_next = 1 - h;
+    c->ws_dev_last = ws;
     return SJMI_OK;
 }
 

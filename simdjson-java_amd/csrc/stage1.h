@@ -44,9 +44,17 @@ constexpr size_t WS_TILE_STATE_OFFSET = 640;   // u64 aggregates[granules], then
 
 size_t stage1_workspace_bytes(uint64_t len, int steps);
 int stage1_pick_steps(uint64_t len);
-// ev_start/ev_stop (optional) bracket the kernel only (not the workspace memset)
+// optional work folded into the kernel (device-resident path): see zero_next_workspace / scanner_wave in stage1.hip
+struct Stage1Extras {
+    bool workspace_is_zero = false;  // skip the workspace memset (a previous launch zeroed this workspace)
+    void* zero_next = nullptr;       // workspace the NEXT launch will use: zeroed by this one (16-byte aligned)
+    size_t zero_bytes = 0;           //   ... this many bytes of it (multiple of 16)
+    void* result_out = nullptr;      // device sjmi_stage1_result written by the scanner (FAST mode only)
+};
+// ev_start/ev_stop (optional) are attached to the kernel's dispatch (not the workspace memset)
 hipError_t stage1_launch(const uint8_t* d_buf, uint64_t len, uint32_t* d_out, uint64_t out_cap, void* d_ws, int steps,
-                         hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg = 0);
+                         hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg = 0,
+                         const Stage1Extras& ex = Stage1Extras());
 size_t unescape_workspace_bytes(uint64_t count, uint64_t len);
 hipError_t unescape_launch(const uint8_t* d_buf, uint64_t len, const uint32_t* d_idx, uint64_t count_bound,
                            const Stage1Result* dev_count, uint8_t* d_sb, uint64_t sb_cap, void* d_ws, UnescapeResult* d_res,

@@ -129,7 +129,8 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // before every launch)
 //   bits 63..62 : 0 = nothing yet, 1 = AGGREGATE, 2 = INCLUSIVE PREFIX
 //   AGGREGATE   : [19:0] structurals if the granule is entered with parity 0, [39:20] with parity 1,
-//                 [40] quote parity of the granule
+//                 [40] quote parity of the granule, [41] UTF-8 error in the granule, [42] / [43] unescaped control
+//                 character inside a string if the granule is entered with parity 0 / 1
 //   PREFIX      : [39:0] structurals in granules 0..t, [40] in-string parity after granule t
 // A granule is one naturally aligned 8-byte relaxed agent-scope store/load: the data is the flag
 // (cdna_hip_programming.md Guideline 16, form R2), so no fences are needed.
@@ -145,12 +146,13 @@ __device__ __forceinline__ sj_u64 ts_load(const sj_u64* p) {
 }
 
 __device__ __forceinline__ void publish_aggregate(sj_u64* tile_state, uint32_t tile, uint32_t T0, uint32_t T1,
-                                                  uint32_t tpar) {
-    ts_store(&tile_state[tile], TS_AGG | ((sj_u64)tpar << 40) | ((sj_u64)T1 << 20) | (sj_u64)T0);
+                                                  uint32_t tpar, uint32_t errbits = 0) {
+    ts_store(&tile_state[tile], TS_AGG | ((sj_u64)errbits << 41) | ((sj_u64)tpar << 40) | ((sj_u64)T1 << 20) | (sj_u64)T0);
 }
 __device__ __forceinline__ void publish_prefix(sj_u64* tile_state, uint32_t tile, uint32_t par_after, sj_u64 cnt_after) {
     ts_store(&tile_state[tile], TS_PFX | ((sj_u64)par_after << 40) | cnt_after);
 }
+
 
 // Executed by all 64 lanes of a wave.  Returns the parity / structural count entering `tile` (> 0).  Reads only.
 // The window is 64 * K tiles wide (lane i looks at the K tiles tile-1-i*K-j, j < K): the prefix frontier can
@@ -248,6 +250,7 @@ constexpr int SCAN_K = 4;  // granules per lane
 struct ScanHandoff {
     uint32_t seq;  // window whose entry state is in P / C; 0xFFFFFFFF = a scanner wave gave up
     uint32_t P;    // in-string parity after the windows scanned so far
+    uint32_t err;  // SJMI_ST_UTF8 / SJMI_ST_UNESCAPED found in the granules scanned so far
     sj_u64 C;      // structurals in them
 };
 
@@ -276,6 +279,26 @@ __device__ __forceinline__ void scanner_fold(const sj_u64 v[SCAN_K], uint32_t* c
     *c1 = b;
     *par = lp;
 }
+// SJMI_ST_* bits of the lane's granules, given the parity entering the first one (the aggregates carry "UTF-8 error" and
+// "unescaped control character if entered outside / inside a string": the status of a launch is complete as soon as
+// the scanner has seen every aggregate, no worker has to be waited for)
+__device__ __forceinline__ uint32_t scanner_errors(const sj_u64 v[SCAN_K], uint32_t q) {
+    uint32_t e = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_K; ++j) {
+        if ((v[j] >> 41) & 1u) e |= SJMI_ST_UTF8;
+        if ((v[j] >> (42 + q)) & 1u) e |= SJMI_ST_UNESCAPED;
+        q ^= (uint32_t)(v[j] >> 40) & 1u;
+    }
+    return e;
+}
+__device__ __forceinline__ void scanner_report(ScanHandoff* hand, uint32_t e) {
+    if (__ballot(e != 0)) {  // rare
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) e |= __shfl_xor(e, d);
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_or(&hand->err, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
 // prefixes of the lane's granules, given the parity entering the first one and the structurals before it
 __device__ __forceinline__ void scanner_publish(const sj_u64 v[SCAN_K], sj_u64* pfx, sj_u64 first, uint32_t n, uint32_t q,
                                                 sj_u64 run) {
@@ -288,7 +311,8 @@ __device__ __forceinline__ void scanner_publish(const sj_u64 v[SCAN_K], sj_u64* 
 }
 
 __device__ __forceinline__ void scanner_wave(ScanHandoff* hand, int wave, const sj_u64* agg, sj_u64* pfx, uint32_t n,
-                                             int lane, uint32_t* out, sj_u64 out_cap, Stage1Result* res) {
+                                             int lane, uint32_t* out, sj_u64 out_cap, Stage1Result* res,
+                                             Stage1Result* result_out) {
     __builtin_amdgcn_s_setprio(3);  // everybody waits for these four waves
     constexpr uint32_t WIN = 64 * SCAN_K;
     const sj_u64 lt_mask = (1ull << lane) - 1ull;
@@ -329,6 +353,7 @@ __device__ __forceinline__ void scanner_wave(ScanHandoff* hand, int wave, const 
             const sj_u64 C = hand->C;
             P2 = P ^ ((uint32_t)__popcll(pb) & 1u);
             C2 = C + (P ? tot1 : tot0);
+            scanner_report(hand, scanner_errors(v, P ^ qrel));
             if (lane == 0) {
                 hand->P = P2;
                 hand->C = C2;
@@ -359,6 +384,7 @@ __device__ __forceinline__ void scanner_wave(ScanHandoff* hand, int wave, const 
                     const uint32_t mine = act ? (q ? c1 : c0) : 0u;
                     const uint32_t incl = wave_incl_scan(mine, lane);
                     if (act) scanner_publish(v, pfx, first, n, q, C + (incl - mine));
+                    scanner_report(hand, act ? scanner_errors(v, q) : 0u);
                     C += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     P ^= (uint32_t)__popcll(pb) & 1u;
                     done = nr;
@@ -369,6 +395,11 @@ __device__ __forceinline__ void scanner_wave(ScanHandoff* hand, int wave, const 
                     if (lane == 0) {
                         __hip_atomic_fetch_or(&res->status, SJMI_ST_INTERNAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(&hand->seq, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (result_out) {
+                            result_out->count = 0;
+                            result_out->status = SJMI_ST_INTERNAL;
+                            result_out->reserved = 0;
+                        }
                     }
                     return;
                 }
@@ -388,13 +419,19 @@ __device__ __forceinline__ void scanner_wave(ScanHandoff* hand, int wave, const 
             }
         }
         if ((win + 1) * WIN >= n && lane == 0) {
-            // that was the last window: count, sentinel, unclosed string
+            // that was the last window: count, sentinel, unclosed string -- and the complete status of the launch
+            // (every window's errors were reported before its wave passed the running state on)
             res->count = C2;
-            uint32_t e = 0;
+            uint32_t e = __hip_atomic_load(&hand->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (P2) e |= SJMI_ST_UNCLOSED;   // StructuralIndexer.java:297-299
             if (C2 < out_cap) out[C2] = 0;   // BitIndexes.finish :82-96
-            else e |= SJMI_ST_CAPACITY;
+            else e |= SJMI_ST_CAPACITY;      // (== some granule did not fit: they are written in order)
             if (e) __hip_atomic_fetch_or(&res->status, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (result_out) {  // device-resident path: the caller's record, without a copy queued behind the kernel
+                result_out->count = C2;
+                result_out->status = e | __hip_atomic_load(&res->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                result_out->reserved = 0;
+            }
         }
     }
 }
@@ -467,6 +504,21 @@ __device__ __forceinline__ void load_step(StepData& d, const uint8_t* __restrict
 #endif
 
 constexpr uint32_t NO_TILE = 0xFFFFFFFFu;
+
+// Device-resident path: nothing but the kernel is queued per launch.  Every worker wave, on its way out, zeroes its
+// slice of the OTHER workspace half, which the next launch of this context will use (the workspace memset was a
+// separate 5 us kernel in front of every launch), and the scanner writes the caller's result record (that copy was a
+// third queue entry behind it).  (A "last wave out copies the result" scheme was tried first: 4096 atomics on one
+// counter at the end of the kernel cost 30 us, an acq_rel one each -- L2 write-back + invalidate -- 120 us.)
+__device__ __forceinline__ void zero_next_workspace(uint4* zero_ptr, uint32_t zero_chunks, uint32_t slot, uint32_t nslots,
+                                                    int lane) {
+    if (zero_ptr && nslots) {
+        const uint32_t per = (zero_chunks + nslots - 1) / nslots;
+        const uint32_t b = slot * per, e = b + per < zero_chunks ? b + per : zero_chunks;
+        for (uint32_t i = b + (uint32_t)lane; i < e; i += 64) zero_ptr[i] = make_uint4(0, 0, 0, 0);
+    }
+}
+
 constexpr uint32_t TICKET_CLASSES = 8;
 constexpr int LB_K = 1;  // SAFE mode's look-back window = 64 * LB_K granules
 
@@ -492,7 +544,8 @@ union WaveShared {
 template <int S, int LDSW, bool SAFE>
 __global__ void __launch_bounds__(256)
 k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out, sj_u64 out_cap,
-         sj_u64* gstate, uint32_t* ticket, Stage1Result* res, uint32_t ngran, uint32_t dbg) {
+         sj_u64* gstate, uint32_t* ticket, Stage1Result* res, uint32_t ngran, uint32_t dbg, uint4* zero_ptr,
+         uint32_t zero_chunks, Stage1Result* result_out) {
     constexpr int E = S, CAP = LDSW / 4;
     static_assert(S <= 4, "meta packs 14-bit offsets: at most 4 steps per granule");
     __shared__ WaveShared<S, LDSW> sh[4];
@@ -513,10 +566,11 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
         if (threadIdx.x == 0) {
             hand.seq = 0;
             hand.P = 0;
+            hand.err = 0;
             hand.C = 0;
         }
         __syncthreads();
-        if (!(dbg & DBG_NO_LOOKBACK)) scanner_wave(&hand, wave, agg, pfx, ngran, lane, out, out_cap, res);
+        if (!(dbg & DBG_NO_LOOKBACK)) scanner_wave(&hand, wave, agg, pfx, ngran, lane, out, out_cap, res, result_out);
         return;
     }
     const uint32_t nworkers = (gridDim.x - (safe ? 0u : 1u)) * 4u;
@@ -648,6 +702,7 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
             }
             // in-string parity, structurals and their offsets, all RELATIVE TO THE GRANULE being entered outside a
             // string (order inside the granule: step, lane)
+            uint32_t gerr = 0;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const sj_u64 bal = __ballot(fl[s] & 1u);
@@ -664,10 +719,13 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
                 const uint32_t ue0 = (fl[s] >> 1) & 1u, ue1 = (fl[s] >> 2) & 1u;  // :252 for entry parity 0 / 1
                 if (fl[s] & 8u) err |= SJMI_ST_UTF8;
                 meta[s] = ex0 | (exp_ << 14) | ((lp ? ue1 : ue0) << 28) | ((lp ? ue0 : ue1) << 29);
+                gerr |= ((fl[s] >> 3) & 1u) | ((meta[s] >> 27) & 6u);  // utf8, unescaped if entered outside / inside
             }
+            // the granule's error bits travel with its aggregate (the scanner composes the launch's status from them)
+            const uint32_t gbits = (__ballot(gerr & 1u) ? 1u : 0u) | (__ballot(gerr & 2u) ? 2u : 0u) | (__ballot(gerr & 4u) ? 4u : 0u);
             if (lane == 0 && !(dbg & DBG_NO_LOOKBACK)) {
                 if (safe && cur == 0) publish_prefix(agg, 0, wpar, (sj_u64)W0);  // nothing to look back at
-                else publish_aggregate(agg, cur, W0, WP - W0, wpar);
+                else publish_aggregate(agg, cur, W0, WP - W0, wpar, gbits);
             }
             SJMI_TSTAMP(cur, 1);
             __builtin_amdgcn_s_setprio(0);
@@ -844,6 +902,7 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
     for (int dd = 32; dd >= 1; dd >>= 1) err |= __shfl_xor(err, dd);
     if (lane == 0 && err && !(dbg & DBG_NO_LOOKBACK))  // (with fake prefixes every granule would report errors)
         __hip_atomic_fetch_or(&res->status, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    zero_next_workspace(zero_ptr, zero_chunks, worker, nworkers, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -890,21 +949,24 @@ static hipError_t resident_workgroups(unsigned* out) {
 template <int S, int LDSW, bool SAFE>
 static hipError_t launch_mode(const uint8_t* d_buf, uint64_t len, uint32_t* d_out, uint64_t out_cap, sj_u64* gs,
                                  uint32_t* ticket, Stage1Result* res, uint64_t ngran, hipStream_t stream,
-                                 hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg) {
+                                 hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg, const Stage1Extras& ex) {
     unsigned resident = 0;
     hipError_t e = resident_workgroups<S, LDSW, SAFE>(&resident);
     if (e != hipSuccess) return e;
     const uint64_t want = (ngran + 3) / 4 + (SAFE ? 0 : 1);  // 4 worker waves each + the scanner workgroup
     if (dbg & DBG_SMALL_GRID) resident = SAFE ? 8 : 9;  // test hook: far fewer granules in flight than a scanner window
     const dim3 grid((unsigned)(want < resident ? want : resident)), block(256);
+    uint4* zp = static_cast<uint4*>(ex.zero_next);
+    const uint32_t zc = (uint32_t)(ex.zero_bytes / 16);
+    Stage1Result* ro = static_cast<Stage1Result*>(ex.result_out);
     if (ev_start && ev_stop) {
         // the events are attached to the dispatch itself (its start / end timestamps), not recorded around it:
         // hipEventRecord pairs added 10-25 us of queue latency to a 200 us kernel
         hipExtLaunchKernelGGL((k_stage1<S, LDSW, SAFE>), grid, block, 0, stream, ev_start, ev_stop, 0, d_buf, (sj_u64)len,
-                              d_out, (sj_u64)out_cap, gs, ticket, res, (uint32_t)ngran, dbg);
+                              d_out, (sj_u64)out_cap, gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro);
     } else {
         hipLaunchKernelGGL((k_stage1<S, LDSW, SAFE>), grid, block, 0, stream, d_buf, (sj_u64)len, d_out, (sj_u64)out_cap,
-                           gs, ticket, res, (uint32_t)ngran, dbg);
+                           gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro);
     }
     return hipGetLastError();
 }
@@ -912,26 +974,26 @@ static hipError_t launch_mode(const uint8_t* d_buf, uint64_t len, uint32_t* d_ou
 template <int S, int LDSW>
 static hipError_t launch_variant(const uint8_t* d_buf, uint64_t len, uint32_t* d_out, uint64_t out_cap, sj_u64* gs,
                                  uint32_t* ticket, Stage1Result* res, uint64_t ngran, hipStream_t stream,
-                                 hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg) {
+                                 hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg, const Stage1Extras& ex) {
     return (dbg & FLAG_SAFE)
-               ? launch_mode<S, LDSW, true>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg)
-               : launch_mode<S, LDSW, false>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg);
+               ? launch_mode<S, LDSW, true>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg, ex)
+               : launch_mode<S, LDSW, false>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg, ex);
 }
 
 hipError_t stage1_launch(const uint8_t* d_buf, uint64_t len, uint32_t* d_out, uint64_t out_cap, void* d_ws,
-                         int steps, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg) {
+                         int steps, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg, const Stage1Extras& ex) {
     const uint64_t ngran = granules_for(len, steps);
     const size_t ws_bytes = WS_TILE_STATE_OFFSET + (2 + SJMI_TRACE_SLOTS) * (size_t)ngran * sizeof(sj_u64);
-    hipError_t e = hipMemsetAsync(d_ws, 0, ws_bytes, stream);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    if (!ex.workspace_is_zero && (e = hipMemsetAsync(d_ws, 0, ws_bytes, stream)) != hipSuccess) return e;
     uint8_t* ws = static_cast<uint8_t*>(d_ws);
     uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + WS_TICKET_OFFSET);
     Stage1Result* res = reinterpret_cast<Stage1Result*>(ws + WS_RESULT_OFFSET);
     sj_u64* gs = reinterpret_cast<sj_u64*>(ws + WS_TILE_STATE_OFFSET);
     switch (steps) {  // granule = steps x 4 KiB
-    case 1: e = launch_variant<1, 6144>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg); break;
-    case 2: e = launch_variant<2, 9216>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg); break;
-    case 4: e = launch_variant<4, 9216>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg); break;
+    case 1: e = launch_variant<1, 6144>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg, ex); break;
+    case 2: e = launch_variant<2, 9216>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg, ex); break;
+    case 4: e = launch_variant<4, 9216>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg, ex); break;
     default: return hipErrorInvalidValue;
     }
     return e;
