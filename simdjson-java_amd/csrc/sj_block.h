@@ -174,20 +174,31 @@ SJ_HD uint32_t sj_is_ws_or_op(uint32_t c) {  // { 09 0A 0D 20 , : [ ] { } } and 
     return (c < 128u) & ((m >> (c & 31u)) & 1u);
 }
 
-// Resolve e_in / p_in from the halo (only its top 4 bytes are used here).  Returns false when the backslash run
-// reaches past them (then the caller counts the run from memory: sj_carry_slow).
+// Resolve e_in / p_in from the halo.  Returns false when the backslash run reaches past its 8 bytes (then the
+// caller counts the run from memory: sj_carry_slow).
 //   e_in = (length of the backslash run ending at byte -1) is odd
 //   p_in = byte -1 is a scalar that is not an (unescaped) quote
+// The common case needs only the top 4 bytes and 32-bit operations; a run that fills them (4 backslashes, or a quote
+// preceded by 3) continues into the low 4 bytes -- rare, but with 10 % escapes in the strings it happened in 1 % of
+// the 64-block wave-steps, and one such block sends the whole wave through the slow path.
 SJ_HD bool sj_carry_from_halo(sj_u64 halo, uint32_t* e_in, uint32_t* p_in) {
     const uint32_t hh = (uint32_t)(halo >> 32);                   // bytes -4..-1, byte -1 on top
     const uint32_t z = hh ^ 0x5C5C5C5Cu;                          // zero bytes = backslashes
     const uint32_t h1 = hh >> 24;
-    const uint32_t run1 = z ? (uint32_t)__builtin_clz(z) >> 3 : 4u;         // backslashes ending at byte -1 (0..4)
-    const uint32_t run2 = (uint32_t)__builtin_clz((z << 8) | 0xFFu) >> 3;   // ... ending at byte -2 (0..3)
+    uint32_t run1 = z ? (uint32_t)__builtin_clz(z) >> 3 : 4u;               // backslashes ending at byte -1 (0..4)
+    uint32_t run2 = (uint32_t)__builtin_clz((z << 8) | 0xFFu) >> 3;         // ... ending at byte -2 (0..3)
     const bool is_q = h1 == 0x22;
+    bool resolved = true;
+    if ((run1 == 4u) | (is_q & (run2 == 3u))) {
+        const uint32_t zl = (uint32_t)halo ^ 0x5C5C5C5Cu;                   // bytes -8..-5
+        const uint32_t more = zl ? (uint32_t)__builtin_clz(zl) >> 3 : 4u;   // backslashes ending at byte -5 (0..4)
+        if (run1 == 4u) run1 += more;  // the run ending at byte -1 goes on
+        else run2 += more;             // (byte -1 is the quote) the run ending at byte -2 goes on
+        resolved = more != 4u;
+    }
     *e_in = run1 & 1u;
     *p_in = run1 ? 1u : (is_q ? (run2 & 1u) : (sj_is_ws_or_op(h1) ^ 1u));
-    return !((run1 == 4u) | (is_q & (run2 == 3u)));
+    return resolved;
 }
 
 // Slow path (backslash run longer than the halo): parity of the run of backslashes that ends
