@@ -691,7 +691,7 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
                     uint32_t e_in = 0, p_in = 0;
                     sj_carry_slow(buf, 0, start, &e_in, &p_in);
                     sj_u64 p[8];
-                    sj_transpose_ref(w, p);
+                    sj_transpose_butterfly(w, p);
                     const sj_u64 rem = len - start;
                     sj_mask_tail(p, rem < 64 ? (uint32_t)rem : 64u);
                     const SjBlockMasks bm = sj_block(p, e_in, p_in, sj_utf8_carry(halo));
