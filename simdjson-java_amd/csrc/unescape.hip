@@ -577,37 +577,43 @@ k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __res
                 if (rec_d[r + half] <= rel) r += half;
                 span -= half;
             }
-            // A 16-byte chunk overlaps at most 5 records (a record has at least 4 bytes).  First all of them are
+            // A 16-byte chunk overlaps at most 5 records (a record has at least 4 bytes).  First the records are
             // looked up and their source bytes requested, then everything is shifted into place: a loop that loads and
             // inserts record by record pays one memory round trip per record.
-            constexpr int MAXREC = 5;
-            bool hdr_on[MAXREC], dat_on[MAXREC];
-            int hdr_p[MAXREC], dat_p[MAXREC];
-            uint32_t hdr_v[MAXREC];
-            U16B w[MAXREC];
-#pragma unroll
-            for (int j = 0; j < MAXREC; ++j) {
-                const uint32_t rr = r + j < nrec ? r + j : nrec - 1;
-                const unsigned long long rd = D0 + rec_d[rr];
-                const bool on = r + j < nrec && rd < hi;
-                const uint32_t L = rec_len[rr];
-                const uint32_t n = (L & REC_FAILED) ? 0u : (L & ~REC_SCRATCH);
-                hdr_v[j] = __builtin_bswap32((L & REC_FAILED) ? (0xFFFFFF00u | (L & 0xFFu)) : n);  // IntegerUtils.toBytes :12-17: big endian
-                hdr_on[j] = on && rd + 4 > lo;
-                hdr_p[j] = (int)((long long)rd - (long long)glo);
-                const unsigned long long g0 = rd + 4 > lo ? rd + 4 : lo, g1 = rd + 4 + n < hi ? rd + 4 + n : hi;
-                dat_on[j] = on && g0 < g1;
-                dat_p[j] = (int)(g0 - glo);
-                const uint8_t* from = ((L & REC_SCRATCH) ? scratch : buf) + rec_src[rr] + (uint32_t)(g0 - (rd + 4));
-                if (dat_on[j]) w[j] = *reinterpret_cast<const U16B*>(from);
-            }
             unsigned long long v0 = 0, v1 = 0;
+            // (two rounds: up to 3 records -- all that most chunks touch -- and, only if some lane of the wave needs
+            //  them, the remaining 2)
+            for (uint32_t r0 = r, round = 0; round < 2; r0 += 3, ++round) {
+                constexpr int NREC = 3;
+                bool hdr_on[NREC], dat_on[NREC];
+                int hdr_p[NREC], dat_p[NREC];
+                uint32_t hdr_v[NREC];
+                U16B w[NREC];
 #pragma unroll
-            for (int j = 0; j < MAXREC; ++j) {
-                if (hdr_on[j]) insert_at(v0, v1, (unsigned long long)hdr_v[j], 0ull, hdr_p[j]);
-                if (dat_on[j])
-                    insert_at(v0, v1, (unsigned long long)w[j].a | ((unsigned long long)w[j].b << 32),
-                              (unsigned long long)w[j].c | ((unsigned long long)w[j].d << 32), dat_p[j]);
+                for (int j = 0; j < NREC; ++j) {
+                    const uint32_t rr = r0 + j < nrec ? r0 + j : nrec - 1;
+                    const unsigned long long rd = D0 + rec_d[rr];
+                    const bool on = r0 + j < nrec && rd < hi && (round == 0 || j < 2);
+                    const uint32_t L = rec_len[rr];
+                    const uint32_t n = (L & REC_FAILED) ? 0u : (L & ~REC_SCRATCH);
+                    hdr_v[j] = __builtin_bswap32((L & REC_FAILED) ? (0xFFFFFF00u | (L & 0xFFu)) : n);  // IntegerUtils.toBytes :12-17: big endian
+                    hdr_on[j] = on && rd + 4 > lo;
+                    hdr_p[j] = (int)((long long)rd - (long long)glo);
+                    const unsigned long long g0 = rd + 4 > lo ? rd + 4 : lo, g1 = rd + 4 + n < hi ? rd + 4 + n : hi;
+                    dat_on[j] = on && g0 < g1;
+                    dat_p[j] = (int)(g0 - glo);
+                    const uint8_t* from = ((L & REC_SCRATCH) ? scratch : buf) + rec_src[rr] + (uint32_t)(g0 - (rd + 4));
+                    if (dat_on[j]) w[j] = *reinterpret_cast<const U16B*>(from);
+                }
+#pragma unroll
+                for (int j = 0; j < NREC; ++j) {
+                    if (hdr_on[j]) insert_at(v0, v1, (unsigned long long)hdr_v[j], 0ull, hdr_p[j]);
+                    if (dat_on[j])
+                        insert_at(v0, v1, (unsigned long long)w[j].a | ((unsigned long long)w[j].b << 32),
+                                  (unsigned long long)w[j].c | ((unsigned long long)w[j].d << 32), dat_p[j]);
+                }
+                // a fourth record can only overlap if the third one did
+                if (!__ballot(hdr_on[NREC - 1] || dat_on[NREC - 1])) break;
             }
             if (lo == glo && hi == glo + 16) {
                 *reinterpret_cast<uint4*>(sb + glo) = make_uint4((uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32));
