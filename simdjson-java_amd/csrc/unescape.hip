@@ -234,13 +234,13 @@ constexpr uint32_t SIZE_SLOW = 0x80000000u;  // sizes[] flag: the string has esc
 // document -- an unescaped string is never longer than its source), so that the write pass copies it like any other
 // string, only from a different base.  A failed string has size 4 | SIZE_SLOW and its SJMI_E_* code in scratch[open].
 //
-// One workgroup per tile of 4096 structurals, 16 per lane, handled four at a time with all their loads in flight
+// One workgroup per tile of 4096 structurals, 16 per lane, handled two at a time with all their loads in flight
 // together: the first version (one structural per lane, one wave per 64) was bound by the workgroup dispatcher and by
 // five dependent round trips per structural.  Now two: the structural and its successor, then the 16 bytes at the
 // structural (is it a quote? backslashes in the head of the string) together with the 16 bytes in front of the
 // successor (the closing quote is the last byte > 0x20 there: between it and the next structural there is only
 // whitespace, or that byte would be a structural itself).
-constexpr int MEAS_GROUP_MAX = 4;
+constexpr int MEAS_GROUP_MAX = 2;  // (4 costs a wave per SIMD in registers: 1.31 -> 1.16 ms with 2)
 constexpr int SPAN_W = 2;  // 64-chunk words of the per-row backslash map: rows spanning up to SPAN_W KiB use it
 
 struct MeasuredString {
