@@ -477,8 +477,9 @@ __device__ __forceinline__ void insert_at(unsigned long long& v0, unsigned long 
     }
 }
 
+// (latency-bound: 6 waves per SIMD instead of 5 -- 78 instead of 85 VGPRs, no spills -- are worth 5 %)
 template <int ITEMS>
-__global__ void __launch_bounds__(UNESC_THREADS)
+__global__ void __launch_bounds__(UNESC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8)))
 k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __restrict__ idx, uint64_t count,
             const Stage1Result* __restrict__ dev_count, const uint32_t* __restrict__ sizes, const unsigned long long* __restrict__ block_offsets,
             const uint8_t* __restrict__ scratch, uint8_t* __restrict__ sb, uint64_t sb_cap, UnescapeResult* res) {
