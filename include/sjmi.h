@@ -167,6 +167,23 @@ int sjmi_stage1_batch_isolated(sjmi_ctx* ctx, const uint8_t* buf, uint64_t total
                                uint64_t n_docs, uint32_t* indexes, uint64_t index_capacity, uint64_t* index_offsets,
                                uint32_t* doc_status, uint64_t* count, uint32_t* status);
 
+/* sjmi_unescape for the batch given to the LAST sjmi_stage1_batch / sjmi_stage1_batch_isolated call on this context:
+ * one string buffer for the whole batch (records in structural order), plus doc_string_offsets[k] (n_docs + 1 entries)
+ * = offset of document k's first record, so that the stage 2 of every document can start at its own offset (documents
+ * can then be walked by parallel host threads). */
+int sjmi_unescape_batch(sjmi_ctx* ctx, uint8_t* string_buffer, uint64_t string_capacity, uint64_t* doc_string_offsets,
+                        uint64_t* total_bytes, uint64_t* first_error_index, uint32_t* first_error_code);
+
+/* Device-resident form of the same, asynchronous on `stream`: indexes / doc_offsets / index_offsets as given to and
+ * produced by sjmi_stage1_batch[_isolated]_device (device pointers, n_docs + 1 uint64 entries each).  Unlike
+ * sjmi_unescape_device it knows the document boundaries: in isolated mode a document that failed stage 1 has no
+ * structurals, so the last string of the document in front of it must end at that document's end, not at the next
+ * structural of the batch.  d_doc_string_offsets may be NULL. */
+int sjmi_unescape_batch_device(sjmi_ctx* ctx, const void* d_buf, uint64_t total_len, const void* d_indexes, uint64_t count,
+                               const void* d_doc_offsets, const void* d_index_offsets, uint64_t n_docs,
+                               void* d_string_buffer, uint64_t string_capacity, void* d_doc_string_offsets, void* d_result,
+                               void* stream);
+
 /* ---- whole parse: SimdJsonParser.parse(byte[], int) (SimdJsonParser.java:35-40) ----------------------------
  * GPU stage 1 + GPU string unescape + the host stage-2 tree builder (C++ mirror of JsonIterator / TapeBuilder /
  * Tape: simdjson-java_amd/csrc/host/simdjson_parser.h).  The tape (Tape.java:5-47 word layout) and string

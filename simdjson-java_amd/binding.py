@@ -46,7 +46,7 @@ def build(force=False, verbose=False):
         [os.path.join(_ROOT, "include", "sjmi.h")]
     if not force and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= max(os.path.getmtime(d) for d in deps):
         return _LIB
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
            "-I", os.path.join(_ROOT, "include")] + srcs + ["-o", _LIB]
     if verbose:
         print(" ".join(cmd))
@@ -62,7 +62,8 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_parser_create", "sjmi_parser_destroy", "sjmi_parser_parse", "sjmi_parser_last_message",
            "sjmi_stage1_batch", "sjmi_stage1_batch_device", "sjmi_parser_parse_batch",
            "sjmi_stage1_batch_isolated", "sjmi_stage1_batch_isolated_device", "sjmi_host_register",
-           "sjmi_host_unregister", "sjmi_stage1_unescape"]
+           "sjmi_host_unregister", "sjmi_stage1_unescape", "sjmi_unescape_batch",
+           "sjmi_unescape_batch_device"]
 
 
 def lib():
@@ -97,11 +98,16 @@ def lib():
         L.sjmi_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.sjmi_debug_set_flags.restype = C.c_int
         L.sjmi_debug_set_flags.argtypes = [C.c_void_p, C.c_uint32]
+        L.sjmi_unescape_batch.restype = C.c_int
+        L.sjmi_unescape_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sjmi_unescape.restype = C.c_int
         L.sjmi_unescape.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sjmi_unescape_device.restype = C.c_int
         L.sjmi_unescape_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                            C.c_void_p, C.c_void_p]
+        L.sjmi_unescape_batch_device.restype = C.c_int
+        L.sjmi_unescape_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                                 C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sjmi_parser_create.restype = C.c_int
         L.sjmi_parser_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
         L.sjmi_parser_destroy.restype = None
@@ -244,9 +250,28 @@ class Context:
         idx = None if fei.value == 0xFFFFFFFFFFFFFFFF else fei.value
         return sb[:total.value].tobytes(), idx, fec.value
 
+    def unescape_batch(self, string_capacity, n_docs):
+        """Unescape the strings of the batch of the last stage1_batch*() call.
+        -> (string_buffer bytes, doc_string_offsets[np.uint64 n_docs+1], first_error_index or None, first_error_code)."""
+        sb = np.empty(max(string_capacity, 1), dtype=np.uint8)
+        dso = np.zeros(n_docs + 1, dtype=np.uint64)
+        total = C.c_uint64(0)
+        fei = C.c_uint64(0)
+        fec = C.c_uint32(0)
+        self._check(lib().sjmi_unescape_batch(self._h, sb.ctypes.data, string_capacity, dso.ctypes.data, C.addressof(total),
+                                              C.addressof(fei), C.addressof(fec)), "sjmi_unescape_batch")
+        idx = None if fei.value == 0xFFFFFFFFFFFFFFFF else fei.value
+        return sb[:total.value].tobytes(), dso, idx, fec.value
+
     def unescape_device(self, d_buf, length, d_indexes, count, d_sb, sb_capacity, d_result, stream=0):
         self._check(lib().sjmi_unescape_device(self._h, d_buf, length, d_indexes, count, d_sb, sb_capacity, d_result,
                                                stream), "sjmi_unescape_device")
+
+    def unescape_batch_device(self, d_buf, total_len, d_indexes, count, d_doc_offsets, d_index_offsets, n_docs, d_sb,
+                              sb_capacity, d_doc_string_offsets, d_result, stream=0):
+        self._check(lib().sjmi_unescape_batch_device(self._h, d_buf, total_len, d_indexes, count, d_doc_offsets, d_index_offsets,
+                                                     n_docs, d_sb, sb_capacity, d_doc_string_offsets, d_result, stream),
+                    "sjmi_unescape_batch_device")
 
     def stage1_batch_device(self, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets,
                             d_result, stream=0):

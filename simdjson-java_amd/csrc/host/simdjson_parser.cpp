@@ -4,6 +4,10 @@
 #include "simdjson_parser.h"
 
 #include <stdlib.h>
+#include <algorithm>
+#include <exception>
+#include <memory>
+#include <thread>
 #include <string.h>
 
 namespace org_simdjson {
@@ -110,15 +114,21 @@ bool JsonValue::get(const std::string& name, JsonValue* out) const {  // JsonVal
 }
 
 SimdJsonParser::SimdJsonParser(int capacity, int maxDepth, int device)
-    : capacity_(capacity), maxDepth_(maxDepth), bitIndexes_((size_t)capacity + 2), tape_((size_t)capacity + 8),
-      paddedBuffer_((size_t)capacity + PADDING), openContainers_((size_t)maxDepth), isArray_((size_t)maxDepth) {
+    : capacity_(capacity), maxDepth_(maxDepth), stringBuffer_((size_t)capacity + 4 * ((size_t)capacity / 2 + 2) + 64),
+      paddedBuffer_((size_t)capacity + PADDING), indexes_((size_t)capacity + 2),
+      walker_(paddedBuffer_.data(), indexes_.data(), indexes_.size(), (size_t)capacity + 8, maxDepth) {
     const int rc = sjmi_create(&ctx_, device, (uint64_t)capacity);
     if (rc != SJMI_OK) throw std::runtime_error("SimdJsonParser: no usable MI355X device (sjmi_create rc=" + std::to_string(rc) + "); there is no CPU fallback");
     // parser-owned buffers that cross PCIe on every parse are page-locked (a hint: failures are ignored)
-    stringBuffer_.resize((size_t)capacity + 4 * ((size_t)capacity / 2 + 2) + 64);
     pinned_[0] = sjmi_host_register(ctx_, paddedBuffer_.data(), paddedBuffer_.size()) == SJMI_OK ? paddedBuffer_.data() : nullptr;
-    pinned_[1] = sjmi_host_register(ctx_, bitIndexes_.array(), bitIndexes_.capacity() * sizeof(uint32_t)) == SJMI_OK ? (void*)bitIndexes_.array() : nullptr;
+    pinned_[1] = sjmi_host_register(ctx_, indexes_.data(), indexes_.size() * sizeof(uint32_t)) == SJMI_OK ? (void*)indexes_.data() : nullptr;
     pinned_[2] = sjmi_host_register(ctx_, stringBuffer_.data(), stringBuffer_.size()) == SJMI_OK ? stringBuffer_.data() : nullptr;
+    unsigned hw = std::thread::hardware_concurrency();
+    batchThreads_ = (int)(hw ? (hw > 32 ? 32 : hw) : 1);
+    if (const char* e = getenv("SJMI_PARSE_THREADS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 1024) batchThreads_ = v;
+    }
 }
 
 SimdJsonParser::~SimdJsonParser() {
@@ -127,39 +137,26 @@ SimdJsonParser::~SimdJsonParser() {
     sjmi_destroy(ctx_);
 }
 
+void SimdJsonParser::growStringBuffer(size_t need) {
+    if (stringBuffer_.size() >= need) return;
+    if (pinned_[2]) (void)sjmi_host_unregister(ctx_, pinned_[2]);
+    pinned_[2] = nullptr;
+    stringBuffer_.resize(need);
+}
+
 // SimdJsonParser.stage1 (SimdJsonParser.java:55-58) on the GPU + the string records stage 2 will need
 void SimdJsonParser::stage1(const uint8_t* buffer, size_t len) {
     uint64_t count = 0, total = 0, fei = 0;
     uint32_t status = 0, fec = 0;
-    const size_t need = len + 4 * (len / 2 + 2) + 64;  // every string takes >= 2 source bytes
-    if (stringBuffer_.size() < need) {
-        if (pinned_[2]) (void)sjmi_host_unregister(ctx_, pinned_[2]);
-        pinned_[2] = nullptr;
-        stringBuffer_.resize(need);
-    }
+    growStringBuffer(len + 4 * (len / 2 + 2) + 64);  // every string takes >= 2 source bytes
     // stage 1 and the string records stage 2 will need, queued together (two synchronisations instead of four)
-    int rc = sjmi_stage1_unescape(ctx_, buffer, len, bitIndexes_.array(), bitIndexes_.capacity(), &count, &status,
+    int rc = sjmi_stage1_unescape(ctx_, buffer, len, indexes_.data(), indexes_.size(), &count, &status,
                                   stringBuffer_.data(), stringBuffer_.size(), &total, &fei, &fec);
     if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_stage1_unescape: ") + sjmi_last_error(ctx_));
-    bitIndexes_.setWriteIdx((size_t)count);
+    walker_.bitIndexes().setWriteIdx((size_t)count);
     if (status & SJMI_ST_UTF8) throw fail(E_UTF8);                 // Utf8Validator.java:165-167 (checked first)
     if (status & SJMI_ST_UNCLOSED) throw fail(E_UNCLOSED_STRING);  // StructuralIndexer.java:297-299
     if (status & SJMI_ST_UNESCAPED) throw fail(E_UNESCAPED_CHARS); // :300-302
-    stringBufferLen_ = (size_t)total;
-}
-
-// every string of the document(s) just indexed, unescaped on the GPU into stringBuffer_[0, stringBufferLen_)
-void SimdJsonParser::unescapeStrings(size_t len, uint64_t count) {
-    const size_t need = len + 4 * (size_t)count + 64;
-    if (stringBuffer_.size() < need) {  // (never for a document within the capacity: every string takes >= 2 source bytes)
-        if (pinned_[2]) (void)sjmi_host_unregister(ctx_, pinned_[2]);
-        pinned_[2] = nullptr;
-        stringBuffer_.resize(need);
-    }
-    uint64_t total = 0, fei = 0;
-    uint32_t fec = 0;
-    const int rc = sjmi_unescape(ctx_, stringBuffer_.data(), stringBuffer_.size(), &total, &fei, &fec);
-    if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_unescape: ") + sjmi_last_error(ctx_));
     stringBufferLen_ = (size_t)total;
 }
 
@@ -169,69 +166,114 @@ JsonValue SimdJsonParser::parse(const uint8_t* buffer, size_t len) {
     memcpy(paddedBuffer_.data(), buffer, len);
     memset(paddedBuffer_.data() + len, 0, PADDING);
     // reset (:50-53)
-    bitIndexes_.reset();
-    tape_.reset();
-    stringBufferIdx_ = 0;
-    docBase_ = 0;
-    memset(isArray_.data(), 0, isArray_.size());
+    walker_.bitIndexes().reset();
+    walker_.resetForDocument(0, 0);
     stage1(paddedBuffer_.data(), len);
-    walkDocument(len);
-    return JsonValue(&tape_, 1, stringBuffer_.data());  // TapeBuilder.createJsonValue :215-217
+    walker_.setStringBuffer(stringBuffer_.data());
+    walker_.walkDocument(len);
+    return JsonValue(&walker_.tape(), 1, stringBuffer_.data());  // TapeBuilder.createJsonValue :215-217
 }
 
+// Batched parse.  GPU: isolated stage 1 (per-document verdicts and index ranges), the string records of all documents,
+// and the string-buffer offset at which each document's records begin.  Host: stage 2 of the documents, spread over
+// threads by structural count; every thread owns a DocWalker and builds its documents' tapes back to back in its own
+// slab, which the threads then copy to their final place in batchTape().
 void SimdJsonParser::parseBatch(const uint8_t* buffer, size_t totalLen, const uint64_t* docOffsets, size_t nDocs) {
     if (totalLen > (size_t)capacity_) throw fail(E_CAPACITY);
     memcpy(paddedBuffer_.data(), buffer, totalLen);
     memset(paddedBuffer_.data() + totalLen, 0, PADDING);
-    bitIndexes_.reset();
+    walker_.bitIndexes().reset();
     indexOffsets_.assign(nDocs + 1, 0);
+    docStringOffsets_.assign(nDocs + 1, 0);
     uint64_t count = 0;
     uint32_t status = 0;
     // isolated mode: a document that fails stage 1 gets its own verdict and contributes no indexes, so the strings
     // and trees of all other documents are exactly what they would be alone
     docStatus_.assign(nDocs ? nDocs : 1, 0);
-    const int rc = sjmi_stage1_batch_isolated(ctx_, paddedBuffer_.data(), totalLen, docOffsets, nDocs, bitIndexes_.array(),
-                                              bitIndexes_.capacity(), indexOffsets_.data(), docStatus_.data(), &count, &status);
+    int rc = sjmi_stage1_batch_isolated(ctx_, paddedBuffer_.data(), totalLen, docOffsets, nDocs, indexes_.data(),
+                                        indexes_.size(), indexOffsets_.data(), docStatus_.data(), &count, &status);
     if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_stage1_batch_isolated: ") + sjmi_last_error(ctx_));
-    unescapeStrings(totalLen, count);
-    batchTape_.clear();
-    batchTapeOffsets_.assign(1, 0);
+    growStringBuffer(totalLen + 4 * (size_t)count + 64);
+    uint64_t total = 0, fei = 0;
+    uint32_t fec = 0;
+    rc = sjmi_unescape_batch(ctx_, stringBuffer_.data(), stringBuffer_.size(), docStringOffsets_.data(), &total, &fei, &fec);
+    if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_unescape_batch: ") + sjmi_last_error(ctx_));
+    stringBufferLen_ = (size_t)total;
+    batchTapeOffsets_.assign(nDocs + 1, 0);
     batchErrors_.assign(nDocs, 0);
-    const uint8_t* buf = paddedBuffer_.data();
-    const uint32_t* ix = bitIndexes_.array();
-    size_t cursor = 0;  // string-buffer offset of the current document's first record
-    for (size_t k = 0; k < nDocs; ++k) {
-        const size_t from = (size_t)indexOffsets_[k], to = (size_t)indexOffsets_[k + 1];
-        docBase_ = (size_t)docOffsets[k];
-        tape_.reset();
-        memset(isArray_.data(), 0, isArray_.size());
-        bitIndexes_.window(from, to, (uint32_t)docBase_);
-        stringBufferIdx_ = cursor;
-        try {
-            // SimdJsonParser.stage1 order: Utf8Validator.validate (:165-167), then StructuralIndexer.index (:297-302)
-            if (docStatus_[k] & SJMI_ST_UTF8) throw fail(E_UTF8);
-            if (docStatus_[k] & SJMI_ST_UNCLOSED) throw fail(E_UNCLOSED_STRING);
-            if (docStatus_[k] & SJMI_ST_UNESCAPED) throw fail(E_UNESCAPED_CHARS);
-            walkDocument((size_t)docOffsets[k + 1]);
-            batchTape_.insert(batchTape_.end(), tape_.data(), tape_.data() + tape_.getCurrentIdx());
-        } catch (const JsonParsingException& e) {
-            batchErrors_[k] = e.code();
-        }
-        batchTapeOffsets_.push_back(batchTape_.size());
-        // records are laid out in structural order over the whole batch: step over this document's strings
-        for (size_t pos = from; pos < to; ++pos) {
-            if (buf[ix[pos]] != '"') continue;
-            const uint8_t* r = stringBuffer_.data() + cursor;
-            const uint32_t n = ((uint32_t)r[0] << 24) | ((uint32_t)r[1] << 16) | ((uint32_t)r[2] << 8) | r[3];
-            cursor += 4 + (n >= 0xFFFFFF00u ? 0 : (size_t)n);
-        }
+
+    // contiguous document ranges of about equal structural count, one per thread
+    size_t nThreads = (size_t)batchThreads_;
+    const size_t minPerThread = 4096;  // structurals: below this a thread costs more than it walks
+    if (nThreads > (size_t)count / minPerThread + 1) nThreads = (size_t)count / minPerThread + 1;
+    if (nThreads > nDocs) nThreads = nDocs ? nDocs : 1;
+    std::vector<size_t> cut(nThreads + 1, nDocs);
+    cut[0] = 0;
+    for (size_t t = 1; t < nThreads; ++t) {
+        const uint64_t want = (uint64_t)count * t / nThreads;
+        cut[t] = (size_t)(std::lower_bound(indexOffsets_.begin(), indexOffsets_.begin() + (ptrdiff_t)nDocs, want) - indexOffsets_.begin());
+        if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
     }
-    docBase_ = 0;
+    struct Slab {
+        std::unique_ptr<uint64_t[]> words;
+        size_t used = 0;
+        std::exception_ptr error;
+    };
+    std::vector<Slab> slabs(nThreads);
+    const uint8_t* padded = paddedBuffer_.data();
+    const uint8_t* strings = stringBuffer_.data();
+    auto walkRange = [&](size_t t) {
+        try {
+            const size_t lo = cut[t], hi = cut[t + 1];
+            // a structural makes at most two tape words (a number); the root adds two
+            const size_t room = 2 * (size_t)(indexOffsets_[hi] - indexOffsets_[lo]) + 8 * (hi - lo) + 8;
+            Slab& slab = slabs[t];
+            slab.words.reset(new uint64_t[room]);
+            DocWalker w(padded, indexes_.data(), indexes_.size(), 0, maxDepth_);
+            w.setStringBuffer(strings);
+            for (size_t k = lo; k < hi; ++k) {
+                const size_t from = (size_t)indexOffsets_[k], to = (size_t)indexOffsets_[k + 1];
+                w.resetForDocument((size_t)docOffsets[k], (size_t)docStringOffsets_[k]);
+                w.tape().rebase(slab.words.get() + slab.used, room - slab.used);
+                w.bitIndexes().window(from, to, (uint32_t)docOffsets[k]);
+                try {
+                    // SimdJsonParser.stage1 order: Utf8Validator.validate (:165-167), then StructuralIndexer.index (:297-302)
+                    if (docStatus_[k] & SJMI_ST_UTF8) throw fail(E_UTF8);
+                    if (docStatus_[k] & SJMI_ST_UNCLOSED) throw fail(E_UNCLOSED_STRING);
+                    if (docStatus_[k] & SJMI_ST_UNESCAPED) throw fail(E_UNESCAPED_CHARS);
+                    w.walkDocument((size_t)docOffsets[k + 1]);
+                    slab.used += w.tape().getCurrentIdx();
+                } catch (const JsonParsingException& e) {
+                    batchErrors_[k] = e.code();  // its partial tape is dropped
+                }
+                batchTapeOffsets_[k + 1] = slab.used;  // slab-relative until the slabs are placed
+            }
+        } catch (...) {
+            slabs[t].error = std::current_exception();
+        }
+    };
+    auto onThreads = [&](auto&& fn) {
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nThreads; ++t) pool.emplace_back(fn, t);
+        fn((size_t)0);
+        for (std::thread& th : pool) th.join();
+    };
+    onThreads(walkRange);
+    for (Slab& s : slabs)
+        if (s.error) std::rethrow_exception(s.error);
+    std::vector<size_t> base(nThreads + 1, 0);
+    for (size_t t = 0; t < nThreads; ++t) base[t + 1] = base[t] + slabs[t].used;
+    batchTape_.resize(base[nThreads]);
+    auto place = [&](size_t t) {
+        if (slabs[t].used) memcpy(batchTape_.data() + base[t], slabs[t].words.get(), slabs[t].used * sizeof(uint64_t));
+        for (size_t k = cut[t]; k < cut[t + 1]; ++k) batchTapeOffsets_[k + 1] += base[t];
+    };
+    onThreads(place);
 }
 
 // TapeBuilder.visitString (TapeBuilder.java:174-177): the record [be32 len][bytes] was produced on the GPU at
 // exactly the offset the sequential StringParser would have used; only the bookkeeping remains.
-void SimdJsonParser::visitString(uint32_t idx, size_t indexPos) {
+void DocWalker::visitString(uint32_t idx, size_t indexPos) {
     (void)idx;
     (void)indexPos;
     tape_.append(stringBufferIdx_, Tape::STRING);
@@ -255,7 +297,7 @@ static inline bool isNull(const uint8_t* b) { return b[0] == 'n' && b[1] == 'u' 
 // NumberParser.parseNumber (NumberParser.java:23-74), ExponentParser.parse (ExponentParser.java:14-69),
 // isOutOfLongRange (NumberParser.java:313-328).  Doubles: the reference's DoubleParser is a correctly rounded,
 // saturating decimal->binary64 conversion (DoubleParser.java:79-330); strtod has the same contract.
-void SimdJsonParser::parseNumber(const uint8_t* p) {
+void DocWalker::parseNumber(const uint8_t* p) {
     const uint8_t* start = p;
     const bool negative = *p == '-';
     if (negative) ++p;
@@ -294,7 +336,7 @@ void SimdJsonParser::parseNumber(const uint8_t* p) {
     }
 }
 
-void SimdJsonParser::visitPrimitive(uint32_t idx, size_t indexPos) {  // TapeBuilder.java:70-79
+void DocWalker::visitPrimitive(uint32_t idx, size_t indexPos) {  // TapeBuilder.java:70-79
     const uint8_t* b = paddedBuffer_.data() + idx;
     switch (*b) {
     case '"': visitString(idx, indexPos); break;
@@ -317,7 +359,7 @@ void SimdJsonParser::visitPrimitive(uint32_t idx, size_t indexPos) {  // TapeBui
     }
 }
 
-void SimdJsonParser::visitRootPrimitive(uint32_t idx, size_t indexPos, size_t len) {  // TapeBuilder.java:59-68 (len = end offset)
+void DocWalker::visitRootPrimitive(uint32_t idx, size_t indexPos, size_t len) {  // TapeBuilder.java:59-68 (len = end offset)
     const uint8_t* b = paddedBuffer_.data() + idx;
     switch (*b) {
     case '"': visitString(idx, indexPos); break;
@@ -344,13 +386,13 @@ void SimdJsonParser::visitRootPrimitive(uint32_t idx, size_t indexPos, size_t le
     }
 }
 
-void SimdJsonParser::emptyContainer(char start, char end) {  // TapeBuilder.java:205-208
+void DocWalker::emptyContainer(char start, char end) {  // TapeBuilder.java:205-208
     tape_.append(tape_.getCurrentIdx() + 2, start);
     tape_.append(tape_.getCurrentIdx(), end);
 }
 
 // JsonIterator.walkDocument (JsonIterator.java:26-200), state for state
-void SimdJsonParser::walkDocument(size_t len) {
+void DocWalker::walkDocument(size_t len) {
     enum { OBJECT_BEGIN, ARRAY_BEGIN, DOCUMENT_END, OBJECT_FIELD, OBJECT_CONTINUE, SCOPE_END, ARRAY_CONTINUE, ARRAY_VALUE };
     const uint8_t* buffer = paddedBuffer_.data();
     BitIndexes& indexer = bitIndexes_;

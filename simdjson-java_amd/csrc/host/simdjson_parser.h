@@ -32,9 +32,13 @@ private:
 // BitIndexes.java:5-101 -- stage-1 output container + stage-2 cursor
 class BitIndexes {
 public:
-    explicit BitIndexes(size_t capacity) : indexes_(capacity) {}
-    uint32_t* array() { return indexes_.data(); }           // filled by the engine (replaces write(), :14-41)
-    size_t capacity() const { return indexes_.size(); }
+    explicit BitIndexes(size_t capacity) : own_(capacity), indexes_(own_.data()), capacity_(capacity) {}
+    // a cursor over somebody else's index array (batch: one per worker thread over the shared array)
+    BitIndexes(uint32_t* shared, size_t capacity) : indexes_(shared), capacity_(capacity) {}
+    BitIndexes(const BitIndexes&) = delete;
+    BitIndexes& operator=(const BitIndexes&) = delete;
+    uint32_t* array() { return indexes_; }                  // filled by the engine (replaces write(), :14-41)
+    size_t capacity() const { return capacity_; }
     void setWriteIdx(size_t n) { writeIdx_ = n; }            // replaces finish() (:82-96): sentinel written by the engine
     // batch: restrict the cursor to one document's slice [from, to) of the shared index array; the sentinel read
     // (index `to`) must land on the document's first structural, as BitIndexes.finish arranges (:82-96)
@@ -53,7 +57,9 @@ private:
     // reads past the sentinel (never observed for any input: the sentinel read already fails the grammar) are defined as 0
     // at/after writeIdx the reference reads its sentinel 0 = the document's first byte (BitIndexes.java:82-96)
     uint32_t at(size_t i) const { return i < writeIdx_ ? indexes_[i] : sentinel_; }
-    std::vector<uint32_t> indexes_;
+    std::vector<uint32_t> own_;
+    uint32_t* indexes_;
+    size_t capacity_;
     size_t writeIdx_ = 0, readIdx_ = 0, base_ = 0;
     uint32_t sentinel_ = 0;
 };
@@ -63,7 +69,11 @@ class Tape {
 public:
     static constexpr char ROOT = 'r', START_ARRAY = '[', START_OBJECT = '{', END_ARRAY = ']', END_OBJECT = '}',
                           STRING = '"', INT64 = 'l', DOUBLE = 'd', TRUE_VALUE = 't', FALSE_VALUE = 'f', NULL_VALUE = 'n';
-    explicit Tape(size_t capacity) : tape_(capacity) {}
+    explicit Tape(size_t capacity) : own_(capacity), tape_(own_.data()), capacity_(capacity) {}
+    Tape(const Tape&) = delete;
+    Tape& operator=(const Tape&) = delete;
+    // batch: build the next document's tape in place at `at` (room for `capacity` words) instead of in own storage
+    void rebase(uint64_t* at, size_t capacity) { tape_ = at; capacity_ = capacity; idx_ = 0; }
     void append(uint64_t val, char type) { tape_[idx_++] = val | ((uint64_t)(uint8_t)type << 56); }  // :28-31
     void appendInt64(int64_t v) { append(0, INT64); tape_[idx_++] = (uint64_t)v; }                   // :33-37
     void appendDouble(double v);                                                                      // :39-43
@@ -78,11 +88,13 @@ public:
     size_t getMatchingBraceIndex(size_t i) const { return (size_t)(uint32_t)tape_[i]; }
     int getScopeCount(size_t i) const { return (int)((tape_[i] >> 32) & 0xFFFFFF); }
     size_t computeNextIndex(size_t i) const;                                                          // :86-98
-    const uint64_t* data() const { return tape_.data(); }
-    size_t capacity() const { return tape_.size(); }
+    const uint64_t* data() const { return tape_; }
+    size_t capacity() const { return capacity_; }
 
 private:
-    std::vector<uint64_t> tape_;
+    std::vector<uint64_t> own_;
+    uint64_t* tape_;
+    size_t capacity_;
     size_t idx_ = 0;
 };
 
@@ -118,6 +130,54 @@ private:
     const uint8_t* sb_;
 };
 
+// The sequential stage 2 of ONE document: JsonIterator.walkDocument (JsonIterator.java:26-200) driving TapeBuilder
+// (TapeBuilder.java:41-217) over the GPU-made structural indexes and string records.  Everything it reads (document
+// bytes, index array, string buffer) is shared and read-only; cursor, tape and container stacks are its own, so a
+// batch can be walked by several of them in parallel threads.
+class DocWalker {
+public:
+    DocWalker(const uint8_t* padded, uint32_t* indexes, size_t indexCapacity, size_t tapeCapacity, int maxDepth)
+        : paddedBuffer_{padded}, bitIndexes_(indexes, indexCapacity), tape_(tapeCapacity), maxDepth_(maxDepth),
+          openContainers_((size_t)maxDepth), isArray_((size_t)maxDepth) {}
+    void setStringBuffer(const uint8_t* sb) { stringBuffer_.p = sb; }
+    // walk the document whose structurals are the current window / contents of bitIndexes(); endOffset = its end
+    void walkDocument(size_t endOffset);
+    // reset (SimdJsonParser.java:50-53) for the document starting at byte docBase whose first string record (if any)
+    // is at stringBufferIdx; the index cursor is set by the caller (bitIndexes().reset()/window())
+    void resetForDocument(size_t docBase, size_t stringBufferIdx) {
+        tape_.reset();
+        docBase_ = docBase;
+        stringBufferIdx_ = stringBufferIdx;
+    }
+    BitIndexes& bitIndexes() { return bitIndexes_; }
+    const BitIndexes& bitIndexes() const { return bitIndexes_; }
+    Tape& tape() { return tape_; }
+    const Tape& tape() const { return tape_; }
+    size_t stringBufferIdx() const { return stringBufferIdx_; }
+
+private:
+    struct Bytes {
+        const uint8_t* p;
+        const uint8_t* data() const { return p; }
+    };
+    static constexpr int PADDING = 64;
+    void visitString(uint32_t idx, size_t indexPos);  // TapeBuilder.visitString :174-177 (record already on the GPU-made buffer)
+    void visitPrimitive(uint32_t idx, size_t indexPos);
+    void visitRootPrimitive(uint32_t idx, size_t indexPos, size_t endOffset);
+    void parseNumber(const uint8_t* p);
+    void emptyContainer(char start, char end);
+
+    Bytes paddedBuffer_, stringBuffer_{nullptr};
+    BitIndexes bitIndexes_;
+    Tape tape_;
+    int maxDepth_;
+    size_t stringBufferIdx_ = 0;
+    struct OpenContainer { size_t tapeIndex; uint32_t count; };
+    std::vector<OpenContainer> openContainers_;
+    std::vector<uint8_t> isArray_;
+    size_t docBase_ = 0;  // batch: byte offset of the current document (error positions are document-relative)
+};
+
 // SimdJsonParser.java:3-59
 class SimdJsonParser {
 public:
@@ -134,45 +194,34 @@ public:
     // parser-owned memory and is invalidated by the next parse(), exactly like the reference.
     JsonValue parse(const uint8_t* buffer, size_t len);
 
-    // Batched parse: documents packed NDJSON-style at doc_offsets[k] (n+1 entries). One GPU pass for the batch,
-    // host stage 2 per document.  Fills batchTape()/batchTapeOffsets()/batchErrors(); throws only for a
-    // stage-1 (batch-level) error.
+    // Batched parse: documents packed NDJSON-style at doc_offsets[k] (n+1 entries).  One GPU pass for the batch (isolated
+    // stage 1 + string unescape + per-document string offsets), then the host stage 2 of the documents on several
+    // threads.  Fills batchTape()/batchTapeOffsets()/batchErrors(); a broken document only affects its own entry.
     void parseBatch(const uint8_t* buffer, size_t totalLen, const uint64_t* docOffsets, size_t nDocs);
     const std::vector<uint64_t>& batchTape() const { return batchTape_; }
     const std::vector<uint64_t>& batchTapeOffsets() const { return batchTapeOffsets_; }
     const std::vector<int32_t>& batchErrors() const { return batchErrors_; }
 
-    const Tape& tape() const { return tape_; }
+    const Tape& tape() const { return walker_.tape(); }
     const std::vector<uint8_t>& stringBuffer() const { return stringBuffer_; }
     size_t stringBufferLen() const { return stringBufferLen_; }
-    const BitIndexes& bitIndexes() const { return bitIndexes_; }
+    const BitIndexes& bitIndexes() const { return walker_.bitIndexes(); }
 
 private:
     void stage1(const uint8_t* buffer, size_t len);   // :55-58 -> GPU
-    void walkDocument(size_t endOffset);              // JsonIterator.walkDocument, JsonIterator.java:26-200
-    void unescapeStrings(size_t len, uint64_t count);
-    void visitString(uint32_t idx, size_t indexPos);  // TapeBuilder.visitString :174-177 (record already on the GPU-made buffer)
-    void visitPrimitive(uint32_t idx, size_t indexPos);
-    void visitRootPrimitive(uint32_t idx, size_t indexPos, size_t endOffset);
-    void parseNumber(const uint8_t* p);
-    void emptyContainer(char start, char end);
+    void growStringBuffer(size_t need);
 
     sjmi_ctx* ctx_ = nullptr;
     int capacity_, maxDepth_;
-    BitIndexes bitIndexes_;
-    Tape tape_;
     std::vector<uint8_t> stringBuffer_, paddedBuffer_;
-    size_t stringBufferLen_ = 0, stringBufferIdx_ = 0;
-    struct OpenContainer { size_t tapeIndex; uint32_t count; };
-    std::vector<OpenContainer> openContainers_;
-    std::vector<uint8_t> isArray_;
-    std::vector<uint64_t> batchTape_, batchTapeOffsets_, indexOffsets_;
+    std::vector<uint32_t> indexes_;  // BitIndexes storage (filled by the engine)
+    DocWalker walker_;
+    size_t stringBufferLen_ = 0;
+    std::vector<uint64_t> batchTape_, batchTapeOffsets_, indexOffsets_, docStringOffsets_;
+    int batchThreads_ = 1;  // host threads walking the documents of a batch (SJMI_PARSE_THREADS overrides)
     std::vector<uint32_t> docStatus_;
     void* pinned_[3] = {nullptr, nullptr, nullptr};  // page-locked parser buffers (sjmi_host_register)
     std::vector<int32_t> batchErrors_;
-    size_t docBase_ = 0;  // batch: byte offset of the current document (error positions are document-relative)
 };
-
-const char* errorMessage(int code);
 
 }  // namespace org_simdjson

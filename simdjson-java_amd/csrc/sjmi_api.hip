@@ -36,6 +36,10 @@ struct sjmi_ctx {
     unsigned long long* d_docoff = nullptr;  // batch: document offsets + index offsets (+ statuses), grown on demand
     uint32_t* d_doccnt = nullptr;            // isolated batch: per-document index counts
     size_t doccnt_bytes = 0;
+    unsigned long long* d_docstr = nullptr;  // batch: per-document string-buffer offsets
+    size_t docstr_bytes = 0;
+    uint64_t last_ndocs = 0;                 // documents of the last batch call (their index offsets are still on the device)
+    bool last_batch = false;
     size_t docoff_bytes = 0;
     int forced_steps = 0;
     uint32_t dbg = 0;  // ablation flags (sjmi_debug_set_flags)
@@ -112,6 +116,7 @@ void sjmi_destroy(sjmi_ctx* c) {
     if (c->d_ures) (void)hipFree(c->d_ures);
     if (c->d_docoff) (void)hipFree(c->d_docoff);
     if (c->d_doccnt) (void)hipFree(c->d_doccnt);
+    if (c->d_docstr) (void)hipFree(c->d_docstr);
     if (c->h_res) (void)hipHostFree(c->h_res);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.first);
@@ -180,6 +185,7 @@ int sjmi_stage1(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes
     c->last_len = len;
     c->last_count = c->h_res->count;
     c->last_valid = true;
+    c->last_batch = false;
     return SJMI_OK;
 }
 
@@ -195,8 +201,9 @@ bool grow(sjmi_ctx* c, void** p, size_t* have, size_t need, const char* what) {
 }
 }  // namespace
 
-int sjmi_unescape_device(sjmi_ctx* c, const void* d_buf, uint64_t len, const void* d_indexes, uint64_t count,
-                         void* d_string_buffer, uint64_t string_capacity, void* d_result, void* stream) {
+static int unescape_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, const void* d_indexes, uint64_t count,
+                                void* d_string_buffer, uint64_t string_capacity, void* d_result, void* stream,
+                                const sjmi::UnescapeBatch& batch) {
     if (!c || !d_buf || !d_indexes || !d_string_buffer || !d_result || len >= (1ull << 32)) return SJMI_ERR_ARG;
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
     if (!grow(c, &c->d_ws_str, &c->ws_str_bytes, sjmi::unescape_workspace_bytes(count, len), "hipMalloc(ws_str)"))
@@ -205,28 +212,55 @@ int sjmi_unescape_device(sjmi_ctx* c, const void* d_buf, uint64_t len, const voi
     if (fail(c, "unescape launch",
              sjmi::unescape_launch((const uint8_t*)d_buf, len, (const uint32_t*)d_indexes, count, nullptr,
                                    (uint8_t*)d_string_buffer, string_capacity, c->d_ws_str,
-                                   (sjmi::UnescapeResult*)d_result, st)))
+                                   (sjmi::UnescapeResult*)d_result, st, batch)))
         return SJMI_ERR_HIP;
     return SJMI_OK;
 }
 
-int sjmi_unescape(sjmi_ctx* c, uint8_t* string_buffer, uint64_t string_capacity, uint64_t* total_bytes,
-                  uint64_t* first_error_index, uint32_t* first_error_code) {
-    if (!c || !string_buffer || !total_bytes || !first_error_index || !first_error_code) return SJMI_ERR_ARG;
-    if (!c->last_valid) {
-        c->err = "sjmi_unescape needs a preceding successful sjmi_stage1 on this context";
-        return SJMI_ERR_ARG;
-    }
+int sjmi_unescape_device(sjmi_ctx* c, const void* d_buf, uint64_t len, const void* d_indexes, uint64_t count,
+                         void* d_string_buffer, uint64_t string_capacity, void* d_result, void* stream) {
+    return unescape_device_impl(c, d_buf, len, d_indexes, count, d_string_buffer, string_capacity, d_result, stream,
+                                sjmi::UnescapeBatch());
+}
+
+int sjmi_unescape_batch_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_indexes, uint64_t count,
+                               const void* d_doc_offsets, const void* d_index_offsets, uint64_t n_docs,
+                               void* d_string_buffer, uint64_t string_capacity, void* d_doc_string_offsets, void* d_result,
+                               void* stream) {
+    if (!d_doc_offsets || !d_index_offsets) return SJMI_ERR_ARG;
+    sjmi::UnescapeBatch batch;
+    batch.d_doc_offsets = (const unsigned long long*)d_doc_offsets;
+    batch.d_index_offsets = (const unsigned long long*)d_index_offsets;
+    batch.n_docs = n_docs;
+    batch.d_doc_str_offsets = (unsigned long long*)d_doc_string_offsets;  // optional
+    return unescape_device_impl(c, d_buf, total_len, d_indexes, count, d_string_buffer, string_capacity, d_result, stream, batch);
+}
+
+// host forms: the document / batch of the last stage-1 call on this context
+static int unescape_host(sjmi_ctx* c, uint8_t* string_buffer, uint64_t string_capacity, uint64_t* doc_string_offsets,
+                         uint64_t* total_bytes, uint64_t* first_error_index, uint32_t* first_error_code) {
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    const uint64_t n_docs = c->last_ndocs;
     const size_t need_sb = (size_t)c->last_len + 4 * (size_t)c->last_count + 64;  // sum(4+len_k) <= len + 4*#strings
+    const size_t ob = (n_docs + 1) * sizeof(unsigned long long);
     if (!grow(c, (void**)&c->d_sb, &c->sb_bytes, need_sb, "hipMalloc(sb)")) return SJMI_ERR_HIP;
+    if (doc_string_offsets && !grow(c, (void**)&c->d_docstr, &c->docstr_bytes, ob + 64, "hipMalloc(docstr)")) return SJMI_ERR_HIP;
     if (!c->d_ures && fail(c, "hipMalloc(ures)", hipMalloc((void**)&c->d_ures, sizeof(sjmi_unescape_result))))
         return SJMI_ERR_HIP;
-    int rc = sjmi_unescape_device(c, c->d_in, c->last_len, c->d_idx, c->last_count, c->d_sb, c->sb_bytes, c->d_ures,
-                                  c->stream);
+    sjmi::UnescapeBatch batch;
+    if (c->last_batch) {  // (also for a plain sjmi_unescape after a batch call: its strings end inside their documents)
+        batch.d_doc_offsets = c->d_docoff;
+        batch.d_index_offsets = c->d_docoff + (n_docs + 1);  // written by the batch call
+        batch.n_docs = n_docs;
+        batch.d_doc_str_offsets = doc_string_offsets ? c->d_docstr : nullptr;
+    }
+    const int rc = unescape_device_impl(c, c->d_in, c->last_len, c->d_idx, c->last_count, c->d_sb, c->sb_bytes, c->d_ures,
+                                        c->stream, batch);
     if (rc != SJMI_OK) return rc;
     sjmi_unescape_result r;
     if (fail(c, "D2H(ures)", hipMemcpyAsync(&r, c->d_ures, sizeof r, hipMemcpyDeviceToHost, c->stream)) ||
+        (doc_string_offsets &&
+         fail(c, "D2H(docstr)", hipMemcpyAsync(doc_string_offsets, c->d_docstr, ob, hipMemcpyDeviceToHost, c->stream))) ||
         fail(c, "sync", hipStreamSynchronize(c->stream)))
         return SJMI_ERR_HIP;
     *total_bytes = r.total_bytes;
@@ -247,6 +281,27 @@ int sjmi_unescape(sjmi_ctx* c, uint8_t* string_buffer, uint64_t string_capacity,
          fail(c, "sync", hipStreamSynchronize(c->stream))))
         return SJMI_ERR_HIP;
     return SJMI_OK;
+}
+
+int sjmi_unescape(sjmi_ctx* c, uint8_t* string_buffer, uint64_t string_capacity, uint64_t* total_bytes,
+                  uint64_t* first_error_index, uint32_t* first_error_code) {
+    if (!c || !string_buffer || !total_bytes || !first_error_index || !first_error_code) return SJMI_ERR_ARG;
+    if (!c->last_valid) {
+        c->err = "sjmi_unescape needs a preceding successful sjmi_stage1 on this context";
+        return SJMI_ERR_ARG;
+    }
+    return unescape_host(c, string_buffer, string_capacity, nullptr, total_bytes, first_error_index, first_error_code);
+}
+
+int sjmi_unescape_batch(sjmi_ctx* c, uint8_t* string_buffer, uint64_t string_capacity, uint64_t* doc_string_offsets,
+                        uint64_t* total_bytes, uint64_t* first_error_index, uint32_t* first_error_code) {
+    if (!c || !string_buffer || !doc_string_offsets || !total_bytes || !first_error_index || !first_error_code)
+        return SJMI_ERR_ARG;
+    if (!c->last_valid || !c->last_batch) {
+        c->err = "sjmi_unescape_batch needs a preceding successful sjmi_stage1_batch[_isolated] on this context";
+        return SJMI_ERR_ARG;
+    }
+    return unescape_host(c, string_buffer, string_capacity, doc_string_offsets, total_bytes, first_error_index, first_error_code);
 }
 
 int sjmi_stage1_unescape(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes, uint64_t index_capacity,
@@ -304,6 +359,7 @@ int sjmi_stage1_unescape(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t
     c->last_len = len;
     c->last_count = c->h_res->count;
     c->last_valid = true;
+    c->last_batch = false;
     const bool strings_ok = *status == 0;  // (a document that fails stage 1 has no meaningful strings: the caller throws)
     if (strings_ok) {
         *total_bytes = r.total_bytes;
@@ -435,6 +491,8 @@ int sjmi_stage1_batch(sjmi_ctx* c, const uint8_t* buf, uint64_t total_len, const
     c->last_len = total_len;
     c->last_count = c->h_res->count;
     c->last_valid = true;
+    c->last_ndocs = n_docs;
+    c->last_batch = true;
     return SJMI_OK;
 }
 
@@ -494,6 +552,8 @@ int sjmi_stage1_batch_isolated(sjmi_ctx* c, const uint8_t* buf, uint64_t total_l
     c->last_len = total_len;
     c->last_count = c->h_res->count;
     c->last_valid = true;
+    c->last_ndocs = n_docs;
+    c->last_batch = true;
     return SJMI_OK;
 }
 

@@ -56,9 +56,19 @@ hipError_t stage1_launch(const uint8_t* d_buf, uint64_t len, uint32_t* d_out, ui
                          hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg = 0,
                          const Stage1Extras& ex = Stage1Extras());
 size_t unescape_workspace_bytes(uint64_t count, uint64_t len);
+// batches: per-document string-buffer offsets (n_docs + 1 device entries), from the device index offsets
+// The indexes belong to a batch of documents (n_docs + 1 byte offsets / index offsets on the device): the last string
+// of a document ends inside that document even when the documents behind it were dropped by the isolated mode; with
+// d_doc_str_offsets also the string-buffer offset of every document's first record (n_docs + 1 entries).
+struct UnescapeBatch {
+    const unsigned long long* d_doc_offsets = nullptr;
+    const unsigned long long* d_index_offsets = nullptr;
+    uint64_t n_docs = 0;
+    unsigned long long* d_doc_str_offsets = nullptr;
+};
 hipError_t unescape_launch(const uint8_t* d_buf, uint64_t len, const uint32_t* d_idx, uint64_t count_bound,
                            const Stage1Result* dev_count, uint8_t* d_sb, uint64_t sb_cap, void* d_ws, UnescapeResult* d_res,
-                           hipStream_t stream);
+                           hipStream_t stream, const UnescapeBatch& batch = UnescapeBatch());
 hipError_t split_docs_launch(const uint32_t* d_idx, const Stage1Result* d_res, const unsigned long long* d_doc_offsets,
                              uint64_t n_docs, unsigned long long* d_index_offsets, hipStream_t stream);
 size_t batch_isolated_workspace_bytes(uint64_t n_docs);

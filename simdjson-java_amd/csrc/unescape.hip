@@ -309,11 +309,41 @@ __device__ __forceinline__ MeasuredString measure_string(const uint8_t* __restri
     return m;
 }
 
+// Batches in isolated mode: a document that failed stage 1 contributes no structurals, so the text between the opening
+// quote of a document's LAST string (a root-level string) and the next structural can hold whole dropped documents
+// instead of white space only.  Such strings (marked by k_doc_mark_tails) end at their own document's end instead.
+struct TailClip {
+    const uint32_t* marks = nullptr;  // one bit per structural
+    const unsigned long long* index_offsets = nullptr;
+    const unsigned long long* doc_offsets = nullptr;
+    uint64_t n_docs = 0;
+};
+__device__ __forceinline__ uint32_t tail_clip_bound(const TailClip& clip, uint64_t i) {
+    uint64_t lo = 0, hi = clip.n_docs;  // the document k with index_offsets[k] <= i < index_offsets[k + 1]
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (clip.index_offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    return (uint32_t)clip.doc_offsets[lo + 1];
+}
+
+// one thread per document: mark its last structural if that is a quote and the next document has no structurals
+__global__ void __launch_bounds__(256)
+k_doc_mark_tails(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ idx,
+                 const unsigned long long* __restrict__ index_offsets, uint64_t n_docs, uint32_t* __restrict__ marks) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k + 1 >= n_docs) return;  // (the batch's last document ends where the batch ends)
+    const unsigned long long from = index_offsets[k], to = index_offsets[k + 1];
+    if (to == from || index_offsets[k + 2] != to) return;
+    if (buf[idx[to - 1]] == '"') atomicOr(&marks[(to - 1) >> 5], 1u << ((to - 1) & 31));
+}
+
 template <int ITEMS>
 __global__ void __launch_bounds__(UNESC_THREADS)
 k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __restrict__ idx, uint64_t count,
               const Stage1Result* __restrict__ dev_count, uint32_t* __restrict__ sizes,
-              unsigned long long* __restrict__ block_sums, uint8_t* __restrict__ scratch, UnescapeResult* res) {
+              unsigned long long* __restrict__ block_sums, uint32_t* __restrict__ group_sums, uint8_t* __restrict__ scratch,
+              UnescapeResult* res, TailClip clip) {
     // dev_count != nullptr: the structural count is still on the device (stage 1 of the same document is queued right
     // in front); the grid was sized for an upper bound, surplus workgroups leave at once
     if (dev_count) count = dev_count->count;
@@ -333,6 +363,7 @@ k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __r
             in_range[q] = i < count;
             open[q] = in_range[q] ? idx[i] : 0u;
             bound[q] = (i + 1 < count) ? idx[i + 1] : len;
+            if (clip.marks && in_range[q] && ((clip.marks[i >> 5] >> (i & 31)) & 1u)) bound[q] = tail_clip_bound(clip, i);
         }
         U16B hw[MEAS_GROUP], tw[MEAS_GROUP];
         uint4 sp[MEAS_GROUP][SPAN_W];
@@ -404,6 +435,12 @@ k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __r
             } else if (in_range[q]) {
                 sizes[i] = 0;
             }
+            if (group_sums) {  // batches: bytes per 64 structurals, for the per-document string-buffer offsets
+                uint32_t gsum = is_str ? 4u + (uint32_t)r : 0u;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) gsum += __shfl_xor(gsum, d);
+                if (lane == 0 && in_range[q]) group_sums[i >> 6] = gsum;
+            }
         }
     }
 #pragma unroll
@@ -441,7 +478,10 @@ k_scan_sums(unsigned long long* __restrict__ block_sums, uint32_t nblocks, const
         if (threadIdx.x == 1023) s_carry = off + x;
         __syncthreads();
     }
-    if (threadIdx.x == 0) res->total_bytes = s_carry;
+    if (threadIdx.x == 0) {
+        res->total_bytes = s_carry;
+        block_sums[nblocks] = s_carry;  // (one spare entry: the offset "behind the last tile")
+    }
 }
 
 // ---- k_str_write ------------------------------------------------------------------------------
@@ -627,27 +667,72 @@ k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __res
     }
 }
 
-// layout: sizes[count] | block sums (sized for the smallest tile) | scratch[len + 128]
+// Batches: doc_str_offsets[k] = string-buffer offset of document k's first record = bytes of all records whose
+// structural comes before index_offsets[k] (n_docs + 1 entries; the host stage 2 of every document can then start at
+// its own offset, so documents can be walked in parallel).  One wave per boundary: tile offset + the tile's full
+// groups of 64 structurals before it + the sizes of the partial group.
+__global__ void __launch_bounds__(256)
+k_doc_str_offsets(const unsigned long long* __restrict__ index_offsets, uint64_t n_docs, uint64_t count,
+                  const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ group_sums,
+                  const unsigned long long* __restrict__ block_offsets, uint32_t tile,
+                  unsigned long long* __restrict__ doc_str_offsets) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t k = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k > n_docs) return;
+    unsigned long long s = index_offsets[k];
+    if (s > count) s = count;
+    const uint64_t t = s / tile, tstart = t * tile;
+    unsigned long long acc = 0;
+    const uint64_t g0 = tstart >> 6, g1 = s >> 6;  // full groups of the tile in front of s (at most tile / 64 <= 64)
+    if (g0 + (uint64_t)lane < g1) acc += group_sums[g0 + lane];
+    if ((uint64_t)lane < (s & 63)) acc += sizes[(s & ~63ull) + lane] & ~SIZE_SLOW;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0) doc_str_offsets[k] = block_offsets[t] + acc;
+}
+
+// layout: sizes[count] | block sums (sized for the smallest tile) | group sums[count / 64] | tail marks[count / 32] |
+// scratch[len + 128]
 static int unescape_items(uint64_t count) { return count >= (1u << 20) ? UNESC_ITEMS_MAX : (count >= (1u << 17) ? 4 : 1); }
 static size_t ws_sums_offset(uint64_t count) { return (((size_t)count * sizeof(uint32_t) + 63) / 64) * 64 + 64; }
-static size_t ws_scratch_offset(uint64_t count) {
+static size_t ws_groups_offset(uint64_t count) {
     const uint64_t nblocks = (count + UNESC_THREADS - 1) / UNESC_THREADS;
-    return ws_sums_offset(count) + (((size_t)(nblocks + 1) * sizeof(unsigned long long) + 63) / 64) * 64 + 64;
+    return ws_sums_offset(count) + (((size_t)(nblocks + 2) * sizeof(unsigned long long) + 63) / 64) * 64 + 64;
 }
+static size_t ws_marks_offset(uint64_t count) {
+    return ws_groups_offset(count) + (((size_t)(count / 64 + 2) * sizeof(uint32_t) + 63) / 64) * 64 + 64;
+}
+static size_t ws_marks_bytes(uint64_t count) { return (((size_t)(count / 32 + 2) * sizeof(uint32_t) + 63) / 64) * 64; }
+static size_t ws_scratch_offset(uint64_t count) { return ws_marks_offset(count) + ws_marks_bytes(count) + 64; }
 size_t unescape_workspace_bytes(uint64_t count, uint64_t len) { return ws_scratch_offset(count) + (size_t)len + 128; }
 
 template <int ITEMS>
 static hipError_t unescape_launch_items(const uint8_t* d_buf, uint64_t len, const uint32_t* d_idx, uint64_t count,
                                         const Stage1Result* dev_count, uint8_t* d_sb, uint64_t sb_cap, uint32_t* sizes,
-                                        unsigned long long* sums, uint8_t* scratch, UnescapeResult* d_res,
-                                        hipStream_t stream) {
+                                        unsigned long long* sums, uint32_t* groups, uint32_t* marks, uint8_t* scratch,
+                                        UnescapeResult* d_res, hipStream_t stream, const UnescapeBatch& batch) {
     const uint64_t tile = (uint64_t)UNESC_THREADS * ITEMS;
     const uint64_t nblocks = (count + tile - 1) / tile;  // (an upper bound if the count is still on the device)
+    TailClip clip;
+    if (batch.d_index_offsets && batch.d_doc_offsets && batch.n_docs > 1) {
+        hipError_t e = hipMemsetAsync(marks, 0, ws_marks_bytes(count), stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_doc_mark_tails, dim3((unsigned)((batch.n_docs + 255) / 256)), dim3(256), 0, stream, d_buf, d_idx,
+                           batch.d_index_offsets, batch.n_docs, marks);
+        clip.marks = marks;
+        clip.index_offsets = batch.d_index_offsets;
+        clip.doc_offsets = batch.d_doc_offsets;
+        clip.n_docs = batch.n_docs;
+    }
     hipLaunchKernelGGL((k_str_measure<ITEMS>), dim3((unsigned)nblocks), dim3(UNESC_THREADS), 0, stream, d_buf, (uint32_t)len,
-                       d_idx, count, dev_count, sizes, sums, scratch, d_res);
+                       d_idx, count, dev_count, sizes, sums, batch.d_doc_str_offsets ? groups : nullptr, scratch, d_res, clip);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, (uint32_t)nblocks, dev_count, (uint32_t)tile, d_res);
     hipLaunchKernelGGL((k_str_write<ITEMS>), dim3((unsigned)nblocks), dim3(UNESC_THREADS), 0, stream, d_buf, (uint32_t)len,
                        d_idx, count, dev_count, sizes, sums, scratch, d_sb, sb_cap, d_res);
+    if (batch.d_doc_str_offsets)
+        hipLaunchKernelGGL(k_doc_str_offsets, dim3((unsigned)((batch.n_docs + 1 + 3) / 4)), dim3(256), 0, stream,
+                           batch.d_index_offsets, batch.n_docs, count, sizes, groups, sums, (uint32_t)tile,
+                           batch.d_doc_str_offsets);
     return hipGetLastError();
 }
 
@@ -655,19 +740,25 @@ static hipError_t unescape_launch_items(const uint8_t* d_buf, uint64_t len, cons
 // sized for the bound; the kernels take the real count from *dev_count)
 hipError_t unescape_launch(const uint8_t* d_buf, uint64_t len, const uint32_t* d_idx, uint64_t count_bound,
                            const Stage1Result* dev_count, uint8_t* d_sb, uint64_t sb_cap, void* d_ws, UnescapeResult* d_res,
-                           hipStream_t stream) {
+                           hipStream_t stream, const UnescapeBatch& batch) {
     uint8_t* ws = static_cast<uint8_t*>(d_ws);
     uint32_t* sizes = reinterpret_cast<uint32_t*>(ws);
     unsigned long long* sums = reinterpret_cast<unsigned long long*>(ws + ws_sums_offset(count_bound));
+    uint32_t* groups = reinterpret_cast<uint32_t*>(ws + ws_groups_offset(count_bound));
+    uint32_t* marks = reinterpret_cast<uint32_t*>(ws + ws_marks_offset(count_bound));
     uint8_t* scratch = ws + ws_scratch_offset(count_bound);
     hipError_t e = hipMemsetAsync(d_res, 0, sizeof(UnescapeResult), stream);
     if (e != hipSuccess) return e;
-    if (count_bound == 0) return hipSuccess;
+    if (count_bound == 0) {
+        if (batch.d_doc_str_offsets)
+            return hipMemsetAsync(batch.d_doc_str_offsets, 0, (batch.n_docs + 1) * sizeof(unsigned long long), stream);
+        return hipSuccess;
+    }
     // (with a bound, judge the size by the document: ~one structural per 8-11 bytes)
     switch (unescape_items(dev_count ? len / 8 : count_bound)) {
-    case 1: return unescape_launch_items<1>(d_buf, len, d_idx, count_bound, dev_count, d_sb, sb_cap, sizes, sums, scratch, d_res, stream);
-    case 4: return unescape_launch_items<4>(d_buf, len, d_idx, count_bound, dev_count, d_sb, sb_cap, sizes, sums, scratch, d_res, stream);
-    default: return unescape_launch_items<UNESC_ITEMS_MAX>(d_buf, len, d_idx, count_bound, dev_count, d_sb, sb_cap, sizes, sums, scratch, d_res, stream);
+    case 1: return unescape_launch_items<1>(d_buf, len, d_idx, count_bound, dev_count, d_sb, sb_cap, sizes, sums, groups, marks, scratch, d_res, stream, batch);
+    case 4: return unescape_launch_items<4>(d_buf, len, d_idx, count_bound, dev_count, d_sb, sb_cap, sizes, sums, groups, marks, scratch, d_res, stream, batch);
+    default: return unescape_launch_items<UNESC_ITEMS_MAX>(d_buf, len, d_idx, count_bound, dev_count, d_sb, sb_cap, sizes, sums, groups, marks, scratch, d_res, stream, batch);
     }
 }
 

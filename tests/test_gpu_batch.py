@@ -98,6 +98,9 @@ def test_parse_batch_trees_and_errors():
     bad += [b'["abc', b'{"k": "v', bytes([0x5B, 0x22, 0xC3, 0x22, 0x5D]), b'["a\x01b"]']
     for b in bad:
         docs.insert(rng.randrange(len(docs)), b)
+    # root-level strings in front of dropped documents (their closing quote is the document's, not the batch's)
+    docs[40:40] = [b'"tail \\t string"', b'"', b'"x"', b'["abc', b'"y"', bytes([0x22, 0x80, 0x22]), b"", b'"z"']
+    docs += [b'"end"', b'"']
     buf, offs = _pack(docs)
     p = S.SimdJsonParser(capacity=len(buf) + 64)
     try:
@@ -131,3 +134,101 @@ def test_twitter_batch_end_to_end(twitter):
             assert O.Parsed(tapes[k], strings, 0, 0, 0).to_python() == want
     finally:
         p.close()
+
+
+def test_unescape_batch_document_string_offsets():
+    """sjmi_unescape_batch: doc_string_offsets[k] is where document k's first string record lies in the batch's string
+    buffer = the sum of the record sizes of all earlier documents (stage-1-failing documents contribute none), for
+    documents whose structurals straddle the 64-structural groups and the measure kernel's tiles."""
+    import simdjson_java_amd as S
+    rng = random.Random(80)
+    docs = _small_docs(rng, 6000)
+    docs.insert(10, load_fixture("github_events.json").rstrip())
+    docs.insert(3000, load_fixture("twitter.json").rstrip())
+    docs.insert(20, b'["unclosed')
+    docs.insert(4000, b"")
+    docs.insert(4001, b"")
+    docs.append(b'["last \\u00e9 \\n"]')
+    # a root-level string is its document's last structural: when the documents behind it are dropped (or empty), its
+    # closing quote must still be found inside its own document -- dropped documents ending in a quote included
+    docs[30:30] = [b'"tail \\n string"', b'"', b'"plain tail"', bytes([0x22, 0x80, 0x22]), b'["abc', b"", b'"next"', b'"a"', b'"']
+    docs += [b'"end"', b'["unclosed at the very end', b'"']
+    buf, offs = _pack(docs)
+    ctx = S.Context(0, len(buf) + 64)
+    try:
+        idx, io, ds, st = ctx.stage1_batch_isolated(buf, offs)
+        sb, dso, fei, fec = ctx.unescape_batch(len(buf) + 4 * idx.size + 64, len(docs))
+        want_sb, want_offs, feo, _ = O.unescape_all(buf + b"\0" * 64, idx)
+        assert feo < 0 and fei is None and sb == want_sb
+        assert int(dso[0]) == 0 and int(dso[-1]) == len(sb)
+        cursor = 0
+        for k, d in enumerate(docs):
+            assert int(dso[k]) == cursor, k
+            if ds[k]:
+                continue
+            one_sb, _, _, _ = O.unescape_all(d + b"\0" * 64, O.stage1(d + b"\n")[0])
+            assert sb[cursor:cursor + len(one_sb)] == one_sb, k
+            cursor += len(one_sb)
+        assert cursor == len(sb)
+        # a plain sjmi_unescape after the batch call knows the documents too
+        sb1, fei1, _ = ctx.unescape(len(buf) + 4 * idx.size + 64)
+        assert fei1 is None and sb1 == want_sb
+        # device-resident form
+        import torch
+        d_buf = torch.zeros(len(buf) + 128, dtype=torch.uint8, device="cuda")
+        d_buf[:len(buf)] = torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
+        d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+        d_idx = torch.zeros(len(buf) + 2, dtype=torch.int32, device="cuda")
+        d_io = torch.zeros(len(docs) + 1, dtype=torch.int64, device="cuda")
+        d_ds = torch.zeros(len(docs), dtype=torch.int32, device="cuda")
+        d_res = torch.zeros(2, dtype=torch.int64, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        ctx.stage1_batch_isolated_device(d_buf.data_ptr(), len(buf), d_offs.data_ptr(), len(docs), d_idx.data_ptr(), d_idx.numel(),
+                                         d_io.data_ptr(), d_ds.data_ptr(), d_res.data_ptr(), stream)
+        torch.cuda.synchronize()
+        count = int(d_res[0].item())
+        assert count == idx.size
+        d_sb = torch.zeros(len(buf) + 4 * count + 64, dtype=torch.uint8, device="cuda")
+        d_dso = torch.zeros(len(docs) + 1, dtype=torch.int64, device="cuda")
+        d_ures = torch.zeros(3, dtype=torch.int64, device="cuda")
+        ctx.unescape_batch_device(d_buf.data_ptr(), len(buf), d_idx.data_ptr(), count, d_offs.data_ptr(), d_io.data_ptr(),
+                                  len(docs), d_sb.data_ptr(), d_sb.numel(), d_dso.data_ptr(), d_ures.data_ptr(), stream)
+        torch.cuda.synchronize()
+        ures = d_ures.cpu().numpy()
+        assert int(ures[0]) == len(want_sb) and int(ures[1]) == 0
+        assert bytes(d_sb[:len(want_sb)].cpu().numpy()) == want_sb
+        assert np.array_equal(d_dso.cpu().numpy().astype(np.uint64), dso)
+    finally:
+        ctx.close()
+
+
+def test_parse_batch_on_many_host_threads(monkeypatch):
+    """The host stage 2 of a batch runs on several threads (document ranges balanced by structural count): trees, errors
+    and tape offsets must not depend on the thread count, including failing documents at range boundaries."""
+    import simdjson_java_amd as S
+    rng = random.Random(81)
+    docs = _small_docs(rng, 30000)
+    bad = [b"[1 1]", b'{"a" 1}', b"[1,2", b'["\\q"]', b'["abc', bytes([0x5B, 0x22, 0xC3, 0x22, 0x5D]), b"", b"[-]"]
+    for i in range(200):
+        docs.insert(rng.randrange(len(docs)), bad[i % len(bad)])
+    docs.insert(7, load_fixture("github_events.json").rstrip())
+    buf, offs = _pack(docs)
+    results = []
+    for threads in ("1", "7", "64"):
+        monkeypatch.setenv("SJMI_PARSE_THREADS", threads)
+        p = S.SimdJsonParser(capacity=len(buf) + 64)
+        try:
+            results.append(p.parse_batch(buf, offs))
+        finally:
+            p.close()
+    tapes1, strings1, errors1 = results[0]
+    for tapes, strings, errors in results[1:]:
+        assert strings == strings1 and np.array_equal(errors, errors1)
+        for a, b in zip(tapes, tapes1):
+            assert (a is None and b is None) or np.array_equal(a, b)
+    assert int((errors1 != 0).sum()) >= 200
+    for k in rng.sample(range(len(docs)), 600) + [7]:
+        want = O.parse(docs[k] + b"\n")
+        assert int(errors1[k]) == want.error, (k, docs[k])
+        if not want.error:
+            assert O.Parsed(tapes1[k], strings1, 0, 0, 0).to_python() == want.to_python(), k
