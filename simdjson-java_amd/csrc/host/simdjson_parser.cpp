@@ -3,8 +3,13 @@
 // re-implemented in C++.  Citations: /root/reference/src/main/java/org/simdjson/<file>:<lines>.
 #include "simdjson_parser.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <exception>
 #include <memory>
 #include <thread>
@@ -113,6 +118,72 @@ bool JsonValue::get(const std::string& name, JsonValue* out) const {  // JsonVal
     return false;
 }
 
+// The host threads of parseBatch: n - 1 helpers that sleep between batches; run(k, fn) executes fn(0..k-1), fn(0) on
+// the caller.  (Creating threads per batch cost ~1 ms per phase at 32 threads.)
+class WorkerPool {
+public:
+    explicit WorkerPool(size_t n) {
+        for (size_t t = 1; t < n; ++t) helpers_.emplace_back([this, t] { loop(t); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+            ++generation_;
+        }
+        wake_.notify_all();
+        for (std::thread& th : helpers_) th.join();
+    }
+    size_t size() const { return helpers_.size() + 1; }
+    void run(size_t tasks, const std::function<void(size_t)>& fn) {
+        if (tasks > size()) tasks = size();
+        if (tasks > 1) {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &fn;
+            tasks_ = tasks;
+            pending_ = tasks - 1;
+            ++generation_;
+        }
+        if (tasks > 1) wake_.notify_all();
+        if (tasks) fn(0);
+        if (tasks > 1) {
+            std::unique_lock<std::mutex> g(m_);
+            done_.wait(g, [this] { return pending_ == 0; });
+            fn_ = nullptr;
+        }
+    }
+
+private:
+    void loop(size_t t) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(size_t)>* fn = nullptr;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                wake_.wait(g, [&] { return generation_ != seen; });
+                seen = generation_;
+                if (stop_) return;
+                if (t < tasks_) fn = fn_;
+            }
+            if (!fn) continue;
+            (*fn)(t);  // (fn never throws: parseBatch's tasks catch into their lane)
+            bool last;
+            {
+                std::lock_guard<std::mutex> g(m_);
+                last = --pending_ == 0;
+            }
+            if (last) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> helpers_;
+    std::mutex m_;
+    std::condition_variable wake_, done_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t tasks_ = 0, pending_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+
 SimdJsonParser::SimdJsonParser(int capacity, int maxDepth, int device)
     : capacity_(capacity), maxDepth_(maxDepth), stringBuffer_((size_t)capacity + 4 * ((size_t)capacity / 2 + 2) + 64),
       paddedBuffer_((size_t)capacity + PADDING), indexes_((size_t)capacity + 2),
@@ -132,6 +203,7 @@ SimdJsonParser::SimdJsonParser(int capacity, int maxDepth, int device)
 }
 
 SimdJsonParser::~SimdJsonParser() {
+    pool_.reset();
     for (void* p : pinned_)
         if (p) (void)sjmi_host_unregister(ctx_, p);
     sjmi_destroy(ctx_);
@@ -180,8 +252,30 @@ JsonValue SimdJsonParser::parse(const uint8_t* buffer, size_t len) {
 // slab, which the threads then copy to their final place in batchTape().
 void SimdJsonParser::parseBatch(const uint8_t* buffer, size_t totalLen, const uint64_t* docOffsets, size_t nDocs) {
     if (totalLen > (size_t)capacity_) throw fail(E_CAPACITY);
-    memcpy(paddedBuffer_.data(), buffer, totalLen);
-    memset(paddedBuffer_.data() + totalLen, 0, PADDING);
+    // SJMI_PARSE_TIMING=1: phase times of every batch on stderr (tools/batch_e2e.py)
+    static const bool timing = getenv("SJMI_PARSE_TIMING") != nullptr;
+    using Clock = std::chrono::steady_clock;
+    Clock::time_point mark = Clock::now();
+    double phase[6] = {0, 0, 0, 0, 0, 0};
+    auto lap = [&](int i) {
+        const Clock::time_point now = Clock::now();
+        phase[i] = std::chrono::duration<double, std::milli>(now - mark).count();
+        mark = now;
+    };
+    if (!pool_) {
+        pool_.reset(new WorkerPool((size_t)batchThreads_));
+        lanes_.resize((size_t)batchThreads_);
+    }
+    {   // padIfNeeded for the batch, on the pool (one thread copies ~25 GB/s)
+        const size_t parts = std::min<size_t>((size_t)batchThreads_, std::min<size_t>(8, totalLen / (1u << 20) + 1));
+        const std::function<void(size_t)> copyPart = [&](size_t t) {
+            const size_t lo = totalLen * t / parts, hi = totalLen * (t + 1) / parts;
+            memcpy(paddedBuffer_.data() + lo, buffer + lo, hi - lo);
+        };
+        pool_->run(parts, copyPart);
+        memset(paddedBuffer_.data() + totalLen, 0, PADDING);
+    }
+    lap(0);
     walker_.bitIndexes().reset();
     indexOffsets_.assign(nDocs + 1, 0);
     docStringOffsets_.assign(nDocs + 1, 0);
@@ -193,12 +287,14 @@ void SimdJsonParser::parseBatch(const uint8_t* buffer, size_t totalLen, const ui
     int rc = sjmi_stage1_batch_isolated(ctx_, paddedBuffer_.data(), totalLen, docOffsets, nDocs, indexes_.data(),
                                         indexes_.size(), indexOffsets_.data(), docStatus_.data(), &count, &status);
     if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_stage1_batch_isolated: ") + sjmi_last_error(ctx_));
+    lap(1);
     growStringBuffer(totalLen + 4 * (size_t)count + 64);
     uint64_t total = 0, fei = 0;
     uint32_t fec = 0;
     rc = sjmi_unescape_batch(ctx_, stringBuffer_.data(), stringBuffer_.size(), docStringOffsets_.data(), &total, &fei, &fec);
     if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_unescape_batch: ") + sjmi_last_error(ctx_));
     stringBufferLen_ = (size_t)total;
+    lap(2);
     batchTapeOffsets_.assign(nDocs + 1, 0);
     batchErrors_.assign(nDocs, 0);
 
@@ -214,27 +310,28 @@ void SimdJsonParser::parseBatch(const uint8_t* buffer, size_t totalLen, const ui
         cut[t] = (size_t)(std::lower_bound(indexOffsets_.begin(), indexOffsets_.begin() + (ptrdiff_t)nDocs, want) - indexOffsets_.begin());
         if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
     }
-    struct Slab {
-        std::unique_ptr<uint64_t[]> words;
-        size_t used = 0;
-        std::exception_ptr error;
-    };
-    std::vector<Slab> slabs(nThreads);
     const uint8_t* padded = paddedBuffer_.data();
     const uint8_t* strings = stringBuffer_.data();
-    auto walkRange = [&](size_t t) {
+    const std::function<void(size_t)> walkRange = [&](size_t t) {
+        BatchLane& lane = lanes_[t];
+        lane.used = 0;
+        lane.error = nullptr;
         try {
             const size_t lo = cut[t], hi = cut[t + 1];
             // a structural makes at most two tape words (a number); the root adds two
             const size_t room = 2 * (size_t)(indexOffsets_[hi] - indexOffsets_[lo]) + 8 * (hi - lo) + 8;
-            Slab& slab = slabs[t];
-            slab.words.reset(new uint64_t[room]);
-            DocWalker w(padded, indexes_.data(), indexes_.size(), 0, maxDepth_);
+            if (lane.room < room) {
+                lane.words.reset();
+                lane.words.reset(new uint64_t[room + room / 4]);
+                lane.room = room + room / 4;
+            }
+            if (!lane.walker) lane.walker.reset(new DocWalker(padded, indexes_.data(), indexes_.size(), 0, maxDepth_));
+            DocWalker& w = *lane.walker;
             w.setStringBuffer(strings);
             for (size_t k = lo; k < hi; ++k) {
                 const size_t from = (size_t)indexOffsets_[k], to = (size_t)indexOffsets_[k + 1];
                 w.resetForDocument((size_t)docOffsets[k], (size_t)docStringOffsets_[k]);
-                w.tape().rebase(slab.words.get() + slab.used, room - slab.used);
+                w.tape().rebase(lane.words.get() + lane.used, lane.room - lane.used);
                 w.bitIndexes().window(from, to, (uint32_t)docOffsets[k]);
                 try {
                     // SimdJsonParser.stage1 order: Utf8Validator.validate (:165-167), then StructuralIndexer.index (:297-302)
@@ -242,33 +339,33 @@ void SimdJsonParser::parseBatch(const uint8_t* buffer, size_t totalLen, const ui
                     if (docStatus_[k] & SJMI_ST_UNCLOSED) throw fail(E_UNCLOSED_STRING);
                     if (docStatus_[k] & SJMI_ST_UNESCAPED) throw fail(E_UNESCAPED_CHARS);
                     w.walkDocument((size_t)docOffsets[k + 1]);
-                    slab.used += w.tape().getCurrentIdx();
+                    lane.used += w.tape().getCurrentIdx();
                 } catch (const JsonParsingException& e) {
                     batchErrors_[k] = e.code();  // its partial tape is dropped
                 }
-                batchTapeOffsets_[k + 1] = slab.used;  // slab-relative until the slabs are placed
+                batchTapeOffsets_[k + 1] = lane.used;  // lane-relative until the slabs are placed
             }
         } catch (...) {
-            slabs[t].error = std::current_exception();
+            lane.error = std::current_exception();
         }
     };
-    auto onThreads = [&](auto&& fn) {
-        std::vector<std::thread> pool;
-        for (size_t t = 1; t < nThreads; ++t) pool.emplace_back(fn, t);
-        fn((size_t)0);
-        for (std::thread& th : pool) th.join();
-    };
-    onThreads(walkRange);
-    for (Slab& s : slabs)
-        if (s.error) std::rethrow_exception(s.error);
+    pool_->run(nThreads, walkRange);
+    lap(3);
+    for (size_t t = 0; t < nThreads; ++t)
+        if (lanes_[t].error) std::rethrow_exception(lanes_[t].error);
     std::vector<size_t> base(nThreads + 1, 0);
-    for (size_t t = 0; t < nThreads; ++t) base[t + 1] = base[t] + slabs[t].used;
+    for (size_t t = 0; t < nThreads; ++t) base[t + 1] = base[t] + lanes_[t].used;
     batchTape_.resize(base[nThreads]);
-    auto place = [&](size_t t) {
-        if (slabs[t].used) memcpy(batchTape_.data() + base[t], slabs[t].words.get(), slabs[t].used * sizeof(uint64_t));
+    const std::function<void(size_t)> place = [&](size_t t) {
+        if (lanes_[t].used) memcpy(batchTape_.data() + base[t], lanes_[t].words.get(), lanes_[t].used * sizeof(uint64_t));
         for (size_t k = cut[t]; k < cut[t + 1]; ++k) batchTapeOffsets_[k + 1] += base[t];
     };
-    onThreads(place);
+    pool_->run(nThreads, place);
+    lap(4);
+    if (timing)
+        fprintf(stderr, "parseBatch %zu docs %zu B, %zu threads: copy+pad %.2f ms, stage 1 (H2D, kernels, D2H) %.2f ms, strings "
+                "(kernels, D2H) %.2f ms, walk %.2f ms, place tapes %.2f ms\n", nDocs, totalLen, nThreads, phase[0], phase[1],
+                phase[2], phase[3], phase[4]);
 }
 
 // TapeBuilder.visitString (TapeBuilder.java:174-177): the record [be32 len][bytes] was produced on the GPU at

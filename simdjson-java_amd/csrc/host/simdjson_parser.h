@@ -8,6 +8,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <exception>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -178,6 +180,8 @@ private:
     size_t docBase_ = 0;  // batch: byte offset of the current document (error positions are document-relative)
 };
 
+class WorkerPool;  // simdjson_parser.cpp: the host threads of parseBatch
+
 // SimdJsonParser.java:3-59
 class SimdJsonParser {
 public:
@@ -219,6 +223,15 @@ private:
     size_t stringBufferLen_ = 0;
     std::vector<uint64_t> batchTape_, batchTapeOffsets_, indexOffsets_, docStringOffsets_;
     int batchThreads_ = 1;  // host threads walking the documents of a batch (SJMI_PARSE_THREADS overrides)
+    // one per batch thread, kept between batches: the walker and the slab its documents' tapes are built in
+    struct BatchLane {
+        std::unique_ptr<DocWalker> walker;
+        std::unique_ptr<uint64_t[]> words;
+        size_t room = 0, used = 0;
+        std::exception_ptr error;
+    };
+    std::vector<BatchLane> lanes_;
+    std::unique_ptr<WorkerPool> pool_;  // created by the first parseBatch
     std::vector<uint32_t> docStatus_;
     void* pinned_[3] = {nullptr, nullptr, nullptr};  // page-locked parser buffers (sjmi_host_register)
     std::vector<int32_t> batchErrors_;
