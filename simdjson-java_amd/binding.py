@@ -383,9 +383,11 @@ class SimdJsonParser:
             raise JsonParsingException(rc, lib().sjmi_parser_last_message(self._h).decode("utf-8"))
         if rc < 0:
             raise SjmiError("sjmi_parser_parse_batch failed (rc=%d): %s" % (rc, lib().sjmi_parser_last_message(self._h).decode()))
+        def view(ptr, count, dtype):  # (an empty result may come back as a NULL pointer)
+            return np.ctypeslib.as_array(ptr, shape=(count,)).copy() if count and bool(ptr) else np.zeros(0, dtype=dtype)
         to = np.ctypeslib.as_array(to_p, shape=(n + 1,)).copy()
-        errors = np.ctypeslib.as_array(err_p, shape=(max(n, 1),))[:n].copy()
-        alltape = np.ctypeslib.as_array(tape_p, shape=(max(int(to[-1]), 1),))[:int(to[-1])].copy()
-        strings = bytes(np.ctypeslib.as_array(sb_p, shape=(max(sb_len.value, 1),))[:sb_len.value])
+        errors = view(err_p, n, np.int32)
+        alltape = view(tape_p, int(to[-1]), np.uint64)
+        strings = bytes(view(sb_p, sb_len.value, np.uint8))
         tapes = [alltape[int(to[k]):int(to[k + 1])] if errors[k] == 0 else None for k in range(n)]
         return tapes, strings, errors

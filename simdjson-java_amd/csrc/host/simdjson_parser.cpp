@@ -185,7 +185,7 @@ private:
 };
 
 SimdJsonParser::SimdJsonParser(int capacity, int maxDepth, int device)
-    : capacity_(capacity), maxDepth_(maxDepth), stringBuffer_((size_t)capacity + 4 * ((size_t)capacity / 2 + 2) + 64),
+    : capacity_(capacity), maxDepth_(maxDepth), device_(device), stringBuffer_(3 * (size_t)capacity + 256),
       paddedBuffer_((size_t)capacity + PADDING), indexes_((size_t)capacity + 2),
       walker_(paddedBuffer_.data(), indexes_.data(), indexes_.size(), (size_t)capacity + 8, maxDepth) {
     const int rc = sjmi_create(&ctx_, device, (uint64_t)capacity);
@@ -200,10 +200,15 @@ SimdJsonParser::SimdJsonParser(int capacity, int maxDepth, int device)
         const int v = atoi(e);
         if (v >= 1 && v <= 1024) batchThreads_ = v;
     }
+    if (const char* e = getenv("SJMI_PARSE_PIPELINE")) {  // sub-batches per batch (default: by size, 1..4)
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) batchPipeline_ = v;
+    }
 }
 
 SimdJsonParser::~SimdJsonParser() {
     pool_.reset();
+    if (ctx2_) sjmi_destroy(ctx2_);
     for (void* p : pinned_)
         if (p) (void)sjmi_host_unregister(ctx_, p);
     sjmi_destroy(ctx_);
@@ -246,28 +251,30 @@ JsonValue SimdJsonParser::parse(const uint8_t* buffer, size_t len) {
     return JsonValue(&walker_.tape(), 1, stringBuffer_.data());  // TapeBuilder.createJsonValue :215-217
 }
 
-// Batched parse.  GPU: isolated stage 1 (per-document verdicts and index ranges), the string records of all documents,
-// and the string-buffer offset at which each document's records begin.  Host: stage 2 of the documents, spread over
-// threads by structural count; every thread owns a DocWalker and builds its documents' tapes back to back in its own
-// slab, which the threads then copy to their final place in batchTape().
+// Batched parse.  The batch is cut into up to eight sub-batches of whole documents (about 8 MB or more each); two feeder threads, each with its
+// own engine context (= its own stream), take them alternately through the GPU: isolated stage 1 (per-document
+// verdicts and index ranges), the string records, and the string-buffer offset at which each document's records
+// begin.  So the upload of one sub-batch overlaps the kernels and downloads of the other (PCIe is full duplex), and
+// the host stage 2 of a finished sub-batch -- its documents spread over the worker pool by structural count, every
+// thread with a DocWalker building tapes back to back in a slab, then the slabs copied to their place in batchTape() --
+// overlaps the GPU part of the next.
+// Sub-batch j's indexes / string records are placed at fixed bases of the shared arrays (sized for the worst case:
+// one structural per byte, three string-buffer bytes per document byte), so with more than one sub-batch the string
+// buffer has unused gaps between them; tape STRING payloads are offsets into that one buffer.
 void SimdJsonParser::parseBatch(const uint8_t* buffer, size_t totalLen, const uint64_t* docOffsets, size_t nDocs) {
     if (totalLen > (size_t)capacity_) throw fail(E_CAPACITY);
     // SJMI_PARSE_TIMING=1: phase times of every batch on stderr (tools/batch_e2e.py)
     static const bool timing = getenv("SJMI_PARSE_TIMING") != nullptr;
     using Clock = std::chrono::steady_clock;
-    Clock::time_point mark = Clock::now();
-    double phase[6] = {0, 0, 0, 0, 0, 0};
-    auto lap = [&](int i) {
-        const Clock::time_point now = Clock::now();
-        phase[i] = std::chrono::duration<double, std::milli>(now - mark).count();
-        mark = now;
-    };
+    const Clock::time_point t0 = Clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); };
     if (!pool_) {
         pool_.reset(new WorkerPool((size_t)batchThreads_));
         lanes_.resize((size_t)batchThreads_);
     }
+    const size_t T = (size_t)batchThreads_;
     {   // padIfNeeded for the batch, on the pool (one thread copies ~25 GB/s)
-        const size_t parts = std::min<size_t>((size_t)batchThreads_, std::min<size_t>(8, totalLen / (1u << 20) + 1));
+        const size_t parts = std::min<size_t>(T, std::min<size_t>(8, totalLen / (1u << 20) + 1));
         const std::function<void(size_t)> copyPart = [&](size_t t) {
             const size_t lo = totalLen * t / parts, hi = totalLen * (t + 1) / parts;
             memcpy(paddedBuffer_.data() + lo, buffer + lo, hi - lo);
@@ -275,97 +282,191 @@ void SimdJsonParser::parseBatch(const uint8_t* buffer, size_t totalLen, const ui
         pool_->run(parts, copyPart);
         memset(paddedBuffer_.data() + totalLen, 0, PADDING);
     }
-    lap(0);
-    walker_.bitIndexes().reset();
-    indexOffsets_.assign(nDocs + 1, 0);
-    docStringOffsets_.assign(nDocs + 1, 0);
-    uint64_t count = 0;
-    uint32_t status = 0;
-    // isolated mode: a document that fails stage 1 gets its own verdict and contributes no indexes, so the strings
-    // and trees of all other documents are exactly what they would be alone
+    const double tCopy = since();
+
+    // sub-batches: whole documents, about equal bytes
+    size_t J = std::min<size_t>(8, totalLen / (8u << 20) + 1);
+    if (batchPipeline_ > 0) J = (size_t)batchPipeline_;
+    if (J > nDocs) J = nDocs ? nDocs : 1;
+    struct SubBatch {
+        size_t docLo = 0, docHi = 0, byteStart = 0, byteLen = 0, idxBase = 0, sbBase = 0, offBase = 0;
+        uint64_t count = 0, total = 0;
+        std::vector<uint64_t> rel;  // document offsets relative to byteStart
+        std::vector<size_t> cut;    // document ranges of the walk
+        size_t walkers = 0;
+        bool ready = false;
+        std::exception_ptr error;
+        double tGpu = 0, tWalk = 0;
+    };
+    std::vector<SubBatch> subs(J);
+    for (size_t j = 0; j < J; ++j) {
+        SubBatch& sb = subs[j];
+        sb.docLo = j == 0 ? 0 : subs[j - 1].docHi;
+        if (j + 1 == J) sb.docHi = nDocs;
+        else {
+            const uint64_t want = (uint64_t)totalLen * (j + 1) / J;
+            sb.docHi = (size_t)(std::lower_bound(docOffsets, docOffsets + nDocs, want) - docOffsets);
+            if (sb.docHi < sb.docLo) sb.docHi = sb.docLo;
+        }
+        sb.byteStart = nDocs ? (size_t)docOffsets[sb.docLo] : 0;
+        sb.byteLen = nDocs ? (size_t)docOffsets[sb.docHi] - sb.byteStart : 0;
+        sb.idxBase = sb.byteStart + 2 * j;       // count + sentinel <= byteLen + 1
+        sb.sbBase = 3 * sb.byteStart + 8 * j;    // 4 + L <= 2 (L + 2) for every string: total <= 2 byteLen
+        sb.offBase = sb.docLo + j;               // n + 1 offsets per sub-batch
+    }
+    growStringBuffer(3 * totalLen + 8 * J + 64);
+    indexOffsets_.assign(nDocs + J + 1, 0);
+    docStringOffsets_.assign(nDocs + J + 1, 0);
     docStatus_.assign(nDocs ? nDocs : 1, 0);
-    int rc = sjmi_stage1_batch_isolated(ctx_, paddedBuffer_.data(), totalLen, docOffsets, nDocs, indexes_.data(),
-                                        indexes_.size(), indexOffsets_.data(), docStatus_.data(), &count, &status);
-    if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_stage1_batch_isolated: ") + sjmi_last_error(ctx_));
-    lap(1);
-    growStringBuffer(totalLen + 4 * (size_t)count + 64);
-    uint64_t total = 0, fei = 0;
-    uint32_t fec = 0;
-    rc = sjmi_unescape_batch(ctx_, stringBuffer_.data(), stringBuffer_.size(), docStringOffsets_.data(), &total, &fei, &fec);
-    if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_unescape_batch: ") + sjmi_last_error(ctx_));
-    stringBufferLen_ = (size_t)total;
-    lap(2);
     batchTapeOffsets_.assign(nDocs + 1, 0);
     batchErrors_.assign(nDocs, 0);
-
-    // contiguous document ranges of about equal structural count, one per thread
-    size_t nThreads = (size_t)batchThreads_;
-    const size_t minPerThread = 4096;  // structurals: below this a thread costs more than it walks
-    if (nThreads > (size_t)count / minPerThread + 1) nThreads = (size_t)count / minPerThread + 1;
-    if (nThreads > nDocs) nThreads = nDocs ? nDocs : 1;
-    std::vector<size_t> cut(nThreads + 1, nDocs);
-    cut[0] = 0;
-    for (size_t t = 1; t < nThreads; ++t) {
-        const uint64_t want = (uint64_t)count * t / nThreads;
-        cut[t] = (size_t)(std::lower_bound(indexOffsets_.begin(), indexOffsets_.begin() + (ptrdiff_t)nDocs, want) - indexOffsets_.begin());
-        if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    batchTapeLen_ = 0;
+    if (!batchTape_) {
+        batchTape_.reset(new uint64_t[1024]);
+        batchTapeRoom_ = 1024;
     }
-    const uint8_t* padded = paddedBuffer_.data();
-    const uint8_t* strings = stringBuffer_.data();
-    const std::function<void(size_t)> walkRange = [&](size_t t) {
-        BatchLane& lane = lanes_[t];
-        lane.used = 0;
-        lane.error = nullptr;
-        try {
-            const size_t lo = cut[t], hi = cut[t + 1];
-            // a structural makes at most two tape words (a number); the root adds two
-            const size_t room = 2 * (size_t)(indexOffsets_[hi] - indexOffsets_[lo]) + 8 * (hi - lo) + 8;
-            if (lane.room < room) {
-                lane.words.reset();
-                lane.words.reset(new uint64_t[room + room / 4]);
-                lane.room = room + room / 4;
+    if (J > 1 && !ctx2_) {
+        const int rc = sjmi_create(&ctx2_, device_, (uint64_t)capacity_);
+        if (rc != SJMI_OK) throw std::runtime_error("SimdJsonParser: second engine context: sjmi_create rc=" + std::to_string(rc));
+    }
+    if (pieces_.size() < J * T) pieces_.resize(J * T);
+
+    std::mutex m;
+    std::condition_variable readyCv;
+    // the GPU part of sub-batches j = first, first + 2, ... on one context
+    auto feed = [&](sjmi_ctx* ctx, size_t first) {
+        for (size_t j = first; j < J; j += 2) {
+            SubBatch& sb = subs[j];
+            try {
+                const size_t n = sb.docHi - sb.docLo;
+                sb.rel.resize(n + 1);
+                for (size_t i = 0; i <= n; ++i) sb.rel[i] = docOffsets[sb.docLo + i] - sb.byteStart;
+                uint32_t status = 0;
+                // isolated mode: a document that fails stage 1 gets its own verdict and contributes no indexes, so
+                // the strings and trees of all other documents are exactly what they would be alone
+                int rc = sjmi_stage1_batch_isolated(ctx, paddedBuffer_.data() + sb.byteStart, sb.byteLen, sb.rel.data(), n,
+                                                    indexes_.data() + sb.idxBase, sb.byteLen + 2,
+                                                    indexOffsets_.data() + sb.offBase, docStatus_.data() + sb.docLo,
+                                                    &sb.count, &status);
+                if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_stage1_batch_isolated: ") + sjmi_last_error(ctx));
+                uint64_t fei = 0;
+                uint32_t fec = 0;
+                rc = sjmi_unescape_batch(ctx, stringBuffer_.data() + sb.sbBase, 3 * sb.byteLen + 8,
+                                         docStringOffsets_.data() + sb.offBase, &sb.total, &fei, &fec);
+                if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_unescape_batch: ") + sjmi_last_error(ctx));
+            } catch (...) {
+                sb.error = std::current_exception();
             }
-            if (!lane.walker) lane.walker.reset(new DocWalker(padded, indexes_.data(), indexes_.size(), 0, maxDepth_));
-            DocWalker& w = *lane.walker;
-            w.setStringBuffer(strings);
-            for (size_t k = lo; k < hi; ++k) {
-                const size_t from = (size_t)indexOffsets_[k], to = (size_t)indexOffsets_[k + 1];
-                w.resetForDocument((size_t)docOffsets[k], (size_t)docStringOffsets_[k]);
-                w.tape().rebase(lane.words.get() + lane.used, lane.room - lane.used);
-                w.bitIndexes().window(from, to, (uint32_t)docOffsets[k]);
-                try {
-                    // SimdJsonParser.stage1 order: Utf8Validator.validate (:165-167), then StructuralIndexer.index (:297-302)
-                    if (docStatus_[k] & SJMI_ST_UTF8) throw fail(E_UTF8);
-                    if (docStatus_[k] & SJMI_ST_UNCLOSED) throw fail(E_UNCLOSED_STRING);
-                    if (docStatus_[k] & SJMI_ST_UNESCAPED) throw fail(E_UNESCAPED_CHARS);
-                    w.walkDocument((size_t)docOffsets[k + 1]);
-                    lane.used += w.tape().getCurrentIdx();
-                } catch (const JsonParsingException& e) {
-                    batchErrors_[k] = e.code();  // its partial tape is dropped
-                }
-                batchTapeOffsets_[k + 1] = lane.used;  // lane-relative until the slabs are placed
+            sb.tGpu = since();
+            {
+                std::lock_guard<std::mutex> g(m);
+                sb.ready = true;
             }
-        } catch (...) {
-            lane.error = std::current_exception();
+            readyCv.notify_all();
         }
     };
-    pool_->run(nThreads, walkRange);
-    lap(3);
-    for (size_t t = 0; t < nThreads; ++t)
-        if (lanes_[t].error) std::rethrow_exception(lanes_[t].error);
-    std::vector<size_t> base(nThreads + 1, 0);
-    for (size_t t = 0; t < nThreads; ++t) base[t + 1] = base[t] + lanes_[t].used;
-    batchTape_.resize(base[nThreads]);
-    const std::function<void(size_t)> place = [&](size_t t) {
-        if (lanes_[t].used) memcpy(batchTape_.data() + base[t], lanes_[t].words.get(), lanes_[t].used * sizeof(uint64_t));
-        for (size_t k = cut[t]; k < cut[t + 1]; ++k) batchTapeOffsets_[k + 1] += base[t];
-    };
-    pool_->run(nThreads, place);
-    lap(4);
-    if (timing)
-        fprintf(stderr, "parseBatch %zu docs %zu B, %zu threads: copy+pad %.2f ms, stage 1 (H2D, kernels, D2H) %.2f ms, strings "
-                "(kernels, D2H) %.2f ms, walk %.2f ms, place tapes %.2f ms\n", nDocs, totalLen, nThreads, phase[0], phase[1],
-                phase[2], phase[3], phase[4]);
+    std::thread feeders[2];
+    feeders[0] = std::thread(feed, ctx_, (size_t)0);
+    if (J > 1) feeders[1] = std::thread(feed, ctx2_, (size_t)1);
+
+    const uint8_t* strings = stringBuffer_.data();
+    std::exception_ptr failure;
+    for (size_t j = 0; j < J; ++j) {
+        SubBatch& sb = subs[j];
+        {
+            std::unique_lock<std::mutex> g(m);
+            readyCv.wait(g, [&] { return sb.ready; });
+        }
+        if (sb.error && !failure) failure = sb.error;
+        if (failure) continue;  // (still wait for the feeders' remaining sub-batches)
+        // contiguous document ranges of about equal structural count, one per thread
+        const size_t n = sb.docHi - sb.docLo;
+        const uint64_t* io = indexOffsets_.data() + sb.offBase;
+        const uint64_t* so = docStringOffsets_.data() + sb.offBase;
+        size_t W = T;
+        const size_t minPerThread = 4096;  // structurals: below this a thread costs more than it walks
+        if (W > (size_t)sb.count / minPerThread + 1) W = (size_t)sb.count / minPerThread + 1;
+        if (W > n) W = n ? n : 1;
+        sb.walkers = W;
+        sb.cut.assign(W + 1, n);
+        sb.cut[0] = 0;
+        for (size_t t = 1; t < W; ++t) {
+            const uint64_t want = sb.count * t / W;
+            sb.cut[t] = (size_t)(std::lower_bound(io, io + n, want) - io);
+            if (sb.cut[t] < sb.cut[t - 1]) sb.cut[t] = sb.cut[t - 1];
+        }
+        const std::function<void(size_t)> walkRange = [&](size_t t) {
+            BatchLane& lane = lanes_[t];
+            TapeSlab& slab = pieces_[j * T + t];
+            slab.used = 0;
+            lane.error = nullptr;
+            try {
+                const size_t lo = sb.cut[t], hi = sb.cut[t + 1];
+                // a structural makes at most two tape words (a number); the root adds two
+                const size_t room = 2 * (size_t)(io[hi] - io[lo]) + 8 * (hi - lo) + 8;
+                if (slab.room < room) {
+                    slab.words.reset();
+                    slab.words.reset(new uint64_t[room + room / 4]);
+                    slab.room = room + room / 4;
+                }
+                if (!lane.walker) lane.walker.reset(new DocWalker(nullptr, nullptr, 0, 0, maxDepth_));
+                DocWalker& w = *lane.walker;
+                w.rebind(paddedBuffer_.data() + sb.byteStart, indexes_.data() + sb.idxBase, sb.byteLen + 2);
+                w.setStringBuffer(strings);
+                for (size_t k = lo; k < hi; ++k) {
+                    const size_t doc = sb.docLo + k;
+                    w.resetForDocument((size_t)sb.rel[k], sb.sbBase + (size_t)so[k]);
+                    w.tape().rebase(slab.words.get() + slab.used, slab.room - slab.used);
+                    w.bitIndexes().window((size_t)io[k], (size_t)io[k + 1], (uint32_t)sb.rel[k]);
+                    try {
+                        // SimdJsonParser.stage1 order: Utf8Validator.validate (:165-167), then StructuralIndexer.index (:297-302)
+                        if (docStatus_[doc] & SJMI_ST_UTF8) throw fail(E_UTF8);
+                        if (docStatus_[doc] & SJMI_ST_UNCLOSED) throw fail(E_UNCLOSED_STRING);
+                        if (docStatus_[doc] & SJMI_ST_UNESCAPED) throw fail(E_UNESCAPED_CHARS);
+                        w.walkDocument((size_t)sb.rel[k + 1]);
+                        slab.used += w.tape().getCurrentIdx();
+                    } catch (const JsonParsingException& e) {
+                        batchErrors_[doc] = e.code();  // its partial tape is dropped
+                    }
+                    batchTapeOffsets_[doc + 1] = slab.used;  // slab-relative until the slabs are placed
+                }
+            } catch (...) {
+                lane.error = std::current_exception();
+            }
+        };
+        pool_->run(W, walkRange);
+        for (size_t t = 0; t < W && !failure; ++t)
+            if (lanes_[t].error) failure = lanes_[t].error;
+        if (failure) continue;
+        // slabs -> batchTape(), in document order (while the GPU works on the next sub-batch)
+        std::vector<size_t> base(W + 1, batchTapeLen_);
+        for (size_t t = 0; t < W; ++t) base[t + 1] = base[t] + pieces_[j * T + t].used;
+        if (base[W] > batchTapeRoom_) {
+            const size_t room = base[W] + base[W] / 2 + 1024;
+            std::unique_ptr<uint64_t[]> grown(new uint64_t[room]);
+            if (batchTapeLen_) memcpy(grown.get(), batchTape_.get(), batchTapeLen_ * sizeof(uint64_t));
+            batchTape_ = std::move(grown);
+            batchTapeRoom_ = room;
+        }
+        const std::function<void(size_t)> place = [&](size_t t) {
+            const TapeSlab& slab = pieces_[j * T + t];
+            if (slab.used) memcpy(batchTape_.get() + base[t], slab.words.get(), slab.used * sizeof(uint64_t));
+            for (size_t k = sb.cut[t]; k < sb.cut[t + 1]; ++k) batchTapeOffsets_[sb.docLo + k + 1] += base[t];
+        };
+        pool_->run(W, place);
+        batchTapeLen_ = base[W];
+        sb.tWalk = since();
+    }
+    for (std::thread& th : feeders)
+        if (th.joinable()) th.join();
+    if (failure) std::rethrow_exception(failure);
+    stringBufferLen_ = subs[J - 1].sbBase + (size_t)subs[J - 1].total;
+
+    if (timing) {
+        fprintf(stderr, "parseBatch %zu docs %zu B, %zu threads, %zu sub-batches: copy+pad done at %.2f ms;", nDocs, totalLen, T, J, tCopy);
+        for (size_t j = 0; j < J; ++j) fprintf(stderr, " [%zu] gpu %.2f walked+placed %.2f;", j, subs[j].tGpu, subs[j].tWalk);
+        fprintf(stderr, " done at %.2f ms\n", since());
+    }
 }
 
 // TapeBuilder.visitString (TapeBuilder.java:174-177): the record [be32 len][bytes] was produced on the GPU at
@@ -663,7 +764,7 @@ int sjmi_parser_parse_batch(sjmi_parser* h, const uint8_t* buf, uint64_t total_l
     h->msg.clear();
     try {
         h->p->parseBatch(buf, (size_t)total_len, doc_offsets, (size_t)n_docs);
-        *tape = h->p->batchTape().data();
+        *tape = h->p->batchTape();
         *tape_offsets = h->p->batchTapeOffsets().data();
         *strings = h->p->stringBuffer().data();
         *strings_len = h->p->stringBufferLen();

@@ -39,6 +39,7 @@ public:
     BitIndexes(uint32_t* shared, size_t capacity) : indexes_(shared), capacity_(capacity) {}
     BitIndexes(const BitIndexes&) = delete;
     BitIndexes& operator=(const BitIndexes&) = delete;
+    void rebind(uint32_t* shared, size_t capacity) { indexes_ = shared; capacity_ = capacity; reset(); }
     uint32_t* array() { return indexes_; }                  // filled by the engine (replaces write(), :14-41)
     size_t capacity() const { return capacity_; }
     void setWriteIdx(size_t n) { writeIdx_ = n; }            // replaces finish() (:82-96): sentinel written by the engine
@@ -142,6 +143,11 @@ public:
         : paddedBuffer_{padded}, bitIndexes_(indexes, indexCapacity), tape_(tapeCapacity), maxDepth_(maxDepth),
           openContainers_((size_t)maxDepth), isArray_((size_t)maxDepth) {}
     void setStringBuffer(const uint8_t* sb) { stringBuffer_.p = sb; }
+    // point the walker at another document buffer / index array (batch: one per sub-batch)
+    void rebind(const uint8_t* padded, uint32_t* indexes, size_t indexCapacity) {
+        paddedBuffer_.p = padded;
+        bitIndexes_.rebind(indexes, indexCapacity);
+    }
     // walk the document whose structurals are the current window / contents of bitIndexes(); endOffset = its end
     void walkDocument(size_t endOffset);
     // reset (SimdJsonParser.java:50-53) for the document starting at byte docBase whose first string record (if any)
@@ -202,7 +208,8 @@ public:
     // stage 1 + string unescape + per-document string offsets), then the host stage 2 of the documents on several
     // threads.  Fills batchTape()/batchTapeOffsets()/batchErrors(); a broken document only affects its own entry.
     void parseBatch(const uint8_t* buffer, size_t totalLen, const uint64_t* docOffsets, size_t nDocs);
-    const std::vector<uint64_t>& batchTape() const { return batchTape_; }
+    const uint64_t* batchTape() const { return batchTape_.get(); }  // batchTapeLen() words; document k: [offsets[k], offsets[k+1])
+    size_t batchTapeLen() const { return batchTapeLen_; }
     const std::vector<uint64_t>& batchTapeOffsets() const { return batchTapeOffsets_; }
     const std::vector<int32_t>& batchErrors() const { return batchErrors_; }
 
@@ -216,21 +223,28 @@ private:
     void growStringBuffer(size_t need);
 
     sjmi_ctx* ctx_ = nullptr;
-    int capacity_, maxDepth_;
+    sjmi_ctx* ctx2_ = nullptr;  // parseBatch: the second stream of the sub-batch pipeline (created on first use)
+    int capacity_, maxDepth_, device_;
     std::vector<uint8_t> stringBuffer_, paddedBuffer_;
     std::vector<uint32_t> indexes_;  // BitIndexes storage (filled by the engine)
     DocWalker walker_;
     size_t stringBufferLen_ = 0;
-    std::vector<uint64_t> batchTape_, batchTapeOffsets_, indexOffsets_, docStringOffsets_;
+    std::unique_ptr<uint64_t[]> batchTape_;  // (not a vector: grown without zero-filling, kept between batches)
+    size_t batchTapeLen_ = 0, batchTapeRoom_ = 0;
+    std::vector<uint64_t> batchTapeOffsets_, indexOffsets_, docStringOffsets_;
     int batchThreads_ = 1;  // host threads walking the documents of a batch (SJMI_PARSE_THREADS overrides)
-    // one per batch thread, kept between batches: the walker and the slab its documents' tapes are built in
+    int batchPipeline_ = 0;  // sub-batches per batch, 0 = by size (SJMI_PARSE_PIPELINE overrides)
+    // kept between batches: a walker per batch thread, and per (sub-batch, thread) the slab its tapes are built in
     struct BatchLane {
         std::unique_ptr<DocWalker> walker;
-        std::unique_ptr<uint64_t[]> words;
-        size_t room = 0, used = 0;
         std::exception_ptr error;
     };
+    struct TapeSlab {
+        std::unique_ptr<uint64_t[]> words;
+        size_t room = 0, used = 0;
+    };
     std::vector<BatchLane> lanes_;
+    std::vector<TapeSlab> pieces_;
     std::unique_ptr<WorkerPool> pool_;  // created by the first parseBatch
     std::vector<uint32_t> docStatus_;
     void* pinned_[3] = {nullptr, nullptr, nullptr};  // page-locked parser buffers (sjmi_host_register)

@@ -203,32 +203,68 @@ def test_unescape_batch_document_string_offsets():
 
 
 def test_parse_batch_on_many_host_threads(monkeypatch):
-    """The host stage 2 of a batch runs on several threads (document ranges balanced by structural count): trees, errors
-    and tape offsets must not depend on the thread count, including failing documents at range boundaries."""
+    """The host stage 2 of a batch runs on several threads (document ranges balanced by structural count) and the batch
+    goes through the GPU as a pipeline of sub-batches on two contexts: trees, errors and tape offsets must not depend on
+    the thread count or the number of sub-batches, including failing documents at range boundaries."""
     import simdjson_java_amd as S
     rng = random.Random(81)
     docs = _small_docs(rng, 30000)
-    bad = [b"[1 1]", b'{"a" 1}', b"[1,2", b'["\\q"]', b'["abc', bytes([0x5B, 0x22, 0xC3, 0x22, 0x5D]), b"", b"[-]"]
+    bad = [b"[1 1]", b'{"a" 1}', b"[1,2", b'["\\q"]', b'["abc', bytes([0x5B, 0x22, 0xC3, 0x22, 0x5D]), b"", b"[-]", b'"']
     for i in range(200):
         docs.insert(rng.randrange(len(docs)), bad[i % len(bad)])
     docs.insert(7, load_fixture("github_events.json").rstrip())
     buf, offs = _pack(docs)
-    results = []
-    for threads in ("1", "7", "64"):
+    results = {}
+    for threads, pipeline in (("1", "1"), ("7", "1"), ("64", "3"), ("5", "2"), ("3", "64")):
         monkeypatch.setenv("SJMI_PARSE_THREADS", threads)
+        monkeypatch.setenv("SJMI_PARSE_PIPELINE", pipeline)
         p = S.SimdJsonParser(capacity=len(buf) + 64)
         try:
-            results.append(p.parse_batch(buf, offs))
+            results[(threads, pipeline)] = p.parse_batch(buf, offs)
+            if pipeline == "2":  # the parser's second batch reuses pool, slabs and contexts
+                again = p.parse_batch(buf, offs)
+                assert again[1] == results[(threads, pipeline)][1]
+                assert all((a is None and b is None) or np.array_equal(a, b) for a, b in zip(again[0], results[(threads, pipeline)][0]))
         finally:
             p.close()
-    tapes1, strings1, errors1 = results[0]
-    for tapes, strings, errors in results[1:]:
-        assert strings == strings1 and np.array_equal(errors, errors1)
-        for a, b in zip(tapes, tapes1):
-            assert (a is None and b is None) or np.array_equal(a, b)
+    tapes1, strings1, errors1 = results[("1", "1")]
     assert int((errors1 != 0).sum()) >= 200
-    for k in rng.sample(range(len(docs)), 600) + [7]:
-        want = O.parse(docs[k] + b"\n")
-        assert int(errors1[k]) == want.error, (k, docs[k])
-        if not want.error:
-            assert O.Parsed(tapes1[k], strings1, 0, 0, 0).to_python() == want.to_python(), k
+    sample = rng.sample(range(len(docs)), 600) + [7]
+    want = {}
+    for k in sample:
+        w = O.parse(docs[k] + b"\n")
+        assert int(errors1[k]) == w.error, (k, docs[k])
+        want[k] = None if w.error else w.to_python()
+    for (threads, pipeline), (tapes, strings, errors) in results.items():
+        assert np.array_equal(errors, errors1), (threads, pipeline)
+        if pipeline == "1":  # same string-buffer layout: the tapes are equal word for word
+            assert strings == strings1
+            for a, b in zip(tapes, tapes1):
+                assert (a is None and b is None) or np.array_equal(a, b)
+        for k in sample:
+            if want[k] is not None:
+                assert O.Parsed(tapes[k], strings, 0, 0, 0).to_python() == want[k], (threads, pipeline, k)
+
+
+def test_parse_batch_odd_shapes(monkeypatch):
+    """Sub-batch cuts with nothing in them: an empty batch, a single document, one huge document among small ones (some
+    sub-batches get no document at all), only failing documents."""
+    import simdjson_java_amd as S
+    big = load_fixture("twitter.json").rstrip()
+    shapes = [[], [b"[1]"], [b"1", big, b'"s"', b"[2]"], [big, b"{}"], [b"[", b'"', b"nul"], [b""] * 5]
+    for pipeline in ("1", "3", "8"):
+        monkeypatch.setenv("SJMI_PARSE_PIPELINE", pipeline)
+        monkeypatch.setenv("SJMI_PARSE_THREADS", "4")
+        p = S.SimdJsonParser(capacity=2 * len(big))
+        try:
+            for docs in shapes:
+                buf, offs = _pack(docs)
+                tapes, strings, errors = p.parse_batch(buf, offs)
+                assert len(tapes) == len(docs)
+                for k, d in enumerate(docs):
+                    want = O.parse(d + b"\n")
+                    assert int(errors[k]) == want.error, (pipeline, k, d[:20])
+                    if not want.error:
+                        assert O.Parsed(tapes[k], strings, 0, 0, 0).to_python() == want.to_python(), (pipeline, k)
+        finally:
+            p.close()
