@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _CSRC = os.path.join(_HERE, "csrc")
 _LIB = os.path.join(_HERE, "libsjmi.so")
-SOURCES = ["stage1.hip", "unescape.hip", "batch.hip", "sjmi_api.hip", "host/simdjson_parser.cpp"]
+SOURCES = ["stage1.hip", "unescape.hip", "batch.hip", "walk.hip", "sjmi_api.hip", "host/simdjson_parser.cpp"]
 
 ST_UTF8, ST_UNCLOSED, ST_UNESCAPED, ST_CAPACITY, ST_INTERNAL = 1, 2, 4, 0x100, 0x200
 PADDING = 64
@@ -63,7 +63,7 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_stage1_batch", "sjmi_stage1_batch_device", "sjmi_parser_parse_batch",
            "sjmi_stage1_batch_isolated", "sjmi_stage1_batch_isolated_device", "sjmi_host_register",
            "sjmi_host_unregister", "sjmi_stage1_unescape", "sjmi_unescape_batch",
-           "sjmi_unescape_batch_device"]
+           "sjmi_unescape_batch_device", "sjmi_walk_batch_device"]
 
 
 def lib():
@@ -108,6 +108,10 @@ def lib():
         L.sjmi_unescape_batch_device.restype = C.c_int
         L.sjmi_unescape_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                                  C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sjmi_walk_batch_device.restype = C.c_int
+        L.sjmi_walk_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sjmi_parser_create.restype = C.c_int
         L.sjmi_parser_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
         L.sjmi_parser_destroy.restype = None
@@ -272,6 +276,14 @@ class Context:
         self._check(lib().sjmi_unescape_batch_device(self._h, d_buf, total_len, d_indexes, count, d_doc_offsets, d_index_offsets,
                                                      n_docs, d_sb, sb_capacity, d_doc_string_offsets, d_result, stream),
                     "sjmi_unescape_batch_device")
+
+    def walk_batch_device(self, d_buf, d_doc_offsets, n_docs, d_indexes, count, d_index_offsets, d_doc_status, d_sb,
+                          d_doc_string_offsets, string_base, max_depth, d_tape, tape_capacity, d_tape_offsets, d_doc_errors,
+                          d_result, stream=0):
+        self._check(lib().sjmi_walk_batch_device(self._h, d_buf, d_doc_offsets, n_docs, d_indexes, count, d_index_offsets,
+                                                 d_doc_status, d_sb, d_doc_string_offsets, string_base, max_depth, d_tape,
+                                                 tape_capacity, d_tape_offsets, d_doc_errors, d_result, stream),
+                    "sjmi_walk_batch_device")
 
     def stage1_batch_device(self, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets,
                             d_result, stream=0):

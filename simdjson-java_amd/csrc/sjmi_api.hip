@@ -38,6 +38,8 @@ struct sjmi_ctx {
     size_t doccnt_bytes = 0;
     unsigned long long* d_docstr = nullptr;  // batch: per-document string-buffer offsets
     size_t docstr_bytes = 0;
+    void* d_ws_walk = nullptr;               // batch walk: scratch tape, tape lengths, chunk sums
+    size_t ws_walk_bytes = 0;
     uint64_t last_ndocs = 0;                 // documents of the last batch call (their index offsets are still on the device)
     bool last_batch = false;
     size_t docoff_bytes = 0;
@@ -117,6 +119,7 @@ void sjmi_destroy(sjmi_ctx* c) {
     if (c->d_docoff) (void)hipFree(c->d_docoff);
     if (c->d_doccnt) (void)hipFree(c->d_doccnt);
     if (c->d_docstr) (void)hipFree(c->d_docstr);
+    if (c->d_ws_walk) (void)hipFree(c->d_ws_walk);
     if (c->h_res) (void)hipHostFree(c->h_res);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.first);
@@ -378,6 +381,28 @@ int sjmi_stage1_unescape(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t
         (strings_ok && r.total_bytes &&
          fail(c, "D2H(sb)", hipMemcpyAsync(string_buffer, c->d_sb, r.total_bytes, hipMemcpyDeviceToHost, c->stream))) ||
         fail(c, "sync", hipStreamSynchronize(c->stream)))
+        return SJMI_ERR_HIP;
+    return SJMI_OK;
+}
+
+int sjmi_walk_batch_device(sjmi_ctx* c, const void* d_buf, const void* d_doc_offsets, uint64_t n_docs, const void* d_indexes,
+                           uint64_t count, const void* d_index_offsets, const void* d_doc_status,
+                           const void* d_string_buffer, const void* d_doc_string_offsets, uint64_t string_base,
+                           int max_depth, void* d_tape, uint64_t tape_capacity, void* d_tape_offsets, void* d_doc_errors,
+                           void* d_result, void* stream) {
+    if (!c || !d_buf || !d_doc_offsets || !d_indexes || !d_index_offsets || !d_doc_status || !d_string_buffer ||
+        !d_doc_string_offsets || !d_tape || !d_tape_offsets || !d_doc_errors || !d_result || max_depth < 1)
+        return SJMI_ERR_ARG;
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    if (!grow(c, &c->d_ws_walk, &c->ws_walk_bytes, sjmi::walk_workspace_bytes(count, n_docs), "hipMalloc(ws_walk)"))
+        return SJMI_ERR_HIP;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (fail(c, "walk launch",
+             sjmi::walk_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs, (const uint32_t*)d_indexes,
+                               count, (const unsigned long long*)d_index_offsets, (const uint32_t*)d_doc_status,
+                               (const uint8_t*)d_string_buffer, (const unsigned long long*)d_doc_string_offsets, string_base,
+                               max_depth, (unsigned long long*)d_tape, tape_capacity, (unsigned long long*)d_tape_offsets,
+                               (int32_t*)d_doc_errors, c->d_ws_walk, (sjmi::WalkResult*)d_result, st)))
         return SJMI_ERR_HIP;
     return SJMI_OK;
 }

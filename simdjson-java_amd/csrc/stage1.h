@@ -25,6 +25,13 @@ struct UnescapeResult {
 };
 static_assert(sizeof(UnescapeResult) == sizeof(sjmi_unescape_result), "ABI struct mismatch");
 
+// device-side result of one batch walk; mirrors sjmi_walk_result in include/sjmi.h
+struct WalkResult {
+    unsigned long long tape_words, host_documents, failed_documents;
+    uint32_t flags, reserved;
+};
+static_assert(sizeof(WalkResult) == sizeof(sjmi_walk_result), "ABI struct mismatch");
+
 // ablation switches for performance experiments only (results are NOT valid with any of them set)
 constexpr uint32_t DBG_NO_WRITE = 1, DBG_NO_LOOKBACK = 2;
 // test hook: a fast-mode launch reports SJMI_ST_INTERNAL as if its look-back spin had tripped
@@ -72,6 +79,13 @@ hipError_t unescape_launch(const uint8_t* d_buf, uint64_t len, const uint32_t* d
 hipError_t split_docs_launch(const uint32_t* d_idx, const Stage1Result* d_res, const unsigned long long* d_doc_offsets,
                              uint64_t n_docs, unsigned long long* d_index_offsets, hipStream_t stream);
 size_t batch_isolated_workspace_bytes(uint64_t n_docs);
+// walk.hip: stage 2 of every document of a batch, one lane per document
+size_t walk_workspace_bytes(uint64_t count, uint64_t n_docs);
+hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_idx,
+                       uint64_t count, const unsigned long long* d_index_offsets, const uint32_t* d_doc_status,
+                       const uint8_t* d_sb, const unsigned long long* d_doc_str_offsets, uint64_t string_base, int max_depth,
+                       unsigned long long* d_tape, uint64_t tape_capacity, unsigned long long* d_tape_offsets,
+                       int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream);
 hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint32_t* d_out,
                                  uint64_t out_cap, unsigned long long* d_index_offsets, uint32_t* d_doc_status,
                                  uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream);
