@@ -194,7 +194,8 @@ int sjmi_unescape_batch_device(sjmi_ctx* ctx, const void* d_buf, uint64_t total_
  * with an empty tape: the document nests deeper than 64 levels or holds a floating-point literal outside the range in
  * which one IEEE operation is the correctly rounded result (more than 19 significant digits, significand > 2^53,
  * |decimal exponent| > 22) -- the host walker (sjmi_parser_*) takes those.  d_result: sjmi_walk_result, bit 0 of flags =
- * tape_capacity exceeded (offsets valid, tapes not written).  Asynchronous on `stream`. */
+ * tape_capacity exceeded (offsets valid, tapes not written).  d_buf needs 64 readable bytes after the batch (the
+ * reference's padding, SimdJsonParser.java:42-48).  Asynchronous on `stream`. */
 #define SJMI_WALK_NEEDS_HOST (-1)
 typedef struct sjmi_walk_result {
     uint64_t tape_words;       /* total tape words = tape_offsets[n_docs] */

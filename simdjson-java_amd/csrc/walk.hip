@@ -28,9 +28,22 @@ constexpr int WALK_THREADS = 64;
 
 namespace {
 
+// byte-granular wide loads (gfx950 global memory is in unaligned-access mode)
+struct __attribute__((packed, aligned(1))) W16B { uint32_t a, b, c, d; };
+struct __attribute__((packed, aligned(1))) W4B { uint32_t a; };
+
+// A lane streams through its own document, so every access of a wave touches 64 different cache lines and nothing
+// stays in the L1 between two accesses of the same lane: bytes and indexes are therefore fetched 16 bytes at a time
+// into registers (a document has a structural every ~5 bytes, so a window serves about three of them; an index
+// window serves four).
 struct Lane {
     const uint8_t* buf;
     const uint32_t* ix;  // the batch's index array
+    uint32_t ix_entries; // readable entries of it (count + sentinel)
+    uint32_t iw_base;    // index window: entries [iw_base, iw_base + 4)
+    uint32_t iw0, iw1, iw2, iw3;  // (scalars, not a uint4: hipcc 7.2's machine copy propagation crashes on the vector form)
+    uint32_t bw_base;    // byte window: bytes [bw_base, bw_base + 16)
+    uint32_t bw0, bw1, bw2, bw3;
     uint32_t from, to, rd;
     uint32_t doc_start, doc_end;
     unsigned long long* tape;
@@ -41,7 +54,26 @@ struct Lane {
     int code;                  // first error
 };
 
-__device__ __forceinline__ uint32_t at(const Lane& w, uint32_t i) { return i < w.to ? w.ix[i] : w.doc_start; }  // BitIndexes.java:82-96
+__device__ __forceinline__ uint32_t pick4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t j) { return j == 0 ? a : (j == 1 ? b : (j == 2 ? c : d)); }
+__device__ __forceinline__ uint32_t at(Lane& w, uint32_t i) {  // BitIndexes.java:82-96 (past the end: the sentinel)
+    if (i >= w.to) return w.doc_start;
+    if ((i & ~3u) != w.iw_base) {
+        if ((i | 3u) >= w.ix_entries) return w.ix[i];
+        w.iw_base = i & ~3u;
+        const W16B v = *reinterpret_cast<const W16B*>(w.ix + w.iw_base);
+        w.iw0 = v.a; w.iw1 = v.b; w.iw2 = v.c; w.iw3 = v.d;
+    }
+    return pick4(w.iw0, w.iw1, w.iw2, w.iw3, i & 3u);
+}
+__device__ __forceinline__ uint32_t byte_at(Lane& w, uint32_t p) {
+    if (p - w.bw_base >= 16u) {
+        w.bw_base = p;
+        const W16B v = *reinterpret_cast<const W16B*>(w.buf + p);
+        w.bw0 = v.a; w.bw1 = v.b; w.bw2 = v.c; w.bw3 = v.d;
+    }
+    const uint32_t o = p - w.bw_base;
+    return (pick4(w.bw0, w.bw1, w.bw2, w.bw3, o >> 2) >> (8u * (o & 3u))) & 0xFFu;
+}
 __device__ __forceinline__ void append(Lane& w, unsigned long long v, char type) {                                // Tape.java:28-31
     w.tape[w.tl++] = v | ((unsigned long long)(uint8_t)type << 56);
 }
@@ -55,8 +87,7 @@ __device__ const double P10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7
 // TapeBuilder.visitString (TapeBuilder.java:174-177): the record was written by the unescape kernels
 __device__ __forceinline__ bool visit_string(Lane& w) {
     append(w, w.sbase + w.sc, '"');
-    const uint8_t* r = w.sb + w.sc;
-    const uint32_t n = ((uint32_t)r[0] << 24) | ((uint32_t)r[1] << 16) | ((uint32_t)r[2] << 8) | r[3];
+    const uint32_t n = __builtin_bswap32(reinterpret_cast<const W4B*>(w.sb + w.sc)->a);  // be32 length
     if (n >= 0xFFFFFF00u) {  // a string StringParser would have thrown on: FF FF FF <code>
         w.code = (int)(n & 0xFFu);
         return false;
@@ -68,8 +99,7 @@ __device__ __forceinline__ bool visit_string(Lane& w) {
 // NumberParser.parseNumber (NumberParser.java:23-74) at p; bytes at or after `limit` read as spaces (the root number's
 // padded copy, TapeBuilder.java:183-189)
 __device__ bool parse_number(Lane& w, uint32_t p, uint32_t limit) {
-    const uint8_t* buf = w.buf;
-    auto B = [&](uint32_t q) -> uint32_t { return q < limit ? (uint32_t)buf[q] : 0x20u; };
+    auto B = [&](uint32_t q) -> uint32_t { return q < limit ? byte_at(w, q) : 0x20u; };
     const bool negative = B(p) == '-';
     if (negative) ++p;
     const uint32_t digits_start = p;
@@ -147,30 +177,34 @@ __device__ bool parse_number(Lane& w, uint32_t p, uint32_t limit) {
     return true;
 }
 
-__device__ __forceinline__ bool lit(const uint8_t* b, uint32_t word4) {
-    return ((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24)) == word4;
+// four bytes at p, little endian
+__device__ __forceinline__ uint32_t word_at(Lane& w, uint32_t p) {
+    return byte_at(w, p) | (byte_at(w, p + 1) << 8) | (byte_at(w, p + 2) << 16) | (byte_at(w, p + 3) << 24);
 }
 constexpr uint32_t W_TRUE = 0x65757274u, W_FALS = 0x736c6166u, W_NULL = 0x6c6c756eu;
 
 // TapeBuilder.visitPrimitive (TapeBuilder.java:70-79) / visitRootPrimitive (:59-68): root = the document is this value
 __device__ bool visit_primitive(Lane& w, uint32_t idx, bool root) {
-    const uint8_t* b = w.buf + idx;
     const uint32_t end = w.doc_end;
-    switch (*b) {
+    switch (byte_at(w, idx)) {
     case '"': return visit_string(w);
     case 't':
-        if (root ? !(idx + 4 <= end && lit(b, W_TRUE) && (idx + 4 == end || is_structural_or_ws(b[4])))
-                 : !(lit(b, W_TRUE) && is_structural_or_ws(b[4]))) { w.code = SJMI_E_INVALID_TRUE; return false; }
+        if (root ? !(idx + 4 <= end && word_at(w, idx) == W_TRUE && (idx + 4 == end || is_structural_or_ws(byte_at(w, idx + 4))))
+                 : !(word_at(w, idx) == W_TRUE && is_structural_or_ws(byte_at(w, idx + 4)))) { w.code = SJMI_E_INVALID_TRUE; return false; }
         append(w, 0, 't');
         return true;
     case 'f':
-        if (root ? !(idx + 5 <= end && lit(b, W_FALS) && b[4] == 'e' && (idx + 5 == end || is_structural_or_ws(b[5])))
-                 : !(lit(b, W_FALS) && b[4] == 'e' && is_structural_or_ws(b[5]))) { w.code = SJMI_E_INVALID_FALSE; return false; }
+        if (root ? !(idx + 5 <= end && word_at(w, idx) == W_FALS && byte_at(w, idx + 4) == 'e' &&
+                     (idx + 5 == end || is_structural_or_ws(byte_at(w, idx + 5))))
+                 : !(word_at(w, idx) == W_FALS && byte_at(w, idx + 4) == 'e' && is_structural_or_ws(byte_at(w, idx + 5)))) {
+            w.code = SJMI_E_INVALID_FALSE;
+            return false;
+        }
         append(w, 0, 'f');
         return true;
     case 'n':
-        if (root ? !(idx + 4 <= end && lit(b, W_NULL) && (idx + 4 == end || is_structural_or_ws(b[4])))
-                 : !(lit(b, W_NULL) && is_structural_or_ws(b[4]))) { w.code = SJMI_E_INVALID_NULL; return false; }
+        if (root ? !(idx + 4 <= end && word_at(w, idx) == W_NULL && (idx + 4 == end || is_structural_or_ws(byte_at(w, idx + 4))))
+                 : !(word_at(w, idx) == W_NULL && is_structural_or_ws(byte_at(w, idx + 4)))) { w.code = SJMI_E_INVALID_NULL; return false; }
         append(w, 0, 'n');
         return true;
     case '-': case '0': case '1': case '2': case '3': case '4': case '5': case '6': case '7': case '8': case '9':
@@ -184,7 +218,6 @@ __device__ bool walk_document(Lane& w, int max_depth) {
     enum { OBJECT_BEGIN, ARRAY_BEGIN, DOCUMENT_END, OBJECT_FIELD, OBJECT_CONTINUE, SCOPE_END, ARRAY_CONTINUE, ARRAY_VALUE };
     uint32_t st_tape[WALK_MAX_DEPTH], st_count[WALK_MAX_DEPTH];  // TapeBuilder.OpenContainer (:210-213)
     unsigned long long is_array = 0;
-    const uint8_t* buf = w.buf;
     if (w.from == w.to) { w.code = SJMI_E_NO_STRUCTURAL; return false; }
 #define SJ_FAIL(c) do { w.code = (c); return false; } while (0)
 #define START_CONTAINER(d) do { st_tape[d] = w.tl; st_count[d] = 0; ++w.tl; } while (0)  /* TapeBuilder.java:191-195 */
@@ -199,15 +232,15 @@ __device__ bool walk_document(Lane& w, int max_depth) {
     START_CONTAINER(0);  // visitDocumentStart :41-43
     int depth = 0, state;
     uint32_t idx = at(w, w.rd++);
-    switch (buf[idx]) {
+    switch (byte_at(w, idx)) {
     case '{':
-        if (buf[w.ix[w.to - 1]] != '}') SJ_FAIL(SJMI_E_UNCLOSED_OBJECT);
-        if (buf[at(w, w.rd)] == '}') { ++w.rd; EMPTY_CONTAINER('{', '}'); state = DOCUMENT_END; }
+        if (w.buf[w.ix[w.to - 1]] != '}') SJ_FAIL(SJMI_E_UNCLOSED_OBJECT);
+        if (byte_at(w, at(w, w.rd)) == '}') { ++w.rd; EMPTY_CONTAINER('{', '}'); state = DOCUMENT_END; }
         else state = OBJECT_BEGIN;
         break;
     case '[':
-        if (buf[w.ix[w.to - 1]] != ']') SJ_FAIL(SJMI_E_UNCLOSED_ARRAY);
-        if (buf[at(w, w.rd)] == ']') { ++w.rd; EMPTY_CONTAINER('[', ']'); state = DOCUMENT_END; }
+        if (w.buf[w.ix[w.to - 1]] != ']') SJ_FAIL(SJMI_E_UNCLOSED_ARRAY);
+        if (byte_at(w, at(w, w.rd)) == ']') { ++w.rd; EMPTY_CONTAINER('[', ']'); state = DOCUMENT_END; }
         else state = ARRAY_BEGIN;
         break;
     default:
@@ -222,21 +255,21 @@ __device__ bool walk_document(Lane& w, int max_depth) {
             is_array &= ~(1ull << depth);
             START_CONTAINER(depth);
             const uint32_t key = at(w, w.rd++);
-            if (buf[key] != '"') SJ_FAIL(SJMI_E_OBJECT_NO_KEY);
+            if (byte_at(w, key) != '"') SJ_FAIL(SJMI_E_OBJECT_NO_KEY);
             st_count[depth]++;
             if (!visit_string(w)) return false;
             state = OBJECT_FIELD;
         }
         if (state == OBJECT_FIELD) {
-            if (buf[at(w, w.rd++)] != ':') SJ_FAIL(SJMI_E_MISSING_COLON);
+            if (byte_at(w, at(w, w.rd++)) != ':') SJ_FAIL(SJMI_E_MISSING_COLON);
             idx = at(w, w.rd++);
-            switch (buf[idx]) {
+            switch (byte_at(w, idx)) {
             case '{':
-                if (buf[at(w, w.rd)] == '}') { ++w.rd; EMPTY_CONTAINER('{', '}'); state = OBJECT_CONTINUE; }
+                if (byte_at(w, at(w, w.rd)) == '}') { ++w.rd; EMPTY_CONTAINER('{', '}'); state = OBJECT_CONTINUE; }
                 else state = OBJECT_BEGIN;
                 break;
             case '[':
-                if (buf[at(w, w.rd)] == ']') { ++w.rd; EMPTY_CONTAINER('[', ']'); state = OBJECT_CONTINUE; }
+                if (byte_at(w, at(w, w.rd)) == ']') { ++w.rd; EMPTY_CONTAINER('[', ']'); state = OBJECT_CONTINUE; }
                 else state = ARRAY_BEGIN;
                 break;
             default:
@@ -245,11 +278,11 @@ __device__ bool walk_document(Lane& w, int max_depth) {
             }
         }
         if (state == OBJECT_CONTINUE) {
-            switch (buf[at(w, w.rd++)]) {
+            switch (byte_at(w, at(w, w.rd++))) {
             case ',': {
                 st_count[depth]++;
                 const uint32_t key = at(w, w.rd++);
-                if (buf[key] != '"') SJ_FAIL(SJMI_E_KEY_MISSING);
+                if (byte_at(w, key) != '"') SJ_FAIL(SJMI_E_KEY_MISSING);
                 if (!visit_string(w)) return false;
                 state = OBJECT_FIELD;
                 break;
@@ -278,13 +311,13 @@ __device__ bool walk_document(Lane& w, int max_depth) {
         }
         if (state == ARRAY_VALUE) {
             idx = at(w, w.rd++);
-            switch (buf[idx]) {
+            switch (byte_at(w, idx)) {
             case '{':
-                if (buf[at(w, w.rd)] == '}') { ++w.rd; EMPTY_CONTAINER('{', '}'); state = ARRAY_CONTINUE; }
+                if (byte_at(w, at(w, w.rd)) == '}') { ++w.rd; EMPTY_CONTAINER('{', '}'); state = ARRAY_CONTINUE; }
                 else state = OBJECT_BEGIN;
                 break;
             case '[':
-                if (buf[at(w, w.rd)] == ']') { ++w.rd; EMPTY_CONTAINER('[', ']'); state = ARRAY_CONTINUE; }
+                if (byte_at(w, at(w, w.rd)) == ']') { ++w.rd; EMPTY_CONTAINER('[', ']'); state = ARRAY_CONTINUE; }
                 else state = ARRAY_BEGIN;
                 break;
             default:
@@ -293,7 +326,7 @@ __device__ bool walk_document(Lane& w, int max_depth) {
             }
         }
         if (state == ARRAY_CONTINUE) {
-            switch (buf[at(w, w.rd++)]) {
+            switch (byte_at(w, at(w, w.rd++))) {
             case ',':
                 st_count[depth]++;
                 state = ARRAY_VALUE;
@@ -323,7 +356,7 @@ __device__ __forceinline__ unsigned long long scratch_slot(unsigned long long fr
 
 __global__ void __launch_bounds__(WALK_THREADS)
 k_doc_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restrict__ doc_offsets, uint64_t n_docs,
-           const uint32_t* __restrict__ idx, const unsigned long long* __restrict__ index_offsets,
+           const uint32_t* __restrict__ idx, uint32_t ix_entries, const unsigned long long* __restrict__ index_offsets,
            const uint32_t* __restrict__ doc_status, const uint8_t* __restrict__ sb,
            const unsigned long long* __restrict__ doc_str_offsets, unsigned long long string_base, int max_depth,
            unsigned long long* __restrict__ scratch_tape, uint32_t* __restrict__ tape_lens, int32_t* __restrict__ doc_errors) {
@@ -340,6 +373,9 @@ k_doc_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restrict
         Lane w;
         w.buf = buf;
         w.ix = idx;
+        w.ix_entries = ix_entries;
+        w.iw_base = 0xFFFFFFFFu;  // (never a multiple of four)
+        w.bw_base = 0xFFFFFFF0u;  // p - base >= 16 for every p the lane can ask for
         w.from = (uint32_t)index_offsets[k];
         w.to = (uint32_t)index_offsets[k + 1];
         w.rd = w.from;
@@ -466,7 +502,7 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
     const uint64_t nchunks = (n_docs + PACK_DOCS - 1) / PACK_DOCS;
     if (n_docs) {
         hipLaunchKernelGGL(k_doc_walk, dim3((unsigned)((n_docs + WALK_THREADS - 1) / WALK_THREADS)), dim3(WALK_THREADS), 0, stream,
-                           d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets, d_doc_status, d_sb, d_doc_str_offsets,
+                           d_buf, d_doc_offsets, n_docs, d_idx, (uint32_t)(count + 1), d_index_offsets, d_doc_status, d_sb, d_doc_str_offsets,
                            (unsigned long long)string_base, max_depth, scratch, lens, d_doc_errors);
         hipLaunchKernelGGL(k_tape_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, lens, d_doc_errors, n_docs, sums, d_res);
     }
