@@ -221,10 +221,13 @@ void sjmi_parser_destroy(sjmi_parser* p);
 int sjmi_parser_parse(sjmi_parser* p, const uint8_t* buf, uint64_t len, const uint64_t** tape, uint64_t* tape_len,
                       const uint8_t** strings, uint64_t* strings_len, uint64_t* error_pos);
 const char* sjmi_parser_last_message(const sjmi_parser* p);
-/* Batched parse (BASELINE.json configs[4]): one GPU stage-1 + unescape pass over the whole batch, then the host
- * stage 2 per document.  Document k's tape is tape[tape_offsets[k] .. tape_offsets[k+1]) (its STRING payloads are
- * offsets into the shared `strings` buffer) and errors[k] is 0 or document k's own SJMI_E_* error -- stage-1 errors
- * included (isolated batch mode: one broken document never affects another). */
+/* Batched parse (BASELINE.json configs[3]/[4]): the batch goes through the GPU (isolated stage 1 + string records)
+ * as a pipeline of sub-batches on two streams, the host stage 2 of the documents runs on a pool of threads
+ * (SJMI_PARSE_THREADS, default min(32, cores)) while the GPU works on the next sub-batch.  Document k's tape is
+ * tape[tape_offsets[k] .. tape_offsets[k+1]) (container words relative to its own start, STRING payloads = offsets
+ * into the shared `strings` buffer, which has unused gaps between sub-batches) and errors[k] is 0 or document k's
+ * own SJMI_E_* error -- stage-1 errors included (isolated batch mode: one broken document never affects another).
+ * The call itself is made from one thread; the parser is not thread-safe (like the reference's). */
 int sjmi_parser_parse_batch(sjmi_parser* p, const uint8_t* buf, uint64_t total_len, const uint64_t* doc_offsets,
                             uint64_t n_docs, const uint64_t** tape, const uint64_t** tape_offsets,
                             const uint8_t** strings, uint64_t* strings_len, const int32_t** errors);
