@@ -69,8 +69,12 @@ def synth_tile(seed=20250824, target_bytes=4 << 20):
     return ("[\n" + ",\n".join(recs) + "\n]\n").encode("utf-8")
 
 
-def small_docs(seed=20250825, n=1000, lo=768, hi=1280):
+def small_docs(seed=20250825, n=1000, lo=768, hi=1280, same_schema=False):
+    """same_schema: every document has the same sequence of field types (records of one log / table, the usual NDJSON
+    case) instead of a random type per field."""
     rng = random.Random(seed)
+    schema_rng = random.Random(seed + 1)
+    kinds = [schema_rng.random() for _ in range(256)]
     docs = []
     for _ in range(n):
         target = rng.randint(lo, hi)
@@ -78,7 +82,7 @@ def small_docs(seed=20250825, n=1000, lo=768, hi=1280):
         size = 2
         i = 0
         while size < target - 60:
-            k = rng.random()
+            k = kinds[i % 256] if same_schema else rng.random()
             if k < 0.40:
                 v = _string(rng, rng.randint(8, 60), esc=0.05, nonascii=0.05)
             elif k < 0.70:

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Device-resident full parse of a batch (BASELINE.json configs[3] shape: ~1 KB documents): isolated stage 1 ->
-string records -> GPU walk (tapes), each timed with events on the launch stream.  usage: walk_bench.py [n_docs]"""
+string records -> GPU walk (tapes), each timed with events on the launch stream.
+usage: walk_bench.py [n_docs] [schema]   (schema: all documents share one sequence of field types)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -10,7 +11,8 @@ import simdjson_java_amd as S
 import synth
 
 n_want = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
-docs = synth.small_docs(n=4000)
+same = len(sys.argv) > 2 and sys.argv[2] == "schema"
+docs = synth.small_docs(n=4000, same_schema=same)
 unit = b"".join(d + b"\n" for d in docs)
 lens = np.array([len(d) + 1 for d in docs], dtype=np.uint64)
 reps = max(1, n_want // len(docs))
@@ -74,6 +76,7 @@ w = d_wres.cpu().numpy()
 assert int(w[1]) == 0 and int(w[2]) == 0 and (int(w[3]) & 1) == 0, w
 words = int(w[0])
 tall = timed(lambda: (stage1(), strings(), walk()))
+print("field types: %s" % ("one schema for all documents" if same else "random per field"))
 print("%d documents, %d B, %d structurals, %d string bytes, %d tape words" % (n_docs, n, count, int(d_ures[0].item()), words))
 print("isolated stage 1 %.3f ms | string records %.3f ms | GPU walk + pack %.3f ms | all three back to back %.3f ms = "
       "%.1f M documents/s, %.0f GB/s of JSON, device-resident in and out" % (t1, t2, t3, tall, n_docs / tall / 1e3, n / tall / 1e6))
