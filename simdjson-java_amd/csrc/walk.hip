@@ -354,7 +354,9 @@ __device__ __forceinline__ unsigned long long scratch_slot(unsigned long long fr
 
 }  // namespace
 
-__global__ void __launch_bounds__(WALK_THREADS)
+// (latency-bound: 64 % of the wave cycles wait for memory, profiles/r1/batch_pmc.txt -- a sixth wave per SIMD, 80
+// instead of 82 VGPRs, is worth 8 %; a seventh needs SGPR spills and adds nothing)
+__global__ void __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
 k_doc_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restrict__ doc_offsets, uint64_t n_docs,
            const uint32_t* __restrict__ idx, uint32_t ix_entries, const unsigned long long* __restrict__ index_offsets,
            const uint32_t* __restrict__ doc_status, const uint8_t* __restrict__ sb,

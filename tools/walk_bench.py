@@ -8,6 +8,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import torch
 import simdjson_java_amd as S
+import simdjson_java_amd.binding as B
+if os.environ.get("SJMI_LIB"):  # A/B of library variants (tools/variants/*.so)
+    B._LIB = os.environ["SJMI_LIB"]
 import synth
 
 n_want = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
@@ -59,7 +62,12 @@ def walk():
                           d_wres.data_ptr(), st)
 
 
-def timed(fn, iters=20, warm=5):
+ITERS = int(os.environ.get("WALK_BENCH_ITERS", "20"))  # (3 under rocprofv3 --pmc)
+
+
+def timed(fn, iters=None, warm=None):
+    iters = iters or ITERS
+    warm = warm if warm is not None else max(1, ITERS // 4)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(warm):
         fn()
