@@ -339,7 +339,9 @@ k_doc_mark_tails(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ i
 }
 
 template <int ITEMS>
-__global__ void __launch_bounds__(UNESC_THREADS)
+// (7 waves per SIMD, 69 instead of 74 VGPRs with some SGPRs parked in VGPR lanes: -4 % on twitter, -6 % on the
+// escape-heavy synthetic batches; half of the wave cycles here are waits, profiles/r1/batch_pmc.txt)
+__global__ void __launch_bounds__(UNESC_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7)))
 k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __restrict__ idx, uint64_t count,
               const Stage1Result* __restrict__ dev_count, uint32_t* __restrict__ sizes,
               unsigned long long* __restrict__ block_sums, uint32_t* __restrict__ group_sums, uint8_t* __restrict__ scratch,
