@@ -10,10 +10,10 @@ import pytest
 from oracle import oracle as O
 from tests.conftest import load_fixture
 from tests.test_gpu_batch import _pack, _small_docs
+from tests.walk_common import NEEDS_HOST, number_documents
 
 pytestmark = pytest.mark.gpu
 
-NEEDS_HOST = -1
 
 
 def gpu_walk(ctx, docs, max_depth=1024):
@@ -157,57 +157,17 @@ def test_walk_equals_host_walker_on_a_large_batch():
         c.close()
 
 
-def _exact_range(lit):
-    """Independent statement of the range the GPU converts itself: significand (zeros at either end stripped) of at
-    most 19 digits and at most 2^53, |decimal exponent| <= 22."""
-    s = lit.lstrip("-").lower()
-    mant, _, e = s.partition("e")
-    ip, _, fp = mant.partition(".")
-    exp = int(e) if e else 0
-    digits = (ip + fp).lstrip("0")
-    q = exp - len(fp)
-    stripped = digits.rstrip("0")
-    q += len(digits) - len(stripped)
-    if not stripped:
-        return True if abs(q) <= 22 else None  # zero: either answer is right
-    return len(stripped) <= 19 and int(stripped) <= (1 << 53) and -22 <= q <= 22
-
-
 def test_walk_number_fuzz(ctx):
     """Random number literals in arrays: every value the GPU converts equals the oracle's (strtod, correctly rounded)
     bit for bit, and it hands back exactly the documents holding a literal outside its exact range."""
     rng = random.Random(92)
-
-    def literal():
-        k = rng.random()
-        sign = "-" if rng.random() < 0.3 else ""
-        if k < 0.25:
-            return sign + str(rng.randrange(10 ** rng.randint(1, 18)))
-        ip = str(rng.randrange(10 ** rng.randint(1, rng.choice([1, 3, 8, 16, 21])))) if rng.random() < 0.8 else "0"
-        fp = ""
-        if rng.random() < 0.8:
-            fp = "." + "".join(rng.choice("0000123456789") for _ in range(rng.randint(1, rng.choice([1, 2, 6, 12, 20]))))
-        ex = ""
-        if rng.random() < 0.4 or not fp:
-            ex = rng.choice("eE") + rng.choice(["", "+", "-"]) + str(rng.randrange(rng.choice([3, 10, 25, 40, 400])))
-        return sign + ip + fp + ex
-
-    docs, hard = [], set()
-    for k in range(6000):
-        lits = [literal() for _ in range(rng.randint(1, 6))]
-        docs.append(("[" + ", ".join(lits) + "]").encode())
-        verdicts = [_exact_range(x) for x in lits if any(c in x for c in ".eE")]
-        if any(v is False for v in verdicts):
-            hard.add(k)
-        elif any(v is None for v in verdicts):
-            hard.add(-k - 1)  # undecided: a zero with a huge exponent
+    docs, hard, either = number_documents(rng, 6000)
     tapes, strings, errors = gpu_walk(ctx, docs)
     n_host = 0
     for k, d in enumerate(docs):
-        if -k - 1 in hard:
-            if int(errors[k]) == NEEDS_HOST:
-                continue
-        elif k in hard:
+        if k in either and int(errors[k]) == NEEDS_HOST:
+            continue
+        if k in hard:
             assert int(errors[k]) == NEEDS_HOST, (k, d)
             n_host += 1
             continue

@@ -1,0 +1,48 @@
+"""Shared by the CPU and GPU tests of the GPU walker (csrc/walk_doc.h / walk.hip)."""
+NEEDS_HOST = -1
+
+
+def exact_range(lit):
+    """Independent statement of the range the GPU converts itself: significand (zeros at either end stripped) of at
+    most 19 digits and at most 2^53, |decimal exponent| <= 22.  None: a zero whose exponent is out of range (either
+    answer is right)."""
+    s = lit.lstrip("-").lower()
+    mant, _, e = s.partition("e")
+    ip, _, fp = mant.partition(".")
+    exp = int(e) if e else 0
+    digits = (ip + fp).lstrip("0")
+    q = exp - len(fp)
+    stripped = digits.rstrip("0")
+    q += len(digits) - len(stripped)
+    if not stripped:
+        return True if abs(q) <= 22 else None
+    return len(stripped) <= 19 and int(stripped) <= (1 << 53) and -22 <= q <= 22
+
+
+def random_number_literal(rng):
+    k = rng.random()
+    sign = "-" if rng.random() < 0.3 else ""
+    if k < 0.25:
+        return sign + str(rng.randrange(10 ** rng.randint(1, 18)))
+    ip = str(rng.randrange(10 ** rng.randint(1, rng.choice([1, 3, 8, 16, 21])))) if rng.random() < 0.8 else "0"
+    fp = ""
+    if rng.random() < 0.8:
+        fp = "." + "".join(rng.choice("0000123456789") for _ in range(rng.randint(1, rng.choice([1, 2, 6, 12, 20]))))
+    ex = ""
+    if rng.random() < 0.4 or not fp:
+        ex = rng.choice("eE") + rng.choice(["", "+", "-"]) + str(rng.randrange(rng.choice([3, 10, 25, 40, 400])))
+    return sign + ip + fp + ex
+
+
+def number_documents(rng, n):
+    """-> (documents, set of indexes that must be handed back, set of indexes where either answer is right)"""
+    docs, hard, either = [], set(), set()
+    for k in range(n):
+        lits = [random_number_literal(rng) for _ in range(rng.randint(1, 6))]
+        docs.append(("[" + ", ".join(lits) + "]").encode())
+        verdicts = [exact_range(x) for x in lits if any(c in x for c in ".eE")]
+        if any(v is False for v in verdicts):
+            hard.add(k)
+        elif any(v is None for v in verdicts):
+            either.add(k)
+    return docs, hard, either
