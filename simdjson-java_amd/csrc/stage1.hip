@@ -30,6 +30,8 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "sj_block.h"
 #include "stage1.h"
 
@@ -927,7 +929,7 @@ int stage1_pick_steps(uint64_t len) {
 // workgroups of k_stage1<...> that are resident at the same time on the current device (fast mode's grid)
 template <int S, int LDSW, bool SAFE>
 static hipError_t resident_workgroups(unsigned* out) {
-    static unsigned cached[16] = {0};
+    static std::atomic<unsigned> cached[16];  // (contexts on several host threads may get here together)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -940,7 +942,7 @@ static hipError_t resident_workgroups(unsigned* out) {
             *out = n;
             return hipSuccess;
         }
-        cached[dev] = n;
+        cached[dev].store(n, std::memory_order_relaxed);
     }
     *out = cached[dev];
     return hipSuccess;
