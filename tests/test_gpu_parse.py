@@ -144,3 +144,19 @@ def test_random_documents(parser):
             _same(parser, bytes(b))
         else:
             _same(parser, doc)
+
+
+def test_large_array_size_saturates():
+    """ArrayParsingTest.java:74-95 largeArraySize: [0,0,...] with 0xFFFFFF + 1 elements (33.5 MB, 33.5 M structurals) parses
+    and reports getSize() == 0xFFFFFF; tape equal to the oracle's."""
+    import simdjson_java_amd as S
+    n = 0xFFFFFF + 1
+    doc = b"[" + b"0," * (n - 1) + b"0]"
+    p = S.SimdJsonParser(capacity=len(doc) + 64)
+    try:
+        got = p.parse(doc)
+        want = O.parse(doc)
+        assert want.error == 0 and (int(got.tape[1]) >> 32) & 0xFFFFFF == 0xFFFFFF
+        assert np.array_equal(got.tape, want.tape)
+    finally:
+        p.close()

@@ -100,3 +100,10 @@ def test_fuzz_documents(walk):
     for _ in range(3000):
         checked += _check(walk, value(0).encode())
     assert checked > 2500
+
+
+def test_large_array_size_saturates(walk):
+    """ArrayParsingTest.java:74-95: 0xFFFFFF + 1 elements -> count field 0xFFFFFF, through the host walker."""
+    n = 0xFFFFFF + 1
+    tape, rc = walk(b"[" + b"0," * (n - 1) + b"0]")
+    assert rc == 0 and (int(tape[1]) >> 32) & 0xFFFFFF == 0xFFFFFF and tape.size == 2 * n + 4

@@ -130,3 +130,10 @@ def test_fuzz_documents(walk):
     for it in range(4000):
         checked += _check(walk, value(0).encode(), lead=b"x" * (it % 37), host_ok=False)
     assert checked > 3000
+
+
+def test_large_array_size_saturates(walk):
+    """ArrayParsingTest.java:74-95: 0xFFFFFF + 1 elements -> count field 0xFFFFFF, through the GPU walker's automaton."""
+    n = 0xFFFFFF + 1
+    tape, rc = walk(b"[" + b"0," * (n - 1) + b"0]")
+    assert rc == 0 and (int(tape[1]) >> 32) & 0xFFFFFF == 0xFFFFFF and tape.size == 2 * n + 4

@@ -290,3 +290,15 @@ def test_numbers():
            "12345678901234567890": O.error_message(27)}
     for text, msg in bad.items():
         assert _parse_text("[%s]" % text).message == msg, text
+
+
+def test_large_array_size_saturates():
+    """ArrayParsingTest.java:74-95 largeArraySize: [0,0,...] with 0xFFFFFF + 1 elements reports getSize() == 0xFFFFFF
+    (the 24-bit count field of the container word saturates, TapeBuilder.java:197-203)."""
+    n = 0xFFFFFF + 1
+    doc = b"[" + b"0," * (n - 1) + b"0]"
+    assert len(doc) == n * 2 - 1 + 2
+    p = O.parse(doc)
+    assert p.error == 0
+    assert chr(int(p.tape[1]) >> 56) == "[" and (int(p.tape[1]) >> 32) & 0xFFFFFF == 0xFFFFFF
+    assert int(p.tape[1]) & 0xFFFFFFFF == p.tape.size - 1  # index behind the closing bracket
