@@ -28,3 +28,11 @@ def twitter():
 def _build_oracle():
     from oracle import oracle
     oracle.build()
+
+
+def number_vectors():
+    """The reference's NumberParsingTest literal vectors (tests/golden/number_vectors.json, made by
+    tests/golden/make_number_vectors.py): dicts with input, optional length, and double_bits | long | message."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "number_vectors.json")) as f:
+        return json.load(f)

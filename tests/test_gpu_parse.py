@@ -160,3 +160,18 @@ def test_large_array_size_saturates():
         assert np.array_equal(got.tape, want.tape)
     finally:
         p.close()
+
+
+def test_reference_number_vectors(parser):
+    """NumberParsingTest.java's 158 literal vectors end to end on the GPU path: the value / message the reference asserts."""
+    import simdjson_java_amd as S
+    from tests.conftest import number_vectors
+    for v in number_vectors():
+        doc = v["input"].encode("utf-8")
+        if "message" in v:
+            with pytest.raises(S.JsonParsingException) as e:
+                parser.parse(doc, v.get("length"))
+            assert str(e.value) == v["message"], (v["input"][:40], v["cite"])
+        else:
+            got = O.Parsed(parser.parse(doc, v.get("length")).tape, b"", 0, 0, 0).to_python()
+            assert got == (("l", v["long"]) if "long" in v else ("d", v["double_bits"])), (v["input"][:40], v["cite"], got)

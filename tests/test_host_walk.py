@@ -107,3 +107,14 @@ def test_large_array_size_saturates(walk):
     n = 0xFFFFFF + 1
     tape, rc = walk(b"[" + b"0," * (n - 1) + b"0]")
     assert rc == 0 and (int(tape[1]) >> 32) & 0xFFFFFF == 0xFFFFFF and tape.size == 2 * n + 4
+
+
+def test_reference_number_vectors(walk):
+    """NumberParsingTest.java's literal vectors through the host walker (its doubles come from strtod): same tape / error
+    as the oracle, which tests/test_oracle_golden.py pins to the values the reference asserts."""
+    from tests.conftest import number_vectors
+    n = 0
+    for v in number_vectors():
+        doc = v["input"].encode("utf-8")[:v.get("length")]
+        n += _check(walk, doc)
+    assert n >= 150

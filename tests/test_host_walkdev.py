@@ -137,3 +137,23 @@ def test_large_array_size_saturates(walk):
     n = 0xFFFFFF + 1
     tape, rc = walk(b"[" + b"0," * (n - 1) + b"0]")
     assert rc == 0 and (int(tape[1]) >> 32) & 0xFFFFFF == 0xFFFFFF and tape.size == 2 * n + 4
+
+
+def test_reference_number_vectors(walk):
+    """NumberParsingTest.java's literal vectors through the GPU walker's automaton: it either produces the oracle's tape /
+    error or hands the document back (ties, subnormals, saturation and long significands are outside its exact range) --
+    never a different value."""
+    from tests.conftest import number_vectors
+    converted = handed_back = 0
+    for v in number_vectors():
+        doc = v["input"].encode("utf-8")[:v.get("length")]
+        got = walk(doc)
+        if got is None:
+            continue
+        if got[1] == NEEDS_HOST:
+            assert "message" not in v, v["input"][:40]
+            handed_back += 1
+        else:
+            assert _check(walk, doc), v["input"][:40]
+            converted += 1
+    assert converted >= 55 and handed_back >= 40

@@ -302,3 +302,24 @@ def test_large_array_size_saturates():
     assert p.error == 0
     assert chr(int(p.tape[1]) >> 56) == "[" and (int(p.tape[1]) >> 32) & 0xFFFFFF == 0xFFFFFF
     assert int(p.tape[1]) & 0xFFFFFFFF == p.tape.size - 1  # index behind the closing bracket
+
+
+def test_reference_number_vectors():
+    """Every literal vector of NumberParsingTest.java (158 inputs of 27 tests: grammar messages, long range, infinities,
+    signed zeros, subnormal / normal boundaries, ties-to-even, round up / down, exponents with more digits than a long):
+    the oracle's number path (strtod standing in for DoubleParser) gives the value / message the reference asserts."""
+    from tests.conftest import number_vectors
+    vs = number_vectors()
+    assert len(vs) >= 158
+    for v in vs:
+        doc = v["input"].encode("utf-8")
+        p = O.parse(doc, v.get("length"))
+        if "message" in v:
+            assert p.error != 0 and p.message == v["message"], (v["input"][:40], v["cite"], p.error)
+        else:
+            assert p.error == 0, (v["input"][:40], v["cite"], p.message)
+            got = p.to_python()
+            if "long" in v:
+                assert got == ("l", v["long"]), (v["input"][:40], v["cite"], got)
+            else:
+                assert got == ("d", v["double_bits"]), (v["input"][:40], v["cite"], got)
