@@ -106,6 +106,18 @@ int sjmi_stage1(sjmi_ctx* ctx, const uint8_t* buf, uint64_t len, uint32_t* index
 int sjmi_stage1_device(sjmi_ctx* ctx, const void* d_buf, uint64_t len, void* d_indexes, uint64_t index_capacity,
                        void* d_result, void* stream);
 
+/* Bit-mask parity entry point: the six 64-bit masks one iteration of the reference's stage-1 loop holds for every 64-byte
+ * block (StructuralIndexer.java:210-252), masks[6*b + {0..5}] = {escaped, quote, inString, op, whitespace, structurals}
+ * of block b, for all len / 64 + 1 blocks (the reference always processes one space-padded tail block, :255-294,305-309).
+ * They are internal locals of the reference (never asserted by its tests); north_star asks for them bit-exact, so the
+ * engine reconstructs them from its own per-block formulation + the resolved in-string parity (csrc/masks.hip).
+ * Host form: copies buf[0,len) in, masks out; needs mask_capacity_blocks >= len / 64 + 1; *n_blocks = blocks written.
+ * Device form: d_buf as for sjmi_stage1_device, d_masks holds 6 * (len / 64 + 1) uint64; asynchronous on `stream`. */
+int sjmi_stage1_masks(sjmi_ctx* ctx, const uint8_t* buf, uint64_t len, uint64_t* masks, uint64_t mask_capacity_blocks,
+                      uint64_t* n_blocks);
+int sjmi_stage1_masks_device(sjmi_ctx* ctx, const void* d_buf, uint64_t len, void* d_masks, uint64_t mask_capacity_blocks,
+                             void* stream);
+
 /* device-side result record of one unescape call */
 typedef struct sjmi_unescape_result {
     uint64_t total_bytes;      /* bytes of [be32 length][unescaped bytes] records written */

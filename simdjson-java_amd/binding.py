@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _CSRC = os.path.join(_HERE, "csrc")
 _LIB = os.path.join(_HERE, "libsjmi.so")
-SOURCES = ["stage1.hip", "unescape.hip", "batch.hip", "walk.hip", "sjmi_api.hip", "host/simdjson_parser.cpp"]
+SOURCES = ["stage1.hip", "unescape.hip", "batch.hip", "walk.hip", "masks.hip", "sjmi_api.hip", "host/simdjson_parser.cpp"]
 
 ST_UTF8, ST_UNCLOSED, ST_UNESCAPED, ST_CAPACITY, ST_INTERNAL = 1, 2, 4, 0x100, 0x200
 PADDING = 64
@@ -63,7 +63,7 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_stage1_batch", "sjmi_stage1_batch_device", "sjmi_parser_parse_batch",
            "sjmi_stage1_batch_isolated", "sjmi_stage1_batch_isolated_device", "sjmi_host_register",
            "sjmi_host_unregister", "sjmi_stage1_unescape", "sjmi_unescape_batch",
-           "sjmi_unescape_batch_device", "sjmi_walk_batch_device"]
+           "sjmi_unescape_batch_device", "sjmi_walk_batch_device", "sjmi_stage1_masks", "sjmi_stage1_masks_device"]
 
 
 def lib():
@@ -141,6 +141,10 @@ def lib():
                                               C.c_void_p, C.c_void_p, C.c_void_p]
         L.sjmi_set_tile_mode.restype = C.c_int
         L.sjmi_set_tile_mode.argtypes = [C.c_void_p, C.c_int]
+        L.sjmi_stage1_masks.restype = C.c_int
+        L.sjmi_stage1_masks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.sjmi_stage1_masks_device.restype = C.c_int
+        L.sjmi_stage1_masks_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
         L.sjmi_kernel_time.restype = C.c_int
         L.sjmi_kernel_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -194,6 +198,23 @@ class Context:
                     "sjmi_stage1")
         assert idx[cnt.value] == 0, "sentinel missing"
         return idx[:cnt.value].copy(), st.value
+
+    def stage1_masks(self, data, length=None):
+        """The reference's per-block masks (sjmi_stage1_masks): -> np.uint64 [len // 64 + 1, 6] =
+        {escaped, quote, inString, op, whitespace, structurals} per 64-byte block."""
+        a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, np.uint8)
+        n = a.size if length is None else length
+        nb = n // 64 + 1
+        masks = np.zeros((nb, 6), dtype=np.uint64)
+        got = C.c_uint64(0)
+        self._check(lib().sjmi_stage1_masks(self._h, a.ctypes.data if a.size else None, n, masks.ctypes.data, nb,
+                                            C.addressof(got)), "sjmi_stage1_masks")
+        assert got.value == nb
+        return masks
+
+    def stage1_masks_device(self, d_buf, length, d_masks, capacity_blocks, stream=0):
+        self._check(lib().sjmi_stage1_masks_device(self._h, d_buf, length, d_masks, capacity_blocks, stream),
+                    "sjmi_stage1_masks_device")
 
     def stage1_unescape(self, data, idx=None, sb=None):
         """Fused host path (sjmi_stage1_unescape): -> (indexes, status, string_buffer bytes, first_error_index, code)."""

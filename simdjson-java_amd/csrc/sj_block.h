@@ -46,6 +46,16 @@ struct SjBlockMasks {
     uint32_t utf8;   // block contains a UTF-8 error                          (Utf8Validator.java:109-110,165)
 };
 
+// The reference's own per-block locals that the kernels never materialise (they work with pot / sm0): filled in on
+// request for the bit-mask parity entry point (sjmi_stage1_masks), see sj_reference_masks below.
+struct SjBlockDetail {
+    sj_u64 escaped;  // StructuralIndexer.java:213-228
+    sj_u64 quote;    // :232
+    sj_u64 in0;      // inString for incoming parity 0 (:233)
+    sj_u64 op;       // :239-240
+    sj_u64 ws;       // :237-238
+};
+
 SJ_HD sj_u64 sj_prefix_xor(sj_u64 m) {  // StructuralIndexer.java:311-319
     m ^= m << 1;
     m ^= m << 2;
@@ -69,7 +79,8 @@ SJ_HD void sj_mask_tail(sj_u64 p[8], uint32_t valid) {
 
 // do_utf8 = false skips the UTF-8 algebra; only legal when the caller knows the block is pure ASCII and uc is
 // all zero (the kernel decides per wave with a ballot), in which case the result is identical.
-SJ_HD SjBlockMasks sj_block(const sj_u64 p[8], uint32_t e_in, uint32_t p_in, SjUtf8Carry uc, bool do_utf8 = true) {
+SJ_HD SjBlockMasks sj_block(const sj_u64 p[8], uint32_t e_in, uint32_t p_in, SjUtf8Carry uc, bool do_utf8 = true,
+                            SjBlockDetail* det = nullptr) {
     const sj_u64 p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4], p5 = p[5], p6 = p[6], p7 = p[7];
     const sj_u64 a = ~p7 & ~p6;  // 0x00..0x3F
     const sj_u64 b = ~p7 & p6;   // 0x40..0x7F
@@ -135,6 +146,13 @@ SJ_HD SjBlockMasks sj_block(const sj_u64 p[8], uint32_t e_in, uint32_t p_in, SjU
     err |= sF4 & (p5 | p4);                                // F4 90..BF             (TOO_LARGE)
     }
 
+    if (det) {
+        det->escaped = escaped;
+        det->quote = quote;
+        det->in0 = in0;
+        det->op = op;
+        det->ws = ws;
+    }
     SjBlockMasks r;
     r.pot = pot;
     r.sm0 = in0 ^ quote;
@@ -143,6 +161,19 @@ SJ_HD SjBlockMasks sj_block(const sj_u64 p[8], uint32_t e_in, uint32_t p_in, SjU
     r.ue1 = (ctrl & ~in0) != 0;
     r.utf8 = err != 0;
     return r;
+}
+
+// The six masks one iteration of the reference's loop holds (StructuralIndexer.java:210-252), in the order
+// {escaped, quote, inString, op, whitespace, structurals}, from the kernel's own formulation: the block's masks for an
+// incoming in-string parity of 0 plus the parity resolved by the prefix scan.  inString(p=1) = ~in0 (prefixXor ^
+// all-ones, :233-234); structurals(p=1) = pot & ~(~in0 ^ quote) = pot & sm0 (:251).
+SJ_HD void sj_reference_masks(const SjBlockMasks& bm, const SjBlockDetail& det, uint32_t parity_in, sj_u64 out[6]) {
+    out[0] = det.escaped;
+    out[1] = det.quote;
+    out[2] = parity_in ? ~det.in0 : det.in0;
+    out[3] = det.op;
+    out[4] = det.ws;
+    out[5] = parity_in ? (bm.pot & bm.sm0) : (bm.pot & ~bm.sm0);
 }
 
 // ---- carries from the bytes before the block -------------------------------------------------

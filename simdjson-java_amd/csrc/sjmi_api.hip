@@ -40,6 +40,10 @@ struct sjmi_ctx {
     size_t docstr_bytes = 0;
     void* d_ws_walk = nullptr;               // batch walk: scratch tape, tape lengths, chunk sums
     size_t ws_walk_bytes = 0;
+    void* d_masks = nullptr;                 // sjmi_stage1_masks: 6 x u64 per block + its workspace, grown on demand
+    size_t masks_bytes = 0;
+    void* d_ws_masks = nullptr;
+    size_t ws_masks_bytes = 0;
     uint64_t last_ndocs = 0;                 // documents of the last batch call (their index offsets are still on the device)
     bool last_batch = false;
     size_t docoff_bytes = 0;
@@ -120,6 +124,8 @@ void sjmi_destroy(sjmi_ctx* c) {
     if (c->d_doccnt) (void)hipFree(c->d_doccnt);
     if (c->d_docstr) (void)hipFree(c->d_docstr);
     if (c->d_ws_walk) (void)hipFree(c->d_ws_walk);
+    if (c->d_masks) (void)hipFree(c->d_masks);
+    if (c->d_ws_masks) (void)hipFree(c->d_ws_masks);
     if (c->h_res) (void)hipHostFree(c->h_res);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.first);
@@ -457,6 +463,40 @@ int sjmi_stage1_device(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_ind
     c->ws_dev_clean[1 - h] = need;
     c->ws_dev_next = 1 - h;
     c->ws_dev_last = ws;
+    return SJMI_OK;
+}
+
+int sjmi_stage1_masks_device(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_masks, uint64_t mask_capacity_blocks,
+                             void* stream) {
+    if (!c || !d_buf || !d_masks || len >= (1ull << 32) || ((uintptr_t)d_buf & 15) || ((uintptr_t)d_masks & 7)) return SJMI_ERR_ARG;
+    if (mask_capacity_blocks < len / 64 + 1) return SJMI_ERR_CAPACITY;
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    if (!grow(c, &c->d_ws_masks, &c->ws_masks_bytes, sjmi::masks_workspace_bytes(len), "hipMalloc(ws_masks)")) return SJMI_ERR_HIP;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (fail(c, "masks launch", sjmi::masks_launch((const uint8_t*)d_buf, len, (unsigned long long*)d_masks, c->d_ws_masks, st)))
+        return SJMI_ERR_HIP;
+    return SJMI_OK;
+}
+
+int sjmi_stage1_masks(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint64_t* masks, uint64_t mask_capacity_blocks,
+                      uint64_t* n_blocks) {
+    if (!c || (!buf && len) || !masks || !n_blocks) return SJMI_ERR_ARG;
+    if (len > c->capacity || len >= (1ull << 32)) {
+        c->err = "document larger than the context capacity";
+        return SJMI_ERR_CAPACITY;
+    }
+    const uint64_t nblocks = len / 64 + 1;
+    if (mask_capacity_blocks < nblocks) return SJMI_ERR_CAPACITY;
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    if (!grow(c, &c->d_masks, &c->masks_bytes, (size_t)nblocks * 48, "hipMalloc(masks)")) return SJMI_ERR_HIP;
+    if (len && fail(c, "H2D", hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
+    c->last_valid = false;  // (the context's document buffer now holds this document, without indexes)
+    const int rc = sjmi_stage1_masks_device(c, c->d_in, len, c->d_masks, nblocks, c->stream);
+    if (rc != SJMI_OK) return rc;
+    if (fail(c, "D2H(masks)", hipMemcpyAsync(masks, c->d_masks, (size_t)nblocks * 48, hipMemcpyDeviceToHost, c->stream)) ||
+        fail(c, "sync", hipStreamSynchronize(c->stream)))
+        return SJMI_ERR_HIP;
+    *n_blocks = nblocks;
     return SJMI_OK;
 }
 

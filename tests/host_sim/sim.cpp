@@ -53,3 +53,35 @@ extern "C" int sim_stage1(const uint8_t* buf, uint64_t len, uint32_t* idx, uint6
     *status = st;
     return 0;
 }
+
+// The reference's six per-block masks, rebuilt exactly as csrc/masks.hip does on the device: the kernel-side block
+// algebra for an incoming parity of 0 (sj_block) + the XOR-prefix of the block quote parities + sj_reference_masks.
+extern "C" int sim_masks(const uint8_t* buf, uint64_t len, uint64_t* masks) {
+    const uint64_t nblocks = len / 64 + 1;
+    uint32_t parity = 0;
+    for (uint64_t b = 0; b < nblocks; ++b) {
+        const uint64_t start = b * 64;
+        const uint32_t valid = (uint32_t)(len - start < 64 ? len - start : 64);
+        uint32_t w[16];
+        memset(w, 0xA5, sizeof w);  // bytes past the end are garbage on the device too: they must be invisible
+        memcpy(w, buf + start, valid);
+        sj_u64 p[8];
+        sj_transpose_butterfly(w, p);
+        sj_mask_tail(p, valid);
+        uint32_t e_in = 0, p_in = 0;
+        SjUtf8Carry uc = {0, 0, 0, 0};
+        if (b > 0) {
+            sj_u64 halo;
+            memcpy(&halo, buf + start - 8, 8);
+            uc = sj_utf8_carry(halo);
+            if (!sj_carry_from_halo(halo, &e_in, &p_in)) sj_carry_slow(buf, 0, start, &e_in, &p_in);
+        }
+        SjBlockDetail det;
+        const SjBlockMasks m = sj_block(p, e_in, p_in, uc, true, &det);
+        sj_u64 out[6];
+        sj_reference_masks(m, det, parity, out);
+        for (int k = 0; k < 6; ++k) masks[6 * b + k] = out[k];
+        parity ^= m.qpar;
+    }
+    return 0;
+}

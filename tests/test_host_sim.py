@@ -28,6 +28,15 @@ def sim():
     lib.sim_stage1.restype = C.c_int
     lib.sim_stage1.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
 
+    lib.sim_masks.restype = C.c_int
+    lib.sim_masks.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+
+    def masks(data):
+        a = np.frombuffer(bytes(data) + b"\0" * 64, dtype=np.uint8)
+        m = np.zeros((len(data) // 64 + 1, 6), dtype=np.uint64)
+        assert lib.sim_masks(a.ctypes.data, len(data), m.ctypes.data) == 0
+        return m
+
     def run(data):
         a = np.frombuffer(bytes(data) + b"\0" * 64, dtype=np.uint8)
         n = len(data)
@@ -36,6 +45,7 @@ def sim():
         st = C.c_uint32(0)
         assert lib.sim_stage1(a.ctypes.data, n, idx.ctypes.data, n + 2, C.addressof(cnt), C.addressof(st)) == 0
         return idx[:cnt.value].copy(), st.value
+    run.masks = masks
     return run
 
 
@@ -87,3 +97,40 @@ def test_fuzz_utf8(sim):
                 base = base[:rng.randrange(len(base)) + 1]
             d = bytes(base)
         _check(sim, d)
+
+
+MASK_NAMES = ["escaped", "quote", "inString", "op", "whitespace", "structurals"]
+
+
+def _check_masks(sim, d):
+    _, _, want = O.index_blocks(d, want_masks=True)
+    got = sim.masks(d)
+    assert got.shape == want.shape
+    if not np.array_equal(got, want):
+        b, k = [int(x[0]) for x in np.nonzero(got != want)]
+        raise AssertionError("block %d mask %s: got %016x want %016x" % (b, MASK_NAMES[k], int(got[b, k]), int(want[b, k])))
+
+
+def test_reference_bitmasks(sim):
+    """The six per-block masks of StructuralIndexer.java:210-252 rebuilt from the kernel's pot / sm0 formulation
+    (sj_reference_masks, the function csrc/masks.hip runs on the device) equal the oracle's line-by-line restatement:
+    reference files, the reference's StructuralIndexerTest inputs, backslash runs across block boundaries, fuzz."""
+    from tests.golden import vectors as V
+    for name in ("twitter.json", "github_events.json", "wide_bench.json", "malformed.txt"):
+        _check_masks(sim, load_fixture(name))
+    for case in V.STRUCTURAL_INDEXER:
+        _check_masks(sim, case[1])
+    rng = random.Random(15)
+    alphabet = b'\\\\\\"""{}[]:, \t\n\r\x0c\x1a\x01abc019.-e\xc3\xa9'
+    for it in range(3000):
+        n = rng.choice([0, 1, 63, 64, 65, 127, 128, 129, rng.randint(0, 900)])
+        mode = it % 4
+        if mode == 0:
+            d = bytes(rng.choice(alphabet) for _ in range(n))
+        elif mode == 1:
+            d = bytes(rng.choice(b'\\"a ') for _ in range(n))
+        elif mode == 2:
+            d = b"a" * rng.randint(0, 70) + b"\\" * rng.randint(1, 300) + rng.choice([b'"', b"x", b""]) + b'"x' * rng.randint(0, 40)
+        else:
+            d = bytes(rng.getrandbits(8) for _ in range(n))
+        _check_masks(sim, d)
