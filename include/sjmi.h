@@ -244,6 +244,30 @@ int sjmi_parser_parse_batch(sjmi_parser* p, const uint8_t* buf, uint64_t total_l
                             uint64_t n_docs, const uint64_t** tape, const uint64_t** tape_offsets,
                             const uint8_t** strings, uint64_t* strings_len, const int32_t** errors);
 
+/* ---- JsonValue (JsonValue.java:18-221) over the C ABI: the DOM view of the last parse -------------------------------
+ * A value is (document, tape index), like the reference's (tape, tapeIdx, stringBuffer) tuple (JsonValue.java:20-30);
+ * handles stay valid until the next parse / parse_batch on the parser.  Every accessor runs the C++ mirror class
+ * org_simdjson::JsonValue (csrc/host/simdjson_parser.h).  Return 0 = ok, 1 = "null" / no more elements (where Java
+ * returns null or hasNext() is false), < 0 = wrong type or bad handle (where Java would throw). */
+typedef struct sjmi_value {
+    uint64_t doc;      /* UINT64_MAX = the document of the last sjmi_parser_parse; else document index of the last batch */
+    uint64_t tape_idx;
+} sjmi_value;
+int sjmi_parser_root(const sjmi_parser* p, sjmi_value* out);                       /* TapeBuilder.createJsonValue :215-217 */
+int sjmi_parser_batch_root(const sjmi_parser* p, uint64_t doc, sjmi_value* out);   /* > 0: that document's SJMI_E_* error */
+int sjmi_value_type(const sjmi_parser* p, const sjmi_value* v);  /* '[' '{' '"' 'l' 'd' 't' 'f' 'n' (isArray() ... isString(), :32-59) */
+int sjmi_value_as_long(const sjmi_parser* p, const sjmi_value* v, int64_t* out);   /* asLong :69-71 */
+int sjmi_value_as_double(const sjmi_parser* p, const sjmi_value* v, double* out);  /* asDouble :73-75 */
+int sjmi_value_as_boolean(const sjmi_parser* p, const sjmi_value* v, int* out);    /* asBoolean :77-79 */
+/* asString :81-89: copies the UTF-8 bytes (no terminator); *len = their number even when dst_capacity is too small */
+int sjmi_value_as_string(const sjmi_parser* p, const sjmi_value* v, uint8_t* dst, uint64_t dst_capacity, uint64_t* len);
+int sjmi_value_get(const sjmi_parser* p, const sjmi_value* v, const uint8_t* name, uint64_t name_len, sjmi_value* out); /* get :91-107 */
+int sjmi_value_size(const sjmi_parser* p, const sjmi_value* v);                    /* getSize :109-111; < 0 on error */
+/* arrayIterator / objectIterator (:61-67,143-194): first element (or key), then the following one.  In an object the
+ * sequence alternates key (a string value), value, key, value ... exactly as they lie on the tape. */
+int sjmi_value_first(const sjmi_parser* p, const sjmi_value* container, sjmi_value* out);
+int sjmi_value_next(const sjmi_parser* p, const sjmi_value* container, const sjmi_value* child, sjmi_value* out);
+
 /* Optional: page-lock caller-owned host memory that is passed to the host-buffer entry points again and again
  * (SimdJsonParser's padded input, index array and string buffer): H2D / D2H copies of pinned memory skip the
  * driver's staging copy (3-4x faster for the ~1 MB transfers of a single-document parse).  Purely a performance

@@ -7,4 +7,4 @@ There is deliberately NO CPU fallback: without libsjmi.so + a GPU every call rai
 """
 from .binding import (Context, SjmiError, build, lib, lib_path, ST_CAPACITY, ST_INTERNAL, ST_UNCLOSED,  # noqa: F401
                       ST_UNESCAPED, ST_UTF8, PADDING, status_message, SimdJsonParser, JsonParsingException,
-                      ParsedDocument)
+                      ParsedDocument, JsonValue)

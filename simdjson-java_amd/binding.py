@@ -63,7 +63,10 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_stage1_batch", "sjmi_stage1_batch_device", "sjmi_parser_parse_batch",
            "sjmi_stage1_batch_isolated", "sjmi_stage1_batch_isolated_device", "sjmi_host_register",
            "sjmi_host_unregister", "sjmi_stage1_unescape", "sjmi_unescape_batch",
-           "sjmi_unescape_batch_device", "sjmi_walk_batch_device", "sjmi_stage1_masks", "sjmi_stage1_masks_device"]
+           "sjmi_unescape_batch_device", "sjmi_walk_batch_device", "sjmi_stage1_masks", "sjmi_stage1_masks_device",
+           "sjmi_parser_root", "sjmi_parser_batch_root", "sjmi_value_type", "sjmi_value_as_long", "sjmi_value_as_double",
+           "sjmi_value_as_boolean", "sjmi_value_as_string", "sjmi_value_get", "sjmi_value_size", "sjmi_value_first",
+           "sjmi_value_next"]
 
 
 def lib():
@@ -145,6 +148,16 @@ def lib():
         L.sjmi_stage1_masks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
         L.sjmi_stage1_masks_device.restype = C.c_int
         L.sjmi_stage1_masks_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
+        for name, extra in (("sjmi_parser_root", [C.c_void_p]), ("sjmi_parser_batch_root", [C.c_uint64, C.c_void_p]),
+                            ("sjmi_value_type", [C.c_void_p]), ("sjmi_value_as_long", [C.c_void_p, C.c_void_p]),
+                            ("sjmi_value_as_double", [C.c_void_p, C.c_void_p]), ("sjmi_value_as_boolean", [C.c_void_p, C.c_void_p]),
+                            ("sjmi_value_as_string", [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+                            ("sjmi_value_get", [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+                            ("sjmi_value_size", [C.c_void_p]), ("sjmi_value_first", [C.c_void_p, C.c_void_p]),
+                            ("sjmi_value_next", [C.c_void_p, C.c_void_p, C.c_void_p])):
+            f = getattr(L, name)
+            f.restype = C.c_int
+            f.argtypes = [C.c_void_p] + extra
         L.sjmi_kernel_time.restype = C.c_int
         L.sjmi_kernel_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -349,6 +362,123 @@ class JsonParsingException(Exception):
         self.position = position
 
 
+class _Value(C.Structure):
+    _fields_ = [("doc", C.c_uint64), ("tape_idx", C.c_uint64)]
+
+
+class JsonValue:
+    """org.simdjson.JsonValue (JsonValue.java:18-221) through the sjmi_value_* C ABI (which runs the C++ mirror class
+    org_simdjson::JsonValue); valid until the next parse on its parser, like the reference's."""
+
+    def __init__(self, parser, handle):
+        self._p = parser
+        self._v = handle
+
+    def _call(self, fn, *args):
+        rc = fn(self._p._h, C.byref(self._v), *args)
+        if rc < 0:
+            raise SjmiError("%s failed (rc=%d): wrong type or stale handle" % (fn.__name__, rc))
+        return rc
+
+    def type(self):
+        return chr(self._call(lib().sjmi_value_type))
+
+    def isArray(self):
+        return self.type() == "["
+
+    def isObject(self):
+        return self.type() == "{"
+
+    def isString(self):
+        return self.type() == '"'
+
+    def isLong(self):
+        return self.type() == "l"
+
+    def isDouble(self):
+        return self.type() == "d"
+
+    def isBoolean(self):
+        return self.type() in "tf"
+
+    def isNull(self):
+        return self.type() == "n"
+
+    def asLong(self):
+        out = C.c_int64(0)
+        self._call(lib().sjmi_value_as_long, C.byref(out))
+        return out.value
+
+    def asDouble(self):
+        out = C.c_double(0)
+        self._call(lib().sjmi_value_as_double, C.byref(out))
+        return out.value
+
+    def asBoolean(self):
+        out = C.c_int(0)
+        self._call(lib().sjmi_value_as_boolean, C.byref(out))
+        return bool(out.value)
+
+    def asString(self):
+        n = C.c_uint64(0)
+        buf = (C.c_uint8 * 256)()
+        rc = lib().sjmi_value_as_string(self._p._h, C.byref(self._v), buf, 256, C.byref(n))
+        if rc == -3:  # SJMI_ERR_CAPACITY: n holds the length
+            buf = (C.c_uint8 * n.value)()
+            rc = lib().sjmi_value_as_string(self._p._h, C.byref(self._v), buf, n.value, C.byref(n))
+        if rc != 0:
+            raise SjmiError("sjmi_value_as_string failed (rc=%d)" % rc)
+        return bytes(buf[:n.value]).decode("utf-8")
+
+    def get(self, name):
+        """JsonValue.get(String): the field's value or None."""
+        key = name.encode("utf-8")
+        out = _Value()
+        rc = self._call(lib().sjmi_value_get, key, len(key), C.byref(out))
+        return None if rc == 1 else JsonValue(self._p, out)
+
+    def getSize(self):
+        return self._call(lib().sjmi_value_size)
+
+    def _children(self):
+        cur = _Value()
+        rc = self._call(lib().sjmi_value_first, C.byref(cur))
+        while rc == 0:
+            yield JsonValue(self._p, cur)
+            nxt = _Value()
+            rc = lib().sjmi_value_next(self._p._h, C.byref(self._v), C.byref(cur), C.byref(nxt))
+            if rc < 0:
+                raise SjmiError("sjmi_value_next failed (rc=%d)" % rc)
+            cur = nxt
+
+    def arrayIterator(self):
+        assert self.isArray()
+        return self._children()
+
+    def objectIterator(self):
+        """-> (key str, JsonValue) pairs in document order."""
+        assert self.isObject()
+        it = self._children()
+        for k in it:
+            yield k.asString(), next(it)
+
+    def to_python(self):
+        """The whole subtree in the oracle's Parsed.to_python() notation (type tags, raw IEEE bits, UTF-8 bytes)."""
+        t = self.type()
+        if t == '"':
+            return ("s", self.asString().encode("utf-8"))
+        if t == "l":
+            return ("l", self.asLong())
+        if t == "d":
+            import struct
+            return ("d", struct.unpack("<Q", struct.pack("<d", self.asDouble()))[0])
+        if t in "tfn":
+            return (t,)
+        if t == "[":
+            return ("a", self.getSize(), [c.to_python() for c in self.arrayIterator()])
+        return ("o", self.getSize(), [(k.encode("utf-8"), v.to_python()) for k, v in self.objectIterator()])
+
+
 class ParsedDocument:
     """Tape + string buffer of one parse (views copied out of the parser)."""
 
@@ -399,6 +529,24 @@ class SimdJsonParser:
         tape = np.ctypeslib.as_array(tape_p, shape=(tape_len.value,)).copy()
         strings = bytes(np.ctypeslib.as_array(sb_p, shape=(max(sb_len.value, 1),))[:sb_len.value])
         return ParsedDocument(tape, strings)
+
+    def root(self):
+        """JsonValue of the last parse() (what SimdJsonParser.parse returns in the reference)."""
+        v = _Value()
+        rc = lib().sjmi_parser_root(self._h, C.byref(v))
+        if rc != 0:
+            raise SjmiError("sjmi_parser_root failed (rc=%d): no successful parse on this parser" % rc)
+        return JsonValue(self, v)
+
+    def batch_root(self, doc):
+        """JsonValue of document `doc` of the last parse_batch(); raises JsonParsingException with that document's code."""
+        v = _Value()
+        rc = lib().sjmi_parser_batch_root(self._h, doc, C.byref(v))
+        if rc > 0:
+            raise JsonParsingException(rc, "document %d of the batch failed with code %d" % (doc, rc))
+        if rc < 0:
+            raise SjmiError("sjmi_parser_batch_root failed (rc=%d)" % rc)
+        return JsonValue(self, v)
 
     def parse_batch(self, buffer, doc_offsets):
         """-> (list of per-document tapes (np.uint64) or None where errors[k] != 0, shared strings bytes, errors)."""

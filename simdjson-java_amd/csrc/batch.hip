@@ -64,7 +64,8 @@ template <bool WRITE>
 __global__ void __launch_bounds__(256)
 k_doc_pass(const uint8_t* __restrict__ buf, const unsigned long long* __restrict__ doc_offsets, uint64_t n_docs,
            uint32_t* __restrict__ counts, uint32_t* __restrict__ doc_status,
-           const unsigned long long* __restrict__ index_offsets, uint32_t* __restrict__ out, uint64_t out_cap) {
+           const unsigned long long* __restrict__ index_offsets, uint32_t* __restrict__ out, uint64_t out_cap,
+           sj_u64 total_len) {
     const int lane = threadIdx.x & 63;
     const int rl = lane & 15;         // lane inside the row
     const int rshift = lane & ~15;    // first lane of the row
@@ -73,10 +74,16 @@ k_doc_pass(const uint8_t* __restrict__ buf, const unsigned long long* __restrict
     for (uint64_t k0 = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 6) * 4; k0 < n_docs; k0 += nrows) {
         const uint64_t k = k0 + (uint64_t)(lane >> 4);
         bool live = k < n_docs;
+        bool bad_range = false;
         sj_u64 s = 0, len = 0, base = 0;
         if (live) {
+            // (device-resident offsets cannot be validated by the host: a non-monotonic pair or an offset past the end
+            //  becomes an empty / clipped document with SJMI_ST_INTERNAL instead of a wrapped length)
             s = doc_offsets[k];
-            len = doc_offsets[k + 1] - s;
+            const sj_u64 e = doc_offsets[k + 1];
+            bad_range = e < s || e > total_len;
+            if (s > total_len) s = total_len;
+            len = (e < s ? s : (e > total_len ? total_len : e)) - s;
             if (WRITE) {
                 live = doc_status[k] == 0;
                 base = index_offsets[k];
@@ -141,6 +148,7 @@ k_doc_pass(const uint8_t* __restrict__ buf, const unsigned long long* __restrict
 #pragma unroll
             for (int d = 8; d >= 1; d >>= 1) all |= __shfl_xor(all, d);  // (stays inside the row)
             if (parity) all |= SJMI_ST_UNCLOSED;  // :297-299
+            if (bad_range) all |= SJMI_ST_INTERNAL;
             if (rl == 0 && k < n_docs) {
                 doc_status[k] = all;
                 counts[k] = all ? 0u : (uint32_t)cnt;
@@ -222,7 +230,7 @@ k_doc_scan(unsigned long long* __restrict__ chunk_sums, uint64_t nchunks, const 
     if (threadIdx.x == 0) {
         index_offsets[n_docs] = carry;
         res->count = carry;
-        uint32_t e = *status_or & 0xFFu;
+        uint32_t e = *status_or & (0xFFu | SJMI_ST_INTERNAL);
         if (carry < out_cap) out[carry] = 0;  // BitIndexes.finish :82-96
         else e |= SJMI_ST_CAPACITY;
         res->status = e;
@@ -254,7 +262,8 @@ size_t batch_isolated_workspace_bytes(uint64_t n_docs) {
 
 hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs,
                                  uint32_t* d_out, uint64_t out_cap, unsigned long long* d_index_offsets,
-                                 uint32_t* d_doc_status, uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream) {
+                                 uint32_t* d_doc_status, uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream,
+                                 uint64_t total_len) {
     uint8_t* ws = reinterpret_cast<uint8_t*>(d_counts);
     uint32_t* status_or = reinterpret_cast<uint32_t*>(ws + iso_status_offset(n_docs));
     unsigned long long* chunk_sums = reinterpret_cast<unsigned long long*>(ws + iso_chunks_offset(n_docs));
@@ -265,7 +274,7 @@ hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long*
     const unsigned grid = (unsigned)(want < 8192 ? want : 8192);  // grid-stride over the documents
     if (n_docs) {
         hipLaunchKernelGGL(k_doc_pass<false>, dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_counts,
-                           d_doc_status, (const unsigned long long*)nullptr, (uint32_t*)nullptr, (uint64_t)0);
+                           d_doc_status, (const unsigned long long*)nullptr, (uint32_t*)nullptr, (uint64_t)0, (sj_u64)total_len);
         hipLaunchKernelGGL(k_doc_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, d_counts, d_doc_status, n_docs,
                            chunk_sums, status_or);
     }
@@ -275,7 +284,7 @@ hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long*
         hipLaunchKernelGGL(k_doc_offsets, dim3((unsigned)nchunks), dim3(1024), 0, stream, d_counts, n_docs, chunk_sums,
                            d_index_offsets);
         hipLaunchKernelGGL(k_doc_pass<true>, dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_counts,
-                           d_doc_status, (const unsigned long long*)d_index_offsets, d_out, out_cap);
+                           d_doc_status, (const unsigned long long*)d_index_offsets, d_out, out_cap, (sj_u64)total_len);
     }
     return hipGetLastError();
 }

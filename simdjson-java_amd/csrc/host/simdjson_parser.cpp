@@ -5,6 +5,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <locale.h>
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -186,7 +187,9 @@ private:
 
 SimdJsonParser::SimdJsonParser(int capacity, int maxDepth, int device)
     : capacity_(capacity), maxDepth_(maxDepth), device_(device), stringBuffer_(3 * (size_t)capacity + 256),
-      paddedBuffer_((size_t)capacity + PADDING), indexes_((size_t)capacity + 2),
+      paddedBuffer_((size_t)capacity + PADDING),
+      // (+ 2 per sub-batch of parseBatch: sub-batch j's count + sentinel may end at byteStart + byteLen + 2 j + 1)
+      indexes_((size_t)capacity + 2 + 2 * 64),
       walker_(paddedBuffer_.data(), indexes_.data(), indexes_.size(), (size_t)capacity + 8, maxDepth) {
     const int rc = sjmi_create(&ctx_, device, (uint64_t)capacity);
     if (rc != SJMI_OK) throw std::runtime_error("SimdJsonParser: no usable MI355X device (sjmi_create rc=" + std::to_string(rc) + "); there is no CPU fallback");
@@ -263,6 +266,12 @@ JsonValue SimdJsonParser::parse(const uint8_t* buffer, size_t len) {
 // buffer has unused gaps between them; tape STRING payloads are offsets into that one buffer.
 void SimdJsonParser::parseBatch(const uint8_t* buffer, size_t totalLen, const uint64_t* docOffsets, size_t nDocs) {
     if (totalLen > (size_t)capacity_) throw fail(E_CAPACITY);
+    // the offsets come across the public ABI: a non-monotonic pair or an offset past the end must be an argument
+    // error here, not a wrapped length on the device
+    if (nDocs && docOffsets[0] != 0) throw std::invalid_argument("parseBatch: doc_offsets[0] != 0");
+    for (size_t k = 0; k < nDocs; ++k)
+        if (docOffsets[k + 1] < docOffsets[k]) throw std::invalid_argument("parseBatch: doc_offsets not monotonic");
+    if (nDocs && docOffsets[nDocs] > totalLen) throw std::invalid_argument("parseBatch: doc_offsets[n] > total_len");
     // SJMI_PARSE_TIMING=1: phase times of every batch on stderr (tools/batch_e2e.py)
     static const bool timing = getenv("SJMI_PARSE_TIMING") != nullptr;
     using Clock = std::chrono::steady_clock;
@@ -495,6 +504,11 @@ static inline bool isNull(const uint8_t* b) { return b[0] == 'n' && b[1] == 'u' 
 // NumberParser.parseNumber (NumberParser.java:23-74), ExponentParser.parse (ExponentParser.java:14-69),
 // isOutOfLongRange (NumberParser.java:313-328).  Doubles: the reference's DoubleParser is a correctly rounded,
 // saturating decimal->binary64 conversion (DoubleParser.java:79-330); strtod has the same contract.
+static locale_t cLocale() {
+    static const locale_t c = newlocale(LC_ALL_MASK, "C", (locale_t)0);
+    return c;
+}
+
 void DocWalker::parseNumber(const uint8_t* p) {
     const uint8_t* start = p;
     const bool negative = *p == '-';
@@ -523,8 +537,10 @@ void DocWalker::parseNumber(const uint8_t* p) {
     }
     if (!isStructuralOrWhitespace(*p)) throw fail(E_NUM_FOLLOWED);
     if (floating) {
-        std::string text(reinterpret_cast<const char*>(start), (size_t)(p - start));
-        tape_.appendDouble(strtod(text.c_str(), nullptr));
+        // The literal is parsed in place: it is followed by a structural or whitespace byte (checked above; the buffer is
+        // padded), where the conversion stops.  strtod_l with the "C" locale, never strtod: a JVM host process calls
+        // setlocale(LC_ALL, ""), and under a comma locale strtod("1.5") stops at the '.' and returns 1.0.
+        tape_.appendDouble(strtod_l(reinterpret_cast<const char*>(start), nullptr, cLocale()));
     } else {
         bool out = false;
         if (digitCount > 19) out = true;
@@ -763,7 +779,12 @@ int sjmi_parser_parse_batch(sjmi_parser* h, const uint8_t* buf, uint64_t total_l
         return SJMI_ERR_ARG;
     h->msg.clear();
     try {
-        h->p->parseBatch(buf, (size_t)total_len, doc_offsets, (size_t)n_docs);
+        try {
+            h->p->parseBatch(buf, (size_t)total_len, doc_offsets, (size_t)n_docs);
+        } catch (const std::invalid_argument& e) {
+            h->msg = e.what();
+            return SJMI_ERR_ARG;
+        }
         *tape = h->p->batchTape();
         *tape_offsets = h->p->batchTapeOffsets().data();
         *strings = h->p->stringBuffer().data();
@@ -803,6 +824,128 @@ int sjmi_parser_parse(sjmi_parser* h, const uint8_t* buf, uint64_t len, const ui
         h->msg = e.what();
         return SJMI_ERR_HIP;
     }
+}
+
+// ---- JsonValue over the C ABI (JsonValue.java:25-111): every accessor goes through org_simdjson::JsonValue ----
+namespace {
+// the tape a value handle refers to: the last parse() (doc == UINT64_MAX) or document `doc` of the last parse_batch()
+struct ValueView {
+    std::unique_ptr<org_simdjson::Tape> view;  // a read-only view of one document of the batch tape
+    const org_simdjson::Tape* tape;
+    const uint8_t* sb;
+    ValueView(const sjmi_parser* h, uint64_t doc) : tape(nullptr), sb(h->p->stringBuffer().data()) {
+        if (doc == UINT64_MAX) {
+            tape = &h->p->tape();
+        } else if (doc < h->p->batchErrors().size() && h->p->batchErrors()[doc] == 0) {
+            const std::vector<uint64_t>& o = h->p->batchTapeOffsets();
+            view.reset(new org_simdjson::Tape(h->p->batchTape() + o[doc], (size_t)(o[doc + 1] - o[doc])));
+            tape = view.get();
+        }
+    }
+    bool ok(const sjmi_value* v) const { return tape && v && v->tape_idx >= 1 && v->tape_idx < tape->getCurrentIdx(); }
+    org_simdjson::JsonValue value(const sjmi_value* v) const { return org_simdjson::JsonValue(tape, (size_t)v->tape_idx, sb); }
+};
+}  // namespace
+
+int sjmi_parser_root(const sjmi_parser* h, sjmi_value* out) {
+    if (!h || !out || h->p->tape().getCurrentIdx() < 3) return SJMI_ERR_ARG;
+    out->doc = UINT64_MAX;
+    out->tape_idx = 1;  // TapeBuilder.createJsonValue, TapeBuilder.java:215-217
+    return SJMI_OK;
+}
+
+int sjmi_parser_batch_root(const sjmi_parser* h, uint64_t doc, sjmi_value* out) {
+    if (!h || !out || doc >= h->p->batchErrors().size()) return SJMI_ERR_ARG;
+    if (h->p->batchErrors()[doc] != 0) return h->p->batchErrors()[doc];  // > 0: that document's JSON error
+    out->doc = doc;
+    out->tape_idx = 1;
+    return SJMI_OK;
+}
+
+int sjmi_value_type(const sjmi_parser* h, const sjmi_value* v) {
+    if (!h || !v) return SJMI_ERR_ARG;
+    const ValueView vv(h, v->doc);
+    if (!vv.ok(v)) return SJMI_ERR_ARG;
+    const org_simdjson::JsonValue j = vv.value(v);
+    return j.isArray() ? '[' : j.isObject() ? '{' : j.isString() ? '"' : j.isLong() ? 'l' : j.isDouble() ? 'd'
+           : j.isNull() ? 'n' : j.isBoolean() ? (j.asBoolean() ? 't' : 'f') : SJMI_ERR_ARG;
+}
+
+int sjmi_value_as_long(const sjmi_parser* h, const sjmi_value* v, int64_t* out) {
+    if (!h || !v || !out) return SJMI_ERR_ARG;
+    const ValueView vv(h, v->doc);
+    if (!vv.ok(v) || !vv.value(v).isLong()) return SJMI_ERR_ARG;
+    *out = vv.value(v).asLong();
+    return SJMI_OK;
+}
+
+int sjmi_value_as_double(const sjmi_parser* h, const sjmi_value* v, double* out) {
+    if (!h || !v || !out) return SJMI_ERR_ARG;
+    const ValueView vv(h, v->doc);
+    if (!vv.ok(v) || !vv.value(v).isDouble()) return SJMI_ERR_ARG;
+    *out = vv.value(v).asDouble();
+    return SJMI_OK;
+}
+
+int sjmi_value_as_boolean(const sjmi_parser* h, const sjmi_value* v, int* out) {
+    if (!h || !v || !out) return SJMI_ERR_ARG;
+    const ValueView vv(h, v->doc);
+    if (!vv.ok(v) || !vv.value(v).isBoolean()) return SJMI_ERR_ARG;
+    *out = vv.value(v).asBoolean() ? 1 : 0;
+    return SJMI_OK;
+}
+
+int sjmi_value_as_string(const sjmi_parser* h, const sjmi_value* v, uint8_t* dst, uint64_t dst_capacity, uint64_t* len) {
+    if (!h || !v || !len || (!dst && dst_capacity)) return SJMI_ERR_ARG;
+    const ValueView vv(h, v->doc);
+    if (!vv.ok(v) || !vv.value(v).isString()) return SJMI_ERR_ARG;
+    const std::string s = vv.value(v).asString();
+    *len = s.size();
+    if (s.size() > dst_capacity) return SJMI_ERR_CAPACITY;
+    if (!s.empty()) memcpy(dst, s.data(), s.size());
+    return SJMI_OK;
+}
+
+int sjmi_value_get(const sjmi_parser* h, const sjmi_value* v, const uint8_t* name, uint64_t name_len, sjmi_value* out) {
+    if (!h || !v || !out || (!name && name_len)) return SJMI_ERR_ARG;
+    const ValueView vv(h, v->doc);
+    if (!vv.ok(v) || !vv.value(v).isObject()) return SJMI_ERR_ARG;
+    org_simdjson::JsonValue found(nullptr, 0, nullptr);
+    if (!vv.value(v).get(std::string(reinterpret_cast<const char*>(name), (size_t)name_len), &found)) return 1;  // Java: null
+    out->doc = v->doc;
+    out->tape_idx = found.tapeIdx();
+    return SJMI_OK;
+}
+
+int sjmi_value_size(const sjmi_parser* h, const sjmi_value* v) {
+    if (!h || !v) return SJMI_ERR_ARG;
+    const ValueView vv(h, v->doc);
+    if (!vv.ok(v) || !(vv.value(v).isArray() || vv.value(v).isObject())) return SJMI_ERR_ARG;
+    return vv.value(v).getSize();
+}
+
+int sjmi_value_first(const sjmi_parser* h, const sjmi_value* v, sjmi_value* out) {
+    if (!h || !v || !out) return SJMI_ERR_ARG;
+    const ValueView vv(h, v->doc);
+    if (!vv.ok(v) || !(vv.value(v).isArray() || vv.value(v).isObject())) return SJMI_ERR_ARG;
+    const org_simdjson::JsonValue j = vv.value(v);
+    if (j.firstChild() >= j.endChild()) return 1;  // hasNext() == false
+    out->doc = v->doc;
+    out->tape_idx = j.firstChild();
+    return SJMI_OK;
+}
+
+int sjmi_value_next(const sjmi_parser* h, const sjmi_value* container, const sjmi_value* child, sjmi_value* out) {
+    if (!h || !container || !child || !out) return SJMI_ERR_ARG;
+    const ValueView vv(h, container->doc);
+    if (!vv.ok(container) || !vv.ok(child) || child->doc != container->doc) return SJMI_ERR_ARG;
+    const org_simdjson::JsonValue j = vv.value(container);
+    if (!(j.isArray() || j.isObject()) || child->tape_idx < j.firstChild() || child->tape_idx >= j.endChild()) return SJMI_ERR_ARG;
+    const size_t nx = j.next((size_t)child->tape_idx);
+    if (nx >= j.endChild()) return 1;
+    out->doc = container->doc;
+    out->tape_idx = nx;
+    return SJMI_OK;
 }
 
 }  // extern "C"

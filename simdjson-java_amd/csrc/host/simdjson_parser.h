@@ -73,6 +73,8 @@ public:
     static constexpr char ROOT = 'r', START_ARRAY = '[', START_OBJECT = '{', END_ARRAY = ']', END_OBJECT = '}',
                           STRING = '"', INT64 = 'l', DOUBLE = 'd', TRUE_VALUE = 't', FALSE_VALUE = 'f', NULL_VALUE = 'n';
     explicit Tape(size_t capacity) : own_(capacity), tape_(own_.data()), capacity_(capacity) {}
+    // read-only view of a finished tape somewhere else (one document of batchTape()): JsonValue only reads
+    Tape(const uint64_t* words, size_t n) : tape_(const_cast<uint64_t*>(words)), capacity_(n), idx_(n) {}
     Tape(const Tape&) = delete;
     Tape& operator=(const Tape&) = delete;
     // batch: build the next document's tape in place at `at` (room for `capacity` words) instead of in own storage

@@ -199,6 +199,13 @@ int sjmi_stage1(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes
 }
 
 namespace {
+// document offsets of a batch come across the public ABI: [0] == 0 (isolated mode), monotonic, [n] <= total_len
+bool bad_offsets(sjmi_ctx* c, const uint64_t* offs, uint64_t n_docs, uint64_t total_len, bool first_is_zero) {
+    bool bad = (first_is_zero && n_docs && offs[0] != 0) || offs[n_docs] > total_len;
+    for (uint64_t k = 0; k < n_docs && !bad; ++k) bad = offs[k + 1] < offs[k];
+    if (bad) c->err = "doc_offsets must be monotonic, start at 0 and end at or before total_len";
+    return bad;
+}
 bool grow(sjmi_ctx* c, void** p, size_t* have, size_t need, const char* what) {
     if (need <= *have) return true;
     if (*p) (void)hipFree(*p);
@@ -523,6 +530,7 @@ int sjmi_stage1_batch(sjmi_ctx* c, const uint8_t* buf, uint64_t total_len, const
         c->err = "batch larger than the context capacity";
         return SJMI_ERR_CAPACITY;
     }
+    if (bad_offsets(c, doc_offsets, n_docs, total_len, false)) return SJMI_ERR_ARG;
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
     const size_t ob = (n_docs + 1) * sizeof(unsigned long long);
     if (!grow(c, (void**)&c->d_docoff, &c->docoff_bytes, 2 * ob + 64, "hipMalloc(docoff)")) return SJMI_ERR_HIP;
@@ -573,7 +581,7 @@ int sjmi_stage1_batch_isolated_device(sjmi_ctx* c, const void* d_buf, uint64_t t
     if (fail(c, "isolated batch launch",
              sjmi::batch_isolated_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs,
                                          (uint32_t*)d_indexes, index_capacity, (unsigned long long*)d_index_offsets,
-                                         (uint32_t*)d_doc_status, c->d_doccnt, (sjmi::Stage1Result*)d_result, st)))
+                                         (uint32_t*)d_doc_status, c->d_doccnt, (sjmi::Stage1Result*)d_result, st, total_len)))
         return SJMI_ERR_HIP;
     return SJMI_OK;
 }
@@ -587,6 +595,7 @@ int sjmi_stage1_batch_isolated(sjmi_ctx* c, const uint8_t* buf, uint64_t total_l
         c->err = "batch larger than the context capacity";
         return SJMI_ERR_CAPACITY;
     }
+    if (bad_offsets(c, doc_offsets, n_docs, total_len, false)) return SJMI_ERR_ARG;
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
     const size_t ob = (n_docs + 1) * sizeof(unsigned long long);
     // document offsets | index offsets | document statuses

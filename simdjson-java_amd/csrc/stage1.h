@@ -88,7 +88,7 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
                        int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream);
 hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint32_t* d_out,
                                  uint64_t out_cap, unsigned long long* d_index_offsets, uint32_t* d_doc_status,
-                                 uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream);
+                                 uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream, uint64_t total_len);
 // masks.hip: the reference's six per-block masks (6 x u64 per block, len / 64 + 1 blocks)
 size_t masks_workspace_bytes(uint64_t len);
 hipError_t masks_launch(const uint8_t* d_buf, uint64_t len, unsigned long long* d_masks, void* d_ws, hipStream_t stream);

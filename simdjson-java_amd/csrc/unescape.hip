@@ -348,7 +348,12 @@ k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __r
               UnescapeResult* res, TailClip clip) {
     // dev_count != nullptr: the structural count is still on the device (stage 1 of the same document is queued right
     // in front); the grid was sized for an upper bound, surplus workgroups leave at once
-    if (dev_count) count = dev_count->count;
+    if (dev_count) {
+        // (a stage 1 that ran out of index capacity or tripped a liveness bound left the index array incomplete:
+        //  nothing may be dereferenced; the host reports SJMI_ERR_CAPACITY / SJMI_ERR_INTERNAL from the stage-1 record)
+        if (dev_count->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL)) return;
+        count = dev_count->count;
+    }
     if ((uint64_t)blockIdx.x * (UNESC_THREADS * ITEMS) >= count) return;
     __shared__ unsigned long long s_part[UNESC_THREADS / 64];
     const int lane = threadIdx.x & 63;
@@ -456,7 +461,10 @@ k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __r
 __global__ void __launch_bounds__(1024)
 k_scan_sums(unsigned long long* __restrict__ block_sums, uint32_t nblocks, const Stage1Result* __restrict__ dev_count,
             uint32_t tile, UnescapeResult* res) {
-    if (dev_count) nblocks = (uint32_t)((dev_count->count + tile - 1) / tile);
+    if (dev_count) {
+        if (dev_count->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL)) return;  // (res stays zeroed: no records)
+        nblocks = (uint32_t)((dev_count->count + tile - 1) / tile);
+    }
     __shared__ unsigned long long s_wave[16];
     __shared__ unsigned long long s_carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -530,7 +538,10 @@ k_str_write(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __res
     __shared__ uint32_t s_wave[ITEMS][UNESC_THREADS / 64];  // bytes per (row, wave)
     __shared__ uint32_t s_cnt[ITEMS][UNESC_THREADS / 64];   // strings per (row, wave)
     __shared__ uint32_t rec_d[WSUB], rec_src[WSUB], rec_len[WSUB];
-    if (dev_count) count = dev_count->count;
+    if (dev_count) {
+        if (dev_count->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL)) return;
+        count = dev_count->count;
+    }
     const uint32_t nblocks_w = (uint32_t)((count + (uint64_t)UNESC_THREADS * ITEMS - 1) / ((uint64_t)UNESC_THREADS * ITEMS));
     if (blockIdx.x >= nblocks_w) return;
     const int lane = threadIdx.x & 63;

@@ -175,3 +175,34 @@ def test_reference_number_vectors(parser):
         else:
             got = O.Parsed(parser.parse(doc, v.get("length")).tape, b"", 0, 0, 0).to_python()
             assert got == (("l", v["long"]) if "long" in v else ("d", v["double_bits"])), (v["input"][:40], v["cite"], got)
+
+
+def test_json_value_accessors_through_the_c_abi(parser, twitter):
+    """The JsonValue the boundary advertises (sjmi_value_* -> C++ org_simdjson::JsonValue, JsonValue.java:25-111):
+    BenchmarkCorrectnessTest.java:19-42 written against it -- get("statuses").arrayIterator(), get("user"),
+    asBoolean(), asString() -> 86 users -- and whole trees rebuilt through isX / asX / getSize / iterators equal to
+    the oracle's trees (type, int64, raw double bits, UTF-8 bytes, order, size)."""
+    import simdjson_java_amd as S
+    for _ in range(2):
+        parser.parse(twitter)
+        root = parser.root()
+        assert root.isObject() and not root.isArray() and root.get("no such field") is None
+        users = set()
+        n_tweets = 0
+        for tweet in root.get("statuses").arrayIterator():
+            n_tweets += 1
+            user = tweet.get("user")
+            if user.get("default_profile").asBoolean():
+                users.add(user.get("screen_name").asString())
+        assert len(users) == V.TWITTER_DEFAULT_PROFILE_USERS and n_tweets == root.get("statuses").getSize() == 100
+        assert root.get("search_metadata").get("count").asLong() == 100
+        with pytest.raises(S.SjmiError):
+            root.get("statuses").asLong()  # wrong type: Java would throw
+    for name in ("twitter.json", "github_events.json", "wide_bench.json"):
+        doc = load_fixture(name)
+        parser.parse(doc)
+        assert parser.root().to_python() == O.parse(doc).to_python(), name
+    for text in ["[]", "{}", "[[]]", '{"a":{}}', "[1,-2,3.5,1e300,true,false,null,\"x\\u00e9\\ud83d\\ude00\",\"\"]", "7", '"s"', "null",
+                 '{"k":[{"a":1},{"b":[2,3]}],"é":"€"}']:
+        parser.parse(text.encode())
+        assert parser.root().to_python() == O.parse(text.encode()).to_python(), text

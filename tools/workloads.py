@@ -1,0 +1,67 @@
+"""Workloads of BASELINE.json `configs`, built on the device for bench.py and the full-scale GPU tests.
+
+  configs[1]  twitter.json x reps byte-concatenated (x1024 = 646,671,360 B; x6801 = 4,294,933,515 B, the north-star
+              "4 GiB concatenated twitter.json": the largest multiple that keeps uint32 indexes)
+  configs[2]  4 GiB synthetic JSON (tools/synth.py tile repeated: ~50 % string bytes, 10 % escapes, non-ASCII)
+  configs[3]  1,000,000 ~1 KB documents packed NDJSON-style (a pool of unique documents from tools/synth.small_docs,
+              repeated in order), with their u64 offsets table
+Every builder returns what a closed-form parity check needs (the oracle's result for ONE tile / ONE pool)."""
+import gzip
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.path.join(ROOT, "tools") not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+TWITTER_4G_REPS = 6801  # 6801 * 631,515 = 4,294,933,515 < 2^32 <= 6802 * 631,515
+
+
+def load_twitter():
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "data", "twitter.json.gz"), "rb") as f:
+        return f.read()
+
+
+def repeat_on_device(tile, reps, dev, pad=128):
+    """tile x reps in HBM, 16-byte aligned, `pad` zero bytes behind it -> (uint8 tensor, n)."""
+    import torch
+    n = len(tile) * reps
+    buf = torch.zeros(n + pad, dtype=torch.uint8, device=dev)
+    buf[:n] = torch.frombuffer(bytearray(tile), dtype=torch.uint8).to(dev).repeat(reps)
+    return buf, n
+
+
+def closed_form_ok(out, idx0, n0, reps, chunk=64):
+    """index[k * S + j] == k * n0 + idx0[j] for the whole uint32 array `out` (a device int32 tensor), compared on the
+    device in chunks of `chunk` copies; -> (ok, first bad copy or -1)."""
+    import torch
+    dev = out.device
+    s = idx0.size
+    base = torch.from_numpy(idx0.astype(np.int64)).to(dev)
+    for k0 in range(0, reps, chunk):
+        k1 = min(reps, k0 + chunk)
+        want = (base[None, :] + (torch.arange(k0, k1, device=dev, dtype=torch.int64) * n0)[:, None]).flatten()
+        got = out[k0 * s:k1 * s].to(torch.int64) & 0xFFFFFFFF
+        if not torch.equal(got, want):
+            return False, k0
+    return True, -1
+
+
+def synth_tile(target_bytes=4 << 20):
+    import synth
+    return synth.synth_tile(target_bytes=target_bytes)
+
+
+def small_doc_pool(unique=4000, same_schema=False):
+    """-> (list of documents, unit = the pool packed with one '\\n' behind each document, lens incl. the separator)"""
+    import synth
+    docs = synth.small_docs(n=unique, same_schema=same_schema)
+    unit = b"".join(d + b"\n" for d in docs)
+    lens = np.array([len(d) + 1 for d in docs], dtype=np.uint64)
+    return docs, unit, lens
+
+
+def batch_offsets(lens, reps):
+    return np.concatenate([[0], np.cumsum(np.tile(lens, reps))]).astype(np.uint64)
