@@ -1,39 +1,63 @@
 #!/usr/bin/env python
-"""bench.py -- stage-1 throughput of the MI355X engine on BASELINE.json's metric.
+"""bench.py -- the MI355X engine on BASELINE.json's metrics.
 
-One "step" = one full pass of the hot path (fused UTF-8 validation + structural indexing + index
-compaction, i.e. SimdJsonParser.stage1) over one batch of input that is already resident in HBM:
-twitter.json x 1024 byte-concatenated (646,671,360 B; BASELINE.json configs[1]).  With --gpus N the
-batch is sharded by document (every rank scans its own 1024 copies: weak scaling) and RCCL is used
-only to all-gather the per-shard {count, status} records, as north_star prescribes.
+--gpus 1 (default; the driver's BENCH line)
+    One "step" = one pass of the hot path (fused UTF-8 validation + structural indexing + index compaction, i.e.
+    SimdJsonParser.stage1) over the north-star workload, resident in HBM: twitter.json x 6801 byte-concatenated =
+    4,294,933,515 B ("4 GiB concatenated twitter.json"), checked bit-exactly against the oracle's closed form on the
+    device before anything is timed.  `value` = GB/s of JSON over the K timed steps.  The `roofline` object is about
+    the dominant kernel (k_stage1) and gives BOTH its cold time (the first K launches after the GPU sat idle) and its
+    clock-settled time (`frac` is the settled one; `cold` holds the other).  `extra` carries the other configs of
+    BASELINE.json measured in the same run, each with its own roofline block: configs[1] (twitter x1024), configs[2]
+    (4 GiB synthetic), the string-unescape path on twitter x1024, and configs[3] (1,000,000 ~1 KB documents: isolated
+    stage 1 -> string records -> GPU walk) in documents/s, kernel-only and including the H2D copy.
+--gpus N > 1 (the driver's SCALE lines; launched with torch.distributed.run, one rank per GPU)
+    The batched path, as north_star states it: the 1,000,000-document configs[3] set is sharded by document
+    (sharding.partition_documents: contiguous, byte-balanced), every rank runs sjmi_parse_batch_device on its shard
+    (isolated stage 1 -> string records -> GPU walk, no host round trip), and RCCL is used ONLY for the all_gather of
+    the per-shard counts.  `value` = documents/s of the whole job, "scaling": "strong" (the total is fixed).  Rank 0
+    then runs the whole set alone in the same process: `single_gpu_same_run` is the N=1 figure this N is to be
+    compared with (the --gpus 1 line reports the same figure as extra.batch_1m_docs.value).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel (k_stage1) vs the 8 TB/s HBM peak, timed with HIP events attached to
-                  the kernel's dispatch on its launch stream (sjmi_set_profiling)
-  cpu_baseline -- the C oracle (a port of the reference's Java stage 1) on all host cores, on a
-                  bounded sample of the same workload
-"""
+Prints ONE JSON line on rank 0.  cpu_baseline (N=1 only) = the AVX-512 restatement of the reference's two stage-1
+passes (oracle/sj_avx512.c) on 1 core and on all host cores; the reference itself is Java and needs a JVM, which is
+probed for and reported."""
 import argparse
-import gzip
 import json
 import os
+import shutil
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-
-
-def load_twitter():
-    with gzip.open(os.path.join(ROOT, "tests", "golden", "data", "twitter.json.gz"), "rb") as f:
-        return f.read()
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable)
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r2")
 
 
-def cpu_baseline(doc, seconds=10.0):
-    """Oracle (C port of StructuralIndexer.index512 + Utf8Validator.validate) on ALL host cores: one thread per core,
-    each scanning its own copy of the sample (the C call releases the GIL); plus the single-core rate for reference."""
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ---------------------------------------------------------------------------------------------------------------
+def probe_java():
+    """Is a JDK that could run the reference (JDK >= 24 with jdk.incubator.vector) on this box?  (The reference's sources
+    are not on the GPU box in any case: /root/reference exists only in the build container.)"""
+    exe = shutil.which("java")
+    if not exe:
+        return "no java on PATH"
+    try:
+        out = subprocess.run([exe, "-version"], capture_output=True, text=True, timeout=20)
+        return "java present: " + (out.stderr or out.stdout).splitlines()[0]
+    except Exception as e:  # noqa: BLE001
+        return "java probe failed: %r" % (e,)
+
+
+def cpu_baseline(doc, seconds=8.0):
+    """The reference's stage 1 (Utf8Validator.validate + StructuralIndexer.index at 512 bits) restated with AVX-512
+    intrinsics (oracle/sj_avx512.c), one thread per host core, each over its own copy of twitter.json x16; plus one core
+    alone, plus the scalar port for scale.  The C calls release the GIL."""
     import threading
     import numpy as np
     from oracle import oracle
@@ -41,20 +65,33 @@ def cpu_baseline(doc, seconds=10.0):
     reps = 16
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     base = np.frombuffer(doc * reps, dtype=np.uint8)
-    oracle.stage1(base)  # warm
-    t0 = time.perf_counter()
-    n1 = 0
-    while time.perf_counter() - t0 < 2.0:  # single core
-        oracle.stage1(base)
-        n1 += base.size
-    one = n1 / (time.perf_counter() - t0) / 1e9
+    avx = oracle.avx512_supported()
+
+    def make_fn():
+        if avx:
+            out = np.empty(base.size + 128, dtype=np.uint32)
+            return lambda a: oracle.stage1_avx512(a, out=out)
+        return lambda a: oracle.stage1(a)
+
+    def one_core(fn, secs):
+        fn(base)
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < secs:
+            fn(base)
+            n += base.size
+        return n / (time.perf_counter() - t0) / 1e9
+
+    one = one_core(make_fn(), 1.5)
+    scalar_one = one_core(lambda a: oracle.stage1(a), 1.0) if avx else one
     samples = [base.copy() for _ in range(cores)]
+    fns = [make_fn() for _ in range(cores)]
     done = [0] * cores
     stop = time.perf_counter() + seconds
 
     def work(k):
         while time.perf_counter() < stop:
-            oracle.stage1(samples[k])
+            fns[k](samples[k])
             done[k] += samples[k].size
 
     t0 = time.perf_counter()
@@ -65,143 +102,419 @@ def cpu_baseline(doc, seconds=10.0):
         t.join()
     el = time.perf_counter() - t0
     total = sum(done)
-    return {"value": round(total / el / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "port",
-            "sample": "twitter.json x%d (%d B) per thread, %d threads, %d scans in %.1f s by oracle/sj_oracle.c (scalar C "
-                      "restatement of the reference's Java stage 1; the reference itself needs a JVM, absent here); one "
-                      "core alone: %.3f GB/s" % (reps, base.size, cores, total // base.size, el, one)}
+    what = ("oracle/sj_avx512.c (AVX-512 restatement of the reference's 512-bit Java Vector-API stage 1: vpcmpb/kmov classes, "
+            "vpshufb nibble tables, two passes like SimdJsonParser.stage1)" if avx else
+            "oracle/sj_oracle.c (scalar C port; this host CPU has no AVX-512)")
+    return {"value": round(total / el / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+            "one_core": round(one, 3), "scalar_port_one_core": round(scalar_one, 3),
+            "sample": "twitter.json x%d (%d B) per thread, %d threads, %d scans in %.1f s by %s; the reference itself needs a "
+                      "JVM: %s" % (reps, base.size, cores, total // base.size, el, what, probe_java())}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------------------------------
+def roofline(alg_bytes, ms, input_bytes, kernel, launches, traffic=None, **more):
+    """`achieved` follows SURVEY.md 8(d): input bytes (read once) per kernel second; the traffic form (all algorithmic
+    bytes: input + outputs written once) is given beside it."""
+    s = ms / 1e3
+    r = {"bound": "hbm", "achieved": round(input_bytes / s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(input_bytes / s / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
+         "avg_kernel_ms": round(ms, 4), "launches": launches, "algorithmic_bytes_per_launch": int(alg_bytes),
+         "achieved_all_algorithmic_bytes": round(alg_bytes / s / 1e9, 2),
+         "frac_all_algorithmic_bytes": round(alg_bytes / s / 1e9 / HBM_PEAK_GBS, 4)}
+    r.update(more)
+    return r
+
+
+def pmc_traffic(key):
+    """HBM bytes per launch from the committed PMC passes of this round (rocprofv3 cannot run inside the timed region)."""
+    try:
+        with open(os.path.join(PROFILE_DIR, "pmc_summary.json")) as f:
+            return int(json.load(f)[key]["hbm_traffic_bytes_per_launch"]["total"])
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
+class Stage1Runner:
+    """k_stage1 over one resident buffer through the C ABI, timed with HIP events attached to the dispatch."""
+
+    def __init__(self, torch, S, dev, work, buf, n, s_total):
+        self.torch, self.work, self.buf, self.n = torch, work, buf, n
+        self.cap = s_total + 1
+        self.out = torch.empty(self.cap, dtype=torch.int32, device=dev)
+        self.res = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.ctx = S.Context(device=dev.index, capacity=1 << 20)
+
+    def launch(self, k=1):
+        for _ in range(k):
+            self.ctx.stage1_device(self.buf.data_ptr(), self.n, self.out.data_ptr(), self.cap, self.res.data_ptr(),
+                                   self.work.cuda_stream)
+
+    def kernel_ms(self, k):
+        """average kernel time of k launches (HIP events on the launch stream)"""
+        self.ctx.set_profiling(True)
+        self.launch(k)
+        self.torch.cuda.synchronize()
+        ms, launches = self.ctx.kernel_time()
+        self.ctx.set_profiling(False)
+        return ms / max(launches, 1)
+
+    def cold_and_settled(self, steps, settle_ms=60.0):
+        """cold: the first `steps` launches after the GPU idled for 0.6 s; settled: `steps` launches after at least
+        settle_ms of back-to-back launches (the clock governor needs ~25 ms of this kernel, tools/perlaunch.py)."""
+        self.torch.cuda.synchronize()
+        time.sleep(0.6)
+        cold = self.kernel_ms(steps)
+        self.launch(max(steps, int(settle_ms / max(cold, 1e-3)) + 1))
+        settled = self.kernel_ms(steps)
+        return cold, settled
+
+    def status(self):
+        r = self.res.cpu().numpy()
+        return int(r[0]), int(r[1]) & 0xFFFFFFFF
+
+
+def wall_steps(torch, fn, steps, dist=None):
+    """K steps bracketed by barrier + synchronize on both sides -> seconds (max over ranks)."""
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return el
+
+
+def make_batch_shard(torch, S, W, dev, ctx, lo, hi, docs_unit, lens, reps):
+    """documents [lo, hi) of the configs[3] set (pool x reps) as a BatchShard on `dev`"""
+    import numpy as np
+    from simdjson_java_amd import sharding
+    offs = W.batch_offsets(lens, reps)
+    a, b = int(offs[lo]), int(offs[hi])
+    full, _ = W.repeat_on_device(docs_unit, reps, dev, pad=0)
+    shard_bytes = full[a:b].clone()
+    del full
+    local = (offs[lo:hi + 1] - offs[lo]).astype(np.uint64)
+    # (this set: 5.4 B per structural, 0.84 string-buffer bytes and 0.13 tape words per input byte)
+    return sharding.BatchShard(ctx, shard_bytes, local, dev, index_ratio=4, string_ratio=1.0, tape_ratio=0.2)
+
+
+def batch_algorithmic_bytes(n, c):
+    """input read once + uint32 indexes + string records + tape words, each written once"""
+    return n + 4 * c["structurals"] + c["string_bytes"] + 8 * c["tape_words"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# N = 1
+# ---------------------------------------------------------------------------------------------------------------
+def bench_single(args):
+    import numpy as np
+    import torch
+    import simdjson_java_amd as S
+    import workloads as W
+    from oracle import oracle  # checker only (closed forms of ONE tile) + the cpu_baseline leg
+
+    oracle.build()
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    work = torch.cuda.Stream(device=dev)
+    work.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(work)  # one explicit stream for everything: kernels, torch ops, events
+
+    doc = W.load_twitter()
+    n0 = len(doc)
+    idx0, st0 = oracle.stage1(doc)
+    assert st0 == 0 and idx0.size == 55263
+    reps = args.reps
+    buf, n = W.repeat_on_device(doc, reps, dev)
+    assert n < (1 << 32)
+    s_total = idx0.size * reps
+    r1 = Stage1Runner(torch, S, dev, work, buf, n, s_total)
+    assert r1.ctx.selftest() == 0
+    if args.tile_steps:
+        r1.ctx.set_tile_steps(args.tile_steps)
+    # ---- parity, outside every timed region: the whole uint32 index array against the closed form ----
+    r1.launch()
+    torch.cuda.synchronize()
+    cnt, st = r1.status()
+    assert cnt == s_total and st == 0, (cnt, st)
+    ok, bad = W.closed_form_ok(r1.out, idx0, n0, reps)
+    assert ok, "GPU indexes differ from the oracle's closed form (copies %d..)" % bad
+    assert int(r1.out[s_total].item()) == 0
+    # ---- the dominant kernel, cold and settled ----
+    cold_ms, settled_ms = r1.cold_and_settled(args.steps)
+    # ---- the contract's timed region: W warmup steps, then exactly K steps ----
+    r1.launch(args.warmup + args.preheat)
+    r1.ctx.set_profiling(True)
+    elapsed = wall_steps(torch, r1.launch, args.steps)
+    kern_ms, launches = r1.ctx.kernel_time()
+    r1.ctx.set_profiling(False)
+    timed_kernel_ms = kern_ms / max(launches, 1)
+    cnt, st = r1.status()
+    assert cnt == s_total and st == 0
+    alg = n + 4 * (s_total + 1)
+    name = "twitter.json x%d" % reps
+    line = {
+        "metric": "GB/s JSON scanned (stage-1)", "value": round(n * args.steps / elapsed / 1e9, 2), "unit": "GB/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic: twitter.json (631,515 B reference fixture) x%d byte-concatenated (%d B), resident in HBM" % (reps, n),
+        "config": {"workload": "%s concatenated (north-star '4 GiB concatenated twitter.json'): stage-1 = UTF-8 validation + "
+                               "structural indexing + uint32 index compaction, one fused single-pass kernel; the full index "
+                               "array is checked against the oracle's closed form on the device before timing" % name,
+                   "bytes_per_gpu": n, "structurals_per_gpu": s_total, "tile_steps": args.tile_steps or "auto",
+                   "preheat_launches": args.preheat, "sharding": "none"},
+        "roofline": roofline(alg, timed_kernel_ms, n, "k_stage1", launches, traffic=pmc_traffic("stage1_twitter_4g") if reps == W.TWITTER_4G_REPS else None,
+                             timed_region="the K timed steps (after W warmup + preheat_launches untimed steps)",
+                             settled={"avg_kernel_ms": round(settled_ms, 4), "frac": round(n / settled_ms / 1e6 / HBM_PEAK_GBS, 4),
+                                      "protocol": "K launches after >= 60 ms of back-to-back launches"},
+                             cold={"avg_kernel_ms": round(cold_ms, 4), "frac": round(n / cold_ms / 1e6 / HBM_PEAK_GBS, 4),
+                                   "protocol": "the first K launches after the GPU idled 0.6 s, no warmup at all"}),
+    }
+    extra = {}
+    if not args.no_extras:
+        # ---- configs[1]: twitter x1024 = the first 1024 copies of the same buffer (bytes >= len are invisible) ----
+        reps1 = min(1024, reps)
+        n1, s1 = n0 * reps1, idx0.size * reps1
+        ra = Stage1Runner(torch, S, dev, work, buf, n1, s1)
+        ra.launch()
+        torch.cuda.synchronize()
+        assert ra.status() == (s1, 0)
+        ok, bad = W.closed_form_ok(ra.out, idx0, n0, reps1)
+        assert ok
+        c1, s1ms = ra.cold_and_settled(max(args.steps, 50))
+        extra["stage1_twitter_x1024"] = {
+            "config": "configs[1]: twitter.json x%d (%d B), stage 1, bit-exact index check" % (reps1, n1),
+            "value": round(n1 / s1ms / 1e6, 2), "unit": "GB/s",
+            "roofline": roofline(n1 + 4 * (s1 + 1), s1ms, n1, "k_stage1", max(args.steps, 50), traffic=pmc_traffic("stage1_twitter_x1024"),
+                                 cold={"avg_kernel_ms": round(c1, 4), "frac": round(n1 / c1 / 1e6 / HBM_PEAK_GBS, 4)})}
+        # ---- string unescape (StringParser.parseString for every string) on twitter x1024 ----
+        _, _, masks = oracle.index_blocks(doc, want_masks=True)
+        n_str0 = int((np.frombuffer(doc, dtype=np.uint8)[idx0] == 0x22).sum())
+        raw0 = int(sum(bin(int(x)).count("1") for x in masks[:, 2])) + n_str0  # bytes inside quotes + both quotes
+        want_sb, _, feo, _ = oracle.unescape_all(doc + b"\0" * 64, idx0)
+        assert feo < 0
+        sb_cap = n1 + 4 * (s1 + 1) + 64
+        sb = torch.empty(sb_cap, dtype=torch.uint8, device=dev)
+        ures = torch.zeros(3, dtype=torch.int64, device=dev)
+
+        def unescape():
+            ra.ctx.unescape_device(buf.data_ptr(), n1, ra.out.data_ptr(), s1, sb.data_ptr(), sb_cap, ures.data_ptr(), work.cuda_stream)
+
+        unescape()
+        torch.cuda.synchronize()
+        u = ures.cpu().numpy()
+        assert int(u[0]) == len(want_sb) * reps1 and int(u[1]) == 0, u
+        sbv = sb[:len(want_sb) * reps1].view(reps1, len(want_sb))
+        assert torch.equal(sbv[0].cpu(), torch.frombuffer(bytearray(want_sb), dtype=torch.uint8)), "string buffer differs from the oracle's"
+        assert torch.equal(sbv, sbv[:1].expand(reps1, len(want_sb)))
+        for _ in range(20):
+            unescape()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            unescape()
+        e1.record()
+        torch.cuda.synchronize()
+        ums = e0.elapsed_time(e1) / 20
+        ualg = reps1 * (raw0 + 4 * n_str0 + len(want_sb))
+        extra["unescape_twitter_x1024"] = {
+            "config": "StringParser.parseString for all %d strings of twitter.json x%d: [be32 length][unescaped bytes] records, "
+                      "byte-identical to the oracle's string buffer" % (n_str0 * reps1, reps1),
+            "value": round(n1 / ums / 1e6, 2), "unit": "GB/s of document",
+            "roofline": {"bound": "hbm", "achieved": round(ualg / ums / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ualg / ums / 1e6 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("unescape_twitter_x1024"),
+                         "kernel": "k_str_measure + k_scan_sums + k_str_write", "avg_ms_per_call": round(ums, 4),
+                         "algorithmic_bytes_per_launch": ualg,
+                         "algorithmic_bytes": "string bytes incl. quotes read (%d) + 4 B index word per string + records written (%d), per copy"
+                                              % (raw0, len(want_sb))}}
+        del sb, ra
+        # ---- configs[2]: 4 GiB synthetic ----
+        tile = W.synth_tile()
+        tidx, tst = oracle.stage1(tile)
+        assert tst == 0
+        treps = (1 << 32) // len(tile) - 1
+        tbuf, tn = W.repeat_on_device(tile, treps, dev)
+        rs = Stage1Runner(torch, S, dev, work, tbuf, tn, tidx.size * treps)
+        rs.launch()
+        torch.cuda.synchronize()
+        assert rs.status() == (tidx.size * treps, 0)
+        ok, bad = W.closed_form_ok(rs.out, tidx, len(tile), treps)
+        assert ok
+        c2, s2 = rs.cold_and_settled(args.steps)
+        extra["stage1_synthetic_4g"] = {
+            "config": "configs[2]: 4 GiB synthetic JSON (tools/synth.py 4 MiB tile x%d = %d B; ~50 %% string bytes, 10 %% escapes, "
+                      "10 %% non-ASCII), stage 1 + UTF-8 validation, closed-form index check" % (treps, tn),
+            "value": round(tn / s2 / 1e6, 2), "unit": "GB/s",
+            "roofline": roofline(tn + 4 * (tidx.size * treps + 1), s2, tn, "k_stage1", args.steps, traffic=pmc_traffic("stage1_synthetic_4g"),
+                                 cold={"avg_kernel_ms": round(c2, 4), "frac": round(tn / c2 / 1e6 / HBM_PEAK_GBS, 4)})}
+        del tbuf, rs
+        # ---- configs[3] on ONE GPU: the batched path, 1,000,000 documents ----
+        extra["batch_1m_docs"] = batch_single_gpu(torch, S, W, dev, work, args)
+    line["extra"] = extra
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(doc)
+    print(json.dumps(line))
+    r1.ctx.close()
+
+
+def batch_single_gpu(torch, S, W, dev, work, args, with_h2d=True):
+    docs, unit, lens = W.small_doc_pool(args.pool)
+    reps = max(1, args.docs // len(docs))
+    n_docs = len(docs) * reps
+    ctx = S.Context(device=dev.index, capacity=1 << 20)
+    shard = make_batch_shard(torch, S, W, dev, ctx, 0, n_docs, unit, lens, reps)
+    st = work.cuda_stream
+    for _ in range(3):
+        shard.step(st)
+    torch.cuda.synchronize()
+    c = shard.check()
+    assert c["failed_documents"] == 0 and c["host_documents"] == 0 and c["stage1_status"] == 0, c
+    el = wall_steps(torch, lambda: shard.step(st), args.batch_steps)
+    ms = el / args.batch_steps * 1e3
+    alg = batch_algorithmic_bytes(shard.n, c)
+    out = {"config": "configs[3] on one GPU: %d documents (%d unique ~1 KB documents x%d, %d B), device-resident: isolated stage 1 "
+                     "(per-document verdicts) -> string records -> GPU walk (tapes), sjmi_parse_batch_device" % (n_docs, len(docs), reps, shard.n),
+           "value": round(n_docs / (ms / 1e3), 1), "unit": "docs/s", "ms_per_batch": round(ms, 3), "counts": c,
+           "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("batch_1m_docs"),
+                        "kernel": "k_doc_pass x2 + k_str_measure + k_str_write + k_doc_walk + k_tape_compact (+ small scans)",
+                        "algorithmic_bytes_per_launch": alg,
+                        "algorithmic_bytes": "input read once + uint32 indexes + string records + tape words written once"}}
+    if with_h2d:
+        host = torch.empty(shard.n, dtype=torch.uint8).pin_memory()
+        host.copy_(shard.buf[:shard.n])
+
+        def step_h2d():
+            shard.buf[:shard.n].copy_(host, non_blocking=True)
+            shard.step(st)
+
+        step_h2d()
+        el = wall_steps(torch, step_h2d, max(3, args.batch_steps // 2))
+        ms2 = el / max(3, args.batch_steps // 2) * 1e3
+        out["incl_h2d"] = {"value": round(n_docs / (ms2 / 1e3), 1), "unit": "docs/s", "ms_per_batch": round(ms2, 3),
+                           "note": "pinned host buffer -> HBM copy of the batch inside every step (outputs stay on the device)"}
+    ctx.close()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# N > 1: the sharded batch
+# ---------------------------------------------------------------------------------------------------------------
+def bench_sharded(args, world):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import simdjson_java_amd as S
+    from simdjson_java_amd import sharding
+    import workloads as W
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # (test hook: SJMI_BENCH_BACKEND=gloo runs the ranks on whatever GPUs exist, e.g. two ranks on the one GPU of a test box)
+    backend = os.environ.get("SJMI_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+    work = torch.cuda.Stream(device=dev)
+    work.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(work)
+
+    docs, unit, lens = W.small_doc_pool(args.pool)  # (seeded: every rank builds the same pool)
+    reps = max(1, args.docs // len(docs))
+    n_docs = len(docs) * reps
+    offs = W.batch_offsets(lens, reps)
+    lo, hi = sharding.partition_documents(offs, world)[rank]
+    ctx = S.Context(device=dev.index, capacity=1 << 20)
+    shard = make_batch_shard(torch, S, W, dev, ctx, lo, hi, unit, lens, reps)
+    st = work.cuda_stream
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        gathered = sharding.sharded_step(shard, st)  # kernels of the shard + the count gather (the only collective)
+
+    for _ in range(max(args.warmup, 3)):
+        step()
+    torch.cuda.synchronize()
+    c = shard.check()
+    assert c["failed_documents"] == 0 and c["host_documents"] == 0 and c["stage1_status"] == 0, c
+    elapsed = wall_steps(torch, step, args.steps, dist)
+    g = gathered.cpu().numpy()
+    assert int(g[:, 0].sum()) == n_docs
+    # parity property at full size: the gathered totals must equal those of the whole set run on one GPU (below); the
+    # per-document parity of the same pool against the oracle is tests/test_gpu_fullscale.py
+    single = None
+    if rank == 0:
+        res = batch_single_gpu(torch, S, W, dev, work, args, with_h2d=False)
+        single = {"value": res["value"], "unit": "docs/s", "ms_per_batch": res["ms_per_batch"], "counts": res["counts"]}
+        assert int(g[:, 1].sum()) == res["counts"]["structurals"] and int(g[:, 2].sum()) == res["counts"]["string_bytes"], \
+            "sharded totals differ from the single-GPU run of the same set"
+    dist.barrier()
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = n_docs * args.steps / elapsed
+        total_bytes = int(offs[-1])
+        line = {
+            "metric": "docs/s end-to-end (batched, sharded by document)", "value": round(value, 1), "unit": "docs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 3), "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic: %d ~1 KB JSON documents (%d unique x%d, tools/synth.py seed 20250825), %d B, resident in HBM, "
+                    "sharded over %d GPUs" % (n_docs, len(docs), reps, total_bytes, world),
+            "config": {"workload": "configs[3]: 1M small JSON documents batched across the GPUs: per rank isolated stage 1 -> string "
+                                   "records -> GPU walk on its contiguous byte-balanced shard (sjmi_parse_batch_device), then ONE RCCL "
+                                   "all_gather of 4 x int64 per rank (the count gather) per step",
+                       "documents": n_docs, "bytes": total_bytes, "documents_per_rank": [int(x) for x in g[:, 0]],
+                       "structurals_per_rank": [int(x) for x in g[:, 1]], "sharding": "by document, contiguous, byte-balanced",
+                       "collective": "all_gather_into_tensor of {docs, structurals, string bytes, failed docs} per rank"},
+            "single_gpu_same_run": single,
+            "speedup_vs_single_gpu_same_run": round(value / single["value"], 3) if single else None,
+            "roofline": {"bound": "hbm", "achieved": round(batch_algorithmic_bytes(total_bytes, {"structurals": int(g[:, 1].sum()),
+                         "string_bytes": int(g[:, 2].sum()), "tape_words": single["counts"]["tape_words"]}) / ms / 1e6, 2),
+                         "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": None, "traffic": None,
+                         "kernel": "batched path, all ranks", "note": "aggregate algorithmic bytes per second over all ranks vs N x 8 TB/s"},
+        }
+        line["roofline"]["frac"] = round(line["roofline"]["achieved"] / (HBM_PEAK_GBS * world), 4)
+        print(json.dumps(line))
+    ctx.close()
+    dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--preheat", type=int, default=400,
-                    help="untimed launches before the warmup steps: the GPU's clock governor needs ~100 back-to-back "
-                         "launches (25 ms) of this kernel to settle (per-launch times: tools/perlaunch.py)")
-    ap.add_argument("--reps", type=int, default=1024, help="copies of twitter.json per GPU (1024 = configs[1])")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--preheat", type=int, default=40,
+                    help="N=1: further untimed launches before the timed steps (the clock governor needs ~25 ms of back-to-back "
+                         "launches to settle; the cold figure is reported beside the settled one in `roofline`)")
+    ap.add_argument("--reps", type=int, default=6801, help="N=1: copies of twitter.json (6801 = 4 GiB north-star, 1024 = configs[1])")
     ap.add_argument("--tile-steps", type=int, default=0, help="force the chain granule = N x 4 KiB: 1, 2 or 4 (0 = auto)")
+    ap.add_argument("--docs", type=int, default=1000000, help="documents of the configs[3] batch")
+    ap.add_argument("--pool", type=int, default=4000, help="unique documents of the configs[3] batch")
+    ap.add_argument("--batch-steps", type=int, default=10, help="N=1: timed steps of the configs[3] extra")
+    ap.add_argument("--no-extras", action="store_true", help="N=1: only the primary workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
-
-    import numpy as np
-    import torch
-    import simdjson_java_amd as S
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         print("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus), file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dist = None
     if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    doc = load_twitter()
-    n0 = len(doc)
-    reps = args.reps
-    n = n0 * reps
-    assert n < (1 << 32)
-    from oracle import oracle  # checker only: expected indexes of ONE copy
-    oracle.build()
-    idx0, st0 = oracle.stage1(doc)
-    s_total = idx0.size * reps
-
-    dev = torch.device("cuda", local_rank)
-    buf = torch.zeros(n + 128, dtype=torch.uint8, device=dev)
-    buf[:n] = torch.frombuffer(bytearray(doc), dtype=torch.uint8).to(dev).repeat(reps)
-    cap = s_total + 1
-    out = torch.empty(cap, dtype=torch.int32, device=dev)
-    res = torch.zeros(2, dtype=torch.int64, device=dev)
-    gathered = torch.zeros(2 * world, dtype=torch.int64, device=dev) if world > 1 else None
-
-    ctx = S.Context(device=local_rank, capacity=1 << 20)
-    if args.tile_steps:
-        ctx.set_tile_steps(args.tile_steps)
-    assert ctx.selftest() == 0
-    # one explicit (non-default) stream for kernels, copies and the collective, so that everything is ordered
-    work = torch.cuda.Stream(device=dev)
-    work.wait_stream(torch.cuda.current_stream())
-    stream = work.cuda_stream
-
-    def step():
-        with torch.cuda.stream(work):
-            ctx.stage1_device(buf.data_ptr(), n, out.data_ptr(), cap, res.data_ptr(), stream)
-            if world > 1:
-                dist.all_gather_into_tensor(gathered, res)  # per-shard {count, status}: the only collective
-
-    step()
-    torch.cuda.synchronize()
-    # parity check outside the timed region: closed form index[k*S+j] = k*N0 + index0[j]
-    r = res.cpu().numpy()
-    assert int(r[0]) == s_total and (int(r[1]) & 0xFFFFFFFF) == 0, r
-    want = (torch.from_numpy(idx0.astype(np.int64)).to(dev)[None, :] +
-            (torch.arange(reps, device=dev, dtype=torch.int64) * n0)[:, None]).flatten()
-    got = out[:s_total].to(torch.int64) & 0xFFFFFFFF
-    assert torch.equal(got, want), "GPU indexes differ from the oracle's closed form"
-    assert int(out[s_total].item()) == 0
-    del want, got
-
-    for _ in range(args.preheat + args.warmup):  # untimed
-        step()
-    ctx.set_profiling(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kern_ms, launches = ctx.kernel_time()
-    ctx.set_profiling(False)
-
-    if rank == 0:
-        # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside
-        # the timed region): profiles/r1/pmc_summary.json, FETCH_SIZE doubled per the gfx950 note. null if absent
-        # or if the workload differs from the profiled one.
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")) as f:
-                if reps == 1024:
-                    traffic = int(json.load(f)["hbm_traffic_bytes_per_launch"]["total"])
-        except (OSError, KeyError, ValueError):
-            traffic = None
-        ms_per_step = elapsed / args.steps * 1e3
-        value = n * world * args.steps / elapsed / 1e9
-        avg_kernel_s = kern_ms / max(launches, 1) / 1e3
-        achieved = n / avg_kernel_s / 1e9
-        line = {
-            "metric": "GB/s JSON scanned (stage-1)", "value": round(value, 2), "unit": "GB/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
-            "data": "synthetic: twitter.json (631,515 B reference fixture) x%d byte-concatenated per GPU, resident in HBM" % reps,
-            "config": {"workload": "twitter.json x%d concatenated: stage-1 = UTF-8 validation + structural indexing + "
-                                   "uint32 index compaction, one fused single-pass kernel, bit-exact index check" % reps,
-                       "bytes_per_gpu": n, "structurals_per_gpu": s_total, "tile_steps": args.tile_steps or "auto",
-                       "preheat_launches": args.preheat,
-                       "sharding": "by document, RCCL all_gather of per-shard {count,status} only" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_stage1", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
-                         "algorithmic_bytes_per_launch": n,
-                         "achieved_incl_index_writes": round((n + 4 * (s_total + 1)) / avg_kernel_s / 1e9, 2)},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(doc)
-        print(json.dumps(line))
-    ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+        bench_sharded(args, world)
+    else:
+        bench_single(args)
 
 
 if __name__ == "__main__":

@@ -222,6 +222,22 @@ int sjmi_walk_batch_device(sjmi_ctx* ctx, const void* d_buf, const void* d_doc_o
                            int max_depth, void* d_tape, uint64_t tape_capacity, void* d_tape_offsets, void* d_doc_errors,
                            void* d_result, void* stream);
 
+/* The whole batched parse, device-resident, in ONE call and without a host round trip between the stages:
+ * sjmi_stage1_batch_isolated_device -> sjmi_unescape_batch_device -> sjmi_walk_batch_device (string_base 0), the
+ * structural count handed from stage to stage on the device.  Outputs as documented for the three calls; index_capacity
+ * bounds the structural count (+ sentinel) and sizes the workspaces.  d_result: a device sjmi_batch_result.  This is
+ * what one rank of the sharded multi-GPU batch runs per step (sharding.py); asynchronous on `stream`. */
+typedef struct sjmi_batch_result {
+    sjmi_stage1_result stage1;
+    sjmi_unescape_result strings;
+    sjmi_walk_result walk;
+} sjmi_batch_result;
+int sjmi_parse_batch_device(sjmi_ctx* ctx, const void* d_buf, uint64_t total_len, const void* d_doc_offsets, uint64_t n_docs,
+                            void* d_indexes, uint64_t index_capacity, void* d_index_offsets, void* d_doc_status,
+                            void* d_string_buffer, uint64_t string_capacity, void* d_doc_string_offsets, int max_depth,
+                            void* d_tape, uint64_t tape_capacity, void* d_tape_offsets, void* d_doc_errors, void* d_result,
+                            void* stream);
+
 /* ---- whole parse: SimdJsonParser.parse(byte[], int) (SimdJsonParser.java:35-40) ----------------------------
  * GPU stage 1 + GPU string unescape + the host stage-2 tree builder (C++ mirror of JsonIterator / TapeBuilder /
  * Tape: simdjson-java_amd/csrc/host/simdjson_parser.h).  The tape (Tape.java:5-47 word layout) and string

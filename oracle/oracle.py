@@ -11,16 +11,17 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_AVX_PATH = os.path.join(_HERE, "liboracle_avx512.so")
 
 ST_UTF8, ST_UNCLOSED, ST_UNESCAPED = 1, 2, 4
 
 
 def build(force=False):
     """Compile liboracle.so with gcc (portable flags so the .so also runs on the GPU box)."""
-    src = os.path.join(_HERE, "sj_oracle.c")
-    if (not force and os.path.exists(_LIB_PATH)
-            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src),
-                                                   os.path.getmtime(os.path.join(_HERE, "sj_oracle.h")))):
+    srcs = [os.path.join(_HERE, f) for f in ("sj_oracle.c", "sj_oracle.h", "sj_tables.h", "sj_avx512.c", "Makefile")]
+    newest = max(os.path.getmtime(f) for f in srcs)
+    if (not force and os.path.exists(_LIB_PATH) and os.path.exists(_AVX_PATH)
+            and min(os.path.getmtime(_LIB_PATH), os.path.getmtime(_AVX_PATH)) >= newest):
         return _LIB_PATH
     subprocess.check_call(["make", "-C", _HERE, "portable"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -67,6 +68,8 @@ def lib():
         L.sjo_stage2.argtypes = [u8p, C.c_uint64, u32p, C.c_uint64, C.c_int, C.POINTER(_Doc)]
         L.sjo_doc_free.restype = None
         L.sjo_doc_free.argtypes = [C.POINTER(_Doc)]
+        L.sjo_avx512_supported.restype = C.c_int
+        L.sjo_avx512_supported.argtypes = []
         L.sjo_fnv1a64_u32.restype = C.c_uint64
         L.sjo_fnv1a64_u32.argtypes = [u32p, C.c_uint64]
         _lib = L
@@ -142,6 +145,34 @@ def stage1(data, length=None):
     r = lib().sjo_stage1(_ptr(a), n, idx.ctypes.data, cap, C.addressof(cnt), C.addressof(st))
     assert r == 0
     return idx[:cnt.value].copy(), st.value
+
+
+_avx = None
+
+
+def avx512_supported():
+    return bool(lib().sjo_avx512_supported()) and os.path.exists(_AVX_PATH)
+
+
+def stage1_avx512(data, length=None, out=None):
+    """The AVX-512 restatement of the reference's two stage-1 passes (oracle/sj_avx512.c; the CPU timing baseline):
+    -> (indexes, status).  Only on hosts where avx512_supported()."""
+    global _avx
+    if _avx is None:
+        assert avx512_supported(), "this host CPU has no AVX-512 F+BW"
+        _avx = C.CDLL(_AVX_PATH)
+        _avx.sjo_stage1_avx512.restype = C.c_int
+        _avx.sjo_stage1_avx512.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    a = _as_u8(data)
+    n = a.size if length is None else length
+    cap = n + 66
+    idx = out if out is not None else np.empty(cap + 16, dtype=np.uint32)
+    assert idx.size >= cap + 16
+    cnt = C.c_uint64(0)
+    st = C.c_uint32(0)
+    r = _avx.sjo_stage1_avx512(_ptr(a), n, idx.ctypes.data, cap, C.addressof(cnt), C.addressof(st))
+    assert r == 0
+    return idx[:cnt.value], st.value
 
 
 def fnv1a64_u32(arr):

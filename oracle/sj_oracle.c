@@ -12,6 +12,7 @@
  * rounded with the same saturation, so it stands in for it here.
  */
 #include "sj_oracle.h"
+#include "sj_tables.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -68,10 +69,6 @@ const char *sjo_error_message(int code) {
 
 #define EVEN_BITS 0x5555555555555555ULL /* StructuralIndexer.java:20 */
 #define ODD_BITS (~EVEN_BITS)           /* :21 */
-
-/* StructuralIndexer.java:23-28 -- the two 16-entry low-nibble tables, verbatim values */
-static const uint8_t WHITESPACE_TABLE[16] = {' ', 100, 100, 100, 17, 100, 113, 2, 100, '\t', '\n', 112, 100, '\r', 100, 100};
-static const uint8_t OP_TABLE[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, ':', '{', ',', '}', 0, 0};
 
 /* StructuralIndexer.java:311-319 */
 static uint64_t prefix_xor(uint64_t m) {
@@ -216,45 +213,6 @@ int sjo_index_bytewise(const uint8_t *buf, uint64_t len, uint32_t *indexes, uint
 /* ------------------------------------------------------------------------------------------ */
 /* UTF-8: lookup-table form (Utf8Validator.java)                                              */
 /* ------------------------------------------------------------------------------------------ */
-
-#define TOO_SHORT 1          /* Utf8Validator.java:23 */
-#define TOO_LONG (1 << 1)    /* :25 */
-#define OVERLONG_3BYTE (1 << 2)
-#define TOO_LARGE (1 << 3)
-#define SURROGATE (1 << 4)
-#define OVERLONG_2BYTE (1 << 5)
-#define TOO_LARGE_1000 (1 << 6)
-#define OVERLONG_4BYTE (1 << 6)
-#define TWO_CONTINUATIONS (1 << 7)
-#define CARRY (TOO_SHORT | TOO_LONG | TWO_CONTINUATIONS)
-
-/* :182-196 */
-static const uint8_t BYTE_1_HIGH[16] = {
-    TOO_LONG, TOO_LONG, TOO_LONG, TOO_LONG, TOO_LONG, TOO_LONG, TOO_LONG, TOO_LONG,
-    TWO_CONTINUATIONS, TWO_CONTINUATIONS, TWO_CONTINUATIONS, TWO_CONTINUATIONS,
-    TOO_SHORT | OVERLONG_2BYTE, TOO_SHORT,
-    TOO_SHORT | OVERLONG_3BYTE | SURROGATE,
-    TOO_SHORT | TOO_LARGE | TOO_LARGE_1000 | OVERLONG_4BYTE};
-/* :198-226 */
-static const uint8_t BYTE_1_LOW[16] = {
-    CARRY | OVERLONG_2BYTE | OVERLONG_3BYTE | OVERLONG_4BYTE,
-    CARRY | OVERLONG_2BYTE,
-    CARRY, CARRY,
-    CARRY | TOO_LARGE,
-    CARRY | TOO_LARGE | TOO_LARGE_1000, CARRY | TOO_LARGE | TOO_LARGE_1000,
-    CARRY | TOO_LARGE | TOO_LARGE_1000, CARRY | TOO_LARGE | TOO_LARGE_1000,
-    CARRY | TOO_LARGE | TOO_LARGE_1000, CARRY | TOO_LARGE | TOO_LARGE_1000,
-    CARRY | TOO_LARGE | TOO_LARGE_1000, CARRY | TOO_LARGE | TOO_LARGE_1000,
-    CARRY | TOO_LARGE | TOO_LARGE_1000 | SURROGATE,
-    CARRY | TOO_LARGE | TOO_LARGE_1000, CARRY | TOO_LARGE | TOO_LARGE_1000};
-/* :228-241 */
-static const uint8_t BYTE_2_HIGH[16] = {
-    TOO_SHORT, TOO_SHORT, TOO_SHORT, TOO_SHORT, TOO_SHORT, TOO_SHORT, TOO_SHORT, TOO_SHORT,
-    TOO_LONG | TWO_CONTINUATIONS | OVERLONG_2BYTE | OVERLONG_3BYTE | OVERLONG_4BYTE | TOO_LARGE_1000,
-    TOO_LONG | TWO_CONTINUATIONS | OVERLONG_2BYTE | OVERLONG_3BYTE | TOO_LARGE,
-    TOO_LONG | TWO_CONTINUATIONS | OVERLONG_2BYTE | SURROGATE | TOO_LARGE,
-    TOO_LONG | TWO_CONTINUATIONS | OVERLONG_2BYTE | SURROGATE | TOO_LARGE,
-    TOO_SHORT, TOO_SHORT, TOO_SHORT, TOO_SHORT};
 
 /* one chunk of W bytes; prev4 = the previous chunk's last four bytes (prev4[3] is the
  * byte right before chunk[0]).  Mirrors Utf8Validator.java:68-110. Returns error!=0 and
@@ -867,4 +825,16 @@ uint64_t sjo_fnv1a64_u32(const uint32_t *p, uint64_t n) {
         h *= 0x100000001b3ULL;
     }
     return h;
+}
+
+/* does this host CPU run oracle/sj_avx512.c (AVX-512 F + BW, BMI1/2, POPCNT)?  The timing baseline asks before it
+ * loads liboracle_avx512.so. */
+int sjo_avx512_supported(void) {
+#if defined(__x86_64__)
+    __builtin_cpu_init();
+    return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("bmi") &&
+           __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("popcnt");
+#else
+    return 0;
+#endif
 }

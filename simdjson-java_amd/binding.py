@@ -66,7 +66,7 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_unescape_batch_device", "sjmi_walk_batch_device", "sjmi_stage1_masks", "sjmi_stage1_masks_device",
            "sjmi_parser_root", "sjmi_parser_batch_root", "sjmi_value_type", "sjmi_value_as_long", "sjmi_value_as_double",
            "sjmi_value_as_boolean", "sjmi_value_as_string", "sjmi_value_get", "sjmi_value_size", "sjmi_value_first",
-           "sjmi_value_next"]
+           "sjmi_value_next", "sjmi_parse_batch_device"]
 
 
 def lib():
@@ -158,6 +158,10 @@ def lib():
             f = getattr(L, name)
             f.restype = C.c_int
             f.argtypes = [C.c_void_p] + extra
+        L.sjmi_parse_batch_device.restype = C.c_int
+        L.sjmi_parse_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p,
+                                              C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sjmi_kernel_time.restype = C.c_int
         L.sjmi_kernel_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -318,6 +322,17 @@ class Context:
                                                  d_doc_status, d_sb, d_doc_string_offsets, string_base, max_depth, d_tape,
                                                  tape_capacity, d_tape_offsets, d_doc_errors, d_result, stream),
                     "sjmi_walk_batch_device")
+
+    def parse_batch_device(self, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets,
+                           d_doc_status, d_sb, sb_capacity, d_doc_string_offsets, max_depth, d_tape, tape_capacity,
+                           d_tape_offsets, d_doc_errors, d_result, stream=0):
+        """sjmi_parse_batch_device: isolated stage 1 -> string records -> GPU walk, queued without a host round trip;
+        d_result = device sjmi_batch_result (9 x int64: count, status | strings total, first_error_inv, flags |
+        tape words, host documents, failed documents, flags)."""
+        self._check(lib().sjmi_parse_batch_device(self._h, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity,
+                                                  d_index_offsets, d_doc_status, d_sb, sb_capacity, d_doc_string_offsets,
+                                                  max_depth, d_tape, tape_capacity, d_tape_offsets, d_doc_errors, d_result,
+                                                  stream), "sjmi_parse_batch_device")
 
     def stage1_batch_device(self, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets,
                             d_result, stream=0):

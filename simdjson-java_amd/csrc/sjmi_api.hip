@@ -631,6 +631,47 @@ int sjmi_stage1_batch_isolated(sjmi_ctx* c, const uint8_t* buf, uint64_t total_l
     return SJMI_OK;
 }
 
+int sjmi_parse_batch_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets, uint64_t n_docs,
+                            void* d_indexes, uint64_t index_capacity, void* d_index_offsets, void* d_doc_status,
+                            void* d_string_buffer, uint64_t string_capacity, void* d_doc_string_offsets, int max_depth,
+                            void* d_tape, uint64_t tape_capacity, void* d_tape_offsets, void* d_doc_errors, void* d_result,
+                            void* stream) {
+    if (!c || !d_buf || !d_doc_offsets || !d_indexes || !d_index_offsets || !d_doc_status || !d_string_buffer ||
+        !d_doc_string_offsets || !d_tape || !d_tape_offsets || !d_doc_errors || !d_result || max_depth < 1 || index_capacity < 1)
+        return SJMI_ERR_ARG;
+    if (total_len >= (1ull << 32)) return SJMI_ERR_ARG;
+    sjmi_batch_result* r = (sjmi_batch_result*)d_result;
+    // stage 1 (isolated: per-document verdicts), queued
+    int rc = sjmi_stage1_batch_isolated_device(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity,
+                                               d_index_offsets, d_doc_status, &r->stage1, stream);
+    if (rc != SJMI_OK) return rc;
+    // string records: the structural count stays on the device (no host round trip between the stages); workspaces and
+    // grids are sized for the bound index_capacity - 1
+    const uint64_t bound = index_capacity - 1;
+    if (!grow(c, &c->d_ws_str, &c->ws_str_bytes, sjmi::unescape_workspace_bytes(bound, total_len), "hipMalloc(ws_str)") ||
+        !grow(c, &c->d_ws_walk, &c->ws_walk_bytes, sjmi::walk_workspace_bytes(bound, n_docs), "hipMalloc(ws_walk)"))
+        return SJMI_ERR_HIP;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    sjmi::UnescapeBatch batch;
+    batch.d_doc_offsets = (const unsigned long long*)d_doc_offsets;
+    batch.d_index_offsets = (const unsigned long long*)d_index_offsets;
+    batch.n_docs = n_docs;
+    batch.d_doc_str_offsets = (unsigned long long*)d_doc_string_offsets;
+    if (fail(c, "unescape launch",
+             sjmi::unescape_launch((const uint8_t*)d_buf, total_len, (const uint32_t*)d_indexes, bound,
+                                   (const sjmi::Stage1Result*)&r->stage1, (uint8_t*)d_string_buffer, string_capacity,
+                                   c->d_ws_str, (sjmi::UnescapeResult*)&r->strings, st, batch)) ||
+        fail(c, "walk launch",
+             sjmi::walk_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs, (const uint32_t*)d_indexes,
+                               bound, (const unsigned long long*)d_index_offsets, (const uint32_t*)d_doc_status,
+                               (const uint8_t*)d_string_buffer, (const unsigned long long*)d_doc_string_offsets, 0, max_depth,
+                               (unsigned long long*)d_tape, tape_capacity, (unsigned long long*)d_tape_offsets,
+                               (int32_t*)d_doc_errors, c->d_ws_walk, (sjmi::WalkResult*)&r->walk, st,
+                               (const sjmi::Stage1Result*)&r->stage1, (const sjmi::UnescapeResult*)&r->strings)))
+        return SJMI_ERR_HIP;
+    return SJMI_OK;
+}
+
 int sjmi_host_register(sjmi_ctx* c, void* ptr, uint64_t bytes) {
     if (!c || !ptr || !bytes) return SJMI_ERR_ARG;
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;

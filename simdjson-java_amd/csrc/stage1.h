@@ -85,7 +85,8 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
                        uint64_t count, const unsigned long long* d_index_offsets, const uint32_t* d_doc_status,
                        const uint8_t* d_sb, const unsigned long long* d_doc_str_offsets, uint64_t string_base, int max_depth,
                        unsigned long long* d_tape, uint64_t tape_capacity, unsigned long long* d_tape_offsets,
-                       int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream);
+                       int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream,
+                       const Stage1Result* dev_count = nullptr, const UnescapeResult* dev_strings = nullptr);
 hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint32_t* d_out,
                                  uint64_t out_cap, unsigned long long* d_index_offsets, uint32_t* d_doc_status,
                                  uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream, uint64_t total_len);

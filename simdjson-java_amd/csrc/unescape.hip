@@ -688,10 +688,17 @@ __global__ void __launch_bounds__(256)
 k_doc_str_offsets(const unsigned long long* __restrict__ index_offsets, uint64_t n_docs, uint64_t count,
                   const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ group_sums,
                   const unsigned long long* __restrict__ block_offsets, uint32_t tile,
-                  unsigned long long* __restrict__ doc_str_offsets) {
+                  unsigned long long* __restrict__ doc_str_offsets, const Stage1Result* __restrict__ dev_count) {
     const int lane = threadIdx.x & 63;
     const uint64_t k = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k > n_docs) return;
+    if (dev_count) {
+        if (dev_count->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL)) {  // (no records were made)
+            if (lane == 0) doc_str_offsets[k] = 0;
+            return;
+        }
+        count = dev_count->count;
+    }
     unsigned long long s = index_offsets[k];
     if (s > count) s = count;
     const uint64_t t = s / tile, tstart = t * tile;
@@ -745,7 +752,7 @@ static hipError_t unescape_launch_items(const uint8_t* d_buf, uint64_t len, cons
     if (batch.d_doc_str_offsets)
         hipLaunchKernelGGL(k_doc_str_offsets, dim3((unsigned)((batch.n_docs + 1 + 3) / 4)), dim3(256), 0, stream,
                            batch.d_index_offsets, batch.n_docs, count, sizes, groups, sums, (uint32_t)tile,
-                           batch.d_doc_str_offsets);
+                           batch.d_doc_str_offsets, dev_count);
     return hipGetLastError();
 }
 

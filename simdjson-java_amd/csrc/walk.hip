@@ -40,12 +40,21 @@ k_doc_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restrict
            const uint32_t* __restrict__ idx, uint32_t ix_entries, const unsigned long long* __restrict__ index_offsets,
            const uint32_t* __restrict__ doc_status, const uint8_t* __restrict__ sb,
            const unsigned long long* __restrict__ doc_str_offsets, unsigned long long string_base, int max_depth,
-           unsigned long long* __restrict__ scratch_tape, uint32_t* __restrict__ tape_lens, int32_t* __restrict__ doc_errors) {
+           unsigned long long* __restrict__ scratch_tape, uint32_t* __restrict__ tape_lens, int32_t* __restrict__ doc_errors,
+           const Stage1Result* __restrict__ dev_count, const UnescapeResult* __restrict__ dev_strings) {
     const uint64_t k = (uint64_t)blockIdx.x * WALK_THREADS + threadIdx.x;
     if (k >= n_docs) return;
     const uint32_t st = doc_status[k];
     int code = 0;
     uint32_t len = 0;
+    // fused pipeline (sjmi_parse_batch_device): a stage 1 that ran out of index capacity left the index array
+    // incomplete, a string buffer that was too small holds only part of the records -- nothing of them may be
+    // dereferenced; every document reports SJMI_E_CAPACITY
+    if ((dev_count && (dev_count->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL))) || (dev_strings && (dev_strings->flags & 1u))) {
+        tape_lens[k] = 0;
+        doc_errors[k] = SJMI_E_CAPACITY;
+        return;
+    }
     // SimdJsonParser.stage1 order: Utf8Validator.validate (:165-167), then StructuralIndexer.index (:297-302)
     if (st & SJMI_ST_UTF8) code = SJMI_E_UTF8;
     else if (st & SJMI_ST_UNCLOSED) code = SJMI_E_UNCLOSED_STRING;
@@ -173,7 +182,8 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
                        uint64_t count, const unsigned long long* d_index_offsets, const uint32_t* d_doc_status,
                        const uint8_t* d_sb, const unsigned long long* d_doc_str_offsets, uint64_t string_base, int max_depth,
                        unsigned long long* d_tape, uint64_t tape_capacity, unsigned long long* d_tape_offsets,
-                       int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream) {
+                       int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream, const Stage1Result* dev_count,
+                       const UnescapeResult* dev_strings) {
     uint8_t* ws = static_cast<uint8_t*>(d_ws);
     unsigned long long* scratch = reinterpret_cast<unsigned long long*>(ws);
     uint32_t* lens = reinterpret_cast<uint32_t*>(ws + walk_lens_offset(count, n_docs));
@@ -184,7 +194,7 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
     if (n_docs) {
         hipLaunchKernelGGL(k_doc_walk, dim3((unsigned)((n_docs + WALK_THREADS - 1) / WALK_THREADS)), dim3(WALK_THREADS), 0, stream,
                            d_buf, d_doc_offsets, n_docs, d_idx, (uint32_t)(count + 1), d_index_offsets, d_doc_status, d_sb, d_doc_str_offsets,
-                           (unsigned long long)string_base, max_depth, scratch, lens, d_doc_errors);
+                           (unsigned long long)string_base, max_depth, scratch, lens, d_doc_errors, dev_count, dev_strings);
         hipLaunchKernelGGL(k_tape_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, lens, d_doc_errors, n_docs, sums, d_res);
     }
     hipLaunchKernelGGL(k_tape_chunk_scan, dim3(1), dim3(1024), 0, stream, sums, nchunks, n_docs, tape_capacity, d_tape_offsets, d_res);

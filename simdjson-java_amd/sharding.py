@@ -43,3 +43,85 @@ def global_offsets(gathered):
     import torch
     g = gathered.to(torch.int64)
     return torch.cumsum(g, dim=0) - g
+
+
+class BatchShard:
+    """One rank's contiguous share of a batch of documents, resident on its device, and everything one step of the
+    batched path needs: outputs sized once, then `step()` queues sjmi_parse_batch_device (isolated stage 1 -> string
+    records -> GPU walk; no host round trip) on the given stream.  `engine` is a binding.Context (or, in the CPU tests,
+    a stub with the same parse_batch_device signature); tensors are plain torch tensors on `device`."""
+
+    def __init__(self, engine, shard_bytes, local_offsets, device, max_depth=1024, index_ratio=1, string_ratio=1.0,
+                 tape_ratio=1.0):
+        import torch
+        self.engine = engine
+        self.device = device
+        self.n = int(shard_bytes.numel()) if hasattr(shard_bytes, "numel") else len(shard_bytes)
+        offs = np.ascontiguousarray(local_offsets, dtype=np.uint64)
+        assert offs[0] == 0 and int(offs[-1]) <= self.n
+        self.n_docs = offs.size - 1
+        if hasattr(shard_bytes, "numel"):
+            self.buf = torch.zeros(self.n + 128, dtype=torch.uint8, device=device)
+            self.buf[:self.n] = shard_bytes
+        else:
+            self.buf = torch.zeros(self.n + 128, dtype=torch.uint8, device=device)
+            self.buf[:self.n] = torch.frombuffer(bytearray(shard_bytes), dtype=torch.uint8).to(device)
+        self.offs = torch.from_numpy(offs.view(np.int64).copy()).to(device)
+        # the defaults cover the worst cases (one structural per byte: "[[[[", one tape word per byte: "[1,1,1"); real
+        # JSON has one structural per 5-11 bytes, so a caller that knows its data passes tighter ratios (bench.py) -- a
+        # shortfall is reported by the kernels (never overrun) and check() raises
+        self.index_capacity = self.n // index_ratio + self.n_docs + 16
+        self.idx = torch.empty(self.index_capacity, dtype=torch.int32, device=device)
+        self.index_offsets = torch.zeros(self.n_docs + 1, dtype=torch.int64, device=device)
+        self.doc_status = torch.zeros(max(self.n_docs, 1), dtype=torch.int32, device=device)
+        self.sb_capacity = int(self.n * string_ratio) + 4 * self.index_capacity + 64
+        self.sb = torch.empty(self.sb_capacity, dtype=torch.uint8, device=device)
+        self.doc_string_offsets = torch.zeros(self.n_docs + 1, dtype=torch.int64, device=device)
+        self.tape_capacity = int(self.n * tape_ratio) + 2 * self.n_docs + 8
+        self.tape = torch.empty(self.tape_capacity, dtype=torch.int64, device=device)
+        self.tape_offsets = torch.zeros(self.n_docs + 1, dtype=torch.int64, device=device)
+        self.doc_errors = torch.zeros(max(self.n_docs, 1), dtype=torch.int32, device=device)
+        self.result = torch.zeros(9, dtype=torch.int64, device=device)  # sjmi_batch_result
+        self.max_depth = max_depth
+        self._ndocs = torch.tensor([self.n_docs], dtype=torch.int64, device=device)
+
+    def step(self, stream=0):
+        self.engine.parse_batch_device(self.buf.data_ptr(), self.n, self.offs.data_ptr(), self.n_docs, self.idx.data_ptr(),
+                                       self.index_capacity, self.index_offsets.data_ptr(), self.doc_status.data_ptr(),
+                                       self.sb.data_ptr(), self.sb_capacity, self.doc_string_offsets.data_ptr(), self.max_depth,
+                                       self.tape.data_ptr(), self.tape_capacity, self.tape_offsets.data_ptr(),
+                                       self.doc_errors.data_ptr(), self.result.data_ptr(), stream)
+
+    def counts_tensor(self):
+        """The per-shard row of the count gather, on the device, without a host copy:
+        {documents, structurals, string bytes, failed + handed-back documents}."""
+        import torch
+        r = self.result
+        return torch.cat([self._ndocs, r[0:1], r[2:3], r[6:7] + r[7:8]])
+
+    def check(self):
+        """Host-side verdict of the last step (synchronise first): raises if a capacity was exceeded."""
+        r = self.result.cpu().numpy()
+        st1, sflags, wflags = int(r[1]) & 0xFFFFFFFF, int(r[4]) & 0xFFFFFFFF, int(r[8]) & 0xFFFFFFFF
+        if st1 & 0x300:
+            raise RuntimeError("stage 1 of the shard: capacity / internal error (status 0x%x)" % st1)
+        if sflags & 1:
+            raise RuntimeError("string buffer capacity exceeded")
+        if wflags & 1:
+            raise RuntimeError("tape capacity exceeded")
+        return {"documents": self.n_docs, "structurals": int(r[0]), "string_bytes": int(r[2]), "tape_words": int(r[5]),
+                "host_documents": int(r[6]), "failed_documents": int(r[7]), "stage1_status": st1 & 0xFF}
+
+
+def sharded_step(shard, stream=0):
+    """One step of the multi-GPU batched path on this rank: the shard's kernels, then the count gather (the ONLY
+    collective, north_star).  -> gathered [world, 4] int64 tensor on the shard's device."""
+    import torch
+    import torch.distributed as dist
+    shard.step(stream)
+    row = shard.counts_tensor()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return row[None, :]
+    out = torch.empty(dist.get_world_size() * 4, dtype=torch.int64, device=shard.device)
+    dist.all_gather_into_tensor(out, row)
+    return out.view(dist.get_world_size(), 4)

@@ -323,3 +323,52 @@ def test_reference_number_vectors():
                 assert got == ("l", v["long"]), (v["input"][:40], v["cite"], got)
             else:
                 assert got == ("d", v["double_bits"]), (v["input"][:40], v["cite"], got)
+
+
+# ---------------------------------------------------------------------------------------------
+# the AVX-512 restatement used as bench.py's CPU timing baseline (oracle/sj_avx512.c) must give the scalar
+# restatement's result -- it is only ever timed, but a baseline that computes something else would be meaningless
+# ---------------------------------------------------------------------------------------------
+def _avx_same(d):
+    i1, s1 = O.stage1(d)
+    i2, s2 = O.stage1_avx512(d)
+    assert s1 == s2, (s1, s2, bytes(d[:80]).hex())
+    assert np.array_equal(i1, i2)
+
+
+@pytest.mark.skipif(not O.avx512_supported(), reason="host CPU without AVX-512 F+BW")
+def test_avx512_restatement_equals_the_scalar_one():
+    import random
+    for name in ("twitter.json", "github_events.json", "wide_bench.json", "malformed.txt"):
+        _avx_same(load_fixture(name))
+    for case in V.STRUCTURAL_INDEXER:
+        _avx_same(case[1])
+    rng = random.Random(77)
+    filler = ["a", "é", "€", "😀", " ", "x"]
+    for _name, seq, _c in V.UTF8_INVALID_MID + V.UTF8_INVALID_END:
+        for pos in (0, 1, 61, 62, 63, 64, 65, 127, 130):
+            pre = "".join(rng.choice(filler) for _ in range(200)).encode()[:pos]
+            while pre and (pre[-1] & 0xC0) == 0x80 or (pre and pre[-1] >= 0xC0):
+                pre = pre[:-1]
+            _avx_same(pre + b"x" * (pos - len(pre)) + seq)
+            _avx_same(pre + b"x" * (pos - len(pre)) + seq + b"tail " * 20)
+    for _name, seqs, _c in V.UTF8_INVALID_FAMILIES:
+        for j in range(0, len(seqs), 37):
+            _avx_same(b"y" * (j % 70) + seqs[j] + b"z" * (j % 5))
+    alphabet = b'\\\\\\"""{}[]:, \t\n\r\x0c\x1a\x01abc019.-e\xc3\xa9'
+    interesting = [0x00, 0x22, 0x5C, 0x7F, 0x80, 0x8F, 0x90, 0x9F, 0xA0, 0xBF, 0xC0, 0xC1, 0xC2, 0xDF, 0xE0, 0xE1,
+                   0xEC, 0xED, 0xEE, 0xEF, 0xF0, 0xF1, 0xF3, 0xF4, 0xF5, 0xF7, 0xF8, 0xFF, 0x41]
+    for it in range(3000):
+        n = rng.choice([0, 1, 63, 64, 65, 127, 128, 129, rng.randint(0, 900)])
+        mode = it % 5
+        if mode == 0:
+            d = bytes(rng.choice(alphabet) for _ in range(n))
+        elif mode == 1:
+            d = bytes(rng.choice(b'\\"a ') for _ in range(n))
+        elif mode == 2:
+            d = b"a" * rng.randint(0, 70) + b"\\" * rng.randint(1, 300) + rng.choice([b'"', b"x", b""]) + b'"x' * rng.randint(0, 40)
+        elif mode == 3:
+            d = bytes(rng.choice(interesting) for _ in range(n))
+        else:
+            d = bytes(rng.getrandbits(8) for _ in range(n))
+        _avx_same(d)

@@ -44,6 +44,79 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+class _StubEngine:
+    """Stands in for binding.Context in the CPU test: the same parse_batch_device signature, but the per-shard result
+    record comes from the oracle (the kernels need a GPU; what is under test is the sharding / gather logic around them)."""
+
+    def parse_batch_device(self, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets,
+                           d_doc_status, d_sb, sb_capacity, d_doc_string_offsets, max_depth, d_tape, tape_capacity,
+                           d_tape_offsets, d_doc_errors, d_result, stream=0):
+        import ctypes as C
+        from oracle import oracle as O
+        buf = (C.c_uint8 * total_len).from_address(d_buf)
+        offs = (C.c_int64 * (n_docs + 1)).from_address(d_doc_offsets)
+        res = (C.c_int64 * 9).from_address(d_result)
+        raw = bytes(buf)
+        structurals = strings = words = failed = 0
+        for k in range(n_docs):
+            p = O.parse(raw[offs[k]:offs[k + 1]])
+            if p.error:
+                failed += 1
+                continue
+            structurals += p.n_structurals
+            strings += len(p.strings)
+            words += p.tape.size
+        for i, v in enumerate([structurals, 0, strings, 0, 0, words, 0, failed, 0]):
+            res[i] = v
+
+
+def _shard_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import simdjson_java_amd  # noqa: F401
+    from simdjson_java_amd import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    docs = _docs()
+    docs[7] = b"[1 1]"      # one broken document in rank 0's share
+    docs[-3] = b'{"a":1,}'  # and one in the last rank's
+    offs = np.cumsum([0] + [len(d) + 1 for d in docs]).astype(np.uint64)
+    lo, hi = sharding.partition_documents(offs, world)[rank]
+    data = b"".join(d + b"\n" for d in docs[lo:hi])
+    shard = sharding.BatchShard(_StubEngine(), data, offs[lo:hi + 1] - offs[lo], "cpu")
+    g = sharding.sharded_step(shard)
+    q.put((rank, g.tolist(), shard.check()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_step():
+    """bench.py --gpus N's step on two gloo ranks: partition -> BatchShard.step (engine stubbed) -> count gather."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    docs = _docs()
+    docs[7] = b"[1 1]"
+    docs[-3] = b'{"a":1,}'
+    good = [O.parse(d) for d in docs]
+    (r0, g0, c0), (r1, g1, c1) = res
+    assert g0 == g1
+    assert g0[0][0] + g0[1][0] == len(docs)
+    assert g0[0][1] + g0[1][1] == sum(p.n_structurals for p in good if not p.error)
+    assert g0[0][2] + g0[1][2] == sum(len(p.strings) for p in good if not p.error)
+    assert g0[0][3] == 1 and g0[1][3] == 1
+    assert c0["failed_documents"] == 1 and c0["documents"] == g0[0][0]
+
+
 def test_partition_is_contiguous_and_balanced():
     sys.path.insert(0, ROOT)
     import simdjson_java_amd  # noqa: F401
