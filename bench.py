@@ -250,10 +250,11 @@ def bench_single(args):
     ok, bad = W.closed_form_ok(r1.out, idx0, n0, reps)
     assert ok, "GPU indexes differ from the oracle's closed form (copies %d..)" % bad
     assert int(r1.out[s_total].item()) == 0
+    sections = set() if args.no_extras else set(x for x in args.sections.split(",") if x)
     # ---- the dominant kernel, cold and settled ----
-    cold_ms, settled_ms = r1.cold_and_settled(args.steps)
+    cold_ms, settled_ms = (1.0, 1.0) if args.skip_main_timing else r1.cold_and_settled(args.steps)
     # ---- the contract's timed region: W warmup steps, then exactly K steps ----
-    r1.launch(args.warmup + args.preheat)
+    r1.launch(0 if args.skip_main_timing else args.warmup + args.preheat)
     r1.ctx.set_profiling(True)
     elapsed = wall_steps(torch, r1.launch, args.steps)
     kern_ms, launches = r1.ctx.kernel_time()
@@ -281,7 +282,7 @@ def bench_single(args):
                                    "protocol": "the first K launches after the GPU idled 0.6 s, no warmup at all"}),
     }
     extra = {}
-    if not args.no_extras:
+    if sections & {"x1024", "unescape"}:
         # ---- configs[1]: twitter x1024 = the first 1024 copies of the same buffer (bytes >= len are invisible) ----
         reps1 = min(1024, reps)
         n1, s1 = n0 * reps1, idx0.size * reps1
@@ -291,12 +292,14 @@ def bench_single(args):
         assert ra.status() == (s1, 0)
         ok, bad = W.closed_form_ok(ra.out, idx0, n0, reps1)
         assert ok
-        c1, s1ms = ra.cold_and_settled(max(args.steps, 50))
-        extra["stage1_twitter_x1024"] = {
-            "config": "configs[1]: twitter.json x%d (%d B), stage 1, bit-exact index check" % (reps1, n1),
-            "value": round(n1 / s1ms / 1e6, 2), "unit": "GB/s",
-            "roofline": roofline(n1 + 4 * (s1 + 1), s1ms, n1, "k_stage1", max(args.steps, 50), traffic=pmc_traffic("stage1_twitter_x1024"),
-                                 cold={"avg_kernel_ms": round(c1, 4), "frac": round(n1 / c1 / 1e6 / HBM_PEAK_GBS, 4)})}
+        c1, s1ms = ra.cold_and_settled(max(args.steps, 50)) if "x1024" in sections else (1.0, 1.0)
+        if "x1024" in sections:
+            extra["stage1_twitter_x1024"] = {
+                "config": "configs[1]: twitter.json x%d (%d B), stage 1, bit-exact index check" % (reps1, n1),
+                "value": round(n1 / s1ms / 1e6, 2), "unit": "GB/s",
+                "roofline": roofline(n1 + 4 * (s1 + 1), s1ms, n1, "k_stage1", max(args.steps, 50), traffic=pmc_traffic("stage1_twitter_x1024"),
+                                     cold={"avg_kernel_ms": round(c1, 4), "frac": round(n1 / c1 / 1e6 / HBM_PEAK_GBS, 4)})}
+    if "unescape" in sections:
         # ---- string unescape (StringParser.parseString for every string) on twitter x1024 ----
         _, _, masks = oracle.index_blocks(doc, want_masks=True)
         n_str0 = int((np.frombuffer(doc, dtype=np.uint8)[idx0] == 0x22).sum())
@@ -337,7 +340,8 @@ def bench_single(args):
                          "algorithmic_bytes_per_launch": ualg,
                          "algorithmic_bytes": "string bytes incl. quotes read (%d) + 4 B index word per string + records written (%d), per copy"
                                               % (raw0, len(want_sb))}}
-        del sb, ra
+        del sb
+    if "synth" in sections:
         # ---- configs[2]: 4 GiB synthetic ----
         tile = W.synth_tile()
         tidx, tst = oracle.stage1(tile)
@@ -358,6 +362,7 @@ def bench_single(args):
             "roofline": roofline(tn + 4 * (tidx.size * treps + 1), s2, tn, "k_stage1", args.steps, traffic=pmc_traffic("stage1_synthetic_4g"),
                                  cold={"avg_kernel_ms": round(c2, 4), "frac": round(tn / c2 / 1e6 / HBM_PEAK_GBS, 4)})}
         del tbuf, rs
+    if "batch" in sections:
         # ---- configs[3] on ONE GPU: the batched path, 1,000,000 documents ----
         extra["batch_1m_docs"] = batch_single_gpu(torch, S, W, dev, work, args)
     line["extra"] = extra
@@ -506,6 +511,10 @@ def main():
     ap.add_argument("--pool", type=int, default=4000, help="unique documents of the configs[3] batch")
     ap.add_argument("--batch-steps", type=int, default=10, help="N=1: timed steps of the configs[3] extra")
     ap.add_argument("--no-extras", action="store_true", help="N=1: only the primary workload")
+    ap.add_argument("--sections", default="x1024,unescape,synth,batch",
+                    help="N=1: which extras to run (comma list of x1024, unescape, synth, batch); the profiling passes run one each")
+    ap.add_argument("--skip-main-timing", action="store_true",
+                    help="N=1, profiling passes of an extra only: check the primary workload once, do not time it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
