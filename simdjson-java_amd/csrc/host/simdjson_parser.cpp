@@ -2,6 +2,7 @@
 // C ABI, then the reference's sequential stage 2 (JsonIterator + TapeBuilder + Tape + number grammar)
 // re-implemented in C++.  Citations: /root/reference/src/main/java/org/simdjson/<file>:<lines>.
 #include "simdjson_parser.h"
+#include "../sj_number.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -510,43 +511,26 @@ static locale_t cLocale() {
 }
 
 void DocWalker::parseNumber(const uint8_t* p) {
-    const uint8_t* start = p;
-    const bool negative = *p == '-';
-    if (negative) ++p;
-    const uint8_t* digitsStart = p;
-    uint64_t digits = 0;
-    while ((uint8_t)(*p - '0') <= 9) { digits = 10 * digits + (uint64_t)(*p - '0'); ++p; }
-    const ptrdiff_t digitCount = p - digitsStart;
-    if (digitCount == 0) throw fail(E_NUM_MINUS);
-    if (*digitsStart == '0' && digitCount > 1) throw fail(E_NUM_LEADING_ZERO);
-    bool floating = false;
-    if (*p == '.') {
-        floating = true;
-        ++p;
-        const uint8_t* after = p;
-        while ((uint8_t)(*p - '0') <= 9) ++p;
-        if (p == after) throw fail(E_NUM_DECIMAL_POINT);
-    }
-    if (*p == 'e' || *p == 'E') {
-        floating = true;
-        ++p;
-        if (*p == '-' || *p == '+') ++p;
-        const uint8_t* es = p;
-        while ((uint8_t)(*p - '0') <= 9) ++p;
-        if (p == es) throw fail(E_NUM_EXPONENT);
-    }
-    if (!isStructuralOrWhitespace(*p)) throw fail(E_NUM_FOLLOWED);
-    if (floating) {
-        // The literal is parsed in place: it is followed by a structural or whitespace byte (checked above; the buffer is
-        // padded), where the conversion stops.  strtod_l with the "C" locale, never strtod: a JVM host process calls
-        // setlocale(LC_ALL, ""), and under a comma locale strtod("1.5") stops at the '.' and returns 1.0.
-        tape_.appendDouble(strtod_l(reinterpret_cast<const char*>(start), nullptr, cLocale()));
+    // grammar + Clinger / Eisel-Lemire conversion shared with the device walkers (csrc/sj_number.h): locale-independent,
+    // no allocation, the literal is scanned in place (the buffer is padded and the literal ends at a structural or
+    // whitespace byte)
+    const sjmi::SjNumber n = sjmi::sj_scan_number([&](uint32_t q) -> uint32_t { return p[q]; }, 0);
+    if (n.code) throw fail(n.code);
+    if (n.floating) {
+        if (n.wide) {
+            // more than 19 significant digits: the reference's slow path (DoubleParser.java:205-330), a correctly
+            // rounded saturating conversion -- strtod_l in the "C" locale has the same contract.  Never plain strtod: a
+            // JVM host process calls setlocale(LC_ALL, ""), and under a comma locale strtod("1.5") returns 1.0.
+            tape_.appendDouble(strtod_l(reinterpret_cast<const char*>(p), nullptr, cLocale()));
+        } else {
+            const unsigned long long bits = sjmi::sj_compute_double_bits(n.negative, n.w, n.q);
+            double v;
+            memcpy(&v, &bits, 8);
+            tape_.appendDouble(v);
+        }
     } else {
-        bool out = false;
-        if (digitCount > 19) out = true;
-        else if (digitCount == 19) out = (negative && digits == 0x8000000000000000ull) ? false : ((int64_t)digits < 0);
-        if (out) throw fail(E_NUM_LONG_RANGE);
-        tape_.appendInt64((int64_t)(negative ? (~digits + 1) : digits));
+        if (sjmi::sj_out_of_long_range(n.negative, n.digits, n.digit_count)) throw fail(E_NUM_LONG_RANGE);
+        tape_.appendInt64((int64_t)(n.negative ? (~n.digits + 1) : n.digits));
     }
 }
 

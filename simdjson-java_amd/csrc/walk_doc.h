@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "../../include/sjmi.h"
+#include "sj_number.h"
 
 #if defined(__HIPCC__)
 #define SJW_DEV __device__
@@ -85,9 +86,6 @@ SJW_DEV SJW_INL bool is_structural_or_ws(uint32_t b) {  // CharacterUtils.java:6
     return b == 0x20 || b == 0x0A || b == 0x0D || b == 0x09 || b == ',' || b == ':' || b == '[' || b == ']' || b == '{' || b == '}';
 }
 
-SJW_CONST double P10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
-                                   1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
-
 // TapeBuilder.visitString (TapeBuilder.java:174-177): the record was written by the unescape kernels
 SJW_DEV SJW_INL bool visit_string(Lane& w) {
     append(w, w.sbase + w.sc, '"');
@@ -101,82 +99,19 @@ SJW_DEV SJW_INL bool visit_string(Lane& w) {
 }
 
 // NumberParser.parseNumber (NumberParser.java:23-74) at p; bytes at or after `limit` read as spaces (the root number's
-// padded copy, TapeBuilder.java:183-189)
+// padded copy, TapeBuilder.java:183-189).  Grammar and conversion: sj_number.h (Clinger's exact range + Eisel-Lemire for
+// every literal of at most 19 significant digits; longer ones go back to the host).
 SJW_DEV bool parse_number(Lane& w, uint32_t p, uint32_t limit) {
-    auto B = [&](uint32_t q) -> uint32_t { return q < limit ? byte_at(w, q) : 0x20u; };
-    const bool negative = B(p) == '-';
-    if (negative) ++p;
-    const uint32_t digits_start = p;
-    unsigned long long digits = 0;  // (wraps like the reference's long)
-    // the significand for the floating-point case: up to 19 significant digits, zeros held back until a non-zero digit
-    // follows them (trailing zeros of the fraction are dropped, those of the integer part become a power of ten)
-    unsigned long long sig = 0;
-    int nsig = 0, frac_used = 0, pend = 0, pend_int = 0;
-    bool wide = false;
-    auto push = [&](uint32_t d, bool frac) {
-        if (d == 0) {
-            if (sig == 0) frac_used += frac ? 1 : 0;  // a leading zero only moves the decimal point
-            else { ++pend; pend_int += frac ? 0 : 1; }
-            return;
-        }
-        frac_used += pend - pend_int;
-        for (; pend; --pend) {
-            if (nsig < 19) { sig *= 10; ++nsig; } else wide = true;
-        }
-        pend_int = 0;
-        if (nsig < 19) { sig = sig * 10 + d; ++nsig; frac_used += frac ? 1 : 0; } else wide = true;
-    };
-    uint32_t c = B(p);
-    while (c - '0' <= 9u) {
-        const uint32_t d = c - '0';
-        digits = 10 * digits + d;
-        push(d, false);
-        c = B(++p);
-    }
-    const uint32_t digit_count = p - digits_start;
-    if (digit_count == 0) { w.code = SJMI_E_NUM_MINUS; return false; }
-    if (B(digits_start) == '0' && digit_count > 1) { w.code = SJMI_E_NUM_LEADING_ZERO; return false; }
-    bool floating = false;
-    if (c == '.') {
-        floating = true;
-        c = B(++p);
-        const uint32_t after = p;
-        while (c - '0' <= 9u) {
-            push(c - '0', true);
-            c = B(++p);
-        }
-        if (p == after) { w.code = SJMI_E_NUM_DECIMAL_POINT; return false; }
-    }
-    int exp10 = 0;
-    if (c == 'e' || c == 'E') {
-        floating = true;
-        c = B(++p);
-        const bool eneg = c == '-';
-        if (c == '-' || c == '+') c = B(++p);
-        const uint32_t es = p;
-        while (c - '0' <= 9u) {
-            if (exp10 < 100000) exp10 = exp10 * 10 + (int)(c - '0');
-            c = B(++p);
-        }
-        if (p == es) { w.code = SJMI_E_NUM_EXPONENT; return false; }
-        if (eneg) exp10 = -exp10;
-    }
-    if (!is_structural_or_ws(c)) { w.code = SJMI_E_NUM_FOLLOWED; return false; }
-    if (floating) {
-        const int q = exp10 + pend_int - frac_used;
-        if (wide || sig > (1ull << 53) || q < -22 || q > 22) { w.code = SJMI_WALK_NEEDS_HOST; return false; }
-        double v = (double)sig;  // exact
-        v = q < 0 ? v / P10[-q] : v * P10[q];
-        if (negative) v = -v;
+    const SjNumber n = sj_scan_number([&](uint32_t q) -> uint32_t { return q < limit ? byte_at(w, q) : 0x20u; }, p);
+    if (n.code) { w.code = n.code; return false; }
+    if (n.floating) {
+        if (n.wide) { w.code = SJMI_WALK_NEEDS_HOST; return false; }  // DoubleParser's slow path (:205-330)
         append(w, 0, 'd');  // Tape.appendDouble :39-43
-        w.tape[w.tl++] = sjw_double_bits(v);
+        w.tape[w.tl++] = sj_compute_double_bits(n.negative, n.w, n.q);
     } else {
-        bool out = false;  // isOutOfLongRange (NumberParser.java:313-328)
-        if (digit_count > 19) out = true;
-        else if (digit_count == 19) out = (negative && digits == 0x8000000000000000ull) ? false : ((long long)digits < 0);
-        if (out) { w.code = SJMI_E_NUM_LONG_RANGE; return false; }
+        if (sj_out_of_long_range(n.negative, n.digits, n.digit_count)) { w.code = SJMI_E_NUM_LONG_RANGE; return false; }
         append(w, 0, 'l');  // Tape.appendInt64 :33-37
-        w.tape[w.tl++] = negative ? (~digits + 1) : digits;
+        w.tape[w.tl++] = n.negative ? (~n.digits + 1) : n.digits;
     }
     return true;
 }
