@@ -330,7 +330,9 @@ __device__ __forceinline__ uint32_t tail_clip_bound(const TailClip& clip, uint64
 // one thread per document: mark its last structural if that is a quote and the next document has no structurals
 __global__ void __launch_bounds__(256)
 k_doc_mark_tails(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ idx,
-                 const unsigned long long* __restrict__ index_offsets, uint64_t n_docs, uint32_t* __restrict__ marks) {
+                 const unsigned long long* __restrict__ index_offsets, uint64_t n_docs, uint32_t* __restrict__ marks,
+                 const Stage1Result* __restrict__ dev_count) {
+    if (dev_count && (dev_count->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL))) return;  // (incomplete index array)
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k + 1 >= n_docs) return;  // (the batch's last document ends where the batch ends)
     const unsigned long long from = index_offsets[k], to = index_offsets[k + 1];
@@ -738,7 +740,7 @@ static hipError_t unescape_launch_items(const uint8_t* d_buf, uint64_t len, cons
         hipError_t e = hipMemsetAsync(marks, 0, ws_marks_bytes(count), stream);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_doc_mark_tails, dim3((unsigned)((batch.n_docs + 255) / 256)), dim3(256), 0, stream, d_buf, d_idx,
-                           batch.d_index_offsets, batch.n_docs, marks);
+                           batch.d_index_offsets, batch.n_docs, marks, dev_count);
         clip.marks = marks;
         clip.index_offsets = batch.d_index_offsets;
         clip.doc_offsets = batch.d_doc_offsets;
