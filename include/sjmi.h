@@ -238,6 +238,15 @@ int sjmi_parse_batch_device(sjmi_ctx* ctx, const void* d_buf, uint64_t total_len
                             void* d_tape, uint64_t tape_capacity, void* d_tape_offsets, void* d_doc_errors, void* d_result,
                             void* stream);
 
+/* One document, ALL stages on the GPU: stage 1, string records and the cooperative walker (csrc/coop_walk.hip: JsonIterator.
+ * walkDocument + TapeBuilder as scans, JsonIterator.java:26-200, TapeBuilder.java:41-217); only the tape (Tape.java:5-47 word
+ * layout, tape[0] = root) and the string buffer come back -- the structural indexes stay on the device.  *error = 0, or the
+ * document's SJMI_E_* code (stage-1 verdicts included; no tape), or SJMI_WALK_NEEDS_HOST (nesting beyond 63 levels, a
+ * floating-point literal of more than 19 significant digits: walk it on the host, sjmi_parser_parse does). */
+int sjmi_parse_document(sjmi_ctx* ctx, const uint8_t* buf, uint64_t len, int max_depth, uint64_t* tape, uint64_t tape_capacity,
+                        uint64_t* tape_len, uint8_t* string_buffer, uint64_t string_capacity, uint64_t* strings_len,
+                        int32_t* error, uint32_t* stage1_status);
+
 /* ---- whole parse: SimdJsonParser.parse(byte[], int) (SimdJsonParser.java:35-40) ----------------------------
  * GPU stage 1 + GPU string unescape + the host stage-2 tree builder (C++ mirror of JsonIterator / TapeBuilder /
  * Tape: simdjson-java_amd/csrc/host/simdjson_parser.h).  The tape (Tape.java:5-47 word layout) and string
@@ -249,6 +258,10 @@ void sjmi_parser_destroy(sjmi_parser* p);
 int sjmi_parser_parse(sjmi_parser* p, const uint8_t* buf, uint64_t len, const uint64_t** tape, uint64_t* tape_len,
                       const uint8_t** strings, uint64_t* strings_len, uint64_t* error_pos);
 const char* sjmi_parser_last_message(const sjmi_parser* p);
+/* Where stage 2 of sjmi_parser_parse runs: 0 (default) = the host walker over the GPU-made indexes and string records,
+ * 1 = the cooperative GPU walker (sjmi_parse_document): the tape comes from the device, and only a document that fails
+ * or is handed back is walked again on the host (for the exact exception).  Results are identical either way. */
+int sjmi_parser_set_gpu_walk(sjmi_parser* p, int on);
 /* Batched parse (BASELINE.json configs[3]/[4]): the batch goes through the GPU (isolated stage 1 + string records)
  * as a pipeline of sub-batches on two streams, the host stage 2 of the documents runs on a pool of threads
  * (SJMI_PARSE_THREADS, default min(32, cores)) while the GPU works on the next sub-batch.  Document k's tape is

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _CSRC = os.path.join(_HERE, "csrc")
 _LIB = os.path.join(_HERE, "libsjmi.so")
-SOURCES = ["stage1.hip", "unescape.hip", "batch.hip", "walk.hip", "masks.hip", "sjmi_api.hip", "host/simdjson_parser.cpp"]
+SOURCES = ["stage1.hip", "unescape.hip", "batch.hip", "walk.hip", "coop_walk.hip", "masks.hip", "sjmi_api.hip", "host/simdjson_parser.cpp"]
 
 ST_UTF8, ST_UNCLOSED, ST_UNESCAPED, ST_CAPACITY, ST_INTERNAL = 1, 2, 4, 0x100, 0x200
 PADDING = 64
@@ -66,7 +66,8 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_unescape_batch_device", "sjmi_walk_batch_device", "sjmi_stage1_masks", "sjmi_stage1_masks_device",
            "sjmi_parser_root", "sjmi_parser_batch_root", "sjmi_value_type", "sjmi_value_as_long", "sjmi_value_as_double",
            "sjmi_value_as_boolean", "sjmi_value_as_string", "sjmi_value_get", "sjmi_value_size", "sjmi_value_first",
-           "sjmi_value_next", "sjmi_parse_batch_device"]
+           "sjmi_value_next", "sjmi_parse_batch_device", "sjmi_parse_document",
+           "sjmi_parser_set_gpu_walk"]
 
 
 def lib():
@@ -158,6 +159,11 @@ def lib():
             f = getattr(L, name)
             f.restype = C.c_int
             f.argtypes = [C.c_void_p] + extra
+        L.sjmi_parser_set_gpu_walk.restype = C.c_int
+        L.sjmi_parser_set_gpu_walk.argtypes = [C.c_void_p, C.c_int]
+        L.sjmi_parse_document.restype = C.c_int
+        L.sjmi_parse_document.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                          C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sjmi_parse_batch_device.restype = C.c_int
         L.sjmi_parse_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p,
@@ -215,6 +221,21 @@ class Context:
                     "sjmi_stage1")
         assert idx[cnt.value] == 0, "sentinel missing"
         return idx[:cnt.value].copy(), st.value
+
+    def parse_document(self, data, length=None, max_depth=1024):
+        """sjmi_parse_document: all three stages on the GPU -> (tape np.uint64 or None, string buffer bytes, error code,
+        stage-1 status)."""
+        a = np.frombuffer(bytes(data), dtype=np.uint8)
+        n = a.size if length is None else length
+        tape = np.zeros(2 * n + 16, dtype=np.uint64)
+        sb = np.zeros(n + 4 * (n // 2 + 2) + 64, dtype=np.uint8)
+        tl, sl = C.c_uint64(0), C.c_uint64(0)
+        err = C.c_int32(0)
+        st = C.c_uint32(0)
+        self._check(lib().sjmi_parse_document(self._h, a.ctypes.data if a.size else None, n, max_depth, tape.ctypes.data, tape.size,
+                                              C.addressof(tl), sb.ctypes.data, sb.size, C.addressof(sl), C.addressof(err),
+                                              C.addressof(st)), "sjmi_parse_document")
+        return (tape[:tl.value].copy() if err.value == 0 else None), bytes(sb[:sl.value]), err.value, st.value
 
     def stage1_masks(self, data, length=None):
         """The reference's per-block masks (sjmi_stage1_masks): -> np.uint64 [len // 64 + 1, 6] =
@@ -509,12 +530,14 @@ class SimdJsonParser:
     DEFAULT_CAPACITY = 34 * 1024 * 1024
     DEFAULT_MAX_DEPTH = 1024
 
-    def __init__(self, capacity=DEFAULT_CAPACITY, max_depth=DEFAULT_MAX_DEPTH, device=0):
+    def __init__(self, capacity=DEFAULT_CAPACITY, max_depth=DEFAULT_MAX_DEPTH, device=0, gpu_walk=False):
         self._h = C.c_void_p()
         rc = lib().sjmi_parser_create(C.byref(self._h), capacity, max_depth, device)
         if rc != 0:
             self._h = C.c_void_p()
             raise SjmiError("sjmi_parser_create failed (rc=%d): no usable MI355X; there is no CPU fallback" % rc)
+        if gpu_walk:  # stage 2 on the GPU too (the cooperative walker): sjmi_parser_set_gpu_walk
+            lib().sjmi_parser_set_gpu_walk(self._h, 1)
 
     def close(self):
         if self._h:

@@ -1,0 +1,437 @@
+// coop_walk.hip -- stage 2 on the GPU, COOPERATIVE form: JsonIterator.walkDocument
+// (/root/reference/src/main/java/org/simdjson/JsonIterator.java:26-200) + TapeBuilder (TapeBuilder.java:41-217) as scans
+// and local predicates instead of a sequential automaton.
+//
+// One WAVE per document, lane j = structural (step * 64 + j) of that document; a document of any length is swept in
+// steps of 64 structurals, so the same kernel builds the tape of one large document (twitter.json: 864 steps) and of
+// every ~1 KB document of a batch (3 steps).  Per step, everything the sequential walker carries in its state is
+// recovered with wave primitives (the formulation was validated first as a Python model against the oracle,
+// tools/coop_walk_model.py):
+//   * class of each structural from its first byte; coalesced loads of the indexes and of the record sizes, one
+//     16-byte window of the document per structural (consecutive lanes share cache lines: the document is read once);
+//   * depth before each structural = running depth + exclusive DPP scan of (+1 open, -1 close);
+//   * the container a structural sits in ("bracket matching") = the last opening bracket in front of it whose depth is
+//     one less: found among the wave's own 64 structurals with one ballot per depth level present in the step, else in
+//     a small per-wave stack in LDS (tape position, comma count and kind of the open container of every level), which
+//     the step then updates -- the only state carried from step to step besides four running sums;
+//   * the role of a structural (value / key / colon / separator) is a function of its predecessor's class, of whether
+//     the predecessor was a key, and of the kind of its container: every grammar test of JsonIterator.java:68-193
+//     becomes a local predicate, and the document's error is the failing predicate at the LOWEST position -- exactly
+//     where the sequential walker stops;
+//   * tape positions = running position + exclusive scan of words per structural (bracket / string / atom 1, number 2,
+//     comma / colon 0); STRING payloads = running offset + exclusive scan of the record sizes the unescape pass left
+//     per structural; a closing bracket writes both container words (its own and the opening one, TapeBuilder.java:
+//     197-203: element count = commas directly inside + 1, saturated at 0xFFFFFF; empty-container quirk :205-208);
+//   * atoms and numbers are parsed by the lane that owns them (sj_number.h: Clinger / Eisel-Lemire on the device).
+// Tape words leave as 8-byte stores at consecutive addresses across the lanes (whole lines per step); nothing is
+// re-read: FETCH ~ document + 8 B per structural, WRITE ~ tape.
+//
+// Handed back to the host walker (doc_errors[k] = SJMI_WALK_NEEDS_HOST), as with the lane-per-document kernel it
+// replaces (walk.hip): a document nested deeper than 63 open containers, a floating-point literal of more than 19
+// significant digits.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sj_number.h"
+#include "stage1.h"
+
+namespace sjmi {
+
+namespace {
+
+constexpr int CW_LEVELS = 64;              // levels of the per-wave stack (a non-empty container at depth 63 is handed back)
+constexpr uint32_t CW_SIZE_SLOW = 0x80000000u;  // unescape.hip: sizes[] flag "this string had escapes / failed"
+
+enum : uint32_t { K_OPEN_A = 0, K_OPEN_O = 1, K_CLOSE_A = 2, K_CLOSE_O = 3, K_COMMA = 4, K_COLON = 5, K_QUOTE = 6, K_PRIM = 7 };
+
+struct __attribute__((packed, aligned(1))) CW16 { uint32_t a, b, c, d; };
+
+__device__ __forceinline__ uint32_t class_of(uint32_t c) {
+    return c == '[' ? K_OPEN_A : c == '{' ? K_OPEN_O : c == ']' ? K_CLOSE_A : c == '}' ? K_CLOSE_O
+           : c == ',' ? K_COMMA : c == ':' ? K_COLON : c == '"' ? K_QUOTE : K_PRIM;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t cw_dpp_add(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+}
+__device__ __forceinline__ uint32_t cw_incl_scan(uint32_t v) {
+    v = cw_dpp_add<0x111, 0xF>(v);
+    v = cw_dpp_add<0x112, 0xF>(v);
+    v = cw_dpp_add<0x114, 0xF>(v);
+    v = cw_dpp_add<0x118, 0xF>(v);
+    v = cw_dpp_add<0x142, 0xA>(v);
+    v = cw_dpp_add<0x143, 0xC>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t cw_last(uint32_t incl) { return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63); }
+
+// a moving 16-byte window over the document, for the lane that parses a primitive
+struct CwWin {
+    const uint8_t* buf;
+    uint32_t base, w0, w1, w2, w3;
+    __device__ __forceinline__ uint32_t at(uint32_t p) {
+        if (p - base >= 16u) {
+            base = p;
+            const CW16 v = *reinterpret_cast<const CW16*>(buf + p);
+            w0 = v.a; w1 = v.b; w2 = v.c; w3 = v.d;
+        }
+        const uint32_t o = p - base, w = o < 8 ? (o < 4 ? w0 : w1) : (o < 12 ? w2 : w3);
+        return (w >> (8u * (o & 3u))) & 0xFFu;
+    }
+    __device__ __forceinline__ uint32_t word(uint32_t p) { return at(p) | (at(p + 1) << 8) | (at(p + 2) << 16) | (at(p + 3) << 24); }
+};
+
+constexpr uint32_t CW_TRUE = 0x65757274u, CW_FALS = 0x736c6166u, CW_NULL = 0x6c6c756eu;
+
+// TapeBuilder.visitPrimitive (TapeBuilder.java:70-79) / visitRootPrimitive (:59-68) for one lane.
+// -> 0 and (type, raw second word for numbers) or the SJMI_E_* / SJMI_WALK_NEEDS_HOST code
+__device__ int cw_primitive(CwWin& w, uint32_t idx, bool root, uint32_t end, uint32_t* type, unsigned long long* raw) {
+    const uint32_t c = w.at(idx);
+    if (c == 't' || c == 'n') {
+        const bool ok = root ? (idx + 4 <= end && w.word(idx) == (c == 't' ? CW_TRUE : CW_NULL) && (idx + 4 == end || sjn_is_structural_or_ws(w.at(idx + 4))))
+                             : (w.word(idx) == (c == 't' ? CW_TRUE : CW_NULL) && sjn_is_structural_or_ws(w.at(idx + 4)));
+        *type = c;
+        return ok ? 0 : (c == 't' ? SJMI_E_INVALID_TRUE : SJMI_E_INVALID_NULL);
+    }
+    if (c == 'f') {
+        const bool ok = root ? (idx + 5 <= end && w.word(idx) == CW_FALS && w.at(idx + 4) == 'e' && (idx + 5 == end || sjn_is_structural_or_ws(w.at(idx + 5))))
+                             : (w.word(idx) == CW_FALS && w.at(idx + 4) == 'e' && sjn_is_structural_or_ws(w.at(idx + 5)));
+        *type = 'f';
+        return ok ? 0 : SJMI_E_INVALID_FALSE;
+    }
+    if (c == '-' || c - '0' <= 9u) {
+        const uint32_t limit = root ? end : 0xFFFFFFFFu;  // the root number's padded copy (TapeBuilder.java:183-189)
+        const SjNumber n = sj_scan_number([&](uint32_t q) -> uint32_t { return q < limit ? w.at(q) : 0x20u; }, idx);
+        if (n.code) return n.code;
+        if (n.floating) {
+            if (n.wide) return SJMI_WALK_NEEDS_HOST;  // DoubleParser's slow path (:205-330)
+            *type = 'd';
+            *raw = sj_compute_double_bits(n.negative, n.w, n.q);
+        } else {
+            if (sj_out_of_long_range(n.negative, n.digits, n.digit_count)) return SJMI_E_NUM_LONG_RANGE;
+            *type = 'l';
+            *raw = n.negative ? (~n.digits + 1) : n.digits;
+        }
+        return 0;
+    }
+    return SJMI_E_UNRECOGNIZED_PRIMITIVE;
+}
+
+__device__ __forceinline__ unsigned long long tape_word(uint32_t type, unsigned long long payload) {
+    return payload | ((unsigned long long)type << 56);
+}
+__device__ __forceinline__ int highest_bit_below(unsigned long long m, unsigned long long lt_mask) {
+    const unsigned long long x = m & lt_mask;
+    return x ? 63 - __builtin_clzll(x) : -1;
+}
+
+}  // namespace
+
+// One wave per document (grid-stride over the documents).  Documents are delimited by index_offsets (n_docs + 1 entries)
+// and doc_offsets; a single document is the batch of one.  Document k's tape is built in its slot of the scratch tape
+// (2 words per structural + 2, walk.hip packs the tapes back to back afterwards); sizes / scratch: the per-structural
+// records of the unescape pass (4 + length | flags per '"' structural, 0 otherwise; scratch[open] = code of a failed
+// string).
+__global__ void __launch_bounds__(256)
+k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restrict__ doc_offsets, uint64_t n_docs,
+            const uint32_t* __restrict__ idx, const unsigned long long* __restrict__ index_offsets,
+            const uint32_t* __restrict__ doc_status, const uint32_t* __restrict__ sizes, const uint8_t* __restrict__ scratch,
+            const unsigned long long* __restrict__ doc_str_offsets, unsigned long long string_base, int max_depth,
+            unsigned long long* __restrict__ scratch_tape, uint32_t* __restrict__ tape_lens, int32_t* __restrict__ doc_errors, const Stage1Result* __restrict__ dev_count,
+            const UnescapeResult* __restrict__ dev_strings, WalkResult* res) {
+    __shared__ uint32_t s_tpos[4][CW_LEVELS], s_cnt[4][CW_LEVELS];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t* const st_tpos = s_tpos[wv];
+    uint32_t* const st_cnt = s_cnt[wv];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    const bool upstream_failed = (dev_count && (dev_count->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL))) ||
+                                 (dev_strings && (dev_strings->flags & 1u));
+    unsigned long long n_host = 0, n_bad = 0;
+    for (uint64_t k = (uint64_t)blockIdx.x * 4 + wv; k < n_docs; k += nwaves) {
+        int code = 0;
+        uint32_t tlen = 0;
+        const uint32_t st = doc_status ? doc_status[k] : 0u;
+        const unsigned long long from = index_offsets[k], to = index_offsets[k + 1];
+        // SimdJsonParser.stage1 order: Utf8Validator.validate (:165-167), then StructuralIndexer.index (:297-302)
+        if (upstream_failed) code = SJMI_E_CAPACITY;
+        else if (st & SJMI_ST_UTF8) code = SJMI_E_UTF8;
+        else if (st & SJMI_ST_UNCLOSED) code = SJMI_E_UNCLOSED_STRING;
+        else if (st & SJMI_ST_UNESCAPED) code = SJMI_E_UNESCAPED_CHARS;
+        else if (from == to) code = SJMI_E_NO_STRUCTURAL;  // JsonIterator.java:27-29
+        if (code == 0) {
+            const uint32_t doc_start = (uint32_t)doc_offsets[k], doc_end = (uint32_t)doc_offsets[k + 1];
+            const uint64_t n = to - from;
+            unsigned long long* const T = scratch_tape + 2 * from + 2 * k;  // this document's slot (word 0 = root)
+            const uint64_t room = 2 * n + 2;                                // a structural makes at most two words
+            const uint32_t last_c = buf[idx[to - 1]];
+            // running state (wave-uniform)
+            uint32_t H0 = 0;                 // open containers in front of the step
+            uint32_t T0 = 1;                 // tape position of the step's first word (0 = the root word)
+            unsigned long long S0 = doc_str_offsets[k];
+            unsigned long long arr_mask = 0; // bit L: the open container of level L is an array
+            uint32_t prev_cls = K_COMMA;     // class of the structural in front of the step (none at the start)
+            bool prev_empty_open = false, prev_is_key = false, root_closed = false;
+            uint32_t root_kind = 0;
+            // software pipeline: positions one step ahead of the windows, windows one step ahead of their use
+            auto load_pos = [&](uint64_t s, uint32_t* p, uint32_t* sz, uint32_t* px) {
+                const uint64_t i = from + s * 64 + lane;
+                *p = i < to ? idx[i] : doc_start;
+                *sz = i < to ? sizes[i] : 0u;
+                const uint64_t ix = from + s * 64 + 64;
+                *px = ix < to ? idx[ix] : doc_start;
+            };
+            uint32_t p_n, sz_n, px_n;
+            load_pos(0, &p_n, &sz_n, &px_n);
+            CW16 win_n = *reinterpret_cast<const CW16*>(buf + p_n);
+            uint32_t bx_n = buf[px_n];
+            const uint64_t nsteps = (n + 63) / 64;
+            for (uint64_t s = 0; s < nsteps && code == 0; ++s) {
+                const uint32_t p = p_n, sz = sz_n, c_extra = bx_n;
+                const CW16 win = win_n;
+                if (s + 1 < nsteps) {
+                    load_pos(s + 1, &p_n, &sz_n, &px_n);
+                    win_n = *reinterpret_cast<const CW16*>(buf + p_n);
+                    bx_n = buf[px_n];
+                }
+                const uint64_t i = from + s * 64 + lane;
+                const bool valid = i < to;
+                const unsigned long long vmask = __ballot(valid);
+                if (root_closed) {  // JsonIterator.java:196-198: something follows the root value
+                    code = SJMI_E_TRAILING_CONTENT;
+                    break;
+                }
+                const uint32_t c = win.a & 0xFFu;
+                const uint32_t cls = valid ? class_of(c) : K_COMMA;
+                const bool is_open = valid && cls <= K_OPEN_O, is_close = valid && (cls == K_CLOSE_A || cls == K_CLOSE_O);
+                // neighbours
+                uint32_t cls_prev = (uint32_t)__shfl_up((int)cls, 1);
+                if (lane == 0) cls_prev = prev_cls;
+                uint32_t cls_next = (uint32_t)__shfl_down((int)cls, 1);
+                const bool has_next = i + 1 < to;
+                if (lane == 63) cls_next = class_of(c_extra);
+                // (1) empty containers: an opening bracket directly followed by its closing bracket is ONE value (:205-208)
+                const bool empty_open = is_open && has_next && cls_next == cls + 2;
+                int eo_prev = __shfl_up((int)empty_open, 1);
+                if (lane == 0) eo_prev = prev_empty_open;
+                const bool empty_close = valid && is_close && eo_prev && i > from;
+                // (2) depth in front of every structural
+                const uint32_t up = is_open ? 1u : 0u, down = is_close ? 1u : 0u;
+                const uint32_t iu = cw_incl_scan(up), id = cw_incl_scan(down);
+                const int h = (int)H0 + (int)(iu - up) - (int)(id - down);  // may go negative behind the root's end: never used there
+                // (3) tape positions and string offsets
+                const bool is_num = valid && cls == K_PRIM && (c == '-' || c - '0' <= 9u);
+                const uint32_t words = !valid || cls == K_COMMA || cls == K_COLON ? 0u : (is_num ? 2u : 1u);
+                const uint32_t iw = cw_incl_scan(words);
+                const uint32_t tpos = T0 + iw - words;
+                const uint32_t ssz = (valid && cls == K_QUOTE) ? (sz & ~CW_SIZE_SLOW) : 0u;
+                // (the records of one step cover at most 64 strings of < 2^32 bytes in total: 64-bit running offset, 32-bit scan;
+                //  a step whose sizes would overflow 32 bits cannot occur: the document itself is < 4 GiB)
+                const uint32_t is_ = cw_incl_scan(ssz);
+                const unsigned long long soff = S0 + (is_ - ssz);
+                // (4) the container of every structural: level loop over the depths present in this step
+                const int plevel = h - 1;  // level of the container this structural sits in
+                int hmin = valid ? plevel : 0x7FFF, hmax = valid ? (is_open ? h : plevel) : -0x7FFF;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    hmin = min(hmin, __shfl_xor(hmin, d));
+                    hmax = max(hmax, __shfl_xor(hmax, d));
+                }
+                if (hmin < 0) hmin = 0;  // (level -1 = in front of / behind the root: no container)
+                bool par_in_wave = false, par_is_array = false;
+                uint32_t par_tpos = 0, par_cnt = 0;
+                // (deeper than the device stack: the non-empty open at depth 63 is handed back below, at a lower position
+                //  than anything that would need a level beyond the stack)
+                if (hmax >= CW_LEVELS) hmax = CW_LEVELS - 1;
+                for (int L = hmin; L <= hmax; ++L) {
+                    const unsigned long long O = __ballot(is_open && h == L);                 // opens of level L
+                    const unsigned long long C = __ballot(valid && cls == K_COMMA && plevel == L);  // commas directly inside level L
+                    const unsigned long long Z = __ballot(is_close && plevel == L);            // closes of level-L containers
+                    const bool mine = valid && plevel == L;
+                    const int a = highest_bit_below(O, lt_mask);
+                    uint32_t a_tpos = (uint32_t)__shfl((int)tpos, a < 0 ? 0 : a);
+                    uint32_t a_cls = (uint32_t)__shfl((int)cls, a < 0 ? 0 : a);
+                    const uint32_t sk_tpos = st_tpos[L], sk_cnt = st_cnt[L];
+                    if (mine) {
+                        par_in_wave = a >= 0;
+                        par_is_array = a >= 0 ? a_cls == K_OPEN_A : ((arr_mask >> L) & 1ull) != 0;
+                        par_tpos = a >= 0 ? a_tpos : sk_tpos;
+                        const unsigned long long between = C & lt_mask & (a >= 0 ? ~((2ull << a) - 1ull) : ~0ull);
+                        par_cnt = (a >= 0 ? 0u : sk_cnt) + (uint32_t)__popcll(between);
+                    }
+                    // stack update for the next steps (wave-uniform)
+                    __builtin_amdgcn_wave_barrier();
+                    if (O) {
+                        const int al = 63 - __builtin_clzll(O);  // the last open of this level in the step
+                        const unsigned long long above = al == 63 ? 0ull : ~((2ull << al) - 1ull);
+                        if (!(Z & above)) {  // still open at the end of the step
+                            const uint32_t tp = (uint32_t)__builtin_amdgcn_readlane((int)tpos, al);
+                            const uint32_t kc = (uint32_t)__builtin_amdgcn_readlane((int)cls, al);
+                            if (lane == 0) {
+                                st_tpos[L] = tp;
+                                st_cnt[L] = (uint32_t)__popcll(C & above);
+                            }
+                            arr_mask = kc == K_OPEN_A ? (arr_mask | (1ull << L)) : (arr_mask & ~(1ull << L));
+                        }
+                    } else if (!Z) {
+                        if (lane == 0 && C) st_cnt[L] = sk_cnt + (uint32_t)__popcll(C);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                // (5) roles and their local predicates (JsonIterator.java:68-193)
+                const bool prev_open_nonempty = (cls_prev <= K_OPEN_O) && !eo_prev;
+                const bool first_key = prev_open_nonempty && cls_prev == K_OPEN_O;
+                const bool key_after_comma = cls_prev == K_COMMA && !par_is_array && i > from;
+                const bool is_key = valid && (first_key || key_after_comma) && cls == K_QUOTE && i > from;
+                int ik_prev = __shfl_up((int)is_key, 1);
+                if (lane == 0) ik_prev = prev_is_key;
+                int err = 0;
+                uint32_t ptype = 0;
+                unsigned long long praw = 0;
+                bool want_value = false;
+                if (valid && !empty_close) {
+                    if (i == from) {
+                        if (cls <= K_OPEN_O && last_c != c + 2) err = cls == K_OPEN_O ? SJMI_E_UNCLOSED_OBJECT : SJMI_E_UNCLOSED_ARRAY;  // :39-41,:51-53
+                        else want_value = true;
+                    } else if (prev_open_nonempty) {
+                        if (cls_prev == K_OPEN_A) want_value = true;
+                        else if (cls != K_QUOTE) err = SJMI_E_OBJECT_NO_KEY;  // :75-77
+                    } else if (cls_prev == K_COMMA) {
+                        if (par_is_array) want_value = true;
+                        else if (cls != K_QUOTE) err = SJMI_E_KEY_MISSING;    // :121-123
+                    } else if (cls_prev == K_COLON) {
+                        want_value = true;
+                    } else if (ik_prev) {
+                        if (cls != K_COLON) err = SJMI_E_MISSING_COLON;       // :84-86
+                    } else {  // the predecessor ended a value
+                        const bool ok = cls == K_COMMA || cls == (par_is_array ? K_CLOSE_A : K_CLOSE_O);
+                        if (!ok) err = par_is_array ? SJMI_E_NO_COMMA_ARRAY : SJMI_E_NO_COMMA_OBJECT;  // :131,:189
+                    }
+                    if (!err && cls == K_QUOTE && (is_key || want_value)) {
+                        // a string the reference's StringParser would have thrown on: size 4 | SLOW, code in scratch[open]
+                        if (sz == (4u | CW_SIZE_SLOW)) err = (int)scratch[p];
+                    } else if (!err && want_value) {
+                        if (cls <= K_OPEN_O) {
+                            if (!empty_open) {
+                                if (h + 1 >= max_depth) err = SJMI_E_DEPTH;                  // JsonIterator.java:69-70
+                                else if (h + 1 >= CW_LEVELS) err = SJMI_WALK_NEEDS_HOST;     // deeper than the device stack
+                            }
+                        } else if (cls != K_QUOTE) {
+                            CwWin w = {buf, p, win.a, win.b, win.c, win.d};
+                            err = cw_primitive(w, p, i == from, doc_end, &ptype, &praw);
+                        }
+                    }
+                }
+                // (6) where the root value ends; the first error by position
+                if (s == 0) root_kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cls <= K_OPEN_O ? 1u + cls : 0u));
+                const bool closes_root = (is_close && h == 1 && root_kind != 0) || (valid && i == from && root_kind == 0);
+                const unsigned long long rc = __ballot(closes_root);
+                const int rc_lane = rc ? __builtin_ctzll(rc) : 64;
+                if (lane == rc_lane + 1 && valid) err = SJMI_E_TRAILING_CONTENT;
+                const unsigned long long em = __ballot(err != 0 && lane <= rc_lane + 1);
+                if (em) {
+                    code = __builtin_amdgcn_readlane(err, __builtin_ctzll(em));
+                    break;
+                }
+                if (rc) root_closed = true;
+                // (7) the tape words of this step
+                const bool live = valid && lane <= rc_lane;
+                if (live) {
+                    if (cls == K_QUOTE) {
+                        if (tpos < room) T[tpos] = tape_word('"', string_base + soff);
+                    } else if (cls == K_PRIM) {
+                        if (tpos < room) T[tpos] = tape_word(ptype, 0);
+                        if (is_num && tpos + 1 < room) T[tpos + 1] = praw;
+                    } else if (empty_open) {
+                        if (tpos < room) T[tpos] = tape_word(c, tpos + 2);          // TapeBuilder.java:205-208
+                    } else if (empty_close) {
+                        if (tpos < room) T[tpos] = tape_word(c, tpos);              // (= position of the opening word + 1)
+                    } else if (is_close) {
+                        uint32_t cnt = par_cnt + 1u;
+                        if (cnt > 0xFFFFFFu) cnt = 0xFFFFFFu;
+                        if (tpos < room) T[tpos] = tape_word(c, par_tpos);                                                    // :197-203
+                        if (par_tpos < room) T[par_tpos] = tape_word(c - 2, (unsigned long long)(tpos + 1) | ((unsigned long long)cnt << 32));
+                    }
+                }
+                // (8) carries
+                const uint32_t live_words = (uint32_t)__builtin_amdgcn_readlane((int)iw, rc_lane < 64 ? rc_lane : 63);
+                H0 = (uint32_t)((int)H0 + (int)cw_last(iu) - (int)cw_last(id));
+                T0 += rc_lane < 64 ? live_words : cw_last(iw);
+                S0 += cw_last(is_);
+                const int lastv = 63 - __builtin_clzll(vmask);
+                prev_cls = (uint32_t)__builtin_amdgcn_readlane((int)cls, lastv);
+                prev_empty_open = __builtin_amdgcn_readlane((int)empty_open, lastv) != 0;
+                prev_is_key = __builtin_amdgcn_readlane((int)is_key, lastv) != 0;
+            }
+            if (code == 0 && !root_closed) {
+                // the walker reads on past the last structural: BitIndexes' sentinel = the document's first byte, an opening
+                // bracket where a separator is due (BitIndexes.java:82-96, JsonIterator.java:131,:189)
+                const int top = (int)H0 - 1;
+                code = (top >= 0 && top < CW_LEVELS && ((arr_mask >> top) & 1ull)) ? SJMI_E_NO_COMMA_ARRAY : SJMI_E_NO_COMMA_OBJECT;
+            }
+            if (code == 0) {
+                tlen = T0 + 1;  // + the closing root word
+                if (lane == 0) {
+                    if (tlen <= room) {
+                        T[T0] = tape_word('r', 0);      // visitDocumentEnd, TapeBuilder.java:45-48
+                        T[0] = tape_word('r', tlen);
+                    }
+                }
+                if (tlen > room) {  // (cannot happen: two words per structural + 2)
+                    tlen = 0;
+                    code = SJMI_E_INTERNAL;
+                }
+            }
+        }
+        if (lane == 0) {
+            tape_lens[k] = tlen;
+            doc_errors[k] = code;
+        }
+        n_host += code == SJMI_WALK_NEEDS_HOST;
+        n_bad += code > 0;
+    }
+    (void)res;
+    (void)n_host;
+    (void)n_bad;  // (host / failed documents are counted by the packing kernels from doc_errors)
+}
+
+// single document: the delimiters the batch kernels expect, from the stage-1 record that is still on the device
+__global__ void k_single_doc_setup(const Stage1Result* __restrict__ res, unsigned long long len, unsigned long long* doc_offsets,
+                                   unsigned long long* index_offsets, uint32_t* doc_status, unsigned long long* doc_str_offsets) {
+    if (threadIdx.x == 0) {
+        doc_offsets[0] = 0;
+        doc_offsets[1] = len;
+        index_offsets[0] = 0;
+        index_offsets[1] = (res->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL)) ? 0ull : res->count;
+        doc_status[0] = res->status & 0xFFu;
+        doc_str_offsets[0] = 0;
+        doc_str_offsets[1] = 0;
+    }
+}
+
+hipError_t single_doc_setup_launch(const Stage1Result* d_res, uint64_t len, unsigned long long* d_doc_offsets,
+                                   unsigned long long* d_index_offsets, uint32_t* d_doc_status, unsigned long long* d_doc_str_offsets,
+                                   hipStream_t stream) {
+    hipLaunchKernelGGL(k_single_doc_setup, dim3(1), dim3(64), 0, stream, d_res, (unsigned long long)len, d_doc_offsets, d_index_offsets,
+                       d_doc_status, d_doc_str_offsets);
+    return hipGetLastError();
+}
+
+hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_idx,
+                            const unsigned long long* d_index_offsets, const uint32_t* d_doc_status, const uint32_t* d_sizes,
+                            const uint8_t* d_scratch, const unsigned long long* d_doc_str_offsets, uint64_t string_base,
+                            int max_depth, unsigned long long* d_scratch_tape, uint32_t* d_tape_lens, int32_t* d_doc_errors,
+                            const Stage1Result* dev_count, const UnescapeResult* dev_strings, WalkResult* d_res,
+                            hipStream_t stream) {
+    if (!n_docs) return hipSuccess;
+    const uint64_t want = (n_docs + 3) / 4;  // four documents (waves) per workgroup and trip
+    const unsigned grid = (unsigned)(want < 16384 ? want : 16384);
+    hipLaunchKernelGGL(k_coop_walk, dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets,
+                       d_doc_status, d_sizes, d_scratch, d_doc_str_offsets, (unsigned long long)string_base, max_depth,
+                       d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res);
+    return hipGetLastError();
+}
+
+}  // namespace sjmi

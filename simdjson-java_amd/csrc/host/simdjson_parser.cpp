@@ -249,6 +249,22 @@ JsonValue SimdJsonParser::parse(const uint8_t* buffer, size_t len) {
     // reset (:50-53)
     walker_.bitIndexes().reset();
     walker_.resetForDocument(0, 0);
+    if (gpuWalk_) {
+        // all three stages on the GPU: the tape arrives ready; a document that fails (or that the device hands back) takes
+        // the host path below, which raises the reference's exception with its exact message and position
+        uint64_t words = 0, sbLen = 0;
+        int32_t err = 0;
+        uint32_t status = 0;
+        growStringBuffer(len + 4 * (len / 2 + 2) + 64);
+        const int rc = sjmi_parse_document(ctx_, paddedBuffer_.data(), len, maxDepth_, walker_.tape().raw(), walker_.tape().capacity(),
+                                           &words, stringBuffer_.data(), stringBuffer_.size(), &sbLen, &err, &status);
+        if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_parse_document: ") + sjmi_last_error(ctx_));
+        if (err == 0) {
+            walker_.tape().setCurrentIdx((size_t)words);
+            stringBufferLen_ = (size_t)sbLen;
+            return JsonValue(&walker_.tape(), 1, stringBuffer_.data());
+        }
+    }
     stage1(paddedBuffer_.data(), len);
     walker_.setStringBuffer(stringBuffer_.data());
     walker_.walkDocument(len);
@@ -755,6 +771,12 @@ void sjmi_parser_destroy(sjmi_parser* h) {
 }
 
 const char* sjmi_parser_last_message(const sjmi_parser* h) { return h ? h->msg.c_str() : ""; }
+
+int sjmi_parser_set_gpu_walk(sjmi_parser* h, int on) {
+    if (!h) return SJMI_ERR_ARG;
+    h->p->setGpuWalk(on != 0);
+    return SJMI_OK;
+}
 
 int sjmi_parser_parse_batch(sjmi_parser* h, const uint8_t* buf, uint64_t total_len, const uint64_t* doc_offsets,
                             uint64_t n_docs, const uint64_t** tape, const uint64_t** tape_offsets,

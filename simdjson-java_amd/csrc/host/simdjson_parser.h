@@ -94,6 +94,8 @@ public:
     int getScopeCount(size_t i) const { return (int)((tape_[i] >> 32) & 0xFFFFFF); }
     size_t computeNextIndex(size_t i) const;                                                          // :86-98
     const uint64_t* data() const { return tape_; }
+    uint64_t* raw() { return tape_; }                 // filled by the GPU walker (sjmi_parse_document)
+    void setCurrentIdx(size_t n) { idx_ = n; }
     size_t capacity() const { return capacity_; }
 
 private:
@@ -205,6 +207,8 @@ public:
     // parse(byte[] buffer, int len) :35-40.  Only buffer[0,len) is read.  The returned JsonValue aliases
     // parser-owned memory and is invalidated by the next parse(), exactly like the reference.
     JsonValue parse(const uint8_t* buffer, size_t len);
+    // stage 2 of parse() on the GPU (the cooperative walker) instead of the host walker; identical results
+    void setGpuWalk(bool on) { gpuWalk_ = on; }
 
     // Batched parse: documents packed NDJSON-style at doc_offsets[k] (n+1 entries).  One GPU pass for the batch (isolated
     // stage 1 + string unescape + per-document string offsets), then the host stage 2 of the documents on several
@@ -234,6 +238,7 @@ private:
     std::unique_ptr<uint64_t[]> batchTape_;  // (not a vector: grown without zero-filling, kept between batches)
     size_t batchTapeLen_ = 0, batchTapeRoom_ = 0;
     std::vector<uint64_t> batchTapeOffsets_, indexOffsets_, docStringOffsets_;
+    bool gpuWalk_ = false;
     int batchThreads_ = 1;  // host threads walking the documents of a batch (SJMI_PARSE_THREADS overrides)
     int batchPipeline_ = 0;  // sub-batches per batch, 0 = by size (SJMI_PARSE_PIPELINE overrides)
     // kept between batches: a walker per batch thread, and per (sub-batch, thread) the slab its tapes are built in

@@ -44,6 +44,12 @@ struct sjmi_ctx {
     size_t masks_bytes = 0;
     void* d_ws_masks = nullptr;
     size_t ws_masks_bytes = 0;
+    void* d_single = nullptr;                // sjmi_parse_document: delimiters, tape offsets, error and results of ONE document
+    unsigned long long* d_tape = nullptr;    // ... and its tape, grown on demand
+    size_t tape_bytes = 0;
+    void* h_single = nullptr;                // pinned copy of the three result records
+    const void* unesc_idx = nullptr;         // index array and count bound of the last unescape launch on this context: its
+    uint64_t unesc_bound = 0;                // per-structural records (sizes, scratch copy) are still in d_ws_str
     uint64_t last_ndocs = 0;                 // documents of the last batch call (their index offsets are still on the device)
     bool last_batch = false;
     size_t docoff_bytes = 0;
@@ -124,6 +130,9 @@ void sjmi_destroy(sjmi_ctx* c) {
     if (c->d_doccnt) (void)hipFree(c->d_doccnt);
     if (c->d_docstr) (void)hipFree(c->d_docstr);
     if (c->d_ws_walk) (void)hipFree(c->d_ws_walk);
+    if (c->d_single) (void)hipFree(c->d_single);
+    if (c->d_tape) (void)hipFree(c->d_tape);
+    if (c->h_single) (void)hipHostFree(c->h_single);
     if (c->d_masks) (void)hipFree(c->d_masks);
     if (c->d_ws_masks) (void)hipFree(c->d_ws_masks);
     if (c->h_res) (void)hipHostFree(c->h_res);
@@ -225,11 +234,14 @@ static int unescape_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, co
     if (!grow(c, &c->d_ws_str, &c->ws_str_bytes, sjmi::unescape_workspace_bytes(count, len), "hipMalloc(ws_str)"))
         return SJMI_ERR_HIP;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    c->unesc_idx = nullptr;
     if (fail(c, "unescape launch",
              sjmi::unescape_launch((const uint8_t*)d_buf, len, (const uint32_t*)d_indexes, count, nullptr,
                                    (uint8_t*)d_string_buffer, string_capacity, c->d_ws_str,
                                    (sjmi::UnescapeResult*)d_result, st, batch)))
         return SJMI_ERR_HIP;
+    c->unesc_idx = d_indexes;
+    c->unesc_bound = count;
     return SJMI_OK;
 }
 
@@ -410,12 +422,21 @@ int sjmi_walk_batch_device(sjmi_ctx* c, const void* d_buf, const void* d_doc_off
     if (!grow(c, &c->d_ws_walk, &c->ws_walk_bytes, sjmi::walk_workspace_bytes(count, n_docs), "hipMalloc(ws_walk)"))
         return SJMI_ERR_HIP;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    // The cooperative walker (coop_walk.hip) works from the per-structural records the unescape pass of THESE indexes
+    // left on this context; without them (another context made the string buffer) the lane-per-document walker reads
+    // the record headers out of the string buffer instead.  SJMI_WALK=lane forces the latter (A/B measurements).
+    const uint32_t* sizes = nullptr;
+    const uint8_t* str_scratch = nullptr;
+    static const bool force_lane = getenv("SJMI_WALK") && strcmp(getenv("SJMI_WALK"), "lane") == 0;
+    if (!force_lane && c->unesc_idx == d_indexes && c->unesc_idx && c->d_ws_str)
+        sjmi::unescape_records(c->d_ws_str, c->unesc_bound, &sizes, &str_scratch);
     if (fail(c, "walk launch",
              sjmi::walk_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs, (const uint32_t*)d_indexes,
                                count, (const unsigned long long*)d_index_offsets, (const uint32_t*)d_doc_status,
                                (const uint8_t*)d_string_buffer, (const unsigned long long*)d_doc_string_offsets, string_base,
                                max_depth, (unsigned long long*)d_tape, tape_capacity, (unsigned long long*)d_tape_offsets,
-                               (int32_t*)d_doc_errors, c->d_ws_walk, (sjmi::WalkResult*)d_result, st)))
+                               (int32_t*)d_doc_errors, c->d_ws_walk, (sjmi::WalkResult*)d_result, st, nullptr, nullptr, sizes,
+                               str_scratch)))
         return SJMI_ERR_HIP;
     return SJMI_OK;
 }
@@ -657,6 +678,12 @@ int sjmi_parse_batch_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, 
     batch.d_index_offsets = (const unsigned long long*)d_index_offsets;
     batch.n_docs = n_docs;
     batch.d_doc_str_offsets = (unsigned long long*)d_doc_string_offsets;
+    const uint32_t* sizes = nullptr;
+    const uint8_t* str_scratch = nullptr;
+    static const bool force_lane = getenv("SJMI_WALK") && strcmp(getenv("SJMI_WALK"), "lane") == 0;
+    if (!force_lane) sjmi::unescape_records(c->d_ws_str, bound, &sizes, &str_scratch);
+    c->unesc_idx = d_indexes;
+    c->unesc_bound = bound;
     if (fail(c, "unescape launch",
              sjmi::unescape_launch((const uint8_t*)d_buf, total_len, (const uint32_t*)d_indexes, bound,
                                    (const sjmi::Stage1Result*)&r->stage1, (uint8_t*)d_string_buffer, string_capacity,
@@ -667,8 +694,91 @@ int sjmi_parse_batch_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, 
                                (const uint8_t*)d_string_buffer, (const unsigned long long*)d_doc_string_offsets, 0, max_depth,
                                (unsigned long long*)d_tape, tape_capacity, (unsigned long long*)d_tape_offsets,
                                (int32_t*)d_doc_errors, c->d_ws_walk, (sjmi::WalkResult*)&r->walk, st,
-                               (const sjmi::Stage1Result*)&r->stage1, (const sjmi::UnescapeResult*)&r->strings)))
+                               (const sjmi::Stage1Result*)&r->stage1, (const sjmi::UnescapeResult*)&r->strings, sizes, str_scratch)))
         return SJMI_ERR_HIP;
+    return SJMI_OK;
+}
+
+// SimdJsonParser.parse(byte[], int) with ALL THREE stages on the GPU (SimdJsonParser.java:35-40): H2D of the document,
+// stage 1, string records, the cooperative walker, D2H of the tape and the string buffer -- the structural indexes never
+// leave the device.  Two host synchronisations (the result records, then the outputs).
+int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_depth, uint64_t* tape, uint64_t tape_capacity,
+                        uint64_t* tape_len, uint8_t* string_buffer, uint64_t string_capacity, uint64_t* strings_len,
+                        int32_t* error, uint32_t* stage1_status) {
+    if (!c || (!buf && len) || !tape || !tape_len || !string_buffer || !strings_len || !error || !stage1_status || max_depth < 1)
+        return SJMI_ERR_ARG;
+    if (len > c->capacity || len >= (1ull << 32)) {
+        c->err = "document larger than the context capacity";
+        return SJMI_ERR_CAPACITY;
+    }
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    const uint64_t bound = len + 1;  // structurals: at most one per byte
+    const size_t need_sb = (size_t)len + 4 * ((size_t)len / 2 + 2) + 64;
+    if (!grow(c, (void**)&c->d_sb, &c->sb_bytes, need_sb, "hipMalloc(sb)") ||
+        !grow(c, &c->d_ws_str, &c->ws_str_bytes, sjmi::unescape_workspace_bytes(bound, len), "hipMalloc(ws_str)") ||
+        !grow(c, &c->d_ws_walk, &c->ws_walk_bytes, sjmi::walk_workspace_bytes(bound, 1), "hipMalloc(ws_walk)") ||
+        !grow(c, (void**)&c->d_tape, &c->tape_bytes, (2 * (size_t)bound + 16) * sizeof(unsigned long long), "hipMalloc(tape)"))
+        return SJMI_ERR_HIP;
+    if (!c->d_single && fail(c, "hipMalloc(single)", hipMalloc(&c->d_single, 512))) return SJMI_ERR_HIP;
+    if (!c->h_single && fail(c, "hipHostMalloc(single)", hipHostMalloc(&c->h_single, 256))) return SJMI_ERR_HIP;
+    // layout of d_single: doc_offsets[2] | index_offsets[2] | doc_str_offsets[2] | tape_offsets[2] | status | error | results
+    unsigned long long* d64 = (unsigned long long*)c->d_single;
+    unsigned long long *d_doc = d64, *d_io = d64 + 2, *d_dso = d64 + 4, *d_to = d64 + 6;
+    uint32_t* d_st = (uint32_t*)(d64 + 8);
+    int32_t* d_err = (int32_t*)(d64 + 9);
+    sjmi::UnescapeResult* d_ures = (sjmi::UnescapeResult*)(d64 + 10);
+    sjmi::WalkResult* d_wres = (sjmi::WalkResult*)(d64 + 13);
+    const sjmi::Stage1Result* d_res1 = (const sjmi::Stage1Result*)((uint8_t*)c->d_ws + sjmi::WS_RESULT_OFFSET);
+    struct Host { sjmi_stage1_result s1; sjmi_unescape_result u; sjmi_walk_result w; unsigned long long to[2]; int32_t err; };
+    Host* h = (Host*)c->h_single;
+    const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(len);
+    if (len && fail(c, "H2D", hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
+    const uint32_t* sizes = nullptr;
+    const uint8_t* str_scratch = nullptr;
+    sjmi::unescape_records(c->d_ws_str, bound, &sizes, &str_scratch);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (fail(c, "launch", sjmi::stage1_launch(c->d_in, len, c->d_idx, c->capacity + 2, c->d_ws, steps, c->stream, nullptr, nullptr,
+                                                  launch_flags(c))) ||
+            fail(c, "unescape launch", sjmi::unescape_launch(c->d_in, len, c->d_idx, bound, d_res1, c->d_sb, c->sb_bytes, c->d_ws_str,
+                                                             d_ures, c->stream)) ||
+            fail(c, "setup", sjmi::single_doc_setup_launch(d_res1, len, d_doc, d_io, d_st, d_dso, c->stream)) ||
+            fail(c, "walk launch",
+                 sjmi::walk_launch(c->d_in, d_doc, 1, c->d_idx, bound, d_io, d_st, c->d_sb, d_dso, 0, max_depth, c->d_tape,
+                                   2 * bound + 8, d_to, d_err, c->d_ws_walk, d_wres, c->stream, d_res1, d_ures, sizes, str_scratch)) ||
+            fail(c, "D2H", hipMemcpyAsync(&h->s1, d_res1, sizeof h->s1, hipMemcpyDeviceToHost, c->stream)) ||
+            fail(c, "D2H", hipMemcpyAsync(&h->u, d_ures, sizeof h->u, hipMemcpyDeviceToHost, c->stream)) ||
+            fail(c, "D2H", hipMemcpyAsync(&h->w, d_wres, sizeof h->w, hipMemcpyDeviceToHost, c->stream)) ||
+            fail(c, "D2H", hipMemcpyAsync(h->to, d_to, 16, hipMemcpyDeviceToHost, c->stream)) ||
+            fail(c, "D2H", hipMemcpyAsync(&h->err, d_err, 4, hipMemcpyDeviceToHost, c->stream)) ||
+            fail(c, "sync", hipStreamSynchronize(c->stream)))
+            return SJMI_ERR_HIP;
+        if (!(h->s1.status & SJMI_ST_INTERNAL) || c->ticket_mode) break;
+        c->ticket_mode = true;  // fast-mode liveness assumption failed: latch the safe mode and run again
+    }
+    c->last_valid = false;
+    c->unesc_idx = nullptr;
+    *stage1_status = h->s1.status & 0xFFu;
+    *tape_len = 0;
+    *strings_len = 0;
+    *error = h->err;
+    if (h->s1.status & SJMI_ST_INTERNAL) {
+        c->err = "look-back timeout";
+        return SJMI_ERR_INTERNAL;
+    }
+    if (h->s1.status & SJMI_ST_CAPACITY) return SJMI_ERR_CAPACITY;
+    if (h->err != 0) return SJMI_OK;  // a JSON error or SJMI_WALK_NEEDS_HOST: no tape
+    const uint64_t words = h->to[1] - h->to[0];
+    if (words > tape_capacity || h->u.total_bytes > string_capacity || (h->u.flags & 1u)) {
+        c->err = "tape or string capacity too small";
+        return SJMI_ERR_CAPACITY;
+    }
+    if (fail(c, "D2H(tape)", hipMemcpyAsync(tape, c->d_tape + h->to[0], words * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream)) ||
+        (h->u.total_bytes &&
+         fail(c, "D2H(sb)", hipMemcpyAsync(string_buffer, c->d_sb, h->u.total_bytes, hipMemcpyDeviceToHost, c->stream))) ||
+        fail(c, "sync", hipStreamSynchronize(c->stream)))
+        return SJMI_ERR_HIP;
+    *tape_len = words;
+    *strings_len = h->u.total_bytes;
     return SJMI_OK;
 }
 

@@ -86,7 +86,21 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
                        const uint8_t* d_sb, const unsigned long long* d_doc_str_offsets, uint64_t string_base, int max_depth,
                        unsigned long long* d_tape, uint64_t tape_capacity, unsigned long long* d_tape_offsets,
                        int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream,
-                       const Stage1Result* dev_count = nullptr, const UnescapeResult* dev_strings = nullptr);
+                       const Stage1Result* dev_count = nullptr, const UnescapeResult* dev_strings = nullptr,
+                       const uint32_t* d_sizes = nullptr, const uint8_t* d_str_scratch = nullptr);
+// coop_walk.hip: the cooperative walker (a wave per document); d_sizes / d_scratch = the per-structural records and the
+// scratch copy of the unescape pass that produced the string buffer (unescape_records below)
+hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_idx,
+                            const unsigned long long* d_index_offsets, const uint32_t* d_doc_status, const uint32_t* d_sizes,
+                            const uint8_t* d_scratch, const unsigned long long* d_doc_str_offsets, uint64_t string_base,
+                            int max_depth, unsigned long long* d_scratch_tape, uint32_t* d_tape_lens, int32_t* d_doc_errors,
+                            const Stage1Result* dev_count, const UnescapeResult* dev_strings, WalkResult* d_res,
+                            hipStream_t stream);
+hipError_t single_doc_setup_launch(const Stage1Result* d_res, uint64_t len, unsigned long long* d_doc_offsets,
+                                   unsigned long long* d_index_offsets, uint32_t* d_doc_status, unsigned long long* d_doc_str_offsets,
+                                   hipStream_t stream);
+// where unescape_launch(count_bound, ...) keeps its per-structural sizes and its scratch copy inside d_ws
+void unescape_records(void* d_ws, uint64_t count_bound, const uint32_t** sizes, const uint8_t** scratch);
 hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint32_t* d_out,
                                  uint64_t out_cap, unsigned long long* d_index_offsets, uint32_t* d_doc_status,
                                  uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream, uint64_t total_len);

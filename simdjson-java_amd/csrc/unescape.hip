@@ -728,6 +728,11 @@ static size_t ws_marks_bytes(uint64_t count) { return (((size_t)(count / 32 + 2)
 static size_t ws_scratch_offset(uint64_t count) { return ws_marks_offset(count) + ws_marks_bytes(count) + 64; }
 size_t unescape_workspace_bytes(uint64_t count, uint64_t len) { return ws_scratch_offset(count) + (size_t)len + 128; }
 
+void unescape_records(void* d_ws, uint64_t count_bound, const uint32_t** sizes, const uint8_t** scratch) {
+    *sizes = reinterpret_cast<const uint32_t*>(d_ws);
+    *scratch = static_cast<const uint8_t*>(d_ws) + ws_scratch_offset(count_bound);
+}
+
 template <int ITEMS>
 static hipError_t unescape_launch_items(const uint8_t* d_buf, uint64_t len, const uint32_t* d_idx, uint64_t count,
                                         const Stage1Result* dev_count, uint8_t* d_sb, uint64_t sb_cap, uint32_t* sizes,

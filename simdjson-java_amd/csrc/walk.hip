@@ -183,7 +183,7 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
                        const uint8_t* d_sb, const unsigned long long* d_doc_str_offsets, uint64_t string_base, int max_depth,
                        unsigned long long* d_tape, uint64_t tape_capacity, unsigned long long* d_tape_offsets,
                        int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream, const Stage1Result* dev_count,
-                       const UnescapeResult* dev_strings) {
+                       const UnescapeResult* dev_strings, const uint32_t* d_sizes, const uint8_t* d_str_scratch) {
     uint8_t* ws = static_cast<uint8_t*>(d_ws);
     unsigned long long* scratch = reinterpret_cast<unsigned long long*>(ws);
     uint32_t* lens = reinterpret_cast<uint32_t*>(ws + walk_lens_offset(count, n_docs));
@@ -191,7 +191,14 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
     hipError_t e = hipMemsetAsync(d_res, 0, sizeof(WalkResult), stream);
     if (e != hipSuccess) return e;
     const uint64_t nchunks = (n_docs + PACK_DOCS - 1) / PACK_DOCS;
-    if (n_docs) {
+    if (n_docs && d_sizes) {
+        // the cooperative walker (coop_walk.hip): a wave per document over the per-structural records of the unescape pass
+        e = coop_walk_launch(d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets, d_doc_status, d_sizes, d_str_scratch,
+                             d_doc_str_offsets, string_base, max_depth, scratch, lens, d_doc_errors, dev_count, dev_strings, d_res,
+                             stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_tape_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, lens, d_doc_errors, n_docs, sums, d_res);
+    } else if (n_docs) {
         hipLaunchKernelGGL(k_doc_walk, dim3((unsigned)((n_docs + WALK_THREADS - 1) / WALK_THREADS)), dim3(WALK_THREADS), 0, stream,
                            d_buf, d_doc_offsets, n_docs, d_idx, (uint32_t)(count + 1), d_index_offsets, d_doc_status, d_sb, d_doc_str_offsets,
                            (unsigned long long)string_base, max_depth, scratch, lens, d_doc_errors, dev_count, dev_strings);

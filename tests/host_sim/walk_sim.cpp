@@ -16,6 +16,8 @@ int sjmi_stage1_unescape(sjmi_ctx*, const uint8_t*, uint64_t, uint32_t*, uint64_
 int sjmi_stage1_batch_isolated(sjmi_ctx*, const uint8_t*, uint64_t, const uint64_t*, uint64_t, uint32_t*, uint64_t, uint64_t*,
                                uint32_t*, uint64_t*, uint32_t*) { return SJMI_ERR_NO_DEVICE; }
 int sjmi_unescape_batch(sjmi_ctx*, uint8_t*, uint64_t, uint64_t*, uint64_t*, uint64_t*, uint32_t*) { return SJMI_ERR_NO_DEVICE; }
+int sjmi_parse_document(sjmi_ctx*, const uint8_t*, uint64_t, int, uint64_t*, uint64_t, uint64_t*, uint8_t*, uint64_t, uint64_t*, int32_t*,
+                        uint32_t*) { return SJMI_ERR_NO_DEVICE; }
 
 // walk one document: padded = the document + 64 bytes, indexes[0, count) its structurals, sb its string records.
 // Returns 0 and the tape, or the SJMI_E_* code of the JsonParsingException.

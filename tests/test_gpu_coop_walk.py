@@ -1,0 +1,122 @@
+"""The cooperative GPU walker (csrc/coop_walk.hip: stage 2 as scans and local predicates, a wave per document) against
+the oracle's sequential walker: error code for error code, tape word for tape word -- single documents of any size
+through sjmi_parse_document (all three stages on the device, twitter.json = 864 steps of one wave), and batches through
+the same gpu_walk harness as the lane-per-document kernel it replaces."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.conftest import load_fixture
+from tests.golden import vectors as V
+from tests.test_gpu_walk import check_against_oracle, gpu_walk
+from tests.test_host_walk import GRAMMAR
+from tests.walk_common import NEEDS_HOST
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import simdjson_java_amd as S
+    c = S.Context(device=0, capacity=48 * 1024 * 1024)
+    yield c
+    c.close()
+
+
+def _adversarial(rng, n):
+    """tests/test_coop_walk_model.py's generator: every grammar error of JsonIterator.java:68-193, brackets of the wrong kind,
+    missing / doubled separators, broken atoms and numbers, at every depth."""
+    def value(d):
+        r = rng.random()
+        if d > 4 or r < 0.4:
+            return rng.choice(['"s"', '"a\\nb"', '"é€"', "1", "-2.5e3", "true", "false", "null", '""', "12345678", "0.000001", "tru", "01",
+                               "1.", "", "falsey", "nul", "]", "}", ":", ",", "[", "{", '"\\q"', '"\\ud800"', "1e400", "-0", "[]", "{}"])
+        if r < 0.7:
+            return "[" + rng.choice([",", ", ", " ,", " "]).join(value(d + 1) for _ in range(rng.randint(0, 5))) + rng.choice(["]", "]", "]", "}", ""])
+        return "{" + rng.choice([",", ",", " "]).join('%s%s%s' % (rng.choice(['"k%d"' % i, '"k"', "1", ""]), rng.choice([":", ":", " : ", "", ","]), value(d + 1))
+                                                      for i in range(rng.randint(0, 5))) + rng.choice(["}", "}", "}", "]", ""])
+    return [value(0).encode() for _ in range(n)]
+
+
+def _single(ctx, doc, max_depth=1024):
+    want = O.parse(doc, max_depth=max_depth)
+    tape, strings, err, st = ctx.parse_document(doc, max_depth=max_depth)
+    assert st == want.stage1_status
+    if err == NEEDS_HOST:
+        return "host"
+    assert err == want.error, (doc[:80], err, want.error)
+    if err == 0:
+        assert np.array_equal(tape, want.tape), doc[:80]
+        assert strings == want.strings
+    return "ok"
+
+
+@pytest.mark.parametrize("name", ["twitter.json", "github_events.json", "wide_bench.json"])
+def test_reference_files_as_single_documents(ctx, name):
+    assert _single(ctx, load_fixture(name)) == "ok"
+    assert _single(ctx, load_fixture(name).rstrip()) == "ok"
+
+
+def test_grammar_vectors_single(ctx):
+    for doc in GRAMMAR:
+        assert _single(ctx, doc) == "ok", doc
+    for text, n, msg, cite in V.GRAMMAR:
+        d = text.encode()
+        assert _single(ctx, d[:n] if n is not None else d) == "ok", cite
+    for text, msg, cite in V.STRING_ERRORS:
+        assert _single(ctx, text.encode()) == "ok", cite
+    for text, want, cite in V.VALID_DOCS:
+        assert _single(ctx, text.encode()) == "ok", cite
+    for depth in (3, 4, 5, 10):
+        for doc in (b"[[[[1]]]]", b'{"a":{"b":{"c":1}}}', b"[[[[]]]]", b"[" * 10 + b"]" * 10, b'[{"a":[{}]}]'):
+            assert _single(ctx, doc, max_depth=depth) == "ok"
+
+
+def test_adversarial_documents_single_and_batched(ctx):
+    rng = random.Random(331)
+    docs = _adversarial(rng, 3000)
+    for d in docs[:700]:
+        _single(ctx, d)
+    tapes, strings, errors = gpu_walk(ctx, docs)
+    check_against_oracle(docs, tapes, strings, errors)
+    assert int((errors > 0).sum()) > 1000 and int((errors == 0).sum()) > 300
+
+
+def test_documents_spanning_many_steps(ctx):
+    """Containers that open in one 64-structural step and close many steps later (the per-wave stack in LDS), long arrays
+    whose element count accumulates over steps, nesting to the device limit, and the count saturation of
+    ArrayParsingTest.java:74-95 at reduced scale."""
+    rng = random.Random(332)
+
+    def nested(depth, width):
+        if depth == 0:
+            return rng.choice(["1", '"x"', "true", "null", "-2.5", "[]", "{}"])
+        if rng.random() < 0.5:
+            return "[" + ",".join(nested(depth - 1, width) for _ in range(rng.randint(1, width))) + "]"
+        return "{" + ",".join('"k%d":%s' % (i, nested(depth - 1, width)) for i in range(rng.randint(1, width))) + "}"
+    docs = [nested(6, 4).encode() for _ in range(40)]
+    docs += [("[" + ",".join(str(i) for i in range(n)) + "]").encode() for n in (1, 63, 64, 65, 127, 128, 129, 1000, 70000)]
+    docs += [("[" * d + "7" + "]" * d).encode() for d in (1, 31, 32, 33, 62, 63)]
+    docs += [("[" * d + "]" * d).encode() for d in (1, 2, 63, 64)]
+    docs += [b'{"a":' * 40 + b"[1,2,3]" + b"}" * 40, b"[" + b"[1,[2,[3,[4]]]]," * 200 + b"0]"]
+    for d in docs:
+        assert _single(ctx, d) == "ok", d[:60]
+    tapes, strings, errors = gpu_walk(ctx, docs)
+    check_against_oracle(docs, tapes, strings, errors)
+    # handed back: a non-empty container at depth 63
+    tape, strings, err, st = ctx.parse_document(b"[" * 64 + b"1" + b"]" * 64)
+    assert err == NEEDS_HOST and tape is None
+    # the same document with a depth limit below the device stack: the reference's depth error instead
+    tape, strings, err, st = ctx.parse_document(b"[" * 64 + b"1" + b"]" * 64, max_depth=20)
+    assert err == 28
+
+
+def test_large_array_count_saturates(ctx):
+    """ArrayParsingTest.java:74-95: 0xFFFFFF + 1 elements -> count field 0xFFFFFF (33.5 M structurals, 524,288 steps)."""
+    n = 0xFFFFFF + 1
+    doc = b"[" + b"0," * (n - 1) + b"0]"
+    tape, strings, err, st = ctx.parse_document(doc)
+    assert err == 0 and (int(tape[1]) >> 32) & 0xFFFFFF == 0xFFFFFF and tape.size == 2 * n + 4
+    assert np.array_equal(tape, O.parse(doc).tape)

@@ -13,10 +13,12 @@ from tests.golden import vectors as V
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def parser():
+@pytest.fixture(scope="module", params=["host_walk", "gpu_walk"])
+def parser(request):
+    """Both homes of stage 2: the host walker over GPU-made indexes / strings (default), and the cooperative GPU walker
+    (sjmi_parser_set_gpu_walk: the tape itself comes from the device).  Every test below holds for both, bit for bit."""
     import simdjson_java_amd as S
-    p = S.SimdJsonParser(capacity=8 * 1024 * 1024)
+    p = S.SimdJsonParser(capacity=8 * 1024 * 1024, gpu_walk=request.param == "gpu_walk")
     yield p
     p.close()
 
