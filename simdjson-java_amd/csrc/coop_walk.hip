@@ -140,21 +140,67 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
             const unsigned long long* __restrict__ doc_str_offsets, unsigned long long string_base, int max_depth,
             unsigned long long* __restrict__ scratch_tape, uint32_t* __restrict__ tape_lens, int32_t* __restrict__ doc_errors, const Stage1Result* __restrict__ dev_count,
             const UnescapeResult* __restrict__ dev_strings, WalkResult* res) {
-    __shared__ uint32_t s_tpos[4][CW_LEVELS], s_cnt[4][CW_LEVELS];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t* const st_tpos = s_tpos[wv];
-    uint32_t* const st_cnt = s_cnt[wv];
+    // the per-wave stack of open containers lives in two VGPRs: LANE L holds level L (tape position of the opening word,
+    // commas seen so far); a level is read with v_readlane and written with v_writelane -- no LDS round trip on the
+    // step-to-step dependency chain
+    uint32_t st_tpos = 0, st_cnt = 0;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
     const bool upstream_failed = (dev_count && (dev_count->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL))) ||
                                  (dev_strings && (dev_strings->flags & 1u));
     unsigned long long n_host = 0, n_bad = 0;
-    for (uint64_t k = (uint64_t)blockIdx.x * 4 + wv; k < n_docs; k += nwaves) {
+    // A document costs three dependent round trips before its first step can run (its delimiters, then the positions of
+    // its first structurals, then the bytes there): with ~3 steps per ~1 KB document that chain, not the steps, bounded
+    // the kernel.  So the delimiters of the wave's NEXT document are requested when the current one starts, and the
+    // positions of its first two steps when the current one ends.
+    struct Meta {
+        unsigned long long from, to, dso;
+        uint32_t doc_start, doc_end, st;
+    };
+    struct Head {
+        uint32_t p_n, sz_n, px_n, p_nn, sz_nn, px_nn;
+    };
+    auto load_meta = [&](uint64_t k) {
+        Meta m;
+        m.from = index_offsets[k];
+        m.to = index_offsets[k + 1];
+        m.dso = doc_str_offsets[k];
+        m.doc_start = (uint32_t)doc_offsets[k];
+        m.doc_end = (uint32_t)doc_offsets[k + 1];
+        m.st = doc_status ? doc_status[k] : 0u;
+        return m;
+    };
+    auto load_pos = [&](const Meta& m, uint64_t s, uint32_t* p, uint32_t* sz, uint32_t* px) {
+        const uint64_t i = m.from + s * 64 + lane;
+        *p = i < m.to ? idx[i] : m.doc_start;
+        *sz = i < m.to ? sizes[i] : 0u;
+        const uint64_t ix = m.from + s * 64 + 64;
+        *px = ix < m.to ? idx[ix] : m.doc_start;
+    };
+    auto load_head = [&](const Meta& m) {
+        Head h;
+        load_pos(m, 0, &h.p_n, &h.sz_n, &h.px_n);
+        h.p_nn = m.doc_start;
+        h.sz_nn = 0;
+        h.px_nn = m.doc_start;
+        if (m.to - m.from > 64) load_pos(m, 1, &h.p_nn, &h.sz_nn, &h.px_nn);
+        return h;
+    };
+    uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
+    Meta m = {0, 0, 0, 0, 0, 0}, m_next = m;
+    Head hd = {0, 0, 0, 0, 0, 0};
+    if (k < n_docs) {
+        m = load_meta(k);
+        hd = load_head(m);
+    }
+    for (; k < n_docs; k += nwaves) {
+        if (k + nwaves < n_docs) m_next = load_meta(k + nwaves);
         int code = 0;
         uint32_t tlen = 0;
-        const uint32_t st = doc_status ? doc_status[k] : 0u;
-        const unsigned long long from = index_offsets[k], to = index_offsets[k + 1];
+        const uint32_t st = m.st;
+        const unsigned long long from = m.from, to = m.to;
         // SimdJsonParser.stage1 order: Utf8Validator.validate (:165-167), then StructuralIndexer.index (:297-302)
         if (upstream_failed) code = SJMI_E_CAPACITY;
         else if (st & SJMI_ST_UTF8) code = SJMI_E_UTF8;
@@ -162,40 +208,35 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
         else if (st & SJMI_ST_UNESCAPED) code = SJMI_E_UNESCAPED_CHARS;
         else if (from == to) code = SJMI_E_NO_STRUCTURAL;  // JsonIterator.java:27-29
         if (code == 0) {
-            const uint32_t doc_start = (uint32_t)doc_offsets[k], doc_end = (uint32_t)doc_offsets[k + 1];
+            const uint32_t doc_start = m.doc_start, doc_end = m.doc_end;
             const uint64_t n = to - from;
             unsigned long long* const T = scratch_tape + 2 * from + 2 * k;  // this document's slot (word 0 = root)
             const uint64_t room = 2 * n + 2;                                // a structural makes at most two words
-            const uint32_t last_c = buf[idx[to - 1]];
             // running state (wave-uniform)
             uint32_t H0 = 0;                 // open containers in front of the step
             uint32_t T0 = 1;                 // tape position of the step's first word (0 = the root word)
-            unsigned long long S0 = doc_str_offsets[k];
+            unsigned long long S0 = m.dso;
             unsigned long long arr_mask = 0; // bit L: the open container of level L is an array
             uint32_t prev_cls = K_COMMA;     // class of the structural in front of the step (none at the start)
             bool prev_empty_open = false, prev_is_key = false, root_closed = false;
-            uint32_t root_kind = 0;
-            // software pipeline: positions one step ahead of the windows, windows one step ahead of their use
-            auto load_pos = [&](uint64_t s, uint32_t* p, uint32_t* sz, uint32_t* px) {
-                const uint64_t i = from + s * 64 + lane;
-                *p = i < to ? idx[i] : doc_start;
-                *sz = i < to ? sizes[i] : 0u;
-                const uint64_t ix = from + s * 64 + 64;
-                *px = ix < to ? idx[ix] : doc_start;
-            };
-            uint32_t p_n, sz_n, px_n;
-            load_pos(0, &p_n, &sz_n, &px_n);
+            uint32_t root_kind = 0, root_c = 0;
+            // positions (and sizes) are requested TWO steps ahead, the 16-byte windows they point at one step ahead: neither
+            // round trip is on the step-to-step critical path
+            const uint64_t nsteps = (n + 63) / 64;
+            uint32_t p_n = hd.p_n, sz_n = hd.sz_n, px_n = hd.px_n, p_nn = hd.p_nn, sz_nn = hd.sz_nn, px_nn = hd.px_nn;
             CW16 win_n = *reinterpret_cast<const CW16*>(buf + p_n);
             uint32_t bx_n = buf[px_n];
-            const uint64_t nsteps = (n + 63) / 64;
             for (uint64_t s = 0; s < nsteps && code == 0; ++s) {
                 const uint32_t p = p_n, sz = sz_n, c_extra = bx_n;
                 const CW16 win = win_n;
+                p_n = p_nn;
+                sz_n = sz_nn;
+                px_n = px_nn;
                 if (s + 1 < nsteps) {
-                    load_pos(s + 1, &p_n, &sz_n, &px_n);
                     win_n = *reinterpret_cast<const CW16*>(buf + p_n);
                     bx_n = buf[px_n];
                 }
+                if (s + 2 < nsteps) load_pos(m, s + 2, &p_nn, &sz_nn, &px_nn);
                 const uint64_t i = from + s * 64 + lane;
                 const bool valid = i < to;
                 const unsigned long long vmask = __ballot(valid);
@@ -253,7 +294,8 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                     const int a = highest_bit_below(O, lt_mask);
                     uint32_t a_tpos = (uint32_t)__shfl((int)tpos, a < 0 ? 0 : a);
                     uint32_t a_cls = (uint32_t)__shfl((int)cls, a < 0 ? 0 : a);
-                    const uint32_t sk_tpos = st_tpos[L], sk_cnt = st_cnt[L];
+                    const uint32_t sk_tpos = (uint32_t)__builtin_amdgcn_readlane((int)st_tpos, L);
+                    const uint32_t sk_cnt = (uint32_t)__builtin_amdgcn_readlane((int)st_cnt, L);
                     if (mine) {
                         par_in_wave = a >= 0;
                         par_is_array = a >= 0 ? a_cls == K_OPEN_A : ((arr_mask >> L) & 1ull) != 0;
@@ -262,23 +304,19 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                         par_cnt = (a >= 0 ? 0u : sk_cnt) + (uint32_t)__popcll(between);
                     }
                     // stack update for the next steps (wave-uniform)
-                    __builtin_amdgcn_wave_barrier();
                     if (O) {
                         const int al = 63 - __builtin_clzll(O);  // the last open of this level in the step
                         const unsigned long long above = al == 63 ? 0ull : ~((2ull << al) - 1ull);
                         if (!(Z & above)) {  // still open at the end of the step
                             const uint32_t tp = (uint32_t)__builtin_amdgcn_readlane((int)tpos, al);
                             const uint32_t kc = (uint32_t)__builtin_amdgcn_readlane((int)cls, al);
-                            if (lane == 0) {
-                                st_tpos[L] = tp;
-                                st_cnt[L] = (uint32_t)__popcll(C & above);
-                            }
+                            st_tpos = lane == L ? tp : st_tpos;
+                            st_cnt = lane == L ? (uint32_t)__popcll(C & above) : st_cnt;
                             arr_mask = kc == K_OPEN_A ? (arr_mask | (1ull << L)) : (arr_mask & ~(1ull << L));
                         }
-                    } else if (!Z) {
-                        if (lane == 0 && C) st_cnt[L] = sk_cnt + (uint32_t)__popcll(C);
+                    } else if (!Z && C) {
+                        st_cnt = lane == L ? sk_cnt + (uint32_t)__popcll(C) : st_cnt;
                     }
-                    __builtin_amdgcn_wave_barrier();
                 }
                 // (5) roles and their local predicates (JsonIterator.java:68-193)
                 const bool prev_open_nonempty = (cls_prev <= K_OPEN_O) && !eo_prev;
@@ -293,8 +331,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 bool want_value = false;
                 if (valid && !empty_close) {
                     if (i == from) {
-                        if (cls <= K_OPEN_O && last_c != c + 2) err = cls == K_OPEN_O ? SJMI_E_UNCLOSED_OBJECT : SJMI_E_UNCLOSED_ARRAY;  // :39-41,:51-53
-                        else want_value = true;
+                        want_value = true;  // (the root bracket's "is the last structural my closing bracket" test: below)
                     } else if (prev_open_nonempty) {
                         if (cls_prev == K_OPEN_A) want_value = true;
                         else if (cls != K_QUOTE) err = SJMI_E_OBJECT_NO_KEY;  // :75-77
@@ -325,7 +362,10 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                     }
                 }
                 // (6) where the root value ends; the first error by position
-                if (s == 0) root_kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cls <= K_OPEN_O ? 1u + cls : 0u));
+                if (s == 0) {
+                    root_kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cls <= K_OPEN_O ? 1u + cls : 0u));
+                    root_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                }
                 const bool closes_root = (is_close && h == 1 && root_kind != 0) || (valid && i == from && root_kind == 0);
                 const unsigned long long rc = __ballot(closes_root);
                 const int rc_lane = rc ? __builtin_ctzll(rc) : 64;
@@ -365,6 +405,16 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 prev_empty_open = __builtin_amdgcn_readlane((int)empty_open, lastv) != 0;
                 prev_is_key = __builtin_amdgcn_readlane((int)is_key, lastv) != 0;
             }
+            // JsonIterator.java:39-41,:51-53: a root bracket whose closing bracket is not the document's LAST structural fails
+            // before anything else is looked at (position 0 is the lowest there is).  The last structural's class is known
+            // for free when the sweep reached the end; only a document that failed earlier has to go and look.
+            if (root_kind != 0) {
+                if (code != 0) {                      // failed (or handed back) on the way: go and look
+                    if ((uint32_t)buf[idx[to - 1]] != root_c + 2) code = root_kind == 2 ? SJMI_E_UNCLOSED_OBJECT : SJMI_E_UNCLOSED_ARRAY;
+                } else if (!root_closed) {            // swept to the end: prev_cls is the last structural's class
+                    if (prev_cls != root_kind + 1) code = root_kind == 2 ? SJMI_E_UNCLOSED_OBJECT : SJMI_E_UNCLOSED_ARRAY;
+                }                                     // (closed exactly at the end: the last structural IS the closing bracket)
+            }
             if (code == 0 && !root_closed) {
                 // the walker reads on past the last structural: BitIndexes' sentinel = the document's first byte, an opening
                 // bracket where a separator is due (BitIndexes.java:82-96, JsonIterator.java:131,:189)
@@ -391,6 +441,8 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
         }
         n_host += code == SJMI_WALK_NEEDS_HOST;
         n_bad += code > 0;
+        m = m_next;
+        if (k + nwaves < n_docs) hd = load_head(m);
     }
     (void)res;
     (void)n_host;
