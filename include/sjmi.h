@@ -319,6 +319,17 @@ int sjmi_set_tile_steps(sjmi_ctx* ctx, int steps);
  * and re-run the launch; the *_device entry points return the status bit to the caller.
  * Environment: SJMI_TILE_MODE=ticket selects SAFE mode at context creation. */
 int sjmi_set_tile_mode(sjmi_ctx* ctx, int ticket);
+/* Forward-progress assumption, stated once: a FAST launch spins (bounded: tens of milliseconds) on values only OTHER
+ * workgroups of the same launch produce, so it needs its whole grid -- sized with the occupancy API to what fits the
+ * device -- resident at the same time.  That holds when the kernel has the GPU to itself and, by giving up the static first
+ * granule (done automatically while another context of this process still has a stage-1 launch running), when two such
+ * kernels share it; it can fail when foreign kernels (another process, PyTorch on another stream) hold CUs for longer
+ * than the spin bound.  Results never depend on it -- a launch either completes correctly or reports SJMI_ST_INTERNAL.
+ * The host-buffer entry points then latch SAFE mode and re-run by themselves.  For the asynchronous *_device entry
+ * point the caller chooses: read SJMI_ST_INTERNAL from its result record and call sjmi_set_tile_mode(ctx, 1), or opt in
+ * here (on = 1): sjmi_stage1_device then synchronises its stream after every FAST launch, and on a tripped bound latches
+ * SAFE mode and repeats the launch before returning (costs the asynchrony; SAFE mode itself has no residency assumption). */
+int sjmi_set_auto_safe(sjmi_ctx* ctx, int on);
 
 /* Measurement hooks for bench.py: when on, every sjmi_stage1_device launch is bracketed by HIP events
  * on the launch stream (kernel only); sjmi_kernel_time returns their summed duration and count. */

@@ -67,7 +67,7 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_parser_root", "sjmi_parser_batch_root", "sjmi_value_type", "sjmi_value_as_long", "sjmi_value_as_double",
            "sjmi_value_as_boolean", "sjmi_value_as_string", "sjmi_value_get", "sjmi_value_size", "sjmi_value_first",
            "sjmi_value_next", "sjmi_parse_batch_device", "sjmi_parse_document",
-           "sjmi_parser_set_gpu_walk"]
+           "sjmi_parser_set_gpu_walk", "sjmi_set_auto_safe"]
 
 
 def lib():
@@ -143,6 +143,8 @@ def lib():
         L.sjmi_parser_parse_batch.restype = C.c_int
         L.sjmi_parser_parse_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sjmi_set_auto_safe.restype = C.c_int
+        L.sjmi_set_auto_safe.argtypes = [C.c_void_p, C.c_int]
         L.sjmi_set_tile_mode.restype = C.c_int
         L.sjmi_set_tile_mode.argtypes = [C.c_void_p, C.c_int]
         L.sjmi_stage1_masks.restype = C.c_int
@@ -371,6 +373,9 @@ class Context:
         """Device-resident path; arguments are raw device pointers (ints) and a hipStream_t handle."""
         self._check(lib().sjmi_stage1_device(self._h, d_buf, length, d_indexes, index_capacity, d_result, stream),
                     "sjmi_stage1_device")
+
+    def set_auto_safe(self, on):
+        self._check(lib().sjmi_set_auto_safe(self._h, 1 if on else 0), "sjmi_set_auto_safe")
 
     def set_tile_mode(self, ticket):
         self._check(lib().sjmi_set_tile_mode(self._h, 1 if ticket else 0), "sjmi_set_tile_mode")

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <mutex>
 #include <new>
 #include <string>
 #include <utility>
@@ -56,6 +57,9 @@ struct sjmi_ctx {
     int forced_steps = 0;
     uint32_t dbg = 0;  // ablation flags (sjmi_debug_set_flags)
     bool ticket_mode = false;  // safe tile assignment (latched on after a look-back timeout in fast mode)
+    bool auto_safe = false;    // sjmi_set_auto_safe: the *_device stage-1 entry point synchronises, checks and re-runs in SAFE mode
+    hipStream_t last_launch_stream = nullptr;  // stream of this context's last stage-1 launch (is it still running?)
+    bool launched = false;
     bool profiling = false;  // bracket every stage-1 kernel with HIP events (bench.py roofline)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
@@ -68,8 +72,25 @@ namespace {
 // time, each with only part of its grid -- the kernels then take every granule by ticket (FLAG_ALL_TICKETS), so that
 // a workgroup that has not started holds nothing the others could wait for (costs ~6 % on a GPU it has to itself)
 std::atomic<int> g_live_contexts{0};
+// Contexts of this process, so that a launch can ask whether ANOTHER context's persistent stage-1 kernel may still be
+// running: only then do two kernels compete for residency and only then is the static first granule given up
+// (FLAG_ALL_TICKETS, ~6 % slower).  A context that exists but is idle (parseBatch's second feeder context between
+// batches) costs nothing.  hipStreamQuery is a non-blocking poll of the other context's last launch stream.
+std::mutex g_registry_mutex;
+std::vector<sjmi_ctx*> g_registry;
+bool another_context_busy(const sjmi_ctx* self) {
+    if (g_live_contexts.load() <= 1) return false;
+    std::lock_guard<std::mutex> g(g_registry_mutex);
+    for (sjmi_ctx* o : g_registry)
+        if (o != self && o->launched && o->device == self->device && hipStreamQuery(o->last_launch_stream) == hipErrorNotReady) return true;
+    return false;
+}
 uint32_t launch_flags(const sjmi_ctx* c) {
-    return c->dbg | (c->ticket_mode ? sjmi::FLAG_SAFE : 0u) | (g_live_contexts.load() > 1 ? sjmi::FLAG_ALL_TICKETS : 0u);
+    return c->dbg | (c->ticket_mode ? sjmi::FLAG_SAFE : 0u) | (another_context_busy(c) ? sjmi::FLAG_ALL_TICKETS : 0u);
+}
+void note_launch(sjmi_ctx* c, hipStream_t st) {
+    c->last_launch_stream = st;
+    c->launched = true;
 }
 
 bool fail(sjmi_ctx* c, const char* what, hipError_t e) {
@@ -111,12 +132,24 @@ int sjmi_create(sjmi_ctx** out, int device, uint64_t capacity_bytes) {
     }
     const char* mode = getenv("SJMI_TILE_MODE");  // "ticket" = start in the safe tile-assignment mode
     c->ticket_mode = mode && strcmp(mode, "ticket") == 0;
+    {
+        std::lock_guard<std::mutex> g(g_registry_mutex);
+        g_registry.push_back(c);
+    }
     *out = c;
     return SJMI_OK;
 }
 
 void sjmi_destroy(sjmi_ctx* c) {
     if (!c) return;
+    {
+        std::lock_guard<std::mutex> g(g_registry_mutex);
+        for (size_t i = 0; i < g_registry.size(); ++i)
+            if (g_registry[i] == c) {
+                g_registry.erase(g_registry.begin() + i);
+                break;
+            }
+    }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_in) (void)hipFree(c->d_in);
@@ -174,6 +207,7 @@ int sjmi_stage1(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes
     if (len && fail(c, "H2D", hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
     const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(len);
     const uint64_t dev_cap = c->capacity + 2 < index_capacity ? c->capacity + 2 : index_capacity;
+    note_launch(c, c->stream);
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (fail(c, "launch", sjmi::stage1_launch(c->d_in, len, c->d_idx, dev_cap, c->d_ws, steps, c->stream, nullptr,
                                                   nullptr, launch_flags(c))) ||
@@ -484,6 +518,7 @@ int sjmi_stage1_device(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_ind
     if (fail(c, "launch", sjmi::stage1_launch((const uint8_t*)d_buf, len, (uint32_t*)d_indexes, index_capacity, ws, steps,
                                               st, ev0, ev1, launch_flags(c), ex)))
         return SJMI_ERR_HIP;
+    note_launch(c, st);
     if (!fast && fail(c, "D2D(result)", hipMemcpyAsync(d_result, ws + sjmi::WS_RESULT_OFFSET, sizeof(sjmi_stage1_result),
                                                        hipMemcpyDeviceToDevice, st)))
         return SJMI_ERR_HIP;
@@ -491,6 +526,19 @@ int sjmi_stage1_device(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_ind
     c->ws_dev_clean[1 - h] = need;
     c->ws_dev_next = 1 - h;
     c->ws_dev_last = ws;
+    if (c->auto_safe && !c->ticket_mode) {
+        // opt-in (sjmi_set_auto_safe): the FAST kernel's liveness rests on its whole grid being resident; a caller that
+        // shares the GPU with other kernels can ask for the check here -- one synchronisation per launch -- instead of
+        // finding SJMI_ST_INTERNAL in its result record: on a tripped spin bound SAFE mode is latched and the launch repeated
+        sjmi_stage1_result r;
+        if (fail(c, "D2H(result)", hipMemcpyAsync(&r, d_result, sizeof r, hipMemcpyDeviceToHost, st)) ||
+            fail(c, "sync", hipStreamSynchronize(st)))
+            return SJMI_ERR_HIP;
+        if (r.status & SJMI_ST_INTERNAL) {
+            c->ticket_mode = true;
+            return sjmi_stage1_device(c, d_buf, len, d_indexes, index_capacity, d_result, stream);
+        }
+    }
     return SJMI_OK;
 }
 
@@ -792,6 +840,12 @@ int sjmi_host_register(sjmi_ctx* c, void* ptr, uint64_t bytes) {
 int sjmi_host_unregister(sjmi_ctx* c, void* ptr) {
     if (!c || !ptr) return SJMI_ERR_ARG;
     if (fail(c, "hipHostUnregister", hipHostUnregister(ptr))) return SJMI_ERR_HIP;
+    return SJMI_OK;
+}
+
+int sjmi_set_auto_safe(sjmi_ctx* c, int on) {
+    if (!c) return SJMI_ERR_ARG;
+    c->auto_safe = on != 0;
     return SJMI_OK;
 }
 

@@ -138,7 +138,9 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // (cdna_hip_programming.md Guideline 16, form R2), so no fences are needed.
 // ---------------------------------------------------------------------------------------------
 constexpr sj_u64 TS_AGG = 1ull << 62, TS_PFX = 2ull << 62;
-constexpr uint32_t SPIN_LIMIT = 1u << 21;  // ~ seconds; a healthy chain needs a handful of polls
+// bounded spins: ~2^19 polls of >= 100 cycles (s_sleep 1 + an uncached load) = tens of milliseconds; a healthy chain needs
+// a handful of polls, a launch whose grid is not resident trips this, reports SJMI_ST_INTERNAL and is re-run in SAFE mode
+constexpr uint32_t SPIN_LIMIT = 1u << 19;
 
 __device__ __forceinline__ void ts_store(sj_u64* p, sj_u64 v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -1,0 +1,66 @@
+"""Liveness of the persistent stage-1 kernel when the GPU is shared: two PROCESSES launching FAST-mode
+kernels on device 0 at the same time, each with sjmi_set_auto_safe; and the opt-in SAFE re-run of the device-resident
+entry point on a (faked) tripped spin bound."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_processes_share_the_gpu():
+    worker = os.path.join(ROOT, "tools", "two_proc_worker.py")
+    env = dict(os.environ)
+    procs = [subprocess.Popen([sys.executable, worker, "proc%d" % k, "400", "256"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+             for k in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+            outs.append(o.decode(errors="replace") + "\nTIMEOUT")
+            continue
+        outs.append(o.decode(errors="replace"))
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-2000:]
+        assert "0 bad, final indexes ok" in o, o[-2000:]
+
+
+def test_device_entry_point_auto_safe_rerun(twitter):
+    """sjmi_set_auto_safe: a FAST launch of sjmi_stage1_device that reports SJMI_ST_INTERNAL (faked with debug flag 16) is
+    repeated in SAFE mode before the call returns; the result record the caller reads is the good one, SAFE mode stays on."""
+    import torch
+    import simdjson_java_amd as S
+    reps = 16
+    n0 = len(twitter)
+    idx0, _ = O.stage1(twitter)
+    buf = torch.zeros(n0 * reps + 128, dtype=torch.uint8, device="cuda")
+    buf[:n0 * reps] = torch.frombuffer(bytearray(twitter), dtype=torch.uint8).cuda().repeat(reps)
+    cap = idx0.size * reps + 1
+    out = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    res = torch.zeros(2, dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    c = S.Context(0, 1 << 20)
+    try:
+        c.debug_set_flags(16)
+        c.stage1_device(buf.data_ptr(), n0 * reps, out.data_ptr(), cap, res.data_ptr(), st)  # without the opt-in: reported
+        torch.cuda.synchronize()
+        assert (int(res[1].item()) & 0x200) != 0
+        c.set_auto_safe(True)
+        out.zero_()
+        c.stage1_device(buf.data_ptr(), n0 * reps, out.data_ptr(), cap, res.data_ptr(), st)
+        torch.cuda.synchronize()
+        r = res.cpu().numpy()
+        assert int(r[0]) == idx0.size * reps and (int(r[1]) & 0xFFFFFFFF) == 0
+        want = (torch.from_numpy(idx0.astype(np.int64)).cuda()[None, :] + (torch.arange(reps, device="cuda") * n0)[:, None]).flatten()
+        assert torch.equal(out[:idx0.size * reps].to(torch.int64) & 0xFFFFFFFF, want)
+    finally:
+        c.close()
