@@ -67,7 +67,8 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_parser_root", "sjmi_parser_batch_root", "sjmi_value_type", "sjmi_value_as_long", "sjmi_value_as_double",
            "sjmi_value_as_boolean", "sjmi_value_as_string", "sjmi_value_get", "sjmi_value_size", "sjmi_value_first",
            "sjmi_value_next", "sjmi_parse_batch_device", "sjmi_parse_document",
-           "sjmi_parser_set_gpu_walk", "sjmi_set_auto_safe"]
+           "sjmi_parser_set_gpu_walk", "sjmi_set_auto_safe", "sjmi_match_brackets",
+           "sjmi_match_brackets_device"]
 
 
 def lib():
@@ -143,6 +144,11 @@ def lib():
         L.sjmi_parser_parse_batch.restype = C.c_int
         L.sjmi_parser_parse_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sjmi_match_brackets.restype = C.c_int
+        L.sjmi_match_brackets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.sjmi_match_brackets_device.restype = C.c_int
+        L.sjmi_match_brackets_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p]
         L.sjmi_set_auto_safe.restype = C.c_int
         L.sjmi_set_auto_safe.argtypes = [C.c_void_p, C.c_int]
         L.sjmi_set_tile_mode.restype = C.c_int
@@ -238,6 +244,13 @@ class Context:
                                               C.addressof(tl), sb.ctypes.data, sb.size, C.addressof(sl), C.addressof(err),
                                               C.addressof(st)), "sjmi_parse_document")
         return (tape[:tl.value].copy() if err.value == 0 else None), bytes(sb[:sl.value]), err.value, st.value
+
+    def match_brackets(self, count):
+        """The on-demand skip table of the document of the last stage1() call: -> (up, match) np.uint32 [count]."""
+        up = np.zeros(max(count, 1), dtype=np.uint32)
+        match = np.zeros(max(count, 1), dtype=np.uint32)
+        self._check(lib().sjmi_match_brackets(self._h, up.ctypes.data, match.ctypes.data, count), "sjmi_match_brackets")
+        return up[:count], match[:count]
 
     def stage1_masks(self, data, length=None):
         """The reference's per-block masks (sjmi_stage1_masks): -> np.uint64 [len // 64 + 1, 6] =

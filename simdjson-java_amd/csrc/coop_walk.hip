@@ -449,6 +449,103 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
     (void)n_bad;  // (host / failed documents are counted by the packing kernels from doc_errors)
 }
 
+// ---- the skip table of the on-demand front end -------------------------------------------------
+// OnDemandJsonIterator.skipChild (OnDemandJsonIterator.java:43-81) leaves a value by scanning the structurals and counting
+// brackets until the depth drops; with the bracket matching above that scan is a table lookup.  Per structural i of a
+// document (absolute positions in the index array):
+//   up[i]    = the opening bracket of the container i lies in (for a closing bracket: its own opening bracket; for an opening
+//              bracket: the enclosing one); SJMI_MATCH_NONE at the root level
+//   match[i] = for an opening bracket its closing bracket (SJMI_MATCH_NONE if it is never closed), otherwise up[i]
+// "leave k containers from position q" = climb k - 1 times through up[] from up[q], then continue behind match[] of that
+// bracket.  Levels beyond the 64 of the per-wave stack are marked SJMI_MATCH_UNKNOWN (scan there, as the reference does).
+__global__ void __launch_bounds__(256)
+k_coop_match(const uint8_t* __restrict__ buf, uint64_t n_docs, const uint32_t* __restrict__ idx,
+             const unsigned long long* __restrict__ index_offsets, uint32_t* __restrict__ up, uint32_t* __restrict__ match) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    constexpr uint32_t NONE = 0xFFFFFFFFu, UNKNOWN = 0xFFFFFFFEu;
+    for (uint64_t k = (uint64_t)blockIdx.x * 4 + wv; k < n_docs; k += nwaves) {
+        const unsigned long long from = index_offsets[k], to = index_offsets[k + 1];
+        const uint64_t nsteps = (to - from + 63) / 64;
+        uint32_t st_idx = NONE;  // LANE L = the open bracket of level L (structural position), as in k_coop_walk
+        int H0 = 0;
+        bool broken = false;     // a closing bracket without an opening one was seen: everything behind it is left to the scan
+        uint32_t p_n = from + lane < to ? idx[from + lane] : 0u;
+        uint32_t c_n = buf[p_n];
+        for (uint64_t s = 0; s < nsteps; ++s) {
+            const uint64_t i = from + s * 64 + lane;
+            const bool valid = i < to;
+            const uint32_t c = c_n;
+            if (s + 1 < nsteps) {  // (two dependent loads per step; the walker proper pipelines them, this table is built once)
+                const uint64_t in = i + 64;
+                p_n = in < to ? idx[in] : 0u;
+                c_n = buf[p_n];
+            }
+            const uint32_t cls = valid ? class_of(c) : K_COMMA;
+            const bool is_open = valid && cls <= K_OPEN_O, is_close = valid && (cls == K_CLOSE_A || cls == K_CLOSE_O);
+            const uint32_t upb = is_open ? 1u : 0u, down = is_close ? 1u : 0u;
+            const uint32_t iu = cw_incl_scan(upb), id = cw_incl_scan(down);
+            const int h = H0 + (int)(iu - upb) - (int)(id - down);
+            // a closing bracket at depth 0 (only in documents stage 2 rejects): the table stops being defined there --
+            // the reference's skipChild merely counts, and its answers behind such a bracket are whatever the counting gives
+            const unsigned long long under = __ballot(valid && is_close && h <= 0);
+            const int first_bad = broken ? 0 : (under ? __builtin_ctzll(under) : 64);
+            const int plevel = h - 1;
+            int hmin = valid ? plevel : 0x7FFF, hmax = valid ? (is_open ? h : plevel) : -0x7FFF;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                hmin = min(hmin, __shfl_xor(hmin, d));
+                hmax = max(hmax, __shfl_xor(hmax, d));
+            }
+            if (hmin < 0) hmin = 0;
+            const bool deep = hmax >= CW_LEVELS;
+            if (hmax >= CW_LEVELS) hmax = CW_LEVELS - 1;
+            uint32_t my_up = (valid && plevel >= CW_LEVELS) ? UNKNOWN : NONE;
+            if (is_open) match[i] = (h >= CW_LEVELS) ? UNKNOWN : NONE;  // (overwritten by its closing bracket, below or in a later step)
+            for (int L = hmin; L <= hmax; ++L) {
+                const unsigned long long O = __ballot(is_open && h == L);
+                const unsigned long long Z = __ballot(is_close && plevel == L);
+                const int a = highest_bit_below(O, lt_mask);
+                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)st_idx, L);
+                if (valid && plevel == L) my_up = a >= 0 ? (uint32_t)(from + s * 64 + a) : sk;
+                if (O) {
+                    const int al = 63 - __builtin_clzll(O);
+                    const unsigned long long above = al == 63 ? 0ull : ~((2ull << al) - 1ull);
+                    if (!(Z & above)) st_idx = lane == L ? (uint32_t)(from + s * 64 + al) : st_idx;
+                    else st_idx = lane == L ? NONE : st_idx;
+                } else if (Z) {
+                    st_idx = lane == L ? NONE : st_idx;  // the container of this level closed and nothing reopened
+                }
+            }
+            (void)deep;
+            if (valid) {
+                if (lane >= first_bad) {
+                    up[i] = UNKNOWN;
+                    match[i] = UNKNOWN;
+                } else {
+                    up[i] = my_up;
+                    if (!is_open) match[i] = my_up;
+                    if (is_close && my_up < UNKNOWN) match[my_up] = (uint32_t)i;
+                }
+            }
+            if (first_bad < 64) broken = true;
+            H0 = H0 + (int)cw_last(iu) - (int)cw_last(id);
+            if (H0 < 0) H0 = 0;
+        }
+    }
+}
+
+hipError_t coop_match_launch(const uint8_t* d_buf, uint64_t n_docs, const uint32_t* d_idx, const unsigned long long* d_index_offsets,
+                             uint32_t* d_up, uint32_t* d_match, hipStream_t stream) {
+    if (!n_docs) return hipSuccess;
+    const uint64_t want = (n_docs + 3) / 4;
+    hipLaunchKernelGGL(k_coop_match, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, stream, d_buf, n_docs, d_idx,
+                       d_index_offsets, d_up, d_match);
+    return hipGetLastError();
+}
+
 // single document: the delimiters the batch kernels expect, from the stage-1 record that is still on the device
 __global__ void k_single_doc_setup(const Stage1Result* __restrict__ res, unsigned long long len, unsigned long long* doc_offsets,
                                    unsigned long long* index_offsets, uint32_t* doc_status, unsigned long long* doc_str_offsets) {

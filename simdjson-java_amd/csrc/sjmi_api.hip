@@ -830,6 +830,44 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
     return SJMI_OK;
 }
 
+int sjmi_match_brackets_device(sjmi_ctx* c, const void* d_buf, const void* d_indexes, const void* d_index_offsets, uint64_t n_docs,
+                               void* d_up, void* d_match, void* stream) {
+    if (!c || !d_buf || !d_indexes || !d_index_offsets || !d_up || !d_match) return SJMI_ERR_ARG;
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (fail(c, "match launch", sjmi::coop_match_launch((const uint8_t*)d_buf, n_docs, (const uint32_t*)d_indexes,
+                                                        (const unsigned long long*)d_index_offsets, (uint32_t*)d_up,
+                                                        (uint32_t*)d_match, st)))
+        return SJMI_ERR_HIP;
+    return SJMI_OK;
+}
+
+int sjmi_match_brackets(sjmi_ctx* c, uint32_t* up, uint32_t* match, uint64_t capacity) {
+    if (!c || !up || !match) return SJMI_ERR_ARG;
+    if (!c->last_valid || c->last_batch) {
+        c->err = "sjmi_match_brackets needs a preceding successful sjmi_stage1 on this context";
+        return SJMI_ERR_ARG;
+    }
+    const uint64_t count = c->last_count;
+    if (capacity < count) return SJMI_ERR_CAPACITY;
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    if (!c->d_single && fail(c, "hipMalloc(single)", hipMalloc(&c->d_single, 512))) return SJMI_ERR_HIP;
+    // up[] in the (idle) string-buffer allocation, match[] in the tape allocation: both grown on demand
+    if (!grow(c, (void**)&c->d_sb, &c->sb_bytes, (size_t)count * 4 + 64, "hipMalloc(sb)") ||
+        !grow(c, (void**)&c->d_tape, &c->tape_bytes, (size_t)count * 4 + 64, "hipMalloc(tape)"))
+        return SJMI_ERR_HIP;
+    const unsigned long long io[2] = {0ull, count};
+    unsigned long long* d_io = (unsigned long long*)c->d_single + 2;
+    if (fail(c, "H2D", hipMemcpyAsync(d_io, io, sizeof io, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
+    const int rc = sjmi_match_brackets_device(c, c->d_in, c->d_idx, d_io, 1, c->d_sb, c->d_tape, c->stream);
+    if (rc != SJMI_OK) return rc;
+    if (count && (fail(c, "D2H(up)", hipMemcpyAsync(up, c->d_sb, count * 4, hipMemcpyDeviceToHost, c->stream)) ||
+                  fail(c, "D2H(match)", hipMemcpyAsync(match, c->d_tape, count * 4, hipMemcpyDeviceToHost, c->stream))))
+        return SJMI_ERR_HIP;
+    if (fail(c, "sync", hipStreamSynchronize(c->stream))) return SJMI_ERR_HIP;
+    return SJMI_OK;
+}
+
 int sjmi_host_register(sjmi_ctx* c, void* ptr, uint64_t bytes) {
     if (!c || !ptr || !bytes) return SJMI_ERR_ARG;
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;

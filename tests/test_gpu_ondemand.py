@@ -1,0 +1,171 @@
+"""The on-demand front end's skip table (sjmi_match_brackets, csrc/coop_walk.hip k_coop_match) against the reference's own
+way of leaving a value: OnDemandJsonIterator.skipChild(parentDepth) (OnDemandJsonIterator.java:43-81) restated here as the
+scan it is -- from EVERY read position of the reference files and for every number of containers to leave, the table
+lookup must land on the structural the scan lands on (or both must run out of closing brackets)."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.conftest import load_fixture
+
+pytestmark = pytest.mark.gpu
+
+NONE, UNKNOWN = 0xFFFFFFFF, 0xFFFFFFFE
+
+
+def skip_child_scan(doc, idx, r, depth, parent_depth):
+    """OnDemandJsonIterator.skipChild(int parentDepth), :47-81, over the structural positions idx (BitIndexes cursor r).
+    -> (r, depth) after the call, or None for 'Not enough close braces.'"""
+    n = len(idx)
+
+    def byte(k):  # BitIndexes reads its 0 sentinel past the end (BitIndexes.java:82-96)
+        return doc[idx[k]] if k < n else doc[0]
+    if depth <= parent_depth:
+        return r, depth
+    if r >= n:
+        return None
+    ch = byte(r)
+    r += 1
+    if ch in b"[{:,":
+        pass
+    elif ch == 0x22 and byte(r) == 0x3A:
+        r += 1
+    else:
+        depth -= 1
+        if depth <= parent_depth:
+            return r, depth
+    while r < n:
+        ch = byte(r)
+        r += 1
+        delta = 1 if ch in b"[{" else (-1 if ch in b"]}" else 0)
+        depth += delta
+        if delta < 0 and depth <= parent_depth:
+            return r, depth
+    return None
+
+
+def skip_child_table(doc, idx, up, match, r, depth, parent_depth):
+    """The same call with the skip table: the first structural is looked at exactly as the reference does, then k containers
+    are left by k - 1 climbs through up[] and one jump through match[]."""
+    n = len(idx)
+    if depth <= parent_depth:
+        return r, depth
+    if r >= n:
+        return None
+    ch = doc[idx[r]]
+    q = r + 1
+    if ch in b"[{:,":
+        pass
+    elif ch == 0x22 and (doc[idx[q]] if q < n else doc[0]) == 0x3A:
+        q += 1
+    else:
+        depth -= 1
+        if depth <= parent_depth:
+            return q, depth
+    # the scan now counts brackets from q on: it stops at the closing bracket that takes the depth to parent_depth
+    k = depth - parent_depth
+    if q >= n:
+        return None
+    # the container position q lies in: the bracket just consumed if the first structural was an opening one (the
+    # reference breaks out of its switch without counting it, so its closing bracket is the first -1 the scan meets)
+    e = int(up[q]) if ch not in b"[{" else r
+    if e in (NONE, UNKNOWN):
+        return "unknown" if e == UNKNOWN else None
+    for _ in range(k - 1):
+        e = int(up[e])
+        if e in (NONE, UNKNOWN):
+            return "unknown" if e == UNKNOWN else None
+    m = int(match[e])
+    if m in (NONE, UNKNOWN):
+        return "unknown" if m == UNKNOWN else None
+    return m + 1, parent_depth
+
+
+def _tables(ctx, doc):
+    idx, st = ctx.stage1(doc)
+    up, match = ctx.match_brackets(idx.size)
+    return [int(x) for x in idx], up, match
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import simdjson_java_amd as S
+    c = S.Context(device=0, capacity=8 * 1024 * 1024)
+    yield c
+    c.close()
+
+
+def _check_table_against_stack(doc, idx, up, match):
+    """independent of skipChild: up / match against a plain bracket stack"""
+    stack = []
+    for i, p in enumerate(idx):
+        ch = doc[p]
+        if ch in b"]}":
+            assert stack, "test documents are balanced"
+            o = stack[-1]
+            assert int(up[i]) == o and int(match[i]) == o and int(match[o]) == i, i
+            stack.pop()
+        else:
+            want = stack[-1] if stack else NONE
+            assert int(up[i]) == want, (i, int(up[i]), want)
+            if ch in b"[{":
+                stack.append(i)
+            else:
+                assert int(match[i]) == want
+    for o in stack:
+        assert int(match[o]) == NONE
+
+
+@pytest.mark.parametrize("name", ["twitter.json", "github_events.json", "wide_bench.json"])
+def test_skip_child_from_every_position(ctx, name):
+    doc = load_fixture(name)
+    idx, up, match = _tables(ctx, doc)
+    _check_table_against_stack(doc, idx, up, match)
+    rng = random.Random(7)
+    positions = range(len(idx)) if len(idx) < 1500 else sorted(rng.sample(range(len(idx)), 1500))
+    checked = 0
+    for r in positions:
+        for k in (1, 2, 3, 5):
+            depth = 10  # the iterator's own bookkeeping: only depth - parentDepth matters to the scan
+            want = skip_child_scan(doc, idx, r, depth, depth - k)
+            got = skip_child_table(doc, idx, up, match, r, depth, depth - k)
+            assert got != "unknown"
+            assert got == want, (r, k, got, want, bytes(doc[idx[r]:idx[r] + 12]))
+            checked += 1
+    assert checked >= 6000
+
+
+def test_nesting_steps_and_unbalanced_documents(ctx):
+    rng = random.Random(8)
+
+    def nested(d):
+        if d == 0:
+            return rng.choice(["1", '"x"', "true", "[]", "{}"])
+        if rng.random() < 0.5:
+            return "[" + ",".join(nested(d - 1) for _ in range(rng.randint(1, 4))) + "]"
+        return "{" + ",".join('"k%d":%s' % (i, nested(d - 1)) for i in range(rng.randint(1, 4))) + "}"
+    for doc in [nested(7).encode() for _ in range(6)] + [("[" * d + "1" + "]" * d).encode() for d in (1, 63, 64)] + \
+               [b"[" + b"[1,[2,[3]]]," * 300 + b"0]"]:
+        idx, up, match = _tables(ctx, doc)
+        _check_table_against_stack(doc, idx, up, match)
+        for r in range(0, len(idx), 7):
+            for k in (1, 2, 4):
+                assert skip_child_table(doc, idx, up, match, r, 9, 9 - k) == skip_child_scan(doc, idx, r, 9, 9 - k), (r, k)
+    # never-closed brackets: NONE, and the scan runs out of closing brackets exactly where the table says so
+    doc = b'{"a":[1,2,{"b":[3,4'
+    idx, up, match = _tables(ctx, doc)
+    assert [int(match[i]) for i, p in enumerate(idx) if doc[p] in b"[{"] == [NONE] * 4
+    for r in range(len(idx)):
+        for k in (1, 2):
+            assert skip_child_table(doc, idx, up, match, r, 5, 5 - k) == skip_child_scan(doc, idx, r, 5, 5 - k)
+    # a closing bracket without an opening one: everything from there on is left to the scan
+    doc = b"[1,2]] [3,[4]]"
+    idx, up, match = _tables(ctx, doc)
+    bad = [i for i, p in enumerate(idx) if p == 5][0]
+    assert all(int(x) == UNKNOWN for x in up[bad:]) and all(int(x) != UNKNOWN for x in up[:bad])
+    # beyond the 64 levels of the per-wave stack: marked, not guessed
+    doc = ("[" * 70 + "1" + "]" * 70).encode()
+    idx, up, match = _tables(ctx, doc)
+    assert int(up[69]) == UNKNOWN and int(up[30]) == 29 and int(match[0]) == len(idx) - 1
