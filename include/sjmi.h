@@ -118,6 +118,19 @@ int sjmi_stage1_masks(sjmi_ctx* ctx, const uint8_t* buf, uint64_t len, uint64_t*
 int sjmi_stage1_masks_device(sjmi_ctx* ctx, const void* d_buf, uint64_t len, void* d_masks, uint64_t mask_capacity_blocks,
                              void* stream);
 
+/* ONE SHARD of a document that is split over several GPUs, or ONE CHUNK of a document stream (SURVEY.md 8(e) row 2, 8(f)
+ * rank 4; the reference has no counterpart: one byte[] per parse).  d_buf points at the shard's first byte (16-byte
+ * aligned), with halo_bytes (a multiple of 64, >= 64 unless the shard starts the document) of the document's preceding
+ * bytes readable right in front of it: everything stage 1 carries from block to block except the in-string parity is
+ * re-derived from those bytes (escape run, previous scalar, UTF-8 continuation -- a backslash run that fills the whole
+ * halo is the only thing it cannot see through).  is_last = 0: the shard ends on a 64-byte boundary (len % 64 == 0) and has
+ * no tail block -- what straddles the boundary is validated by the next shard.  entry_parity = 1: the shard starts
+ * inside a string.  Indexes are relative to d_buf; result.status bit SJMI_ST_UNCLOSED = the parity AFTER the shard.
+ * Protocol (sharding.py DocumentSplit): run every shard with entry_parity 0; exchange the parities (1 bit per shard: the
+ * first collective); a shard whose true entry parity is 1 runs again with entry_parity 1; exchange the counts. */
+int sjmi_stage1_shard_device(sjmi_ctx* ctx, const void* d_buf, uint64_t len, uint64_t halo_bytes, int is_last, int entry_parity,
+                             void* d_indexes, uint64_t index_capacity, void* d_result, void* stream);
+
 /* device-side result record of one unescape call */
 typedef struct sjmi_unescape_result {
     uint64_t total_bytes;      /* bytes of [be32 length][unescaped bytes] records written */

@@ -68,7 +68,7 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_value_as_boolean", "sjmi_value_as_string", "sjmi_value_get", "sjmi_value_size", "sjmi_value_first",
            "sjmi_value_next", "sjmi_parse_batch_device", "sjmi_parse_document",
            "sjmi_parser_set_gpu_walk", "sjmi_set_auto_safe", "sjmi_match_brackets",
-           "sjmi_match_brackets_device"]
+           "sjmi_match_brackets_device", "sjmi_stage1_shard_device"]
 
 
 def lib():
@@ -149,6 +149,9 @@ def lib():
         L.sjmi_match_brackets_device.restype = C.c_int
         L.sjmi_match_brackets_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                                  C.c_void_p]
+        L.sjmi_stage1_shard_device.restype = C.c_int
+        L.sjmi_stage1_shard_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_uint64,
+                                               C.c_void_p, C.c_void_p]
         L.sjmi_set_auto_safe.restype = C.c_int
         L.sjmi_set_auto_safe.argtypes = [C.c_void_p, C.c_int]
         L.sjmi_set_tile_mode.restype = C.c_int
@@ -386,6 +389,11 @@ class Context:
         """Device-resident path; arguments are raw device pointers (ints) and a hipStream_t handle."""
         self._check(lib().sjmi_stage1_device(self._h, d_buf, length, d_indexes, index_capacity, d_result, stream),
                     "sjmi_stage1_device")
+
+    def stage1_shard_device(self, d_buf, length, halo_bytes, is_last, entry_parity, d_indexes, index_capacity, d_result, stream=0):
+        """One shard / stream chunk of a longer document (sjmi_stage1_shard_device)."""
+        self._check(lib().sjmi_stage1_shard_device(self._h, d_buf, length, halo_bytes, 1 if is_last else 0, 1 if entry_parity else 0,
+                                                   d_indexes, index_capacity, d_result, stream), "sjmi_stage1_shard_device")
 
     def set_auto_safe(self, on):
         self._check(lib().sjmi_set_auto_safe(self._h, 1 if on else 0), "sjmi_set_auto_safe")

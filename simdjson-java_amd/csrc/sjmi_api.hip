@@ -475,8 +475,26 @@ int sjmi_walk_batch_device(sjmi_ctx* c, const void* d_buf, const void* d_doc_off
     return SJMI_OK;
 }
 
+static int stage1_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_indexes, uint64_t index_capacity,
+                              void* d_result, void* stream, uint32_t shard_flags);
+
 int sjmi_stage1_device(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_indexes, uint64_t index_capacity,
                        void* d_result, void* stream) {
+    return stage1_device_impl(c, d_buf, len, d_indexes, index_capacity, d_result, stream, 0);
+}
+
+int sjmi_stage1_shard_device(sjmi_ctx* c, const void* d_buf, uint64_t len, uint64_t halo_bytes, int is_last, int entry_parity,
+                             void* d_indexes, uint64_t index_capacity, void* d_result, void* stream) {
+    // a shard that is not the last one ends on a block boundary (its successor owns what straddles it); the halo is
+    // whole blocks so that the shard itself stays 16-byte aligned
+    if ((halo_bytes & 63) || halo_bytes > 65535ull * 64 || (!is_last && (len & 63)) || (!is_last && len == 0)) return SJMI_ERR_ARG;
+    const uint32_t flags = ((uint32_t)(halo_bytes / 64) << 16) | (is_last ? 0u : sjmi::FLAG_NO_TAIL) |
+                           (entry_parity ? sjmi::FLAG_ENTRY_PARITY : 0u);
+    return stage1_device_impl(c, d_buf, len, d_indexes, index_capacity, d_result, stream, flags);
+}
+
+static int stage1_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_indexes, uint64_t index_capacity,
+                              void* d_result, void* stream, uint32_t shard_flags) {
     if (!c || !d_buf || !d_indexes || !d_result) return SJMI_ERR_ARG;
     if (len >= (1ull << 32) || ((uintptr_t)d_buf & 15) || ((uintptr_t)d_indexes & 15)) return SJMI_ERR_ARG;
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
@@ -516,7 +534,7 @@ int sjmi_stage1_device(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_ind
         ++c->events_used;
     }
     if (fail(c, "launch", sjmi::stage1_launch((const uint8_t*)d_buf, len, (uint32_t*)d_indexes, index_capacity, ws, steps,
-                                              st, ev0, ev1, launch_flags(c), ex)))
+                                              st, ev0, ev1, launch_flags(c) | shard_flags, ex)))
         return SJMI_ERR_HIP;
     note_launch(c, st);
     if (!fast && fail(c, "D2D(result)", hipMemcpyAsync(d_result, ws + sjmi::WS_RESULT_OFFSET, sizeof(sjmi_stage1_result),
@@ -536,7 +554,7 @@ int sjmi_stage1_device(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_ind
             return SJMI_ERR_HIP;
         if (r.status & SJMI_ST_INTERNAL) {
             c->ticket_mode = true;
-            return sjmi_stage1_device(c, d_buf, len, d_indexes, index_capacity, d_result, stream);
+            return stage1_device_impl(c, d_buf, len, d_indexes, index_capacity, d_result, stream, shard_flags);
         }
     }
     return SJMI_OK;

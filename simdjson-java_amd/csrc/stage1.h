@@ -40,6 +40,10 @@ constexpr uint32_t DBG_FAKE_TIMEOUT = 16;
 constexpr uint32_t DBG_SMALL_GRID = 32;
 // kernel flag (not an ablation): SAFE liveness mode -- no scanner workgroup, every worker looks back itself
 constexpr uint32_t FLAG_SAFE = 0x100;
+// shards of a longer document (sjmi_stage1_shard_device): the shard is entered inside a string; it is not the document's
+// last shard (no tail block); bits 16..31 = readable 64-byte blocks in front of the buffer (left halo)
+constexpr uint32_t FLAG_ENTRY_PARITY = 0x1000;
+constexpr uint32_t FLAG_NO_TAIL = 0x4000;
 // kernel flag: FAST mode without static first granules (several contexts may be launching concurrently)
 constexpr uint32_t FLAG_ALL_TICKETS = 0x800;
 

@@ -486,14 +486,15 @@ struct StepData {
 
 // Branch-free on purpose (a block index past the end is clamped and its data ignored by the caller):
 // a conditional load makes hipcc drain the whole load queue (s_waitcnt vmcnt(0)) at the join.
-__device__ __forceinline__ void load_step(StepData& d, const uint8_t* __restrict__ buf, sj_u64 blk, sj_u64 nblocks) {
+__device__ __forceinline__ void load_step(StepData& d, const uint8_t* __restrict__ buf, sj_u64 blk, sj_u64 nblocks, bool left_halo = false) {
     const sj_u64 b = blk < nblocks ? blk : nblocks - 1;
     const uint4* src = reinterpret_cast<const uint4*>(buf + b * 64);
     d.q0 = src[0];
     d.q1 = src[1];
     d.q2 = src[2];
     d.q3 = src[3];
-    d.halo = *reinterpret_cast<const sj_u64*>(buf + (b > 0 ? b * 64 - 8 : 0));  // unused for block 0
+    // (unused for block 0 -- unless the buffer is a shard of a longer document: then the 8 bytes in front of it are real)
+    d.halo = *reinterpret_cast<const sj_u64*>(buf + ((b > 0 || left_halo) ? (long long)(b * 64) - 8 : 0ll));
 }
 
 #ifdef SJMI_TRACE  // experiments only (tools/trace.py): per-granule timestamps behind the granule states
@@ -569,7 +570,7 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
             __hip_atomic_fetch_or(&res->status, SJMI_ST_INTERNAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (threadIdx.x == 0) {
             hand.seq = 0;
-            hand.P = 0;
+            hand.P = (dbg & FLAG_ENTRY_PARITY) ? 1u : 0u;  // (a shard of a longer document may start inside a string)
             hand.err = 0;
             hand.C = 0;
         }
@@ -580,7 +581,12 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
     const uint32_t nworkers = (gridDim.x - (safe ? 0u : 1u)) * 4u;
     const uint32_t worker = (blockIdx.x - (safe ? 0u : 1u)) * 4u + (uint32_t)wave;
     WaveShared<S, LDSW>& ws = sh[wave];
-    const sj_u64 nblocks = len / 64 + 1;  // the reference always processes one tail block (:255-294)
+    // the reference always processes one tail block (:255-294); a shard that is not the document's last one ends on a block
+    // boundary and has none (its successor validates what straddles the boundary from its own left halo)
+    const sj_u64 nblocks = len / 64 + ((dbg & FLAG_NO_TAIL) ? 0 : 1);
+    const uint32_t halo_blocks = dbg >> 16;       // shard: readable 64-byte blocks in front of buf (0 = a whole document)
+    const bool left_halo = halo_blocks != 0;
+    const uint32_t entry_par = (dbg & FLAG_ENTRY_PARITY) ? 1u : 0u;
     const sj_u64 lt_mask = (1ull << lane) - 1ull;
     const uint32_t last = ngran - 1;
 
@@ -617,7 +623,7 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
     uint32_t prev = NO_TILE, prev_par = 0, prev_c0 = 0, prev_c1 = 0;  // the parked granule and its aggregate
     uint32_t err = 0;
     StepData d;  // the step being loaded / classified (single buffer: re-used as soon as it has been transposed)
-    load_step(d, buf, (sj_u64)cur * (64 * S) + lane, nblocks);
+    load_step(d, buf, (sj_u64)cur * (64 * S) + lane, nblocks, left_halo);
 
     for (;;) {
         const bool have = cur < ngran;  // wave-uniform
@@ -650,7 +656,7 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
                 sj_u64 p[8];
                 sj_transpose_butterfly(w, p);
                 asm volatile("" ::: "memory");
-                if (s + 1 < S) load_step(d, buf, blk0 + (sj_u64)(s + 1) * 64 + lane, nblocks);
+                if (s + 1 < S) load_step(d, buf, blk0 + (sj_u64)(s + 1) * 64 + lane, nblocks, left_halo);
                 if (s == S - 1 && !safe) {
                     // requested one step ahead of their use: late enough that granules are started in ticket order
                     // (a ticket held through a whole slow iteration delays every granule behind it), early enough to
@@ -667,7 +673,7 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
                     const sj_u64 start = blk * 64;
                     uint32_t e_in = 0, p_in = 0;
                     SjUtf8Carry uc = {0, 0, 0, 0};
-                    if (blk > 0) {
+                    if (blk > 0 || left_halo) {
                         uc = sj_utf8_carry(halo);
                         unresolved = !sj_carry_from_halo(halo, &e_in, &p_in);
                     }
@@ -693,7 +699,8 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
                     for (int i = 0; i < 16; ++i) w[i] = reinterpret_cast<const uint32_t*>(buf + start)[i];
                     const sj_u64 halo = *reinterpret_cast<const sj_u64*>(buf + start - 8);
                     uint32_t e_in = 0, p_in = 0;
-                    sj_carry_slow(buf, 0, start, &e_in, &p_in);
+                    // (a shard: the run may reach into the left halo, whose first byte bounds the walk)
+                    sj_carry_slow(buf - (sj_u64)halo_blocks * 64, 0, start + (sj_u64)halo_blocks * 64, &e_in, &p_in);
                     sj_u64 p[8];
                     sj_transpose_butterfly(w, p);
                     const sj_u64 rem = len - start;
@@ -728,7 +735,7 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
             // the granule's error bits travel with its aggregate (the scanner composes the launch's status from them)
             const uint32_t gbits = (__ballot(gerr & 1u) ? 1u : 0u) | (__ballot(gerr & 2u) ? 2u : 0u) | (__ballot(gerr & 4u) ? 4u : 0u);
             if (lane == 0 && !(dbg & DBG_NO_LOOKBACK)) {
-                if (safe && cur == 0) publish_prefix(agg, 0, wpar, (sj_u64)W0);  // nothing to look back at
+                if (safe && cur == 0) publish_prefix(agg, 0, wpar ^ entry_par, (sj_u64)(entry_par ? WP - W0 : W0));  // nothing to look back at
                 else publish_aggregate(agg, cur, W0, WP - W0, wpar, gbits);
             }
             SJMI_TSTAMP(cur, 1);
@@ -745,11 +752,11 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
             }
         }
         // first step of the next granule: in flight during the expansion below (clamped, so harmless without one)
-        load_step(d, buf, (sj_u64)nxt * (64 * S) + lane, nblocks);
+        load_step(d, buf, (sj_u64)nxt * (64 * S) + lane, nblocks, left_halo);
 
         // =================== E: resolve granule `prev`'s prefix, expand and store its indexes ===================
         if (prev != NO_TILE) {
-            uint32_t pe = 0;  // parity entering the granule
+            uint32_t pe = entry_par;  // parity entering the granule (granule 0: the document's / shard's own)
             sj_u64 cnt_in = 0;
             SJMI_TSTAMP(prev, 2);
             if (dbg & DBG_NO_LOOKBACK) {  // ablation: no chain (indexes land at fake offsets)
@@ -913,8 +920,8 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
 // granules of steps x 4 KiB (one per worker wave and iteration)
-static uint64_t granules_for(uint64_t len, int steps) {
-    const uint64_t nblocks = len / 64 + 1;
+static uint64_t granules_for(uint64_t len, int steps, bool no_tail = false) {
+    const uint64_t nblocks = len / 64 + (no_tail ? 0 : 1);
     return (nblocks + 64ull * steps - 1) / (64ull * steps);
 }
 
@@ -986,7 +993,8 @@ static hipError_t launch_variant(const uint8_t* d_buf, uint64_t len, uint32_t* d
 
 hipError_t stage1_launch(const uint8_t* d_buf, uint64_t len, uint32_t* d_out, uint64_t out_cap, void* d_ws,
                          int steps, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg, const Stage1Extras& ex) {
-    const uint64_t ngran = granules_for(len, steps);
+    const uint64_t ngran = granules_for(len, steps, (dbg & FLAG_NO_TAIL) != 0);
+    if (ngran == 0) return hipErrorInvalidValue;  // (an empty shard without a tail block: nothing to launch)
     const size_t ws_bytes = WS_TILE_STATE_OFFSET + (2 + SJMI_TRACE_SLOTS) * (size_t)ngran * sizeof(sj_u64);
     hipError_t e = hipSuccess;
     if (!ex.workspace_is_zero && (e = hipMemsetAsync(d_ws, 0, ws_bytes, stream)) != hipSuccess) return e;

@@ -125,3 +125,115 @@ def sharded_step(shard, stream=0):
     out = torch.empty(dist.get_world_size() * 4, dtype=torch.int64, device=shard.device)
     dist.all_gather_into_tensor(out, row)
     return out.view(dist.get_world_size(), 4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ONE document over several GPUs / as a stream of chunks
+# ---------------------------------------------------------------------------------------------------------------------
+def split_points(n_bytes, parts, align=64):
+    """Contiguous byte ranges [(a, b)] covering [0, n_bytes): every boundary a multiple of `align` (stage 1 works in
+    64-byte blocks; a shard that is not the last one has no tail block), about equal sizes."""
+    bounds = [0]
+    for r in range(1, parts):
+        b = (n_bytes * r // parts) // align * align
+        bounds.append(max(b, bounds[-1]))
+    bounds.append(n_bytes)
+    return [(bounds[r], bounds[r + 1]) for r in range(parts)]
+
+
+class DocumentShard:
+    """One rank's shard [a, b) of a document, resident on its device together with `halo` bytes of the document in front
+    of it (the carries stage 1 needs are re-derived from them; only the in-string parity has to come from the ranks in
+    front).  `data` = the document's bytes [a - halo, b) (bytes or a uint8 tensor)."""
+
+    def __init__(self, engine, data, halo, is_last, device, index_ratio=1):
+        import torch
+        self.engine, self.device, self.halo, self.is_last = engine, device, int(halo), bool(is_last)
+        total = int(data.numel()) if hasattr(data, "numel") else len(data)
+        self.length = total - self.halo
+        assert self.halo % 64 == 0 and (self.is_last or self.length % 64 == 0)
+        self.buf = torch.zeros(total + 128, dtype=torch.uint8, device=device)
+        self.buf[:total] = data if hasattr(data, "numel") else torch.frombuffer(bytearray(data), dtype=torch.uint8).to(device)
+        self.capacity = self.length // index_ratio + 66
+        self.idx = torch.empty(self.capacity, dtype=torch.int32, device=device)
+        self.result = torch.zeros(2, dtype=torch.int64, device=device)  # sjmi_stage1_result
+        self.entry_parity = 0
+
+    def run(self, entry_parity, stream=0):
+        self.entry_parity = int(entry_parity)
+        self.engine.stage1_shard_device(self.buf.data_ptr() + self.halo, self.length, self.halo, self.is_last, self.entry_parity,
+                                        self.idx.data_ptr(), self.capacity, self.result.data_ptr(), stream)
+
+    def outcome(self):
+        """(synchronise first) -> (count, status bits without UNCLOSED, parity after the shard)"""
+        r = self.result.cpu().numpy()
+        st = int(r[1]) & 0xFFFFFFFF
+        if st & 0x300:
+            raise RuntimeError("stage 1 of the shard: capacity / internal error (status 0x%x)" % st)
+        return int(r[0]), st & 0xFD, (st >> 1) & 1
+
+
+def resolve_split_document(shard, sync):
+    """The protocol of a document split over the ranks of the default process group (or a single process):
+      1. every rank scans its shard as if it started outside a string;
+      2. all_gather of one word per rank: does the shard flip the in-string parity?  (the first collective)
+      3. a rank whose true entry parity is 1 (XOR of the flips in front of it) scans again with entry parity 1;
+      4. all_gather of {count, status, parity after}: global index offsets, the document's verdict.
+    `sync` = a callable that synchronises the rank's stream.  -> dict(entry_parity, count, offset, total, status)
+    where status has SJMI_ST_UNCLOSED set iff the LAST shard ends inside a string."""
+    import torch
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank = dist.get_rank() if multi else 0
+    world = dist.get_world_size() if multi else 1
+    shard.run(0)
+    sync()
+    _, _, flip = shard.outcome()  # entered with parity 0: the parity after IS the flip
+    flips = torch.tensor([flip], dtype=torch.int64, device=shard.device)
+    if multi:
+        allf = torch.empty(world, dtype=torch.int64, device=shard.device)
+        dist.all_gather_into_tensor(allf, flips)
+    else:
+        allf = flips
+    entry = int(allf[:rank].sum().item()) & 1
+    if entry:
+        shard.run(1)
+        sync()
+    count, st, after = shard.outcome()
+    row = torch.tensor([count, st, after], dtype=torch.int64, device=shard.device)
+    if multi:
+        allr = torch.empty(world * 3, dtype=torch.int64, device=shard.device)
+        dist.all_gather_into_tensor(allr, row)
+        allr = allr.view(world, 3)
+    else:
+        allr = row[None, :]
+    a = allr.cpu().numpy()
+    status = 0
+    for r in range(world):
+        status |= int(a[r, 1])
+    if int(a[world - 1, 2]):
+        status |= 2  # SJMI_ST_UNCLOSED: the document ends inside a string
+    return {"entry_parity": entry, "count": count, "offset": int(a[:rank, 0].sum()), "total": int(a[:, 0].sum()), "status": status}
+
+
+def stream_document(engine, device, chunks, halo=64):
+    """Document-stream mode on ONE GPU: the chunks of a document (bytes; every chunk but the last a multiple of 64 long)
+    are scanned one after the other, the in-string parity carried from chunk to chunk, each chunk seeing `halo` bytes of
+    its predecessor.  -> (list of (base offset, indexes np.uint32 relative to the chunk), status)."""
+    import numpy as np
+    import torch
+    out, status, parity, base, tail = [], 0, 0, 0, b""
+    for k, ch in enumerate(chunks):
+        last = k == len(chunks) - 1
+        h = min(halo, len(tail)) // 64 * 64
+        sh = DocumentShard(engine, tail[len(tail) - h:] + ch if h else ch, h, last, device)
+        sh.run(parity)
+        torch.cuda.synchronize()
+        count, st, parity = sh.outcome()
+        status |= st
+        out.append((base, sh.idx[:count].cpu().numpy().view(np.uint32).copy()))
+        base += len(ch)
+        tail = (tail + ch)[-max(halo, 64):]
+    if parity:
+        status |= 2
+    return out, status

@@ -117,6 +117,87 @@ def test_two_rank_sharded_step():
     assert c0["failed_documents"] == 1 and c0["documents"] == g0[0][0]
 
 
+class _StubShardEngine:
+    """binding.Context.stage1_shard_device for the CPU test: the per-byte form of stage 1 (SURVEY.md 8(a) a3') over the left
+    halo (for the escape / previous-scalar carries only) and then over the shard, entered with the given parity."""
+
+    def stage1_shard_device(self, d_buf, length, halo, is_last, entry_parity, d_indexes, cap, d_result, stream=0):
+        import ctypes as C
+        raw = bytes((C.c_uint8 * (halo + length)).from_address(d_buf - halo))
+        out = (C.c_uint32 * cap).from_address(d_indexes)
+        res = (C.c_int64 * 2).from_address(d_result)
+        esc = prev_nqs = 0
+        in_str, unesc, n = 0, 0, 0
+        for pos, c in enumerate(raw):
+            if pos == halo:
+                in_str = entry_parity
+            escaped = esc
+            esc = 1 if (c == 0x5C and not escaped) else 0
+            q = c == 0x22 and not escaped
+            if q:
+                in_str ^= 1
+            ws = c in (0x20, 0x09, 0x0A, 0x0D)
+            op = c in b",:[]{}\x0c\x1a"
+            scalar = not (op or ws)
+            start = scalar and not prev_nqs
+            prev_nqs = scalar and not q
+            if pos >= halo:
+                if (op or start) and not (in_str ^ q):
+                    out[n] = pos - halo
+                    n += 1
+                if c <= 0x1F and in_str:
+                    unesc = 1
+        res[0] = n
+        res[1] = (2 if in_str else 0) | (4 if unesc else 0)
+
+
+def _split_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import simdjson_java_amd  # noqa: F401
+    from simdjson_java_amd import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    doc = _split_doc()
+    a, b = sharding.split_points(len(doc), world)[rank]
+    h = min(64, a)
+    shard = sharding.DocumentShard(_StubShardEngine(), doc[a - h:b], h, rank == world - 1, "cpu")
+    r = sharding.resolve_split_document(shard, lambda: None)
+    idx = shard.idx[:r["count"]].numpy().view(np.uint32).astype(np.int64) + a
+    q.put((rank, r, idx.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _split_doc():
+    # the boundary of two ranks (byte 640) lies inside the long string: rank 1 must find out that it starts inside one
+    return b'{"k":[1,2,3],"s":"' + b"x y z, " * 120 + b'\\" still inside","t":[true,false,null,{"u":"v"}]}   '
+
+
+def test_two_rank_split_document():
+    """sharding.resolve_split_document over gloo: scan, gather the parity flips, re-scan where the true entry parity is 1,
+    gather the counts -- rank 1 starts inside a string and has to run twice."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    doc = _split_doc()
+    want, wst = O.stage1(doc)
+    (r0, o0, i0), (r1, o1, i1) = res
+    assert o0["entry_parity"] == 0 and o1["entry_parity"] == 1
+    assert o0["total"] == o1["total"] == want.size and o1["offset"] == o0["count"]
+    assert i0 + i1 == want.tolist()
+    assert o0["status"] == o1["status"] == wst == 0
+
+
 def test_partition_is_contiguous_and_balanced():
     sys.path.insert(0, ROOT)
     import simdjson_java_amd  # noqa: F401
