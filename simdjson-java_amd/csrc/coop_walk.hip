@@ -31,6 +31,7 @@
 // significant digits.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "sj_number.h"
 #include "stage1.h"
@@ -66,41 +67,94 @@ __device__ __forceinline__ uint32_t cw_incl_scan(uint32_t v) {
 }
 __device__ __forceinline__ uint32_t cw_last(uint32_t incl) { return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63); }
 
-// a moving 16-byte window over the document, for the lane that parses a primitive
-struct CwWin {
+// The bytes of a primitive, for the lane that parses it: the 16-byte window that was loaded at the structural's own
+// position serves offsets 0..15 out of registers (a whole atom, most numbers); a longer literal fetches the next 16 bytes
+// once, and only literals beyond 32 bytes go to memory byte by byte.
+struct CwBytes {
     const uint8_t* buf;
-    uint32_t base, w0, w1, w2, w3;
-    __device__ __forceinline__ uint32_t at(uint32_t p) {
-        if (p - base >= 16u) {
-            base = p;
-            const CW16 v = *reinterpret_cast<const CW16*>(buf + p);
-            w0 = v.a; w1 = v.b; w2 = v.c; w3 = v.d;
+    uint32_t p;
+    unsigned long long lo, hi, lo2, hi2;
+    bool have2;
+    __device__ __forceinline__ uint32_t at(uint32_t q) {
+        const uint32_t o = q - p;
+        if (o < 16u) return (uint32_t)((o < 8u ? lo >> (8u * o) : hi >> (8u * (o - 8u))) & 0xFFu);
+        if (o < 32u) {
+            if (!have2) {
+                const CW16 v = *reinterpret_cast<const CW16*>(buf + p + 16);
+                lo2 = (unsigned long long)v.a | ((unsigned long long)v.b << 32);
+                hi2 = (unsigned long long)v.c | ((unsigned long long)v.d << 32);
+                have2 = true;
+            }
+            return (uint32_t)((o < 24u ? lo2 >> (8u * (o - 16u)) : hi2 >> (8u * (o - 24u))) & 0xFFu);
         }
-        const uint32_t o = p - base, w = o < 8 ? (o < 4 ? w0 : w1) : (o < 12 ? w2 : w3);
-        return (w >> (8u * (o & 3u))) & 0xFFu;
+        return buf[q];
     }
-    __device__ __forceinline__ uint32_t word(uint32_t p) { return at(p) | (at(p + 1) << 8) | (at(p + 2) << 16) | (at(p + 3) << 24); }
 };
 
 constexpr uint32_t CW_TRUE = 0x65757274u, CW_FALS = 0x736c6166u, CW_NULL = 0x6c6c756eu;
 
-// TapeBuilder.visitPrimitive (TapeBuilder.java:70-79) / visitRootPrimitive (:59-68) for one lane.
+// TapeBuilder.visitPrimitive (TapeBuilder.java:70-79) / visitRootPrimitive (:59-68) for one lane; win = the 16 bytes at idx.
 // -> 0 and (type, raw second word for numbers) or the SJMI_E_* / SJMI_WALK_NEEDS_HOST code
-__device__ int cw_primitive(CwWin& w, uint32_t idx, bool root, uint32_t end, uint32_t* type, unsigned long long* raw) {
-    const uint32_t c = w.at(idx);
-    if (c == 't' || c == 'n') {
-        const bool ok = root ? (idx + 4 <= end && w.word(idx) == (c == 't' ? CW_TRUE : CW_NULL) && (idx + 4 == end || sjn_is_structural_or_ws(w.at(idx + 4))))
-                             : (w.word(idx) == (c == 't' ? CW_TRUE : CW_NULL) && sjn_is_structural_or_ws(w.at(idx + 4)));
+__device__ int cw_primitive(const uint8_t* buf, const CW16& win, uint32_t idx, bool root, uint32_t end, uint32_t* type,
+                            unsigned long long* raw) {
+    const uint32_t c = win.a & 0xFFu;
+    if (c == 't' || c == 'n') {  // the atom and the byte behind it are in the window's first five bytes
+        const bool word_ok = win.a == (c == 't' ? CW_TRUE : CW_NULL);
+        const bool ok = root ? (idx + 4 <= end && word_ok && (idx + 4 == end || sjn_is_structural_or_ws(win.b & 0xFFu)))
+                             : (word_ok && sjn_is_structural_or_ws(win.b & 0xFFu));
         *type = c;
         return ok ? 0 : (c == 't' ? SJMI_E_INVALID_TRUE : SJMI_E_INVALID_NULL);
     }
     if (c == 'f') {
-        const bool ok = root ? (idx + 5 <= end && w.word(idx) == CW_FALS && w.at(idx + 4) == 'e' && (idx + 5 == end || sjn_is_structural_or_ws(w.at(idx + 5))))
-                             : (w.word(idx) == CW_FALS && w.at(idx + 4) == 'e' && sjn_is_structural_or_ws(w.at(idx + 5)));
+        const bool word_ok = win.a == CW_FALS && (win.b & 0xFFu) == 'e';
+        const uint32_t behind = (win.b >> 8) & 0xFFu;
+        const bool ok = root ? (idx + 5 <= end && word_ok && (idx + 5 == end || sjn_is_structural_or_ws(behind)))
+                             : (word_ok && sjn_is_structural_or_ws(behind));
         *type = 'f';
         return ok ? 0 : SJMI_E_INVALID_FALSE;
     }
     if (c == '-' || c - '0' <= 9u) {
+        // ---- fast path: an integer of at most 15 digits whose terminator is inside the window (most numbers of most
+        //      documents): branch-free SWAR -- digit run length from a "byte > 9" mask, eight digits per multiply chain ----
+        if (!root) {
+            unsigned long long x = (unsigned long long)win.a | ((unsigned long long)win.b << 32);
+            unsigned long long y = (unsigned long long)win.c | ((unsigned long long)win.d << 32);
+            const bool neg = c == '-';
+            if (neg) {
+                x = (x >> 8) | (y << 56);
+                y >>= 8;  // (the vacated top byte is 0: not a digit)
+            }
+            const unsigned long long M30 = 0x3030303030303030ull, M76 = 0x7676767676767676ull, H = 0x8080808080808080ull;
+            const unsigned long long tx = x ^ M30, ty = y ^ M30;  // digits become 0x00..0x09
+            const unsigned long long ndx = ((tx + M76) | tx) & H, ndy = ((ty + M76) | ty) & H;  // 0x80 where the byte is no digit
+            const uint32_t nd = ndx ? (uint32_t)__builtin_ctzll(ndx) >> 3 : 8u + (ndy ? (uint32_t)__builtin_ctzll(ndy) >> 3 : 8u);
+            if (nd >= 1u && nd <= 15u) {
+                const uint32_t term = (uint32_t)((nd < 8u ? x >> (8u * nd) : y >> (8u * (nd - 8u))) & 0xFFu);
+                const bool leading_zero = (x & 0xFFu) == '0' && nd > 1u;
+                if (sjn_is_structural_or_ws(term) && !leading_zero) {
+                    // eight little-endian ASCII digits (first digit in the low byte, 0x00..0x09 each) -> their value
+                    auto eight = [](unsigned long long v) -> unsigned long long {
+                        v = (v * 2561ull) >> 8;
+                        v = ((v & 0x00FF00FF00FF00FFull) * 6553601ull) >> 16;
+                        return ((v & 0x0000FFFF0000FFFFull) * 42949672960001ull) >> 32;
+                    };
+                    // the algorithm wants the LAST digit in byte 7: fewer than eight digits are shifted up, zeros below them
+                    unsigned long long value;
+                    if (nd <= 8u) {
+                        value = eight(nd == 8u ? tx : (tx & ((1ull << (8u * nd)) - 1ull)) << (8u * (8u - nd)));
+                    } else {
+                        const uint32_t r = nd - 8u;  // 1..7 digits in the second half
+                        const unsigned long long P10[8] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull};
+                        value = eight(tx) * P10[r] + eight((ty & ((1ull << (8u * r)) - 1ull)) << (8u * (8u - r)));
+                    }
+                    *type = 'l';
+                    *raw = neg ? (~value + 1) : value;
+                    return 0;
+                }
+            }
+        }
+        CwBytes w = {buf, idx, (unsigned long long)win.a | ((unsigned long long)win.b << 32),
+                     (unsigned long long)win.c | ((unsigned long long)win.d << 32), 0ull, 0ull, false};
         const uint32_t limit = root ? end : 0xFFFFFFFFu;  // the root number's padded copy (TapeBuilder.java:183-189)
         const SjNumber n = sj_scan_number([&](uint32_t q) -> uint32_t { return q < limit ? w.at(q) : 0x20u; }, idx);
         if (n.code) return n.code;
@@ -139,7 +193,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
             const uint32_t* __restrict__ doc_status, const uint32_t* __restrict__ sizes, const uint8_t* __restrict__ scratch,
             const unsigned long long* __restrict__ doc_str_offsets, unsigned long long string_base, int max_depth,
             unsigned long long* __restrict__ scratch_tape, uint32_t* __restrict__ tape_lens, int32_t* __restrict__ doc_errors, const Stage1Result* __restrict__ dev_count,
-            const UnescapeResult* __restrict__ dev_strings, WalkResult* res) {
+            const UnescapeResult* __restrict__ dev_strings, WalkResult* res, uint32_t abl) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // the per-wave stack of open containers lives in two VGPRs: LANE L holds level L (tape position of the opening word,
@@ -286,6 +340,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 // (deeper than the device stack: the non-empty open at depth 63 is handed back below, at a lower position
                 //  than anything that would need a level beyond the stack)
                 if (hmax >= CW_LEVELS) hmax = CW_LEVELS - 1;
+                if (abl & 2u) hmax = hmin - 1;
                 for (int L = hmin; L <= hmax; ++L) {
                     const unsigned long long O = __ballot(is_open && h == L);                 // opens of level L
                     const unsigned long long C = __ballot(valid && cls == K_COMMA && plevel == L);  // commas directly inside level L
@@ -356,8 +411,8 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                                 else if (h + 1 >= CW_LEVELS) err = SJMI_WALK_NEEDS_HOST;     // deeper than the device stack
                             }
                         } else if (cls != K_QUOTE) {
-                            CwWin w = {buf, p, win.a, win.b, win.c, win.d};
-                            err = cw_primitive(w, p, i == from, doc_end, &ptype, &praw);
+                            if (!(abl & 1u)) err = cw_primitive(buf, win, p, i == from, doc_end, &ptype, &praw);
+                            else ptype = 'n';
                         }
                     }
                 }
@@ -377,7 +432,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 }
                 if (rc) root_closed = true;
                 // (7) the tape words of this step
-                const bool live = valid && lane <= rc_lane;
+                const bool live = valid && lane <= rc_lane && !(abl & 4u);
                 if (live) {
                     if (cls == K_QUOTE) {
                         if (tpos < room) T[tpos] = tape_word('"', string_base + soff);
@@ -579,7 +634,8 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
     const unsigned grid = (unsigned)(want < 16384 ? want : 16384);
     hipLaunchKernelGGL(k_coop_walk, dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets,
                        d_doc_status, d_sizes, d_scratch, d_doc_str_offsets, (unsigned long long)string_base, max_depth,
-                       d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res);
+                       d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res,
+                       (uint32_t)(getenv("SJMI_COOP_ABLATE") ? atoi(getenv("SJMI_COOP_ABLATE")) : 0));
     return hipGetLastError();
 }
 
