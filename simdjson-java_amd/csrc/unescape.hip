@@ -210,140 +210,6 @@ __device__ __forceinline__ int64_t unescape_wave(const uint8_t* __restrict__ buf
     return (int64_t)n;
 }
 
-// ---- row-cooperative unescape: FOUR strings at a time, one per DPP row of 16 lanes -------------------------------------
-// The strings with escapes of a batch of small documents are short (35 bytes on average in the synthetic batches, 18 % of
-// all strings): the wave-wide form above spends a whole 64-byte window -- ~500 wave instructions -- on each of them with
-// three quarters of the lanes idle.  Here every row of 16 lanes takes its own string, 16 source bytes per step; the four
-// rows only share the trip count of the longest of the four.  Same semantics byte for byte (StringParser.doParseString
-// :29-68,112-153); the escape structure is computed per lane from the row's backslash mask (a character is escaped iff the
-// run of backslashes in front of it has odd length; the run may continue into the previous step: one carried parity bit per
-// row) instead of the 64-bit add-carry trick, which would leak from row to row.
-template <int CTRL>
-__device__ __forceinline__ uint32_t rdpp_add(uint32_t v) {
-    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
-}
-// All 64 lanes call it; s / e / dst are uniform within a row (e = the closing quote; s == e: the row has no string).
-// Returns, uniform within the row, the unescaped length or -(SJMI_E_* code).
-__device__ __forceinline__ int64_t unescape_rows(const uint8_t* __restrict__ buf, uint32_t s, uint32_t e, uint8_t* __restrict__ dst,
-                                                 int lane) {
-    const int rl = lane & 15, rshift = lane & ~15;
-    uint32_t prev_U = 0;   // 'u' positions of \u escapes in the row's previous step (16 bits)
-    uint32_t carry = 0;    // parity of the backslash run that ends at the previous step's last byte
-    uint32_t n = 0;
-    int32_t fail = 0;      // first error of the row (its code), once found the row only idles along
-    // the source bytes of six steps (96 bytes: every string that comes here) are requested together: one memory round trip
-    // per group of four strings instead of one per step
-    constexpr int PRE = 6;
-    uint32_t cw[PRE];
-#pragma unroll
-    for (int u = 0; u < PRE; ++u) {
-        const uint32_t pp = s + 16u * u + (uint32_t)rl;
-        cw[u] = pp < e ? (uint32_t)buf[pp] : 0u;
-    }
-    int step = 0;
-    for (uint32_t wb = s; __ballot(wb < e && fail == 0); wb += 16, ++step) {
-        const uint32_t pos = wb + (uint32_t)rl;
-        const bool valid = pos < e && fail == 0;
-        uint32_t c = 0;
-#pragma unroll
-        for (int u = 0; u < PRE; ++u)
-            if (step == u) c = cw[u];
-        if (step >= PRE) c = pos < e ? (uint32_t)buf[pos] : 0u;
-        if (!valid) c = 0;
-        const uint32_t B = (uint32_t)(__ballot(valid && c == '\\') >> rshift) & 0xFFFFu;
-        // backslashes directly in front of this lane, inside the step
-        const uint32_t below = (1u << rl) - 1u;
-        const uint32_t zeros = ~B & below;  // non-backslashes in front of me
-        const uint32_t run = zeros ? (uint32_t)rl - (32u - (uint32_t)__builtin_clz(zeros)) : (uint32_t)rl;
-        const bool reaches_start = zeros == 0;
-        const uint32_t par = (run + (reaches_start ? carry : 0u)) & 1u;
-        const bool is_bs = (B >> rl) & 1u;
-        const bool is_esc = valid && par;           // an escaped character (possibly itself a backslash)
-        const bool is_start = is_bs && !par;        // a backslash that starts an escape: emits nothing
-        // the run ending at the step's last byte, for the next step (taken from the row's lane 15)
-        const uint32_t my_run_incl = is_bs ? ((run + (reaches_start ? carry : 0u) + 1u) & 1u) : 0u;
-        const uint32_t carry_out = (uint32_t)__shfl((int)my_run_incl, rshift + 15);
-        const uint32_t U = (uint32_t)(__ballot(is_esc && c == 'u') >> rshift) & 0xFFFFu;
-        // hex digits consumed by a \u in front of me (1..4 positions back, possibly in the previous step)
-        const uint32_t Uext = (U << 16) | prev_U;   // bit (16 + i) = this step's position i, bit i = previous step's position i
-        const uint32_t me = 16u + (uint32_t)rl;
-        const bool consumed = ((Uext >> (me - 1u)) | (Uext >> (me - 2u)) | (Uext >> (me - 3u)) | (Uext >> (me - 4u))) & 1u;
-        uint32_t outlen = 1, out = c, err = 0;
-        if (!valid || is_start || consumed) {
-            outlen = 0;
-        } else if (is_esc) {
-            if (c == 'u') {                                                      // StringParser.java:45-57
-                int32_t cp = hex4_word(reinterpret_cast<const U4B*>(buf + pos + 1)->a);
-                if (cp >= 0xD800 && cp <= 0xDBFF) {                              // parseLowSurrogate :112-124
-                    const U8B t = *reinterpret_cast<const U8B*>(buf + pos + 5);
-                    if ((t.a & 0xFFFFu) != (uint32_t)('\\' | ('u' << 8))) {
-                        err = SJMI_E_LOW_SURROGATE_NO_U;
-                    } else {
-                        const int32_t low = hex4_word((t.a >> 16) | (t.b << 16)) - 0xDC00;
-                        if ((low >> 10) != 0) err = SJMI_E_LOW_SURROGATE_RANGE;
-                        else cp = (((cp - 0xD800) << 10) | low) + 0x10000;
-                    }
-                } else if (cp >= 0xDC00 && cp <= 0xDFFF) {
-                    bool paired = false;  // the second half of a pair (its first half emitted all four bytes)?
-                    if (pos >= s + 6 && ((Uext >> (me - 6u)) & 1u)) {
-                        const int32_t hi = hex4_word(reinterpret_cast<const U4B*>(buf + pos - 5)->a);
-                        paired = hi >= 0xD800 && hi <= 0xDBFF;
-                    }
-                    if (paired) cp = -2;
-                    else err = SJMI_E_LOW_SURROGATE_RESERVED;                    // :53-55
-                }
-                if (!err) {
-                    if (cp == -2) {
-                        outlen = 0;
-                    } else if (cp < 0) {
-                        err = SJMI_E_INVALID_UNICODE_ESCAPE;                     // :127-129
-                    } else if (cp <= 0x7F) {
-                        out = (uint32_t)cp;
-                    } else if (cp <= 0x7FF) {
-                        outlen = 2;
-                        out = (uint32_t)((cp >> 6) + 192) | ((uint32_t)((cp & 63) + 128) << 8);
-                    } else if (cp <= 0xFFFF) {
-                        outlen = 3;
-                        out = (uint32_t)((cp >> 12) + 224) | ((uint32_t)(((cp >> 6) & 63) + 128) << 8) |
-                              ((uint32_t)((cp & 63) + 128) << 16);
-                    } else {
-                        outlen = 4;
-                        out = (uint32_t)((cp >> 18) + 240) | ((uint32_t)(((cp >> 12) & 63) + 128) << 8) |
-                              ((uint32_t)(((cp >> 6) & 63) + 128) << 16) | ((uint32_t)((cp & 63) + 128) << 24);
-                    }
-                }
-            } else {                                                             // :58-61
-                const uint32_t r = (c & 0x80u) ? 0u : escape_map(c);
-                if (r == 0) err = SJMI_E_ESCAPE_UNEXPECTED;
-                out = r;
-            }
-        }
-        const uint32_t errs = (uint32_t)(__ballot(err != 0) >> rshift) & 0xFFFFu;
-        if (errs) {  // the lowest failing position of the row is the sequential parser's first error
-            fail = (int32_t)__shfl((int)err, rshift + __builtin_ctz(errs));
-            outlen = 0;
-        }
-        uint32_t incl = outlen;  // inclusive scan inside the row
-        incl = rdpp_add<0x111>(incl);
-        incl = rdpp_add<0x112>(incl);
-        incl = rdpp_add<0x114>(incl);
-        incl = rdpp_add<0x118>(incl);
-        if (fail == 0) {
-            uint8_t* q = dst + n + (incl - outlen);
-            if (outlen >= 1) q[0] = (uint8_t)out;
-            if (__ballot(outlen >= 2)) {  // (only \u escapes make more than one byte: most steps issue one store instruction)
-                if (outlen >= 2) q[1] = (uint8_t)(out >> 8);
-                if (outlen >= 3) q[2] = (uint8_t)(out >> 16);
-                if (outlen >= 4) q[3] = (uint8_t)(out >> 24);
-            }
-        }
-        n += (uint32_t)__shfl((int)incl, rshift + 15);
-        prev_U = U;
-        carry = carry_out;
-    }
-    return fail ? -(int64_t)fail : (int64_t)n;
-}
-
 // any backslash in the aligned 16-byte chunks covering [from, to)?  (May look at up to 15 bytes on either side:
 // a false positive only sends the string down the exact byte-wise path.)
 __device__ __forceinline__ bool has_backslash(const uint8_t* __restrict__ buf, uint32_t from, uint32_t to) {
@@ -548,9 +414,6 @@ k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __r
             const bool is_str = in_range[q] && (hw[q].a & 0xFFu) == '"';
             MeasuredString m = {0u, false};
             if (is_str) m = measure_string(buf, open[q], bound[q], tpos[q], hw[q], tw[q], span_lo[q], span_ok[q], span_bs[q]);
-#ifdef SJMI_STR_ABLATE
-            m.esc = false;
-#endif
             int64_t r = 0;
             uint32_t slow = 0;
             if (is_str) {
@@ -558,34 +421,13 @@ k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __r
                 else if (!m.esc) r = (int64_t)(m.close - open[q] - 1);
                 else slow = SIZE_SLOW;
             }
-            // strings with escapes: long ones by the whole wave, one after the other (64 source bytes per step); short ones
-            // four at a time, one per row of 16 lanes
-            const bool esc_long = m.esc && (m.close - open[q]) > 96u;
-            for (unsigned long long todo = __ballot(esc_long); todo; todo &= todo - 1) {
+            // strings with escapes: the whole wave unescapes them one after the other
+            for (unsigned long long todo = __ballot(m.esc); todo; todo &= todo - 1) {
                 const int j = __builtin_ctzll(todo);
                 const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)open[q], j) + 1u;
                 const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)m.close, j);
                 const int64_t rj = unescape_wave(buf, s0, e0, scratch + s0, lane);
                 if (lane == j) r = rj;
-            }
-            for (unsigned long long todo = __ballot(m.esc && !esc_long); todo;) {
-                int js[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    js[t] = todo ? __builtin_ctzll(todo) : -1;
-                    if (todo) todo &= todo - 1;
-                }
-                const int row = lane >> 4;
-                const int jr = row == 0 ? js[0] : (row == 1 ? js[1] : (row == 2 ? js[2] : js[3]));
-                const uint32_t so = (uint32_t)__shfl((int)open[q], jr < 0 ? 0 : jr) + 1u;
-                const uint32_t sc = (uint32_t)__shfl((int)m.close, jr < 0 ? 0 : jr);
-                const uint32_t s0 = jr < 0 ? 0u : so, e0 = jr < 0 ? 0u : sc;
-                const int64_t rr = unescape_rows(buf, s0, e0, scratch + s0, lane);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int64_t rt = __shfl(rr, 16 * t);
-                    if (js[t] >= 0 && lane == js[t]) r = rt;
-                }
             }
             if (is_str) {
                 if (r == 0) slow = 0;  // (the backslash sweep may be a false positive of a neighbour: an empty string stays empty)

@@ -119,6 +119,11 @@ def sharded_step(shard, stream=0):
     import torch
     import torch.distributed as dist
     shard.step(stream)
+    if not stream and str(shard.device) != "cpu":
+        # stream handle 0 = "the engine context's own stream", which torch knows nothing about: the torch ops that read
+        # the result record below would not be ordered behind the kernels.  Callers that care about overlap pass the
+        # handle of the torch stream they are on (bench.py does).
+        torch.cuda.synchronize()
     row = shard.counts_tensor()
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return row[None, :]
