@@ -78,7 +78,7 @@ json.dump(cal, open(os.path.join(dst, "pmc_calibration.json"), "w"), indent=1)
 KEY = {"main": "stage1_twitter_4g", "x1024": "stage1_twitter_x1024", "unescape": "unescape_twitter_x1024", "synth": "stage1_synthetic_4g",
        "batch": "batch_1m_docs"}
 WANT = {"main": ["k_stage1"], "x1024": ["k_stage1"], "synth": ["k_stage1"], "unescape": ["k_str_", "k_scan_sums"],
-        "batch": ["k_doc_", "k_str_", "k_scan_sums", "k_tape_"]}
+        "batch": ["k_doc_", "k_str_", "k_scan_sums", "k_tape_", "k_coop"]}
 summary = {}
 for sec, key in KEY.items():
     f, w = counters("pmc_%s_FETCH_SIZE" % sec), counters("pmc_%s_WRITE_SIZE" % sec)
