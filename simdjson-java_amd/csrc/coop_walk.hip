@@ -182,18 +182,61 @@ __device__ __forceinline__ int highest_bit_below(unsigned long long m, unsigned 
 
 }  // namespace
 
+// ---- one LARGE document over many waves ----------------------------------------------------------------------------------
+// A wave needs, at the first structural it looks at, what the sequential walker would know there: depth, tape position,
+// string offset, the open containers (their tape positions, comma counts, kinds), whether the root value has ended.  For
+// chunks of CW_CHUNK structurals these are obtained in three launches:
+//   k_chunk_summary  (parallel, a wave per chunk): depth profile of the chunk relative to its start -- net change, minimum,
+//                    words, string bytes -- and its EXPORT: the containers it opens and leaves open (by relative level) and
+//                    the commas it adds to the innermost container it leaves untouched;
+//   k_chunk_scan     (one wave, sequential over the chunks, ~30 instructions each): applies the exports in order and
+//                    writes every chunk's entry state -- the same shape as stage 1's granule chain;
+//   k_coop_walk<true>(parallel, a wave per chunk): the walker proper, started from the chunk's entry state;
+//   k_chunk_finish   (one wave): the document's first error by position, the root words.
+// Relative levels live in the 64 lanes of the stack registers with a bias of 32; a chunk whose depth swings further, or a
+// document deeper than the stack, raises the fall-back flag and the single-wave sweep takes the document.
+constexpr uint32_t CW_CHUNK = 512;   // structurals per chunk (8 steps)
+constexpr int CW_BIAS = 32;
+struct ChunkWs {
+    // per chunk
+    int32_t* delta;          // net depth change
+    int32_t* min_after;      // minimum over the depths AFTER each structural, relative to the chunk's start
+    uint32_t* words;         // tape words
+    uint32_t* ssz;           // string-record bytes
+    uint32_t* exp_tpos;      // [chunk][64] export: tape position (relative to the chunk) of the open bracket left open at relative level lane - BIAS
+    uint32_t* exp_cnt;       // [chunk][64] ... its comma count so far; lane BIAS + min - 1: commas added to the container below
+    unsigned long long* exp_arr;  // [chunk] kinds (bit lane)
+    // entry state per chunk (k_chunk_scan)
+    uint32_t* in_H;
+    uint32_t* in_T;
+    unsigned long long* in_S;
+    uint32_t* in_tpos;       // [chunk][64]
+    uint32_t* in_cnt;        // [chunk][64]
+    unsigned long long* in_arr;
+    uint32_t* in_root_closed;
+    // results per chunk (k_coop_walk<true>)
+    uint32_t* err_pos;       // absolute structural position of the chunk's first error, 0xFFFFFFFF = none
+    int32_t* err_code;
+    // per document
+    uint32_t* fallback;      // != 0: take the single-wave sweep
+    uint32_t* fin;           // [0] final depth, [1] final tape position, [2] kind of the innermost open container (1 = array)
+};
+
 // One wave per document (grid-stride over the documents).  Documents are delimited by index_offsets (n_docs + 1 entries)
 // and doc_offsets; a single document is the batch of one.  Document k's tape is built in its slot of the scratch tape
 // (2 words per structural + 2, walk.hip packs the tapes back to back afterwards); sizes / scratch: the per-structural
 // records of the unescape pass (4 + length | flags per '"' structural, 0 otherwise; scratch[open] = code of a failed
 // string).
+template <bool CHUNKED>
 __global__ void __launch_bounds__(256)
 k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restrict__ doc_offsets, uint64_t n_docs,
             const uint32_t* __restrict__ idx, const unsigned long long* __restrict__ index_offsets,
             const uint32_t* __restrict__ doc_status, const uint32_t* __restrict__ sizes, const uint8_t* __restrict__ scratch,
             const unsigned long long* __restrict__ doc_str_offsets, unsigned long long string_base, int max_depth,
             unsigned long long* __restrict__ scratch_tape, uint32_t* __restrict__ tape_lens, int32_t* __restrict__ doc_errors, const Stage1Result* __restrict__ dev_count,
-            const UnescapeResult* __restrict__ dev_strings, WalkResult* res, uint32_t abl) {
+            const UnescapeResult* __restrict__ dev_strings, WalkResult* res, uint32_t abl, ChunkWs cw, const uint32_t* run_only_if) {
+    if (run_only_if && *run_only_if == 0) return;   // (the single-wave sweep behind a chunked launch: only on fall-back)
+    if (CHUNKED && *cw.fallback != 0) return;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // the per-wave stack of open containers lives in two VGPRs: LANE L holds level L (tape position of the opening word,
@@ -226,35 +269,47 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
         m.st = doc_status ? doc_status[k] : 0u;
         return m;
     };
-    auto load_pos = [&](const Meta& m, uint64_t s, uint32_t* p, uint32_t* sz, uint32_t* px) {
-        const uint64_t i = m.from + s * 64 + lane;
-        *p = i < m.to ? idx[i] : m.doc_start;
-        *sz = i < m.to ? sizes[i] : 0u;
-        const uint64_t ix = m.from + s * 64 + 64;
+    // (wfrom, wto) = the structurals this wave walks: the whole document, or one chunk of it
+    auto load_pos = [&](const Meta& m, uint64_t wfrom, uint64_t wto, uint64_t s, uint32_t* p, uint32_t* sz, uint32_t* px) {
+        const uint64_t i = wfrom + s * 64 + lane;
+        *p = i < wto ? idx[i] : m.doc_start;
+        *sz = i < wto ? sizes[i] : 0u;
+        const uint64_t ix = wfrom + s * 64 + 64;
         *px = ix < m.to ? idx[ix] : m.doc_start;
     };
-    auto load_head = [&](const Meta& m) {
+    auto load_head = [&](const Meta& m, uint64_t wfrom, uint64_t wto) {
         Head h;
-        load_pos(m, 0, &h.p_n, &h.sz_n, &h.px_n);
+        load_pos(m, wfrom, wto, 0, &h.p_n, &h.sz_n, &h.px_n);
         h.p_nn = m.doc_start;
         h.sz_nn = 0;
         h.px_nn = m.doc_start;
-        if (m.to - m.from > 64) load_pos(m, 1, &h.p_nn, &h.sz_nn, &h.px_nn);
+        if (wto - wfrom > 64) load_pos(m, wfrom, wto, 1, &h.p_nn, &h.sz_nn, &h.px_nn);
         return h;
     };
     uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
     Meta m = {0, 0, 0, 0, 0, 0}, m_next = m;
     Head hd = {0, 0, 0, 0, 0, 0};
-    if (k < n_docs) {
+    uint64_t n_items = n_docs;
+    if (CHUNKED) {  // the work items are the chunks of document 0
+        m = load_meta(0);
+        n_items = (m.to - m.from + CW_CHUNK - 1) / CW_CHUNK;
+        if (k < n_items) {
+            const uint64_t a = m.from + k * CW_CHUNK, b = a + CW_CHUNK < m.to ? a + CW_CHUNK : m.to;
+            hd = load_head(m, a, b);
+        }
+    } else if (k < n_docs) {
         m = load_meta(k);
-        hd = load_head(m);
+        hd = load_head(m, m.from, m.to);
     }
-    for (; k < n_docs; k += nwaves) {
-        if (k + nwaves < n_docs) m_next = load_meta(k + nwaves);
+    for (; k < n_items; k += nwaves) {
+        if (!CHUNKED && k + nwaves < n_docs) m_next = load_meta(k + nwaves);
         int code = 0;
-        uint32_t tlen = 0;
+        uint32_t tlen = 0, err_at = 0xFFFFFFFFu;
         const uint32_t st = m.st;
         const unsigned long long from = m.from, to = m.to;
+        const unsigned long long wfrom = CHUNKED ? from + k * CW_CHUNK : from;
+        const unsigned long long wto = CHUNKED ? (wfrom + CW_CHUNK < to ? wfrom + CW_CHUNK : to) : to;
+        const uint64_t kdoc = CHUNKED ? 0 : k;
         // SimdJsonParser.stage1 order: Utf8Validator.validate (:165-167), then StructuralIndexer.index (:297-302)
         if (upstream_failed) code = SJMI_E_CAPACITY;
         else if (st & SJMI_ST_UTF8) code = SJMI_E_UTF8;
@@ -264,7 +319,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
         if (code == 0) {
             const uint32_t doc_start = m.doc_start, doc_end = m.doc_end;
             const uint64_t n = to - from;
-            unsigned long long* const T = scratch_tape + 2 * from + 2 * k;  // this document's slot (word 0 = root)
+            unsigned long long* const T = scratch_tape + 2 * from + 2 * kdoc;  // this document's slot (word 0 = root)
             const uint64_t room = 2 * n + 2;                                // a structural makes at most two words
             // running state (wave-uniform)
             uint32_t H0 = 0;                 // open containers in front of the step
@@ -274,9 +329,34 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
             uint32_t prev_cls = K_COMMA;     // class of the structural in front of the step (none at the start)
             bool prev_empty_open = false, prev_is_key = false, root_closed = false;
             uint32_t root_kind = 0, root_c = 0;
+            uint32_t prev_cls_known = K_COMMA;  // (chunked: class of the structural in front of the chunk, for the empty-bracket test)
+            if (CHUNKED) {  // start from the chunk's entry state (k_chunk_scan)
+                H0 = cw.in_H[k];
+                T0 = cw.in_T[k];
+                S0 = cw.in_S[k];
+                st_tpos = cw.in_tpos[k * 64 + lane];
+                st_cnt = cw.in_cnt[k * 64 + lane];
+                arr_mask = cw.in_arr[k];
+                root_closed = cw.in_root_closed[k] != 0;
+                root_c = buf[idx[from]];
+                const uint32_t rk = class_of(root_c);
+                root_kind = rk <= K_OPEN_O ? 1u + rk : 0u;
+                if (k > 0) {
+                    // what the steps carry from their predecessor: its class, whether it was a key (a string directly
+                    // behind an object's opening bracket or behind a comma inside an object; the container of a
+                    // non-bracket structural in front of the chunk is the innermost open one)
+                    const uint32_t c1 = class_of(buf[idx[wfrom - 1]]);
+                    const uint32_t c2 = wfrom - 1 > from ? class_of(buf[idx[wfrom - 2]]) : K_COLON;
+                    prev_cls = c1;
+                    prev_cls_known = c1;
+                    const bool in_obj = H0 >= 1 && !((arr_mask >> (H0 - 1)) & 1ull);
+                    prev_is_key = c1 == K_QUOTE && (c2 == K_OPEN_O || (c2 == K_COMMA && in_obj));
+                }
+            }
+            (void)prev_cls_known;
             // positions (and sizes) are requested TWO steps ahead, the 16-byte windows they point at one step ahead: neither
             // round trip is on the step-to-step critical path
-            const uint64_t nsteps = (n + 63) / 64;
+            const uint64_t nsteps = (wto - wfrom + 63) / 64;
             uint32_t p_n = hd.p_n, sz_n = hd.sz_n, px_n = hd.px_n, p_nn = hd.p_nn, sz_nn = hd.sz_nn, px_nn = hd.px_nn;
             CW16 win_n = *reinterpret_cast<const CW16*>(buf + p_n);
             uint32_t bx_n = buf[px_n];
@@ -290,12 +370,13 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                     win_n = *reinterpret_cast<const CW16*>(buf + p_n);
                     bx_n = buf[px_n];
                 }
-                if (s + 2 < nsteps) load_pos(m, s + 2, &p_nn, &sz_nn, &px_nn);
-                const uint64_t i = from + s * 64 + lane;
-                const bool valid = i < to;
+                if (s + 2 < nsteps) load_pos(m, wfrom, wto, s + 2, &p_nn, &sz_nn, &px_nn);
+                const uint64_t i = wfrom + s * 64 + lane;
+                const bool valid = i < wto;
                 const unsigned long long vmask = __ballot(valid);
                 if (root_closed) {  // JsonIterator.java:196-198: something follows the root value
                     code = SJMI_E_TRAILING_CONTENT;
+                    err_at = (uint32_t)(wfrom + s * 64);
                     break;
                 }
                 const uint32_t c = win.a & 0xFFu;
@@ -310,6 +391,10 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 // (1) empty containers: an opening bracket directly followed by its closing bracket is ONE value (:205-208)
                 const bool empty_open = is_open && has_next && cls_next == cls + 2;
                 int eo_prev = __shfl_up((int)empty_open, 1);
+                if (CHUNKED && s == 0 && k > 0) {  // was the structural in front of the chunk the opening half of an empty pair?
+                    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cls);
+                    prev_empty_open = prev_cls <= K_OPEN_O && c0 == prev_cls + 2;
+                }
                 if (lane == 0) eo_prev = prev_empty_open;
                 const bool empty_close = valid && is_close && eo_prev && i > from;
                 // (2) depth in front of every structural
@@ -417,7 +502,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                     }
                 }
                 // (6) where the root value ends; the first error by position
-                if (s == 0) {
+                if (!CHUNKED && s == 0) {
                     root_kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cls <= K_OPEN_O ? 1u + cls : 0u));
                     root_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
                 }
@@ -428,6 +513,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 const unsigned long long em = __ballot(err != 0 && lane <= rc_lane + 1);
                 if (em) {
                     code = __builtin_amdgcn_readlane(err, __builtin_ctzll(em));
+                    err_at = (uint32_t)(wfrom + s * 64 + __builtin_ctzll(em));
                     break;
                 }
                 if (rc) root_closed = true;
@@ -460,6 +546,17 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 prev_empty_open = __builtin_amdgcn_readlane((int)empty_open, lastv) != 0;
                 prev_is_key = __builtin_amdgcn_readlane((int)is_key, lastv) != 0;
             }
+            if (CHUNKED) {  // the document's verdict is assembled by k_chunk_finish from the chunks' first errors
+                if (lane == 0) {
+                    cw.err_pos[k] = code ? err_at : 0xFFFFFFFFu;
+                    cw.err_code[k] = code;
+                }
+                if (k + nwaves < n_items) {
+                    const uint64_t a = from + (k + nwaves) * CW_CHUNK, b = a + CW_CHUNK < to ? a + CW_CHUNK : to;
+                    hd = load_head(m, a, b);
+                }
+                continue;
+            }
             // JsonIterator.java:39-41,:51-53: a root bracket whose closing bracket is not the document's LAST structural fails
             // before anything else is looked at (position 0 is the lowest there is).  The last structural's class is known
             // for free when the sweep reached the end; only a document that failed earlier has to go and look.
@@ -490,6 +587,13 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 }
             }
         }
+        if (CHUNKED) {  // (a document that failed stage 1 or has no structurals: decided by k_chunk_finish as well)
+            if (lane == 0) {
+                cw.err_pos[k] = code ? 0u : 0xFFFFFFFFu;
+                cw.err_code[k] = code;
+            }
+            continue;
+        }
         if (lane == 0) {
             tape_lens[k] = tlen;
             doc_errors[k] = code;
@@ -497,11 +601,210 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
         n_host += code == SJMI_WALK_NEEDS_HOST;
         n_bad += code > 0;
         m = m_next;
-        if (k + nwaves < n_docs) hd = load_head(m);
+        if (k + nwaves < n_docs) hd = load_head(m, m.from, m.to);
     }
     (void)res;
     (void)n_host;
     (void)n_bad;  // (host / failed documents are counted by the packing kernels from doc_errors)
+}
+
+// ---- the chunk passes around k_coop_walk<true> --------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_chunk_summary(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ idx, const unsigned long long* __restrict__ index_offsets,
+                const uint32_t* __restrict__ sizes, ChunkWs cw) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    const unsigned long long from = index_offsets[0], to = index_offsets[1];
+    const uint64_t nchunks = (to - from + CW_CHUNK - 1) / CW_CHUNK;
+    for (uint64_t k = (uint64_t)blockIdx.x * 4 + wv; k < nchunks; k += nwaves) {
+        const unsigned long long wfrom = from + k * CW_CHUNK, wto = wfrom + CW_CHUNK < to ? wfrom + CW_CHUNK : to;
+        const uint64_t nsteps = (wto - wfrom + 63) / 64;
+        uint32_t st_tpos = 0, st_cnt = 0;  // LANE = relative level + CW_BIAS
+        unsigned long long arr_mask = 0;
+        int H = CW_BIAS, min_after = 0x7FFF;
+        uint32_t T = 0, S = 0;
+        bool out_of_range = false;
+        uint32_t p_n = wfrom + lane < wto ? idx[wfrom + lane] : 0u;
+        uint32_t sz_n = wfrom + lane < wto ? sizes[wfrom + lane] : 0u;
+        for (uint64_t s = 0; s < nsteps; ++s) {
+            const uint64_t i = wfrom + s * 64 + lane;
+            const bool valid = i < wto;
+            const uint32_t c = buf[p_n], sz = sz_n;
+            if (s + 1 < nsteps) {
+                p_n = i + 64 < wto ? idx[i + 64] : 0u;
+                sz_n = i + 64 < wto ? sizes[i + 64] : 0u;
+            }
+            const uint32_t cls = valid ? class_of(c) : K_COMMA;
+            const bool is_open = valid && cls <= K_OPEN_O, is_close = valid && (cls == K_CLOSE_A || cls == K_CLOSE_O);
+            const uint32_t up = is_open ? 1u : 0u, down = is_close ? 1u : 0u;
+            const uint32_t iu = cw_incl_scan(up), id = cw_incl_scan(down);
+            const int h = H + (int)(iu - up) - (int)(id - down);
+            const bool is_num = valid && cls == K_PRIM && (c == '-' || c - '0' <= 9u);
+            const uint32_t words = !valid || cls == K_COMMA || cls == K_COLON ? 0u : (is_num ? 2u : 1u);
+            const uint32_t iw = cw_incl_scan(words);
+            const uint32_t tpos = T + iw - words;
+            const uint32_t is_ = cw_incl_scan((valid && cls == K_QUOTE) ? (sz & ~CW_SIZE_SLOW) : 0u);
+            const int plevel = h - 1;
+            int after = valid ? h + (int)up - (int)down : 0x7FFF;
+            int hmin = valid ? plevel : 0x7FFF, hmax = valid ? (is_open ? h : plevel) : -0x7FFF;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                hmin = min(hmin, __shfl_xor(hmin, d));
+                hmax = max(hmax, __shfl_xor(hmax, d));
+                after = min(after, __shfl_xor(after, d));
+            }
+            min_after = min(min_after, after);
+            if (hmin < 0 || hmax >= CW_LEVELS) {  // the depth swings out of the biased window: not a chunk for this path
+                out_of_range = true;
+                break;
+            }
+            const unsigned long long lt_mask = (1ull << lane) - 1ull;
+            (void)lt_mask;
+            for (int L = hmin; L <= hmax; ++L) {
+                const unsigned long long O = __ballot(is_open && h == L);
+                const unsigned long long C = __ballot(valid && cls == K_COMMA && plevel == L);
+                const unsigned long long Z = __ballot(is_close && plevel == L);
+                if (O) {
+                    const int al = 63 - __builtin_clzll(O);
+                    const unsigned long long above = al == 63 ? 0ull : ~((2ull << al) - 1ull);
+                    if (!(Z & above)) {
+                        const uint32_t tp = (uint32_t)__builtin_amdgcn_readlane((int)tpos, al);
+                        const uint32_t kc = (uint32_t)__builtin_amdgcn_readlane((int)cls, al);
+                        st_tpos = lane == L ? tp : st_tpos;
+                        st_cnt = lane == L ? (uint32_t)__popcll(C & above) : st_cnt;
+                        arr_mask = kc == K_OPEN_A ? (arr_mask | (1ull << L)) : (arr_mask & ~(1ull << L));
+                    }
+                } else if (!Z && C) {
+                    const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)st_cnt, L);
+                    st_cnt = lane == L ? sk + (uint32_t)__popcll(C) : st_cnt;
+                } else if (Z && !O) {
+                    // the container of this level (from before the chunk) closed: what the lane counted so far belonged to it;
+                    // a container that opens at this level later starts from its own count (the O branch above)
+                    st_cnt = lane == L ? 0u : st_cnt;
+                }
+            }
+            H += (int)cw_last(iu) - (int)cw_last(id);
+            T += cw_last(iw);
+            S += cw_last(is_);
+        }
+        if (out_of_range && lane == 0) atomicOr(cw.fallback, 1u);
+        if (lane == 0) {
+            cw.delta[k] = H - CW_BIAS;
+            cw.min_after[k] = (min_after == 0x7FFF ? CW_BIAS : min_after) - CW_BIAS;
+            cw.words[k] = T;
+            cw.ssz[k] = S;
+            cw.exp_arr[k] = arr_mask;
+        }
+        cw.exp_tpos[k * 64 + lane] = st_tpos;
+        cw.exp_cnt[k * 64 + lane] = st_cnt;
+    }
+}
+
+__global__ void __launch_bounds__(64)
+k_chunk_scan(const unsigned long long* __restrict__ index_offsets, const unsigned long long* __restrict__ doc_str_offsets, ChunkWs cw) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long from = index_offsets[0], to = index_offsets[1];
+    const uint64_t nchunks = (to - from + CW_CHUNK - 1) / CW_CHUNK;
+    if (*cw.fallback != 0) return;
+    uint32_t st_tpos = 0, st_cnt = 0;  // LANE = absolute level
+    unsigned long long arr = 0, S = doc_str_offsets[0];
+    int H = 0;
+    uint32_t T = 1;
+    bool rc = false, deep = false;
+    for (uint64_t k = 0; k < nchunks; ++k) {
+        cw.in_tpos[k * 64 + lane] = st_tpos;
+        cw.in_cnt[k * 64 + lane] = st_cnt;
+        if (lane == 0) {
+            cw.in_H[k] = (uint32_t)H;
+            cw.in_T[k] = T;
+            cw.in_S[k] = S;
+            cw.in_arr[k] = arr;
+            cw.in_root_closed[k] = rc ? 1u : 0u;
+        }
+        const int d = cw.delta[k], ma = cw.min_after[k], m = ma < 0 ? ma : 0;
+        if (H + ma <= 0) rc = true;  // the depth comes back to zero inside this chunk: the root value ends there
+        const int src = lane - H + CW_BIAS;  // my level's lane in the chunk's export
+        const bool in_src = src >= 0 && src < CW_LEVELS;
+        const uint32_t e_tpos = in_src ? cw.exp_tpos[k * 64 + src] : 0u, e_cnt = in_src ? cw.exp_cnt[k * 64 + src] : 0u;
+        const unsigned long long e_arr = cw.exp_arr[k];
+        if (lane == H + m - 1) st_cnt += e_cnt;                 // the innermost container the chunk leaves untouched: its commas
+        if (lane >= H + m && lane < H + d) {                    // opened by the chunk and left open
+            st_tpos = T + e_tpos;
+            st_cnt = e_cnt;
+        }
+        // kinds of the new levels [H + m, H + d): bit (level - H + BIAS) of the export
+        for (int L = (H + m < 0 ? 0 : H + m); L < H + d && L < CW_LEVELS; ++L) {
+            const int sb = L - H + CW_BIAS;
+            if (sb >= 0 && sb < 64 && ((e_arr >> sb) & 1ull)) arr |= 1ull << L;
+            else arr &= ~(1ull << L);
+        }
+        if (H + d >= CW_LEVELS) deep = true;
+        H = H + d < 0 ? 0 : H + d;
+        T += cw.words[k];
+        S += cw.ssz[k];
+    }
+    if (lane == 0) {
+        if (deep) atomicOr(cw.fallback, 1u);
+        cw.fin[0] = (uint32_t)H;
+        cw.fin[1] = T;
+        cw.fin[2] = (H >= 1 && H <= CW_LEVELS && ((arr >> (H - 1)) & 1ull)) ? 1u : 0u;
+    }
+}
+
+__global__ void __launch_bounds__(64)
+k_chunk_finish(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ idx, const unsigned long long* __restrict__ index_offsets,
+               const uint32_t* __restrict__ doc_status, unsigned long long* __restrict__ scratch_tape, uint32_t* __restrict__ tape_lens,
+               int32_t* __restrict__ doc_errors, const Stage1Result* __restrict__ dev_count, const UnescapeResult* __restrict__ dev_strings,
+               ChunkWs cw) {
+    if (*cw.fallback != 0) return;  // the single-wave sweep writes the document's result
+    const int lane = threadIdx.x & 63;
+    const unsigned long long from = index_offsets[0], to = index_offsets[1];
+    const uint64_t nchunks = (to - from + CW_CHUNK - 1) / CW_CHUNK;
+    const uint32_t st = doc_status ? doc_status[0] : 0u;
+    int code = 0;
+    uint32_t tlen = 0;
+    const bool upstream_failed = (dev_count && (dev_count->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL))) ||
+                                 (dev_strings && (dev_strings->flags & 1u));
+    if (upstream_failed) code = SJMI_E_CAPACITY;
+    else if (st & SJMI_ST_UTF8) code = SJMI_E_UTF8;
+    else if (st & SJMI_ST_UNCLOSED) code = SJMI_E_UNCLOSED_STRING;
+    else if (st & SJMI_ST_UNESCAPED) code = SJMI_E_UNESCAPED_CHARS;
+    else if (from == to) code = SJMI_E_NO_STRUCTURAL;
+    if (code == 0) {
+        // the first error by position over the chunks
+        unsigned long long best = ~0ull;  // (position << 32) | chunk
+        for (uint64_t k = lane; k < nchunks; k += 64) {
+            const uint32_t ep = cw.err_pos[k];
+            if (ep != 0xFFFFFFFFu) {
+                const unsigned long long key = ((unsigned long long)ep << 32) | (unsigned long long)k;
+                best = key < best ? key : best;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(best, d);
+            best = o < best ? o : best;
+        }
+        const uint32_t root_c = buf[idx[from]], rk = class_of(root_c);
+        const uint32_t last_c = buf[idx[to - 1]];
+        if (rk <= K_OPEN_O && last_c != root_c + 2) code = rk == K_OPEN_O ? SJMI_E_UNCLOSED_OBJECT : SJMI_E_UNCLOSED_ARRAY;  // JsonIterator.java:39-41,:51-53
+        else if (best != ~0ull) code = cw.err_code[(uint32_t)best];
+        else if (cw.fin[0] != 0) code = cw.fin[2] ? SJMI_E_NO_COMMA_ARRAY : SJMI_E_NO_COMMA_OBJECT;  // the walker reads the sentinel (BitIndexes.java:82-96)
+        if (code == 0) {
+            unsigned long long* const T = scratch_tape + 2 * from;
+            const uint32_t T0 = cw.fin[1];
+            tlen = T0 + 1;
+            if (lane == 0) {
+                T[T0] = tape_word('r', 0);      // visitDocumentEnd, TapeBuilder.java:45-48
+                T[0] = tape_word('r', tlen);
+            }
+        }
+    }
+    if (lane == 0) {
+        tape_lens[0] = tlen;
+        doc_errors[0] = code;
+    }
 }
 
 // ---- the skip table of the on-demand front end -------------------------------------------------
@@ -623,19 +926,73 @@ hipError_t single_doc_setup_launch(const Stage1Result* d_res, uint64_t len, unsi
     return hipGetLastError();
 }
 
+size_t coop_chunk_workspace_bytes(uint64_t count_bound) {
+    const size_t nchunks = (size_t)(count_bound / CW_CHUNK) + 2;
+    return nchunks * (4 * 64 * sizeof(uint32_t) + 16 * sizeof(unsigned long long)) + 256;
+}
+
+static ChunkWs chunk_ws(void* ws, uint64_t count_bound) {
+    const size_t nchunks = (size_t)(count_bound / CW_CHUNK) + 2;
+    uint8_t* p = static_cast<uint8_t*>(ws);
+    ChunkWs c;
+    auto take = [&](size_t bytes) { uint8_t* r = p; p += (bytes + 63) / 64 * 64; return r; };
+    c.fallback = reinterpret_cast<uint32_t*>(take(64));
+    c.fin = c.fallback + 4;
+    c.exp_tpos = reinterpret_cast<uint32_t*>(take(nchunks * 64 * 4));
+    c.exp_cnt = reinterpret_cast<uint32_t*>(take(nchunks * 64 * 4));
+    c.in_tpos = reinterpret_cast<uint32_t*>(take(nchunks * 64 * 4));
+    c.in_cnt = reinterpret_cast<uint32_t*>(take(nchunks * 64 * 4));
+    c.exp_arr = reinterpret_cast<unsigned long long*>(take(nchunks * 8));
+    c.in_S = reinterpret_cast<unsigned long long*>(take(nchunks * 8));
+    c.in_arr = reinterpret_cast<unsigned long long*>(take(nchunks * 8));
+    c.delta = reinterpret_cast<int32_t*>(take(nchunks * 4));
+    c.min_after = reinterpret_cast<int32_t*>(take(nchunks * 4));
+    c.words = reinterpret_cast<uint32_t*>(take(nchunks * 4));
+    c.ssz = reinterpret_cast<uint32_t*>(take(nchunks * 4));
+    c.in_H = reinterpret_cast<uint32_t*>(take(nchunks * 4));
+    c.in_T = reinterpret_cast<uint32_t*>(take(nchunks * 4));
+    c.in_root_closed = reinterpret_cast<uint32_t*>(take(nchunks * 4));
+    c.err_pos = reinterpret_cast<uint32_t*>(take(nchunks * 4));
+    c.err_code = reinterpret_cast<int32_t*>(take(nchunks * 4));
+    return c;
+}
+
+// d_chunk_ws != nullptr and one document of more than COOP_CHUNK_MIN structurals (by its bound): the chunk-parallel path,
+// with the single-wave sweep queued behind it for the (flagged) cases it does not take
+constexpr uint64_t COOP_CHUNK_MIN = 4096;
 hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_idx,
                             const unsigned long long* d_index_offsets, const uint32_t* d_doc_status, const uint32_t* d_sizes,
                             const uint8_t* d_scratch, const unsigned long long* d_doc_str_offsets, uint64_t string_base,
                             int max_depth, unsigned long long* d_scratch_tape, uint32_t* d_tape_lens, int32_t* d_doc_errors,
                             const Stage1Result* dev_count, const UnescapeResult* dev_strings, WalkResult* d_res,
-                            hipStream_t stream) {
+                            hipStream_t stream, void* d_chunk_ws, uint64_t count_bound) {
     if (!n_docs) return hipSuccess;
+    const uint32_t abl = (uint32_t)(getenv("SJMI_COOP_ABLATE") ? atoi(getenv("SJMI_COOP_ABLATE")) : 0);
+    ChunkWs cw = {};
+    static const bool no_chunks = getenv("SJMI_COOP_CHUNKS") && atoi(getenv("SJMI_COOP_CHUNKS")) == 0;
+    const bool chunked = d_chunk_ws && n_docs == 1 && count_bound > COOP_CHUNK_MIN && !no_chunks;
+    const uint32_t* only_if = nullptr;
+    if (chunked) {
+        cw = chunk_ws(d_chunk_ws, count_bound);
+        hipError_t e = hipMemsetAsync(cw.fallback, 0, 64, stream);
+        if (e != hipSuccess) return e;
+        const uint64_t nchunks = count_bound / CW_CHUNK + 1;
+        const uint64_t want = (nchunks + 3) / 4;
+        const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
+        hipLaunchKernelGGL(k_chunk_summary, dim3(grid), dim3(256), 0, stream, d_buf, d_idx, d_index_offsets, d_sizes, cw);
+        hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(64), 0, stream, d_index_offsets, d_doc_str_offsets, cw);
+        hipLaunchKernelGGL((k_coop_walk<true>), dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets,
+                           d_doc_status, d_sizes, d_scratch, d_doc_str_offsets, (unsigned long long)string_base, max_depth,
+                           d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res, abl, cw, (const uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_chunk_finish, dim3(1), dim3(64), 0, stream, d_buf, d_idx, d_index_offsets, d_doc_status, d_scratch_tape,
+                           d_tape_lens, d_doc_errors, dev_count, dev_strings, cw);
+        only_if = cw.fallback;
+    }
     const uint64_t want = (n_docs + 3) / 4;  // four documents (waves) per workgroup and trip
     const unsigned grid = (unsigned)(want < 16384 ? want : 16384);
-    hipLaunchKernelGGL(k_coop_walk, dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets,
+    hipLaunchKernelGGL((k_coop_walk<false>), dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets,
                        d_doc_status, d_sizes, d_scratch, d_doc_str_offsets, (unsigned long long)string_base, max_depth,
-                       d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res,
-                       (uint32_t)(getenv("SJMI_COOP_ABLATE") ? atoi(getenv("SJMI_COOP_ABLATE")) : 0));
+                       d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res, abl, cw, only_if);
     return hipGetLastError();
 }
 

@@ -99,7 +99,9 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
                             const uint8_t* d_scratch, const unsigned long long* d_doc_str_offsets, uint64_t string_base,
                             int max_depth, unsigned long long* d_scratch_tape, uint32_t* d_tape_lens, int32_t* d_doc_errors,
                             const Stage1Result* dev_count, const UnescapeResult* dev_strings, WalkResult* d_res,
-                            hipStream_t stream);
+                            hipStream_t stream, void* d_chunk_ws = nullptr, uint64_t count_bound = 0);
+// workspace of the chunk-parallel path for one large document (coop_walk.hip)
+size_t coop_chunk_workspace_bytes(uint64_t count_bound);
 // the on-demand front end's skip table (coop_walk.hip): up[] / match[] per structural
 hipError_t coop_match_launch(const uint8_t* d_buf, uint64_t n_docs, const uint32_t* d_idx, const unsigned long long* d_index_offsets,
                              uint32_t* d_up, uint32_t* d_match, hipStream_t stream);

@@ -174,8 +174,12 @@ k_tape_compact(const unsigned long long* __restrict__ scratch_tape, const uint32
 // workspace: scratch tape (2 count + 2 n words) | tape lengths [n] | chunk sums
 static size_t walk_lens_offset(uint64_t count, uint64_t n_docs) { return ((2 * count + 2 * n_docs + 8) * sizeof(unsigned long long) + 63) / 64 * 64; }
 static size_t walk_sums_offset(uint64_t count, uint64_t n_docs) { return walk_lens_offset(count, n_docs) + (n_docs * sizeof(uint32_t) + 63) / 64 * 64 + 64; }
+static size_t walk_chunks_offset(uint64_t count, uint64_t n_docs) {
+    return (walk_sums_offset(count, n_docs) + ((n_docs + PACK_DOCS - 1) / PACK_DOCS + 2) * sizeof(unsigned long long) + 64 + 255) / 256 * 256;
+}
 size_t walk_workspace_bytes(uint64_t count, uint64_t n_docs) {
-    return walk_sums_offset(count, n_docs) + ((n_docs + PACK_DOCS - 1) / PACK_DOCS + 2) * sizeof(unsigned long long) + 64;
+    // (+ the chunk states of the chunk-parallel path for one large document)
+    return walk_chunks_offset(count, n_docs) + (n_docs == 1 ? coop_chunk_workspace_bytes(count) : 0);
 }
 
 hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_idx,
@@ -195,7 +199,7 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
         // the cooperative walker (coop_walk.hip): a wave per document over the per-structural records of the unescape pass
         e = coop_walk_launch(d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets, d_doc_status, d_sizes, d_str_scratch,
                              d_doc_str_offsets, string_base, max_depth, scratch, lens, d_doc_errors, dev_count, dev_strings, d_res,
-                             stream);
+                             stream, n_docs == 1 ? ws + walk_chunks_offset(count, n_docs) : nullptr, count);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_tape_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, lens, d_doc_errors, n_docs, sums, d_res);
     } else if (n_docs) {

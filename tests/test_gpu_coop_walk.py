@@ -120,3 +120,50 @@ def test_large_array_count_saturates(ctx):
     tape, strings, err, st = ctx.parse_document(doc)
     assert err == 0 and (int(tape[1]) >> 32) & 0xFFFFFF == 0xFFFFFF and tape.size == 2 * n + 4
     assert np.array_equal(tape, O.parse(doc).tape)
+
+
+def test_large_documents_chunk_parallel(ctx):
+    """One document of more than 4096 structurals is walked by many waves (512-structural chunks: k_chunk_summary ->
+    k_chunk_scan -> k_coop_walk<true> -> k_chunk_finish).  Valid documents whose containers, empty pairs, keys and
+    separators straddle the chunk boundaries at every phase; the reference files cut, spliced and damaged at random
+    positions (first error by position over the chunks); depth swings beyond what a chunk's export holds (the flagged
+    fall-back to the single-wave sweep)."""
+    rng = random.Random(977)
+    docs = []
+    for shift in range(0, 9):
+        pre = "0," * shift
+        docs.append("[" + pre + "[],{}," * 3000 + "1]")
+        docs.append("[" + pre + '{"a":[],"b":{}},' * 1500 + "[]]")
+        docs.append("{" + ",".join('"k%d":{"x":[%s]}' % (i, pre + "1") for i in range(1500)) + "}")
+        docs.append("[" + pre + ",".join("[" * (i % 7) + str(i) + "]" * (i % 7) for i in range(3000)) + "]")
+    # a staircase: the depth climbs over several chunks and comes back (exports of many levels, commas_low at every level)
+    docs.append("[" + ("1," * 200 + "[") * 40 + "2" + ("]" + ",3" * 200) * 40 + "]")
+    docs.append("{" + ('"a":1,' * 150 + '"n":{') * 50 + '"z":0' + ("}" + ',"b":2' * 150) * 50 + "}")
+    # swings of more than 31 levels inside one chunk, and a depth of more than 63 levels across chunks
+    docs.append("[" + "1," * 5000 + "[" * 40 + "7" + "]" * 40 + ",1" * 5000 + "]")
+    docs.append("[" + ("1," * 300 + "[") * 62 + "2" + "]" * 62 + "]")
+    docs.append("[" + ("1," * 300 + "[") * 70 + "2" + "]" * 70 + "]")
+    # trailing content, missing brackets, a root that closes early, far from the start
+    big = "[" + "1," * 6000 + "2]"
+    docs += [big + "1", big + "]", big[:-1], big[:-1] + "}", "[" + "1," * 3000 + "2]" + ",1" * 3000, big.replace("1,", "1 ", 1),
+             "[" + "1," * 5000 + "tru," + "1," * 100 + "]", "[" + "1," * 5000 + '"\\q",' + "1," * 100 + "0]",
+             '{"a":' + big + ',"b"' + "}", '{"a":' + big + ',"b":}', '{"a":' + big + ',}', "7" + " 1" * 5000, '"s"' + ",1" * 5000]
+    handed = 0
+    for d in docs:
+        handed += _single(ctx, d.encode()) == "host"
+    assert handed == 1  # the 70-level staircase
+    for name in ("twitter.json", "github_events.json"):
+        base = load_fixture(name)
+        for _ in range(60):
+            r = rng.random()
+            p = rng.randrange(len(base))
+            if r < 0.25:
+                d = base[:p]
+            elif r < 0.5:
+                d = base[:p] + rng.choice([b"]", b"}", b",", b":", b"[", b"{", b'"', b"x", b"1"]) + base[p:]
+            elif r < 0.75:
+                d = base[:p] + base[p + 1:]
+            else:
+                q = rng.randrange(len(base))
+                d = base[:min(p, q)] + base[max(p, q):]
+            _single(ctx, d)
