@@ -185,35 +185,49 @@ __device__ __forceinline__ int highest_bit_below(unsigned long long m, unsigned 
 // ---- one LARGE document over many waves ----------------------------------------------------------------------------------
 // A wave needs, at the first structural it looks at, what the sequential walker would know there: depth, tape position,
 // string offset, the open containers (their tape positions, comma counts, kinds), whether the root value has ended.  For
-// chunks of CW_CHUNK structurals these are obtained in three launches:
+// chunks of 128 or 512 structurals these are obtained in a few launches:
 //   k_chunk_summary  (parallel, a wave per chunk): depth profile of the chunk relative to its start -- net change, minimum,
 //                    words, string bytes -- and its EXPORT: the containers it opens and leaves open (by relative level) and
 //                    the commas it adds to the innermost container it leaves untouched;
-//   k_chunk_scan     (one wave, sequential over the chunks, ~30 instructions each): applies the exports in order and
-//                    writes every chunk's entry state -- the same shape as stage 1's granule chain;
+//   k_group_summary / k_top_scan / k_group_replay: the scan of the summaries (applying one to a state is associative) that
+//                    gives every chunk its entry state, two levels, groups of ~sqrt(chunks) chunks;
 //   k_coop_walk<true>(parallel, a wave per chunk): the walker proper, started from the chunk's entry state;
 //   k_chunk_finish   (one wave): the document's first error by position, the root words.
 // Relative levels live in the 64 lanes of the stack registers with a bias of 32; a chunk whose depth swings further, or a
 // document deeper than the stack, raises the fall-back flag and the single-wave sweep takes the document.
-constexpr uint32_t CW_CHUNK = 512;   // structurals per chunk (8 steps)
+// structurals per chunk and chunks per group are functions of the document's structural count n alone (every kernel
+// computes them from index_offsets): short chunks while there are fewer chunks than SIMDs to put them on (a step costs a
+// lone wave ~5 us, so a 128-structural chunk = 2 steps), longer ones after that; groups of ~sqrt(chunks)
+constexpr uint64_t CW_SMALL_N = 256u << 10;
+constexpr uint64_t CW_SINGLE_N = 1024;  // at most this many structurals: the single-wave sweep is quicker than the six launches
+__host__ __device__ inline uint32_t cw_chunk_of(uint64_t n) { return n <= CW_SMALL_N ? 128u : 512u; }
+__host__ __device__ inline uint32_t cw_group_of(uint64_t nchunks) {
+    uint32_t g = 8;
+    while ((uint64_t)g * g < nchunks) g <<= 1;
+    return g;
+}
 constexpr int CW_BIAS = 32;
-struct ChunkWs {
-    // per chunk
+struct ChunkSum {            // what a chunk (or a group of chunks) does to the walker's state, relative to its start
     int32_t* delta;          // net depth change
-    int32_t* min_after;      // minimum over the depths AFTER each structural, relative to the chunk's start
+    int32_t* min_after;      // minimum over the depths AFTER each structural
     uint32_t* words;         // tape words
     uint32_t* ssz;           // string-record bytes
-    uint32_t* exp_tpos;      // [chunk][64] export: tape position (relative to the chunk) of the open bracket left open at relative level lane - BIAS
-    uint32_t* exp_cnt;       // [chunk][64] ... its comma count so far; lane BIAS + min - 1: commas added to the container below
-    unsigned long long* exp_arr;  // [chunk] kinds (bit lane)
-    // entry state per chunk (k_chunk_scan)
-    uint32_t* in_H;
-    uint32_t* in_T;
-    unsigned long long* in_S;
-    uint32_t* in_tpos;       // [chunk][64]
-    uint32_t* in_cnt;        // [chunk][64]
-    unsigned long long* in_arr;
-    uint32_t* in_root_closed;
+    uint32_t* exp_tpos;      // [.][64] export: tape position (relative) of the open bracket left open at relative level lane - BIAS
+    uint32_t* exp_cnt;       // [.][64] ... its comma count so far; lane BIAS + min - 1: commas added to the container below
+    unsigned long long* exp_arr;  // [.] kinds (bit lane)
+};
+struct ChunkIn {             // the walker's state in front of a chunk (or group)
+    uint32_t* H;
+    uint32_t* T;
+    unsigned long long* S;
+    uint32_t* tpos;          // [.][64]
+    uint32_t* cnt;           // [.][64]
+    unsigned long long* arr;
+    uint32_t* root_closed;
+};
+struct ChunkWs {
+    ChunkSum sum, gsum;      // per chunk (k_chunk_summary), per group (k_group_summary)
+    ChunkIn in, gin;         // per chunk (k_group_replay), per group (k_top_scan)
     // results per chunk (k_coop_walk<true>)
     uint32_t* err_pos;       // absolute structural position of the chunk's first error, 0xFFFFFFFF = none
     int32_t* err_code;
@@ -290,11 +304,13 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
     Meta m = {0, 0, 0, 0, 0, 0}, m_next = m;
     Head hd = {0, 0, 0, 0, 0, 0};
     uint64_t n_items = n_docs;
+    uint32_t chunk = 0;
     if (CHUNKED) {  // the work items are the chunks of document 0
         m = load_meta(0);
-        n_items = (m.to - m.from + CW_CHUNK - 1) / CW_CHUNK;
+        chunk = cw_chunk_of(m.to - m.from);
+        n_items = (m.to - m.from + chunk - 1) / chunk;
         if (k < n_items) {
-            const uint64_t a = m.from + k * CW_CHUNK, b = a + CW_CHUNK < m.to ? a + CW_CHUNK : m.to;
+            const uint64_t a = m.from + k * chunk, b = a + chunk < m.to ? a + chunk : m.to;
             hd = load_head(m, a, b);
         }
     } else if (k < n_docs) {
@@ -307,8 +323,8 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
         uint32_t tlen = 0, err_at = 0xFFFFFFFFu;
         const uint32_t st = m.st;
         const unsigned long long from = m.from, to = m.to;
-        const unsigned long long wfrom = CHUNKED ? from + k * CW_CHUNK : from;
-        const unsigned long long wto = CHUNKED ? (wfrom + CW_CHUNK < to ? wfrom + CW_CHUNK : to) : to;
+        const unsigned long long wfrom = CHUNKED ? from + k * chunk : from;
+        const unsigned long long wto = CHUNKED ? (wfrom + chunk < to ? wfrom + chunk : to) : to;
         const uint64_t kdoc = CHUNKED ? 0 : k;
         // SimdJsonParser.stage1 order: Utf8Validator.validate (:165-167), then StructuralIndexer.index (:297-302)
         if (upstream_failed) code = SJMI_E_CAPACITY;
@@ -330,14 +346,14 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
             bool prev_empty_open = false, prev_is_key = false, root_closed = false;
             uint32_t root_kind = 0, root_c = 0;
             uint32_t prev_cls_known = K_COMMA;  // (chunked: class of the structural in front of the chunk, for the empty-bracket test)
-            if (CHUNKED) {  // start from the chunk's entry state (k_chunk_scan)
-                H0 = cw.in_H[k];
-                T0 = cw.in_T[k];
-                S0 = cw.in_S[k];
-                st_tpos = cw.in_tpos[k * 64 + lane];
-                st_cnt = cw.in_cnt[k * 64 + lane];
-                arr_mask = cw.in_arr[k];
-                root_closed = cw.in_root_closed[k] != 0;
+            if (CHUNKED) {  // start from the chunk's entry state (k_group_replay)
+                H0 = cw.in.H[k];
+                T0 = cw.in.T[k];
+                S0 = cw.in.S[k];
+                st_tpos = cw.in.tpos[k * 64 + lane];
+                st_cnt = cw.in.cnt[k * 64 + lane];
+                arr_mask = cw.in.arr[k];
+                root_closed = cw.in.root_closed[k] != 0;
                 root_c = buf[idx[from]];
                 const uint32_t rk = class_of(root_c);
                 root_kind = rk <= K_OPEN_O ? 1u + rk : 0u;
@@ -552,7 +568,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                     cw.err_code[k] = code;
                 }
                 if (k + nwaves < n_items) {
-                    const uint64_t a = from + (k + nwaves) * CW_CHUNK, b = a + CW_CHUNK < to ? a + CW_CHUNK : to;
+                    const uint64_t a = from + (k + nwaves) * chunk, b = a + chunk < to ? a + chunk : to;
                     hd = load_head(m, a, b);
                 }
                 continue;
@@ -616,9 +632,14 @@ k_chunk_summary(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ id
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
     const unsigned long long from = index_offsets[0], to = index_offsets[1];
-    const uint64_t nchunks = (to - from + CW_CHUNK - 1) / CW_CHUNK;
+    if (to - from <= CW_SINGLE_N) {  // a short document after all (the host only knows a bound): the single-wave sweep
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(cw.fallback, 1u);
+        return;
+    }
+    const uint32_t chunk = cw_chunk_of(to - from);
+    const uint64_t nchunks = (to - from + chunk - 1) / chunk;
     for (uint64_t k = (uint64_t)blockIdx.x * 4 + wv; k < nchunks; k += nwaves) {
-        const unsigned long long wfrom = from + k * CW_CHUNK, wto = wfrom + CW_CHUNK < to ? wfrom + CW_CHUNK : to;
+        const unsigned long long wfrom = from + k * chunk, wto = wfrom + chunk < to ? wfrom + chunk : to;
         const uint64_t nsteps = (wto - wfrom + 63) / 64;
         uint32_t st_tpos = 0, st_cnt = 0;  // LANE = relative level + CW_BIAS
         unsigned long long arr_mask = 0;
@@ -690,65 +711,181 @@ k_chunk_summary(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ id
         }
         if (out_of_range && lane == 0) atomicOr(cw.fallback, 1u);
         if (lane == 0) {
-            cw.delta[k] = H - CW_BIAS;
-            cw.min_after[k] = (min_after == 0x7FFF ? CW_BIAS : min_after) - CW_BIAS;
-            cw.words[k] = T;
-            cw.ssz[k] = S;
-            cw.exp_arr[k] = arr_mask;
+            cw.sum.delta[k] = H - CW_BIAS;
+            cw.sum.min_after[k] = (min_after == 0x7FFF ? CW_BIAS : min_after) - CW_BIAS;
+            cw.sum.words[k] = T;
+            cw.sum.ssz[k] = S;
+            cw.sum.exp_arr[k] = arr_mask;
         }
-        cw.exp_tpos[k * 64 + lane] = st_tpos;
-        cw.exp_cnt[k * 64 + lane] = st_cnt;
+        cw.sum.exp_tpos[k * 64 + lane] = st_tpos;
+        cw.sum.exp_cnt[k * 64 + lane] = st_cnt;
+    }
+}
+
+// ---- the entry states: a scan over the chunk summaries ------------------------------------------------------------------
+// Applying a summary to a state is associative, so the scan has two levels: a wave per group of 64 chunks composes the
+// group's summary in relative levels (k_group_summary), ONE wave walks the groups with absolute levels (k_top_scan), and
+// a wave per group replays its chunks from the group's entry state (k_group_replay).  A 64 MiB document (35 k chunks)
+// costs 64 + 550 + 64 sequential applications instead of 35 k.
+struct ScanState {
+    int H;
+    uint32_t T;
+    unsigned long long S, arr;
+    uint32_t st_tpos, st_cnt;  // LANE = level
+    bool rc, bad;
+    int min_after;
+};
+struct SumRow {
+    int d, ma;
+    uint32_t words, ssz, row_tpos, row_cnt;
+    unsigned long long arr;
+};
+__device__ inline SumRow load_row(const ChunkSum& q, uint64_t k, int lane) {
+    SumRow r;
+    r.d = q.delta[k];
+    r.ma = q.min_after[k];
+    r.words = q.words[k];
+    r.ssz = q.ssz[k];
+    r.row_tpos = q.exp_tpos[k * 64 + lane];
+    r.row_cnt = q.exp_cnt[k * 64 + lane];
+    r.arr = q.exp_arr[k];
+    return r;
+}
+template <bool RELATIVE>
+__device__ inline void scan_apply(ScanState& s, const SumRow& r, int lane) {
+    const int m = r.ma < 0 ? r.ma : 0;
+    if (s.H + r.ma <= 0) s.rc = true;  // (absolute levels) the depth comes back to zero inside: the root value ends there
+    s.min_after = min(s.min_after, s.H + r.ma);
+    const int src = lane - s.H + CW_BIAS;  // my level's lane in the export
+    const bool in_src = src >= 0 && src < CW_LEVELS;
+    const uint32_t e_tpos = (uint32_t)__shfl((int)r.row_tpos, src & 63), e_cnt = (uint32_t)__shfl((int)r.row_cnt, src & 63);
+    if (in_src && lane == s.H + m - 1) s.st_cnt += e_cnt;              // the innermost container left untouched: its commas
+    if (in_src && lane >= s.H + m && lane < s.H + r.d) {               // opened inside and left open
+        s.st_tpos = s.T + e_tpos;
+        s.st_cnt = e_cnt;
+    }
+    const int lo = s.H + m < 0 ? 0 : s.H + m, hi = s.H + r.d > CW_LEVELS ? CW_LEVELS : s.H + r.d;
+    if (hi > lo) {  // kinds of the levels [lo, hi): bit (level - H + BIAS) of the export
+        const unsigned long long mask = (hi == 64 ? ~0ull : (1ull << hi) - 1ull) & ~((1ull << lo) - 1ull);
+        const int sh = s.H - CW_BIAS;
+        const unsigned long long moved = sh >= 0 ? (sh >= 64 ? 0ull : r.arr << sh) : (-sh >= 64 ? 0ull : r.arr >> -sh);
+        s.arr = (s.arr & ~mask) | (moved & mask);
+    }
+    if (s.H + r.d >= CW_LEVELS) s.bad = true;           // deeper than the stack registers
+    if (RELATIVE && s.H + m < 1) s.bad = true;          // the swing leaves the biased window
+    s.H = s.H + r.d < 0 ? 0 : s.H + r.d;
+    s.T += r.words;
+    s.S += r.ssz;
+}
+__device__ inline void store_in(const ChunkIn& q, uint64_t k, const ScanState& s, int lane) {
+    q.tpos[k * 64 + lane] = s.st_tpos;
+    q.cnt[k * 64 + lane] = s.st_cnt;
+    if (lane == 0) {
+        q.H[k] = (uint32_t)s.H;
+        q.T[k] = s.T;
+        q.S[k] = s.S;
+        q.arr[k] = s.arr;
+        q.root_closed[k] = s.rc ? 1u : 0u;
+    }
+}
+
+// applies the summaries [k0, k1) in order; the rows are requested four ahead (a lone wave pays a full memory latency
+// per dependent load otherwise); pre(k, state) runs in front of summary k
+template <bool RELATIVE, class Pre>
+__device__ inline void scan_range(ScanState& s, const ChunkSum& q, uint64_t k0, uint64_t k1, int lane, Pre&& pre) {
+    SumRow nx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (k0 + j < k1) nx[j] = load_row(q, k0 + j, lane);
+    for (uint64_t k = k0; k < k1; k += 4) {
+        SumRow cur[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = nx[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k + 4 + j < k1) nx[j] = load_row(q, k + 4 + j, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k + j < k1) {
+                pre(k + j, s);
+                scan_apply<RELATIVE>(s, cur[j], lane);
+            }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_group_summary(const unsigned long long* __restrict__ index_offsets, ChunkWs cw) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    const uint64_t n_structurals = index_offsets[1] - index_offsets[0];
+    if (n_structurals <= CW_SINGLE_N) return;
+    const uint32_t chunk = cw_chunk_of(n_structurals);
+    const uint64_t nchunks = (n_structurals + chunk - 1) / chunk;
+    const uint32_t CW_GROUP = cw_group_of(nchunks);
+    const uint64_t ngroups = (nchunks + CW_GROUP - 1) / CW_GROUP;
+    for (uint64_t g = (uint64_t)blockIdx.x * 4 + wv; g < ngroups; g += nwaves) {
+        const uint64_t k0 = g * CW_GROUP, k1 = k0 + CW_GROUP < nchunks ? k0 + CW_GROUP : nchunks;
+        ScanState s = {CW_BIAS, 0u, 0ull, 0ull, 0u, 0u, false, false, 0x7FFF};
+        scan_range<true>(s, cw.sum, k0, k1, lane, [](uint64_t, const ScanState&) {});
+        if (s.bad && lane == 0) atomicOr(cw.fallback, 1u);
+        if (lane == 0) {
+            cw.gsum.delta[g] = s.H - CW_BIAS;
+            cw.gsum.min_after[g] = s.min_after - CW_BIAS;
+            cw.gsum.words[g] = s.T;
+            cw.gsum.ssz[g] = (uint32_t)s.S;
+            cw.gsum.exp_arr[g] = s.arr;
+        }
+        cw.gsum.exp_tpos[g * 64 + lane] = s.st_tpos;
+        cw.gsum.exp_cnt[g * 64 + lane] = s.st_cnt;
     }
 }
 
 __global__ void __launch_bounds__(64)
-k_chunk_scan(const unsigned long long* __restrict__ index_offsets, const unsigned long long* __restrict__ doc_str_offsets, ChunkWs cw) {
+k_top_scan(const unsigned long long* __restrict__ index_offsets, const unsigned long long* __restrict__ doc_str_offsets, ChunkWs cw) {
     const int lane = threadIdx.x & 63;
-    const unsigned long long from = index_offsets[0], to = index_offsets[1];
-    const uint64_t nchunks = (to - from + CW_CHUNK - 1) / CW_CHUNK;
-    if (*cw.fallback != 0) return;
-    uint32_t st_tpos = 0, st_cnt = 0;  // LANE = absolute level
-    unsigned long long arr = 0, S = doc_str_offsets[0];
-    int H = 0;
-    uint32_t T = 1;
-    bool rc = false, deep = false;
-    for (uint64_t k = 0; k < nchunks; ++k) {
-        cw.in_tpos[k * 64 + lane] = st_tpos;
-        cw.in_cnt[k * 64 + lane] = st_cnt;
-        if (lane == 0) {
-            cw.in_H[k] = (uint32_t)H;
-            cw.in_T[k] = T;
-            cw.in_S[k] = S;
-            cw.in_arr[k] = arr;
-            cw.in_root_closed[k] = rc ? 1u : 0u;
-        }
-        const int d = cw.delta[k], ma = cw.min_after[k], m = ma < 0 ? ma : 0;
-        if (H + ma <= 0) rc = true;  // the depth comes back to zero inside this chunk: the root value ends there
-        const int src = lane - H + CW_BIAS;  // my level's lane in the chunk's export
-        const bool in_src = src >= 0 && src < CW_LEVELS;
-        const uint32_t e_tpos = in_src ? cw.exp_tpos[k * 64 + src] : 0u, e_cnt = in_src ? cw.exp_cnt[k * 64 + src] : 0u;
-        const unsigned long long e_arr = cw.exp_arr[k];
-        if (lane == H + m - 1) st_cnt += e_cnt;                 // the innermost container the chunk leaves untouched: its commas
-        if (lane >= H + m && lane < H + d) {                    // opened by the chunk and left open
-            st_tpos = T + e_tpos;
-            st_cnt = e_cnt;
-        }
-        // kinds of the new levels [H + m, H + d): bit (level - H + BIAS) of the export
-        for (int L = (H + m < 0 ? 0 : H + m); L < H + d && L < CW_LEVELS; ++L) {
-            const int sb = L - H + CW_BIAS;
-            if (sb >= 0 && sb < 64 && ((e_arr >> sb) & 1ull)) arr |= 1ull << L;
-            else arr &= ~(1ull << L);
-        }
-        if (H + d >= CW_LEVELS) deep = true;
-        H = H + d < 0 ? 0 : H + d;
-        T += cw.words[k];
-        S += cw.ssz[k];
-    }
+    const uint64_t n_structurals = index_offsets[1] - index_offsets[0];
+    if (n_structurals <= CW_SINGLE_N) return;
+    const uint32_t chunk = cw_chunk_of(n_structurals);
+    const uint64_t nchunks = (n_structurals + chunk - 1) / chunk;
+    const uint32_t CW_GROUP = cw_group_of(nchunks);
+    const uint64_t ngroups = (nchunks + CW_GROUP - 1) / CW_GROUP;
+    if (*cw.fallback != 0 || ngroups == 0) return;
+    ScanState s = {0, 1u, doc_str_offsets[0], 0ull, 0u, 0u, false, false, 0x7FFF};
+    scan_range<false>(s, cw.gsum, 0, ngroups, lane, [&](uint64_t g, const ScanState& at) { store_in(cw.gin, g, at, lane); });
     if (lane == 0) {
-        if (deep) atomicOr(cw.fallback, 1u);
-        cw.fin[0] = (uint32_t)H;
-        cw.fin[1] = T;
-        cw.fin[2] = (H >= 1 && H <= CW_LEVELS && ((arr >> (H - 1)) & 1ull)) ? 1u : 0u;
+        if (s.bad) atomicOr(cw.fallback, 1u);
+        cw.fin[0] = (uint32_t)s.H;
+        cw.fin[1] = s.T;
+        cw.fin[2] = (s.H >= 1 && s.H <= CW_LEVELS && ((s.arr >> (s.H - 1)) & 1ull)) ? 1u : 0u;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_group_replay(const unsigned long long* __restrict__ index_offsets, ChunkWs cw) {
+    if (*cw.fallback != 0) return;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    const uint64_t n_structurals = index_offsets[1] - index_offsets[0];
+    if (n_structurals <= CW_SINGLE_N) return;
+    const uint32_t chunk = cw_chunk_of(n_structurals);
+    const uint64_t nchunks = (n_structurals + chunk - 1) / chunk;
+    const uint32_t CW_GROUP = cw_group_of(nchunks);
+    const uint64_t ngroups = (nchunks + CW_GROUP - 1) / CW_GROUP;
+    for (uint64_t g = (uint64_t)blockIdx.x * 4 + wv; g < ngroups; g += nwaves) {
+        const uint64_t k0 = g * CW_GROUP, k1 = k0 + CW_GROUP < nchunks ? k0 + CW_GROUP : nchunks;
+        ScanState s;
+        s.H = (int)cw.gin.H[g];
+        s.T = cw.gin.T[g];
+        s.S = cw.gin.S[g];
+        s.arr = cw.gin.arr[g];
+        s.st_tpos = cw.gin.tpos[g * 64 + lane];
+        s.st_cnt = cw.gin.cnt[g * 64 + lane];
+        s.rc = cw.gin.root_closed[g] != 0;
+        s.bad = false;
+        s.min_after = 0x7FFF;
+        scan_range<false>(s, cw.sum, k0, k1, lane, [&](uint64_t k, const ScanState& at) { store_in(cw.in, k, at, lane); });
     }
 }
 
@@ -760,7 +897,8 @@ k_chunk_finish(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ idx
     if (*cw.fallback != 0) return;  // the single-wave sweep writes the document's result
     const int lane = threadIdx.x & 63;
     const unsigned long long from = index_offsets[0], to = index_offsets[1];
-    const uint64_t nchunks = (to - from + CW_CHUNK - 1) / CW_CHUNK;
+    const uint32_t chunk = cw_chunk_of(to - from);
+    const uint64_t nchunks = (to - from + chunk - 1) / chunk;
     const uint32_t st = doc_status ? doc_status[0] : 0u;
     int code = 0;
     uint32_t tlen = 0;
@@ -926,34 +1064,50 @@ hipError_t single_doc_setup_launch(const Stage1Result* d_res, uint64_t len, unsi
     return hipGetLastError();
 }
 
+static size_t chunk_bound(uint64_t count_bound) {  // n <= CW_SMALL_N: chunks of 128, else of 512
+    const uint64_t small = (count_bound < CW_SMALL_N ? count_bound : CW_SMALL_N) / 128, large = count_bound / 512;
+    return (size_t)(small > large ? small : large) + 2;
+}
+static size_t group_bound(uint64_t count_bound) { return chunk_bound(count_bound) / 8 + 2; }
 size_t coop_chunk_workspace_bytes(uint64_t count_bound) {
-    const size_t nchunks = (size_t)(count_bound / CW_CHUNK) + 2;
-    return nchunks * (4 * 64 * sizeof(uint32_t) + 16 * sizeof(unsigned long long)) + 256;
+    return (chunk_bound(count_bound) + group_bound(count_bound)) * (4 * 64 * sizeof(uint32_t) + 24 * sizeof(unsigned long long)) + 4096;
 }
 
 static ChunkWs chunk_ws(void* ws, uint64_t count_bound) {
-    const size_t nchunks = (size_t)(count_bound / CW_CHUNK) + 2;
     uint8_t* p = static_cast<uint8_t*>(ws);
     ChunkWs c;
     auto take = [&](size_t bytes) { uint8_t* r = p; p += (bytes + 63) / 64 * 64; return r; };
     c.fallback = reinterpret_cast<uint32_t*>(take(64));
     c.fin = c.fallback + 4;
-    c.exp_tpos = reinterpret_cast<uint32_t*>(take(nchunks * 64 * 4));
-    c.exp_cnt = reinterpret_cast<uint32_t*>(take(nchunks * 64 * 4));
-    c.in_tpos = reinterpret_cast<uint32_t*>(take(nchunks * 64 * 4));
-    c.in_cnt = reinterpret_cast<uint32_t*>(take(nchunks * 64 * 4));
-    c.exp_arr = reinterpret_cast<unsigned long long*>(take(nchunks * 8));
-    c.in_S = reinterpret_cast<unsigned long long*>(take(nchunks * 8));
-    c.in_arr = reinterpret_cast<unsigned long long*>(take(nchunks * 8));
-    c.delta = reinterpret_cast<int32_t*>(take(nchunks * 4));
-    c.min_after = reinterpret_cast<int32_t*>(take(nchunks * 4));
-    c.words = reinterpret_cast<uint32_t*>(take(nchunks * 4));
-    c.ssz = reinterpret_cast<uint32_t*>(take(nchunks * 4));
-    c.in_H = reinterpret_cast<uint32_t*>(take(nchunks * 4));
-    c.in_T = reinterpret_cast<uint32_t*>(take(nchunks * 4));
-    c.in_root_closed = reinterpret_cast<uint32_t*>(take(nchunks * 4));
-    c.err_pos = reinterpret_cast<uint32_t*>(take(nchunks * 4));
-    c.err_code = reinterpret_cast<int32_t*>(take(nchunks * 4));
+    auto sums = [&](size_t n) {
+        ChunkSum q;
+        q.exp_tpos = reinterpret_cast<uint32_t*>(take(n * 64 * 4));
+        q.exp_cnt = reinterpret_cast<uint32_t*>(take(n * 64 * 4));
+        q.exp_arr = reinterpret_cast<unsigned long long*>(take(n * 8));
+        q.delta = reinterpret_cast<int32_t*>(take(n * 4));
+        q.min_after = reinterpret_cast<int32_t*>(take(n * 4));
+        q.words = reinterpret_cast<uint32_t*>(take(n * 4));
+        q.ssz = reinterpret_cast<uint32_t*>(take(n * 4));
+        return q;
+    };
+    auto ins = [&](size_t n) {
+        ChunkIn q;
+        q.tpos = reinterpret_cast<uint32_t*>(take(n * 64 * 4));
+        q.cnt = reinterpret_cast<uint32_t*>(take(n * 64 * 4));
+        q.S = reinterpret_cast<unsigned long long*>(take(n * 8));
+        q.arr = reinterpret_cast<unsigned long long*>(take(n * 8));
+        q.H = reinterpret_cast<uint32_t*>(take(n * 4));
+        q.T = reinterpret_cast<uint32_t*>(take(n * 4));
+        q.root_closed = reinterpret_cast<uint32_t*>(take(n * 4));
+        return q;
+    };
+    const size_t nc = chunk_bound(count_bound), ng = group_bound(count_bound);
+    c.sum = sums(nc);
+    c.in = ins(nc);
+    c.gsum = sums(ng);
+    c.gin = ins(ng);
+    c.err_pos = reinterpret_cast<uint32_t*>(take(nc * 4));
+    c.err_code = reinterpret_cast<int32_t*>(take(nc * 4));
     return c;
 }
 
@@ -976,11 +1130,15 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
         cw = chunk_ws(d_chunk_ws, count_bound);
         hipError_t e = hipMemsetAsync(cw.fallback, 0, 64, stream);
         if (e != hipSuccess) return e;
-        const uint64_t nchunks = count_bound / CW_CHUNK + 1;
+        const uint64_t nchunks = chunk_bound(count_bound);
         const uint64_t want = (nchunks + 3) / 4;
         const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
         hipLaunchKernelGGL(k_chunk_summary, dim3(grid), dim3(256), 0, stream, d_buf, d_idx, d_index_offsets, d_sizes, cw);
-        hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(64), 0, stream, d_index_offsets, d_doc_str_offsets, cw);
+        const uint64_t gwant = (group_bound(count_bound) + 3) / 4;
+        const unsigned ggrid = (unsigned)(gwant < 4096 ? gwant : 4096);
+        hipLaunchKernelGGL(k_group_summary, dim3(ggrid), dim3(256), 0, stream, d_index_offsets, cw);
+        hipLaunchKernelGGL(k_top_scan, dim3(1), dim3(64), 0, stream, d_index_offsets, d_doc_str_offsets, cw);
+        hipLaunchKernelGGL(k_group_replay, dim3(ggrid), dim3(256), 0, stream, d_index_offsets, cw);
         hipLaunchKernelGGL((k_coop_walk<true>), dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets,
                            d_doc_status, d_sizes, d_scratch, d_doc_str_offsets, (unsigned long long)string_base, max_depth,
                            d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res, abl, cw, (const uint32_t*)nullptr);

@@ -765,6 +765,34 @@ int sjmi_parse_batch_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, 
     return SJMI_OK;
 }
 
+// the result records of the three stages in one place: one D2H instead of five
+struct SingleDocResults {
+    sjmi_stage1_result s1;
+    sjmi_unescape_result u;
+    sjmi_walk_result w;
+    unsigned long long to[2];
+    int32_t err;
+};
+static_assert(sizeof(SingleDocResults) <= 256, "d_single / h_single hold 256 bytes of results");
+static_assert(sizeof(sjmi_stage1_result) == sizeof(sjmi::Stage1Result) && sizeof(sjmi_unescape_result) == sizeof(sjmi::UnescapeResult) &&
+              sizeof(sjmi_walk_result) == sizeof(sjmi::WalkResult), "C ABI records mirror the device records");
+__global__ void k_single_doc_results(const sjmi::Stage1Result* s1, const sjmi::UnescapeResult* u, const sjmi::WalkResult* w,
+                                     const unsigned long long* to, const int32_t* err, SingleDocResults* out) {
+    if (threadIdx.x != 0) return;
+    memcpy(&out->s1, s1, sizeof out->s1);
+    memcpy(&out->u, u, sizeof out->u);
+    memcpy(&out->w, w, sizeof out->w);
+    out->to[0] = to[0];
+    out->to[1] = to[1];
+    out->err = *err;
+}
+
+static hipError_t single_doc_results_launch(const sjmi::Stage1Result* s1, const sjmi::UnescapeResult* u, const sjmi::WalkResult* w,
+                                            const unsigned long long* to, const int32_t* err, SingleDocResults* out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_single_doc_results, dim3(1), dim3(64), 0, stream, s1, u, w, to, err, out);
+    return hipGetLastError();
+}
+
 // SimdJsonParser.parse(byte[], int) with ALL THREE stages on the GPU (SimdJsonParser.java:35-40): H2D of the document,
 // stage 1, string records, the cooperative walker, D2H of the tape and the string buffer -- the structural indexes never
 // leave the device.  Two host synchronisations (the result records, then the outputs).
@@ -795,8 +823,7 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
     sjmi::UnescapeResult* d_ures = (sjmi::UnescapeResult*)(d64 + 10);
     sjmi::WalkResult* d_wres = (sjmi::WalkResult*)(d64 + 13);
     const sjmi::Stage1Result* d_res1 = (const sjmi::Stage1Result*)((uint8_t*)c->d_ws + sjmi::WS_RESULT_OFFSET);
-    struct Host { sjmi_stage1_result s1; sjmi_unescape_result u; sjmi_walk_result w; unsigned long long to[2]; int32_t err; };
-    Host* h = (Host*)c->h_single;
+    SingleDocResults* h = (SingleDocResults*)c->h_single;
     const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(len);
     if (len && fail(c, "H2D", hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
     const uint32_t* sizes = nullptr;
@@ -811,11 +838,9 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
             fail(c, "walk launch",
                  sjmi::walk_launch(c->d_in, d_doc, 1, c->d_idx, bound, d_io, d_st, c->d_sb, d_dso, 0, max_depth, c->d_tape,
                                    2 * bound + 8, d_to, d_err, c->d_ws_walk, d_wres, c->stream, d_res1, d_ures, sizes, str_scratch)) ||
-            fail(c, "D2H", hipMemcpyAsync(&h->s1, d_res1, sizeof h->s1, hipMemcpyDeviceToHost, c->stream)) ||
-            fail(c, "D2H", hipMemcpyAsync(&h->u, d_ures, sizeof h->u, hipMemcpyDeviceToHost, c->stream)) ||
-            fail(c, "D2H", hipMemcpyAsync(&h->w, d_wres, sizeof h->w, hipMemcpyDeviceToHost, c->stream)) ||
-            fail(c, "D2H", hipMemcpyAsync(h->to, d_to, 16, hipMemcpyDeviceToHost, c->stream)) ||
-            fail(c, "D2H", hipMemcpyAsync(&h->err, d_err, 4, hipMemcpyDeviceToHost, c->stream)) ||
+            fail(c, "results", single_doc_results_launch(d_res1, d_ures, d_wres, d_to, d_err,
+                                                         (SingleDocResults*)((uint8_t*)c->d_single + 256), c->stream)) ||
+            fail(c, "D2H", hipMemcpyAsync(h, (uint8_t*)c->d_single + 256, sizeof *h, hipMemcpyDeviceToHost, c->stream)) ||
             fail(c, "sync", hipStreamSynchronize(c->stream)))
             return SJMI_ERR_HIP;
         if (!(h->s1.status & SJMI_ST_INTERNAL) || c->ticket_mode) break;

@@ -139,6 +139,7 @@ k_tape_chunk_scan(unsigned long long* __restrict__ chunk_sums, uint64_t nchunks,
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        tape_offsets[0] = 0;  // (the others: k_tape_compact; a single document written in place has no other)
         tape_offsets[n_docs] = carry;
         res->tape_words = carry;
         if (carry > tape_capacity) res->flags |= 1u;
@@ -190,6 +191,9 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
                        const UnescapeResult* dev_strings, const uint32_t* d_sizes, const uint8_t* d_str_scratch) {
     uint8_t* ws = static_cast<uint8_t*>(d_ws);
     unsigned long long* scratch = reinterpret_cast<unsigned long long*>(ws);
+    // one document (its index starts at 0) and room for two words per structural: the walker writes the tape in place
+    const bool direct = d_sizes && n_docs == 1 && tape_capacity >= 2 * count + 2;
+    if (direct) scratch = d_tape;
     uint32_t* lens = reinterpret_cast<uint32_t*>(ws + walk_lens_offset(count, n_docs));
     unsigned long long* sums = reinterpret_cast<unsigned long long*>(ws + walk_sums_offset(count, n_docs));
     hipError_t e = hipMemsetAsync(d_res, 0, sizeof(WalkResult), stream);
@@ -209,7 +213,7 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
         hipLaunchKernelGGL(k_tape_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, lens, d_doc_errors, n_docs, sums, d_res);
     }
     hipLaunchKernelGGL(k_tape_chunk_scan, dim3(1), dim3(1024), 0, stream, sums, nchunks, n_docs, tape_capacity, d_tape_offsets, d_res);
-    if (n_docs)
+    if (n_docs && !direct)
         hipLaunchKernelGGL(k_tape_compact, dim3((unsigned)nchunks), dim3(1024), 0, stream, scratch, lens, d_index_offsets, n_docs,
                            sums, d_tape, tape_capacity, d_tape_offsets);
     return hipGetLastError();
