@@ -159,9 +159,8 @@ __device__ int cw_primitive(const uint8_t* buf, const CW16& win, uint32_t idx, b
         const SjNumber n = sj_scan_number([&](uint32_t q) -> uint32_t { return q < limit ? w.at(q) : 0x20u; }, idx);
         if (n.code) return n.code;
         if (n.floating) {
-            if (n.wide) return SJMI_WALK_NEEDS_HOST;  // DoubleParser's slow path (:205-330)
+            if (!sj_number_double_bits(n, raw)) return SJMI_WALK_NEEDS_HOST;  // DoubleParser's slow path (:205-330)
             *type = 'd';
-            *raw = sj_compute_double_bits(n.negative, n.w, n.q);
         } else {
             if (sj_out_of_long_range(n.negative, n.digits, n.digit_count)) return SJMI_E_NUM_LONG_RANGE;
             *type = 'l';

@@ -533,13 +533,14 @@ void DocWalker::parseNumber(const uint8_t* p) {
     const sjmi::SjNumber n = sjmi::sj_scan_number([&](uint32_t q) -> uint32_t { return p[q]; }, 0);
     if (n.code) throw fail(n.code);
     if (n.floating) {
-        if (n.wide) {
-            // more than 19 significant digits: the reference's slow path (DoubleParser.java:205-330), a correctly
-            // rounded saturating conversion -- strtod_l in the "C" locale has the same contract.  Never plain strtod: a
-            // JVM host process calls setlocale(LC_ALL, ""), and under a comma locale strtod("1.5") returns 1.0.
+        unsigned long long bits;
+        if (!sjmi::sj_number_double_bits(n, &bits)) {
+            // more than 19 significant digits AND within 10^-19 of a rounding boundary: the reference's slow path
+            // (DoubleParser.java:205-330), a correctly rounded saturating conversion -- strtod_l in the "C" locale has
+            // the same contract.  Never plain strtod: a JVM host process calls setlocale(LC_ALL, ""), and under a comma
+            // locale strtod("1.5") returns 1.0.
             tape_.appendDouble(strtod_l(reinterpret_cast<const char*>(p), nullptr, cLocale()));
         } else {
-            const unsigned long long bits = sjmi::sj_compute_double_bits(n.negative, n.w, n.q);
             double v;
             memcpy(&v, &bits, 8);
             tape_.appendDouble(v);

@@ -100,14 +100,16 @@ SJW_DEV SJW_INL bool visit_string(Lane& w) {
 
 // NumberParser.parseNumber (NumberParser.java:23-74) at p; bytes at or after `limit` read as spaces (the root number's
 // padded copy, TapeBuilder.java:183-189).  Grammar and conversion: sj_number.h (Clinger's exact range + Eisel-Lemire for
-// every literal of at most 19 significant digits; longer ones go back to the host).
+// every literal of at most 19 significant digits and for the longer ones whose two 19-digit neighbours round alike; the
+// rest goes back to the host).
 SJW_DEV bool parse_number(Lane& w, uint32_t p, uint32_t limit) {
     const SjNumber n = sj_scan_number([&](uint32_t q) -> uint32_t { return q < limit ? byte_at(w, q) : 0x20u; }, p);
     if (n.code) { w.code = n.code; return false; }
     if (n.floating) {
-        if (n.wide) { w.code = SJMI_WALK_NEEDS_HOST; return false; }  // DoubleParser's slow path (:205-330)
+        unsigned long long bits;
+        if (!sj_number_double_bits(n, &bits)) { w.code = SJMI_WALK_NEEDS_HOST; return false; }  // DoubleParser's slow path (:205-330)
         append(w, 0, 'd');  // Tape.appendDouble :39-43
-        w.tape[w.tl++] = sj_compute_double_bits(n.negative, n.w, n.q);
+        w.tape[w.tl++] = bits;
     } else {
         if (sj_out_of_long_range(n.negative, n.digits, n.digit_count)) { w.code = SJMI_E_NUM_LONG_RANGE; return false; }
         append(w, 0, 'l');  // Tape.appendInt64 :33-37

@@ -94,10 +94,15 @@ def test_reference_files(walk, name):
 
 
 def test_hand_back_and_depth(walk):
-    # handed back: more than 19 significant digits (the reference's slow path), nesting beyond the device stack
-    for doc in (b"[12345678901234567891e0]", b"[1.2345678901234567890123]", b"[" * 65 + b"]" * 65, b"[" * 64 + b"1" + b"]" * 64,
-                b"3.141592653589793238462643383279", b"[0.10000000000000000000000000000000000001]"):
-        assert _check(walk, doc, host_ok=True)
+    # handed back: more than 19 significant digits within 10^-19 of a rounding boundary (the rest of the reference's slow
+    # path is decided by the two 19-digit neighbours), nesting beyond the device stack
+    from tests.walk_common import AMBIGUOUS
+    for doc in [("[%s]" % a).encode() for a in AMBIGUOUS] + [("-" + AMBIGUOUS[0]).encode(), b"[" * 65 + b"]" * 65, b"[" * 64 + b"1" + b"]" * 64]:
+        assert _check(walk, doc, host_ok=True), doc[:60]
+    for doc in (b"[12345678901234567891e0]", b"[1.2345678901234567890123]", b"3.141592653589793238462643383279",
+                b"[0.10000000000000000000000000000000000001]", b"[123456789012345678901234567890.5e-400]",
+                b"[0.000000000000000000000000000000123456789012345678901234567890e+330]", b"[10000000000000000000000000000000000000001]".replace(b"]", b".0]")):
+        assert _check(walk, doc, host_ok=False), doc[:60]
     # converted on the device: everything Eisel-Lemire covers -- ties, subnormals, saturation, 19-digit significands
     for doc in (b"[1e23]", b"[1e-23]", b"[0.1e400]", b"[9007199254740993.0]", b"[1.7976931348623157e308]", b"[4.9e-324]", b"[2.4e-324]",
                 b"[2.2250738585072013e-308]", b"[1.7976931348623159e308]", b"[-1e999]", b"[1e-999]", b"[922337203685477580.5]",
@@ -116,7 +121,7 @@ def test_number_fuzz(walk):
     for k, d in enumerate(docs):
         assert _check(walk, d, host_ok=None if k in either else (k in hard))
         n_host += k in hard
-    assert 1500 < n_host < 20000
+    assert 100 < n_host < 5000
 
 
 def test_fuzz_documents(walk):
@@ -145,8 +150,8 @@ def test_large_array_size_saturates(walk):
 
 def test_reference_number_vectors(walk):
     """NumberParsingTest.java's literal vectors through the GPU walker's automaton: the asserted value / message for every
-    literal of at most 19 significant digits (ties, subnormals, saturation included: Eisel-Lemire on the device); the
-    longer ones are handed back -- never a different value."""
+    literal of at most 19 significant digits (ties, subnormals, saturation included: Eisel-Lemire on the device) and for the
+    longer ones whose two 19-digit neighbours round alike; the others are handed back -- never a different value."""
     from tests.conftest import number_vectors
     converted = handed_back = 0
     for v in number_vectors():
@@ -162,4 +167,4 @@ def test_reference_number_vectors(walk):
         else:
             assert _check(walk, doc), v["input"][:40]
             converted += 1
-    assert converted >= 100 and handed_back >= 10
+    assert converted >= 150 and 1 <= handed_back <= 4  # (two literals sit exactly on a midpoint with a tail behind the 19th digit)
