@@ -435,8 +435,14 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                     hmax = max(hmax, __shfl_xor(hmax, d));
                 }
                 if (hmin < 0) hmin = 0;  // (level -1 = in front of / behind the root: no container)
-                bool par_in_wave = false, par_is_array = false;
-                uint32_t par_tpos = 0, par_cnt = 0;
+                // Per level only what needs the level's ballots: the lane of the nearest opener in front of every structural of
+                // this level, the commas of the level in front of every lane (openers: of the level they open), and the
+                // stack entry as it stood in front of the step.  Everything that needs a cross-lane read of the opener's
+                // values happens ONCE behind the loop (the permutes were the loop's dependency chain).
+                int par_lane = -1;
+                uint32_t kc = 0, sk_t = 0, sk_c = 0;
+                bool sk_arr = false;
+                const int key = valid ? (is_open ? h : plevel) : -1;
                 // (deeper than the device stack: the non-empty open at depth 63 is handed back below, at a lower position
                 //  than anything that would need a level beyond the stack)
                 if (hmax >= CW_LEVELS) hmax = CW_LEVELS - 1;
@@ -445,18 +451,14 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                     const unsigned long long O = __ballot(is_open && h == L);                 // opens of level L
                     const unsigned long long C = __ballot(valid && cls == K_COMMA && plevel == L);  // commas directly inside level L
                     const unsigned long long Z = __ballot(is_close && plevel == L);            // closes of level-L containers
-                    const bool mine = valid && plevel == L;
-                    const int a = highest_bit_below(O, lt_mask);
-                    uint32_t a_tpos = (uint32_t)__shfl((int)tpos, a < 0 ? 0 : a);
-                    uint32_t a_cls = (uint32_t)__shfl((int)cls, a < 0 ? 0 : a);
                     const uint32_t sk_tpos = (uint32_t)__builtin_amdgcn_readlane((int)st_tpos, L);
                     const uint32_t sk_cnt = (uint32_t)__builtin_amdgcn_readlane((int)st_cnt, L);
-                    if (mine) {
-                        par_in_wave = a >= 0;
-                        par_is_array = a >= 0 ? a_cls == K_OPEN_A : ((arr_mask >> L) & 1ull) != 0;
-                        par_tpos = a >= 0 ? a_tpos : sk_tpos;
-                        const unsigned long long between = C & lt_mask & (a >= 0 ? ~((2ull << a) - 1ull) : ~0ull);
-                        par_cnt = (a >= 0 ? 0u : sk_cnt) + (uint32_t)__popcll(between);
+                    if (key == L) kc = (uint32_t)__popcll(C & lt_mask);
+                    if (valid && plevel == L) {
+                        par_lane = highest_bit_below(O, lt_mask);
+                        sk_t = sk_tpos;
+                        sk_c = sk_cnt;
+                        sk_arr = ((arr_mask >> L) & 1ull) != 0;
                     }
                     // stack update for the next steps (wave-uniform)
                     if (O) {
@@ -464,15 +466,21 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                         const unsigned long long above = al == 63 ? 0ull : ~((2ull << al) - 1ull);
                         if (!(Z & above)) {  // still open at the end of the step
                             const uint32_t tp = (uint32_t)__builtin_amdgcn_readlane((int)tpos, al);
-                            const uint32_t kc = (uint32_t)__builtin_amdgcn_readlane((int)cls, al);
+                            const uint32_t kc_ = (uint32_t)__builtin_amdgcn_readlane((int)cls, al);
                             st_tpos = lane == L ? tp : st_tpos;
                             st_cnt = lane == L ? (uint32_t)__popcll(C & above) : st_cnt;
-                            arr_mask = kc == K_OPEN_A ? (arr_mask | (1ull << L)) : (arr_mask & ~(1ull << L));
+                            arr_mask = kc_ == K_OPEN_A ? (arr_mask | (1ull << L)) : (arr_mask & ~(1ull << L));
                         }
                     } else if (!Z && C) {
                         st_cnt = lane == L ? sk_cnt + (uint32_t)__popcll(C) : st_cnt;
                     }
                 }
+                const bool par_in_wave = par_lane >= 0;
+                const int pl = par_in_wave ? par_lane : 0;
+                const uint32_t a_tpos = (uint32_t)__shfl((int)tpos, pl), a_cls = (uint32_t)__shfl((int)cls, pl), a_kc = (uint32_t)__shfl((int)kc, pl);
+                const bool par_is_array = par_in_wave ? a_cls == K_OPEN_A : sk_arr;
+                const uint32_t par_tpos = par_in_wave ? a_tpos : sk_t;
+                const uint32_t par_cnt = par_in_wave ? kc - a_kc : sk_c + kc;  // commas of my container in front of me
                 // (5) roles and their local predicates (JsonIterator.java:68-193)
                 const bool prev_open_nonempty = (cls_prev <= K_OPEN_O) && !eo_prev;
                 const bool first_key = prev_open_nonempty && cls_prev == K_OPEN_O;
