@@ -210,6 +210,165 @@ __device__ __forceinline__ int64_t unescape_wave(const uint8_t* __restrict__ buf
     return (int64_t)n;
 }
 
+// ---- the escaped strings of 64 structurals as ONE packed byte stream -----------------------------------------------------
+// unescape_wave gives a whole wave to one string: a 30-byte string uses 30 lanes and pays a memory round trip of its own,
+// and where most strings carry an escape (synthetic configs: 5 % of the characters) the wave walks through ten of them one
+// after the other.  Here the source bytes of all short escaped strings of the wave's 64 structurals form one virtual
+// stream (string j at [voff_j, voff_j + len_j)), lane t of window w owns virtual byte 64 w + t, and the escape algebra of
+// unescape_wave runs on the stream: 64 source bytes per trip whatever the lengths are.  What makes it legal: a string ends
+// in front of an UNescaped quote, so the backslash run at its end is even (runs may touch across a boundary: harmless, see
+// below) and no \uXXXX of a well-formed string crosses a boundary (the digit masks are cut at the boundaries for the
+// malformed ones, whose hex test then fails on the closing quote).
+// Per-string results through three 64-entry LDS arrays of the wave: first error (lowest position), unescaped length.
+__device__ __forceinline__ void wave_fence_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t udpp_max(uint32_t v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+    return v > o ? v : o;
+}
+__device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t v) {
+    v = udpp_max<0x111, 0xF>(v);
+    v = udpp_max<0x112, 0xF>(v);
+    v = udpp_max<0x114, 0xF>(v);
+    v = udpp_max<0x118, 0xF>(v);
+    v = udpp_max<0x142, 0xA>(v);
+    v = udpp_max<0x143, 0xC>(v);
+    return v;
+}
+constexpr uint32_t PACK_MAX_LEN = 256;  // longer strings keep the wave to themselves (four windows per round trip)
+
+// Must be called by all 64 lanes.  take: this lane's string goes into the stream ([open + 1, close), 1..PACK_MAX_LEN
+// bytes).  -> this lane's unescaped length or -(SJMI_E_* code) (0 if !take); the bytes go to scratch[open + 1 ...].
+__device__ __forceinline__ int64_t unescape_packed(const uint8_t* __restrict__ buf, uint32_t open, uint32_t close, bool take,
+                                                   uint8_t* __restrict__ scratch, int lane, uint32_t* __restrict__ lds) {
+    uint32_t* const l_start = lds;        // [64] window position -> string + 1
+    uint32_t* const l_len = lds + 64;     // [64] string -> bytes emitted so far
+    uint32_t* const l_err = lds + 128;    // [64] string -> (lane << 8 | code) of its first error, ~0 = none
+    const unsigned long long EVEN = 0x5555555555555555ull;
+    const uint32_t slen = take ? close - open - 1u : 0u;
+    const uint32_t voff_incl = wave_incl_scan_u32(slen);
+    const uint32_t voff = voff_incl - slen;
+    const uint32_t V = (uint32_t)__builtin_amdgcn_readlane((int)voff_incl, 63);
+    l_len[lane] = 0;
+    l_err[lane] = 0xFFFFFFFFu;
+    unsigned long long pU = 0, pD1 = 0, pD2 = 0, pD3 = 0;  // bit 0: the previous window's last lane had U / D1 / D2 / D3
+    unsigned long long prev_U = 0;
+    uint32_t carry = 0, cur1 = 0;
+    for (uint32_t w0 = 0; w0 < V; w0 += 64) {
+        l_start[lane] = 0;
+        wave_fence_lds();
+        if (take && voff >= w0 && voff < w0 + 64u) l_start[voff - w0] = (uint32_t)lane + 1u;
+        wave_fence_lds();
+        const uint32_t sj = l_start[lane];
+        uint32_t sidx = wave_incl_max_u32(sj);
+        sidx = sidx > cur1 ? sidx : cur1;  // (no start in front of me in this window: the string that continues)
+        const uint32_t v = w0 + (uint32_t)lane;
+        const bool valid = v < V;
+        const int j = (int)(sidx ? sidx - 1u : 0u);
+        const uint32_t o_j = (uint32_t)__shfl((int)open, j), vo_j = (uint32_t)__shfl((int)voff, j);
+        const uint32_t rel = v - vo_j, pos = o_j + 1u + rel;
+        const uint32_t c = valid ? (uint32_t)buf[pos] : 0u;
+        const uint32_t acc = l_len[j], e_prev = l_err[j];
+        const unsigned long long S = __ballot(sj != 0);
+        // (a backslash run that continues across a string boundary is left whole: the part in front of the boundary has
+        //  even length -- its string ended at an unescaped quote -- so the part behind it is classified as if it stood alone)
+        const unsigned long long B = __ballot(valid && c == '\\');
+        const unsigned long long bs = B & ~(unsigned long long)carry;
+        const unsigned long long follows = (bs << 1) | carry;
+        const unsigned long long odd_starts = bs & ~EVEN & ~follows;
+        const unsigned long long seq_even = odd_starts + bs;
+        const uint32_t carry_out = seq_even < bs ? 1u : 0u;
+        const unsigned long long escaped = (EVEN ^ (seq_even << 1)) & follows;
+        const bool is_esc = valid && ((escaped >> lane) & 1ull);
+        const bool is_start = ((B & ~escaped) >> lane) & 1ull;
+        const unsigned long long U = __ballot(is_esc && c == 'u');
+        const unsigned long long D1 = ((U << 1) | pU) & ~S, D2 = ((D1 << 1) | pD1) & ~S, D3 = ((D2 << 1) | pD2) & ~S,
+                                 D4 = ((D3 << 1) | pD3) & ~S;
+        const unsigned long long digits = D1 | D2 | D3 | D4;
+        uint32_t outlen = 1, out = c, err = 0;
+        if (!valid || is_start || ((digits >> lane) & 1ull)) {
+            outlen = 0;
+        } else if (is_esc) {
+            if (c == 'u') {                                                      // StringParser.java:45-57
+                int32_t cp = hex4_word(reinterpret_cast<const U4B*>(buf + pos + 1)->a);
+                if (cp >= 0xD800 && cp <= 0xDBFF) {                              // parseLowSurrogate :112-124
+                    const U8B t = *reinterpret_cast<const U8B*>(buf + pos + 5);
+                    if ((t.a & 0xFFFFu) != (uint32_t)('\\' | ('u' << 8))) {
+                        err = SJMI_E_LOW_SURROGATE_NO_U;
+                    } else {
+                        const int32_t low = hex4_word((t.a >> 16) | (t.b << 16)) - 0xDC00;
+                        if ((low >> 10) != 0) err = SJMI_E_LOW_SURROGATE_RANGE;
+                        else cp = (((cp - 0xD800) << 10) | low) + 0x10000;
+                    }
+                } else if (cp >= 0xDC00 && cp <= 0xDFFF) {
+                    bool paired = false;
+                    if (rel >= 6u) {  // (the six bytes in front are this string's: same stream, contiguous)
+                        const bool prev_is_u = lane >= 6 ? ((U >> (lane - 6)) & 1ull) : ((prev_U >> (58 + lane)) & 1ull);
+                        if (prev_is_u) {
+                            const int32_t hi = hex4_word(reinterpret_cast<const U4B*>(buf + pos - 5)->a);
+                            paired = hi >= 0xD800 && hi <= 0xDBFF;
+                        }
+                    }
+                    if (paired) cp = -2;
+                    else err = SJMI_E_LOW_SURROGATE_RESERVED;
+                }
+                if (!err) {
+                    if (cp == -2) {
+                        outlen = 0;
+                    } else if (cp < 0) {
+                        err = SJMI_E_INVALID_UNICODE_ESCAPE;                     // :127-129
+                    } else if (cp <= 0x7F) {
+                        out = (uint32_t)cp;
+                    } else if (cp <= 0x7FF) {
+                        outlen = 2;
+                        out = (uint32_t)((cp >> 6) + 192) | ((uint32_t)((cp & 63) + 128) << 8);
+                    } else if (cp <= 0xFFFF) {
+                        outlen = 3;
+                        out = (uint32_t)((cp >> 12) + 224) | ((uint32_t)(((cp >> 6) & 63) + 128) << 8) |
+                              ((uint32_t)((cp & 63) + 128) << 16);
+                    } else {
+                        outlen = 4;
+                        out = (uint32_t)((cp >> 18) + 240) | ((uint32_t)(((cp >> 12) & 63) + 128) << 8) |
+                              ((uint32_t)(((cp >> 6) & 63) + 128) << 16) | ((uint32_t)((cp & 63) + 128) << 24);
+                    }
+                }
+            } else {                                                             // :58-61
+                const uint32_t r = (c & 0x80u) ? 0u : escape_map(c);
+                if (r == 0) err = SJMI_E_ESCAPE_UNEXPECTED;
+                out = r;
+            }
+        }
+        // a string's first error = the lowest position: windows come in order, lanes by atomic min inside one
+        if (err && e_prev == 0xFFFFFFFFu) atomicMin(&l_err[j], ((uint32_t)lane << 8) | err);
+        const uint32_t incl = wave_incl_scan_u32(outlen), excl = incl - outlen;
+        const uint32_t base = wave_incl_max_u32(sj ? excl : 0u);  // output position at which my string's part of the window begins
+        uint8_t* q = scratch + o_j + 1u + acc + (excl - base);
+        if (outlen >= 1) q[0] = (uint8_t)out;
+        if (outlen >= 2) q[1] = (uint8_t)(out >> 8);
+        if (outlen >= 3) q[2] = (uint8_t)(out >> 16);
+        if (outlen >= 4) q[3] = (uint8_t)(out >> 24);
+        uint32_t sidx_next = (uint32_t)__shfl_down((int)sidx, 1);
+        if (lane == 63) sidx_next = 0;
+        const bool last_of_string = valid && (v + 1u == V || sidx_next != sidx);
+        if (last_of_string) l_len[j] = acc + (incl - base);
+        cur1 = (uint32_t)__builtin_amdgcn_readlane((int)sidx, 63);
+        pU = U >> 63;
+        pD1 = D1 >> 63;
+        pD2 = D2 >> 63;
+        pD3 = D3 >> 63;
+        prev_U = U;
+        carry = carry_out;
+        wave_fence_lds();
+    }
+    wave_fence_lds();
+    const uint32_t e = l_err[lane], n = l_len[lane];
+    if (!take) return 0;
+    return e != 0xFFFFFFFFu ? -(int64_t)(e & 0xFFu) : (int64_t)n;
+}
+
 // any backslash in the aligned 16-byte chunks covering [from, to)?  (May look at up to 15 bytes on either side:
 // a false positive only sends the string down the exact byte-wise path.)
 __device__ __forceinline__ bool has_backslash(const uint8_t* __restrict__ buf, uint32_t from, uint32_t to) {
@@ -358,6 +517,7 @@ k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __r
     }
     if ((uint64_t)blockIdx.x * (UNESC_THREADS * ITEMS) >= count) return;
     __shared__ unsigned long long s_part[UNESC_THREADS / 64];
+    __shared__ uint32_t s_pack[UNESC_THREADS / 64][192];
     const int lane = threadIdx.x & 63;
     constexpr int MEAS_GROUP = ITEMS < MEAS_GROUP_MAX ? ITEMS : MEAS_GROUP_MAX;
     const uint64_t base = (uint64_t)blockIdx.x * (UNESC_THREADS * ITEMS);
@@ -421,8 +581,13 @@ k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __r
                 else if (!m.esc) r = (int64_t)(m.close - open[q] - 1);
                 else slow = SIZE_SLOW;
             }
-            // strings with escapes: the whole wave unescapes them one after the other
-            for (unsigned long long todo = __ballot(m.esc); todo; todo &= todo - 1) {
+            // strings with escapes: the short ones together as one packed stream, the long ones one after the other
+            const bool packed = m.esc && m.close - open[q] - 1u <= PACK_MAX_LEN && m.close > open[q] + 1u;
+            if (__ballot(packed)) {
+                const int64_t rp = unescape_packed(buf, open[q], m.close, packed, scratch, lane, s_pack[threadIdx.x >> 6]);
+                if (packed) r = rp;
+            }
+            for (unsigned long long todo = __ballot(m.esc && !packed); todo; todo &= todo - 1) {
                 const int j = __builtin_ctzll(todo);
                 const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)open[q], j) + 1u;
                 const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)m.close, j);

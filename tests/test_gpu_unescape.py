@@ -121,3 +121,37 @@ def test_window_boundaries_of_the_cooperative_path(ctx):
     for tiny in [b'""', b'"a"', b'"\\n"', b'["",""]', b'"\\u0041"', b' "x" ', b'"0123456789abc"', b'"0123456789abcd"',
                  b'"0123456789abcde"']:
         _check(ctx, tiny)
+
+
+def test_packed_stream_of_short_escaped_strings(ctx):
+    """Escaped strings of up to 256 bytes are unescaped together as one packed byte stream per 64 structurals
+    (unescape_packed): token soups of every escape kind and of every length 1..300 (so that string boundaries, escapes,
+    \\uXXXX and surrogate pairs fall on every position of the 64-byte windows of the STREAM, and long strings mix in),
+    strings that end in backslash pairs in front of strings that begin with them, and every error of StringParser placed in
+    one of many escaped strings of the same wave (the first by position wins, the strings in front of it are intact)."""
+    rng = random.Random(4242)
+    toks = ["a", "b", "Z", " ", "é", "€", "\\n", "\\t", "\\\\", "\\\"", "\\/", "\\b", "\\u0041", "\\u00e9", "\\u20AC", "\\uD83D\\uDE00",
+            "\\\\\\\\", "\\\\\\\"", "\\u0000", "\\uFFFF", "\\uDBFF\\uDFFF"]
+
+    def soup(n):
+        out, size = [], 0
+        while size < n:
+            t = rng.choice(toks)
+            out.append(t)
+            size += len(t.encode())
+        return "".join(out)
+    for _ in range(12):
+        parts = ['"%s"' % soup(rng.randint(1, rng.choice([8, 30, 70, 300]))) for _ in range(rng.randint(100, 700))]
+        sep = rng.choice([",", ", ", ",\n  "])
+        _check(ctx, ("[" + sep.join(parts) + "]").encode())
+    # every length, escapes at both ends
+    _check(ctx, ("[" + ",".join('"\\\\%s\\\\"' % ("x" * n) for n in range(0, 300)) + "]").encode())
+    _check(ctx, ("[" + ",".join('"%s\\uD83D\\uDE00"' % ("y" * n) for n in range(0, 200)) + "]").encode())
+    _check(ctx, ('{' + ",".join('"k\\\\":"\\\\v%d\\\\\\\\"' % i for i in range(500)) + "}").encode())
+    # errors: one failing string among escaped neighbours, at every lane phase; two failing strings -> the first
+    bads = ["\\uD83Dx", "\\uD83D\\u0041", "\\uDE00", "\\u12G4", "\\q", "\\uD83D\\uD83D", "\\u", "\\uD83D", "\\u00"]
+    for k, bad in enumerate(bads):
+        for where in (0, 1, 5, 17, 62, 63, 64, 65, 130):
+            parts = ['"n%d\\n"' % i for i in range(where)] + ['"%s%s%s"' % ("p" * (k + where % 7), bad, "s" * (where % 5))]
+            parts += ['"t%d\\t"' % i for i in range(70)] + ['"\\q"'] + ['"u\\n"'] * 10
+            _check(ctx, ("[" + ",".join(parts) + "]").encode())
