@@ -238,6 +238,10 @@ __device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t v) {
     v = udpp_max<0x143, 0xC>(v);
     return v;
 }
+#ifndef SJMI_PACK_MIN_STRINGS
+#define SJMI_PACK_MIN_STRINGS 2
+#endif
+constexpr int PACK_MIN_STRINGS = SJMI_PACK_MIN_STRINGS;
 constexpr uint32_t PACK_MAX_LEN = 256;  // longer strings keep the wave to themselves (four windows per round trip)
 
 // Must be called by all 64 lanes.  take: this lane's string goes into the stream ([open + 1, close), 1..PACK_MAX_LEN
@@ -520,7 +524,8 @@ k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __r
     __shared__ uint32_t s_pack[UNESC_THREADS / 64][192];
     const int lane = threadIdx.x & 63;
     constexpr int MEAS_GROUP = ITEMS < MEAS_GROUP_MAX ? ITEMS : MEAS_GROUP_MAX;
-    const uint64_t base = (uint64_t)blockIdx.x * (UNESC_THREADS * ITEMS);
+    const uint32_t base32 = blockIdx.x * (uint32_t)(UNESC_THREADS * ITEMS);
+    const uint32_t count32 = (uint32_t)count;
     unsigned long long sum = 0;
 #pragma unroll 1
     for (int g = 0; g < ITEMS; g += MEAS_GROUP) {
@@ -528,10 +533,10 @@ k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __r
         bool in_range[MEAS_GROUP];
 #pragma unroll
         for (int q = 0; q < MEAS_GROUP; ++q) {
-            const uint64_t i = base + (uint64_t)(g + q) * UNESC_THREADS + threadIdx.x;
-            in_range[q] = i < count;
+            const uint32_t i = base32 + (uint32_t)(g + q) * UNESC_THREADS + threadIdx.x;  // (< 2^32: one index per document byte at most)
+            in_range[q] = i < count32;
             open[q] = in_range[q] ? idx[i] : 0u;
-            bound[q] = (i + 1 < count) ? idx[i + 1] : len;
+            bound[q] = (i + 1 < count32) ? idx[i + 1] : len;
             if (clip.marks && in_range[q] && ((clip.marks[i >> 5] >> (i & 31)) & 1u)) bound[q] = tail_clip_bound(clip, i);
         }
         U16B hw[MEAS_GROUP], tw[MEAS_GROUP];
@@ -568,32 +573,48 @@ k_str_measure(const uint8_t* __restrict__ buf, uint32_t len, const uint32_t* __r
                 for (int t = 0; t < 4; ++t) hit |= ~(((x[t] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x[t]) & 0x80808080u;
                 span_bs[q][w] = __ballot(hit != 0);
             }
+        // (three passes over the group's items so that the window registers of the fast path are dead while the escaped
+        //  strings are worked on: the kernel sits at its register budget)
+        uint32_t close_[MEAS_GROUP];
+        bool esc_[MEAS_GROUP], is_str_[MEAS_GROUP];
 #pragma unroll
         for (int q = 0; q < MEAS_GROUP; ++q) {
-            const uint64_t i = base + (uint64_t)(g + q) * UNESC_THREADS + threadIdx.x;
-            const bool is_str = in_range[q] && (hw[q].a & 0xFFu) == '"';
+            is_str_[q] = in_range[q] && (hw[q].a & 0xFFu) == '"';
             MeasuredString m = {0u, false};
-            if (is_str) m = measure_string(buf, open[q], bound[q], tpos[q], hw[q], tw[q], span_lo[q], span_ok[q], span_bs[q]);
+            if (is_str_[q]) m = measure_string(buf, open[q], bound[q], tpos[q], hw[q], tw[q], span_lo[q], span_ok[q], span_bs[q]);
+            close_[q] = m.close;
+            esc_[q] = m.esc;
+        }
+        int64_t r_[MEAS_GROUP];
+#pragma unroll
+        for (int q = 0; q < MEAS_GROUP; ++q) {
             int64_t r = 0;
-            uint32_t slow = 0;
-            if (is_str) {
-                if (!m.close) r = -(int64_t)SJMI_E_INTERNAL;
-                else if (!m.esc) r = (int64_t)(m.close - open[q] - 1);
-                else slow = SIZE_SLOW;
+            if (is_str_[q]) {
+                if (!close_[q]) r = -(int64_t)SJMI_E_INTERNAL;
+                else if (!esc_[q]) r = (int64_t)(close_[q] - open[q] - 1);
             }
             // strings with escapes: the short ones together as one packed stream, the long ones one after the other
-            const bool packed = m.esc && m.close - open[q] - 1u <= PACK_MAX_LEN && m.close > open[q] + 1u;
+            bool packed = esc_[q] && close_[q] - open[q] - 1u <= PACK_MAX_LEN && close_[q] > open[q] + 1u;
+            if (__popcll(__ballot(packed)) < PACK_MIN_STRINGS) packed = false;  // (few: a wave each costs less than the stream's bookkeeping)
             if (__ballot(packed)) {
-                const int64_t rp = unescape_packed(buf, open[q], m.close, packed, scratch, lane, s_pack[threadIdx.x >> 6]);
+                const int64_t rp = unescape_packed(buf, open[q], close_[q], packed, scratch, lane, s_pack[threadIdx.x >> 6]);
                 if (packed) r = rp;
             }
-            for (unsigned long long todo = __ballot(m.esc && !packed); todo; todo &= todo - 1) {
+            for (unsigned long long todo = __ballot(esc_[q] && !packed); todo; todo &= todo - 1) {
                 const int j = __builtin_ctzll(todo);
                 const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)open[q], j) + 1u;
-                const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)m.close, j);
+                const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)close_[q], j);
                 const int64_t rj = unescape_wave(buf, s0, e0, scratch + s0, lane);
                 if (lane == j) r = rj;
             }
+            r_[q] = r;
+        }
+#pragma unroll
+        for (int q = 0; q < MEAS_GROUP; ++q) {
+            const uint32_t i = base32 + (uint32_t)(g + q) * UNESC_THREADS + threadIdx.x;  // (< 2^32: one index per document byte at most)
+            const bool is_str = is_str_[q];
+            int64_t r = r_[q];
+            uint32_t slow = (is_str && close_[q] && esc_[q]) ? SIZE_SLOW : 0u;
             if (is_str) {
                 if (r == 0) slow = 0;  // (the backslash sweep may be a false positive of a neighbour: an empty string stays empty)
                 if (r < 0) {
