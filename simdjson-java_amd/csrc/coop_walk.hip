@@ -65,6 +65,23 @@ __device__ __forceinline__ uint32_t cw_incl_scan(uint32_t v) {
     v = cw_dpp_add<0x143, 0xC>(v);
     return v;
 }
+// wave-wide minimum / maximum of a signed value, uniform result: the same DPP ladder with min / max (lanes without a source
+// keep their own value), the full reduction arrives in lane 63 -- no LDS-crossbar shuffles on the step's dependency chain
+template <int CTRL, int ROW_MASK, bool IS_MAX>
+__device__ __forceinline__ int cw_dpp_minmax(int v) {
+    const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+    return IS_MAX ? (o > v ? o : v) : (o < v ? o : v);
+}
+template <bool IS_MAX>
+__device__ __forceinline__ int cw_wave_minmax(int v) {
+    v = cw_dpp_minmax<0x111, 0xF, IS_MAX>(v);
+    v = cw_dpp_minmax<0x112, 0xF, IS_MAX>(v);
+    v = cw_dpp_minmax<0x114, 0xF, IS_MAX>(v);
+    v = cw_dpp_minmax<0x118, 0xF, IS_MAX>(v);
+    v = cw_dpp_minmax<0x142, 0xA, IS_MAX>(v);
+    v = cw_dpp_minmax<0x143, 0xC, IS_MAX>(v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ uint32_t cw_last(uint32_t incl) { return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63); }
 
 // The bytes of a primitive, for the lane that parses it: the 16-byte window that was loaded at the structural's own
@@ -428,12 +445,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 const unsigned long long soff = S0 + (is_ - ssz);
                 // (4) the container of every structural: level loop over the depths present in this step
                 const int plevel = h - 1;  // level of the container this structural sits in
-                int hmin = valid ? plevel : 0x7FFF, hmax = valid ? (is_open ? h : plevel) : -0x7FFF;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) {
-                    hmin = min(hmin, __shfl_xor(hmin, d));
-                    hmax = max(hmax, __shfl_xor(hmax, d));
-                }
+                int hmin = cw_wave_minmax<false>(valid ? plevel : 0x7FFF), hmax = cw_wave_minmax<true>(valid ? (is_open ? h : plevel) : -0x7FFF);
                 if (hmin < 0) hmin = 0;  // (level -1 = in front of / behind the root: no container)
                 // Per level only what needs the level's ballots: the lane of the nearest opener in front of every structural of
                 // this level, the commas of the level in front of every lane (openers: of the level they open), and the
@@ -674,14 +686,8 @@ k_chunk_summary(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ id
             const uint32_t tpos = T + iw - words;
             const uint32_t is_ = cw_incl_scan((valid && cls == K_QUOTE) ? (sz & ~CW_SIZE_SLOW) : 0u);
             const int plevel = h - 1;
-            int after = valid ? h + (int)up - (int)down : 0x7FFF;
-            int hmin = valid ? plevel : 0x7FFF, hmax = valid ? (is_open ? h : plevel) : -0x7FFF;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                hmin = min(hmin, __shfl_xor(hmin, d));
-                hmax = max(hmax, __shfl_xor(hmax, d));
-                after = min(after, __shfl_xor(after, d));
-            }
+            const int after = cw_wave_minmax<false>(valid ? h + (int)up - (int)down : 0x7FFF);
+            const int hmin = cw_wave_minmax<false>(valid ? plevel : 0x7FFF), hmax = cw_wave_minmax<true>(valid ? (is_open ? h : plevel) : -0x7FFF);
             min_after = min(min_after, after);
             if (hmin < 0 || hmax >= CW_LEVELS) {  // the depth swings out of the biased window: not a chunk for this path
                 out_of_range = true;
