@@ -365,11 +365,40 @@ def bench_single(args):
     if "batch" in sections:
         # ---- configs[3] on ONE GPU: the batched path, 1,000,000 documents ----
         extra["batch_1m_docs"] = batch_single_gpu(torch, S, W, dev, work, args)
+    if "parse" in sections:
+        # ---- the drop-in call itself: SimdJsonParser.parse(byte[], len) of ONE twitter.json from a host buffer (H2D, all
+        #      stages, outputs back on the host), with the reference's stage 2 on the host or all three stages on the GPU ----
+        extra["parse_twitter_json"] = parse_single_document(S, doc)
     line["extra"] = extra
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(doc)
     print(json.dumps(line))
     r1.ctx.close()
+
+
+def parse_single_document(S, doc, reps=300):
+    out = {"config": "SimdJsonParser.parse(twitter.json, %d B) from a host buffer, end to end (H2D of the document, stage 1, string "
+                     "records, stage 2, tape + string buffer on the host); tape checked against the oracle once per mode" % len(doc),
+           "unit": "ms per document (through the ctypes binding: includes its copies of the document and of the outputs)"}
+    from oracle import oracle as O
+    want = O.parse(doc)
+    for mode, key in ((False, "host_walker"), (True, "gpu_walker_chunk_parallel")):
+        p = S.SimdJsonParser(capacity=len(doc) + 64, gpu_walk=mode)
+        tape = p.parse(doc).tape
+        if tape.size != want.tape.size or not (tape == want.tape).all():
+            raise SystemExit("parse(twitter.json) tape differs from the oracle's (gpu_walk=%s)" % mode)
+        for _ in range(reps):  # (untimed: ~70 ms of back-to-back parses, see the clock note in DESIGN.md 6.)
+            p.parse(doc)
+        ms = 1e9
+        for _ in range(3):  # best of three timed runs of `reps` parses
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                p.parse(doc)
+            ms = min(ms, (time.perf_counter() - t0) / reps * 1e3)
+        out[key] = {"ms": round(ms, 4), "GB/s": round(len(doc) / ms / 1e6, 3)}
+        p.close()
+    out["value"] = out["gpu_walker_chunk_parallel"]["ms"]
+    return out
 
 
 def batch_single_gpu(torch, S, W, dev, work, args, with_h2d=True):
@@ -511,8 +540,8 @@ def main():
     ap.add_argument("--pool", type=int, default=4000, help="unique documents of the configs[3] batch")
     ap.add_argument("--batch-steps", type=int, default=10, help="N=1: timed steps of the configs[3] extra")
     ap.add_argument("--no-extras", action="store_true", help="N=1: only the primary workload")
-    ap.add_argument("--sections", default="x1024,unescape,synth,batch",
-                    help="N=1: which extras to run (comma list of x1024, unescape, synth, batch); the profiling passes run one each")
+    ap.add_argument("--sections", default="x1024,unescape,synth,batch,parse",
+                    help="N=1: which extras to run (comma list of x1024, unescape, synth, batch, parse); the profiling passes run one each")
     ap.add_argument("--skip-main-timing", action="store_true",
                     help="N=1, profiling passes of an extra only: check the primary workload once, do not time it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
