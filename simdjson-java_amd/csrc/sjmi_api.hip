@@ -778,13 +778,16 @@ static_assert(sizeof(sjmi_stage1_result) == sizeof(sjmi::Stage1Result) && sizeof
               sizeof(sjmi_walk_result) == sizeof(sjmi::WalkResult), "C ABI records mirror the device records");
 __global__ void k_single_doc_results(const sjmi::Stage1Result* s1, const sjmi::UnescapeResult* u, const sjmi::WalkResult* w,
                                      const unsigned long long* to, const int32_t* err, SingleDocResults* out) {
-    if (threadIdx.x != 0) return;
-    memcpy(&out->s1, s1, sizeof out->s1);
-    memcpy(&out->u, u, sizeof out->u);
-    memcpy(&out->w, w, sizeof out->w);
-    out->to[0] = to[0];
-    out->to[1] = to[1];
-    out->err = *err;
+    // (every record is a multiple of four bytes: one dword per lane and record)
+    const uint32_t t = threadIdx.x;
+    auto copy = [&](void* dst, const void* src, size_t bytes) {
+        if (t < bytes / 4) reinterpret_cast<uint32_t*>(dst)[t] = reinterpret_cast<const uint32_t*>(src)[t];
+    };
+    copy(&out->s1, s1, sizeof out->s1);
+    copy(&out->u, u, sizeof out->u);
+    copy(&out->w, w, sizeof out->w);
+    copy(out->to, to, sizeof out->to);
+    copy(&out->err, err, sizeof out->err);
 }
 
 static hipError_t single_doc_results_launch(const sjmi::Stage1Result* s1, const sjmi::UnescapeResult* u, const sjmi::WalkResult* w,
