@@ -304,6 +304,43 @@ int sjmi_parser_parse_batch(sjmi_parser* p, const uint8_t* buf, uint64_t total_l
                             uint64_t n_docs, const uint64_t** tape, const uint64_t** tape_offsets,
                             const uint8_t** strings, uint64_t* strings_len, const int32_t** errors);
 
+/* ---- the on-demand front end --------------------------------------------------------------
+ * OnDemandJsonIterator (OnDemandJsonIterator.java:7-675), the cursor SchemaBasedJsonIterator.java:29-132 drives with one
+ * call per field of the schema: it walks the structural indexes of stage 1 and parses only the values it is asked for.
+ * sjmi_parser_ondemand_init = SimdJsonParser.parse(buffer, len, Class) up to and including iterator.init (:31-41): pad,
+ * GPU stage 1, and -- with_skip_table != 0 -- the GPU skip table (sjmi_match_brackets), with which skipChild leaves k
+ * containers by k - 1 + 1 table reads instead of scanning every structural in between (:47-81).  The calls below mirror
+ * the iterator's methods one to one (root != 0: the Root form; nullable == 0: the NonNull form; *is_null: the method
+ * returned null); each returns 0, or > 0 = the SJMI_E_* code of the JsonParsingException the reference throws there
+ * (exact text: sjmi_parser_last_message), or < 0.  Not built: the byte / short / int / float / char getters. */
+#define SJMI_E_OD_NOT_ENOUGH_CLOSE 40    /* "Not enough close braces."                                   :80 */
+#define SJMI_E_OD_EXPECTED_CHAR 41       /* "Expected 'x' but got: 'y'."                                 :662 */
+#define SJMI_E_OD_EXPECTED_CHAR_END 42   /* "Expected 'x' but reached end of buffer."                    :660 */
+#define SJMI_E_OD_BOOLEAN 43             /* "Unrecognized boolean value. Expected: 'true' or 'false'."   :88,:152 */
+#define SJMI_E_OD_BOOLEAN_OR_NULL 44     /* "... Expected: 'true', 'false' or 'null'."                   :104,:167 */
+#define SJMI_E_OD_STRING_OR_NULL 45      /* "Invalid value starting at N. Expected either string or 'null'."  :455,:470 */
+#define SJMI_E_OD_FLOAT_PART_MISSING 46  /* "Invalid floating-point number. Fraction or exponent part is missing."  NumberParser.java:303 */
+#define SJMI_OD_EMPTY 0                  /* IteratorResult :672-674 */
+#define SJMI_OD_NULL 1
+#define SJMI_OD_NOT_EMPTY 2
+int sjmi_parser_ondemand_init(sjmi_parser* p, const uint8_t* buf, uint64_t len, int with_skip_table);
+int sjmi_od_skip_child(sjmi_parser* p, int parent_depth);             /* skipChild(parentDepth) :47-81; < 0: skipChild() :43-45 */
+int sjmi_od_get_boolean(sjmi_parser* p, int root, int nullable, int* is_null, int* value);     /* :83-109,:147-171 */
+int sjmi_od_get_long(sjmi_parser* p, int root, int nullable, int* is_null, int64_t* value);    /* :321-358 */
+int sjmi_od_get_double(sjmi_parser* p, int root, int nullable, int* is_null, double* value);   /* :383-428 */
+/* getRootString / getString :446-472, getFieldName :646-652: the unescaped bytes, valid until the next of these calls */
+int sjmi_od_get_string(sjmi_parser* p, int root, int* is_null, const uint8_t** bytes, uint64_t* len);
+int sjmi_od_get_field_name(sjmi_parser* p, const uint8_t** bytes, uint64_t* len);
+int sjmi_od_start_array(sjmi_parser* p, int root, int* result);       /* startIterating[Root]Array :522-566 -> SJMI_OD_* */
+int sjmi_od_next_array_element(sjmi_parser* p, int* has_next);        /* :568-579 */
+int sjmi_od_start_object(sjmi_parser* p, int root, int* result);      /* startIterating[Root]Object :581-623 */
+int sjmi_od_next_object_field(sjmi_parser* p, int* has_next);         /* :625-636 */
+int sjmi_od_move_to_field_value(sjmi_parser* p);                      /* :638-644 */
+int sjmi_od_assert_no_more_values(sjmi_parser* p);                    /* :666-670 */
+int sjmi_od_depth(const sjmi_parser* p);                              /* getDepth :654-656 */
+#define SJMI_OD_END 256
+int sjmi_od_peek(const sjmi_parser* p);   /* (extension for schema-less drivers) the byte of the next structural, SJMI_OD_END behind the last */
+
 /* ---- JsonValue (JsonValue.java:18-221) over the C ABI: the DOM view of the last parse -------------------------------
  * A value is (document, tape index), like the reference's (tape, tapeIdx, stringBuffer) tuple (JsonValue.java:20-30);
  * handles stay valid until the next parse / parse_batch on the parser.  Every accessor runs the C++ mirror class

@@ -68,7 +68,11 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_value_as_boolean", "sjmi_value_as_string", "sjmi_value_get", "sjmi_value_size", "sjmi_value_first",
            "sjmi_value_next", "sjmi_parse_batch_device", "sjmi_parse_document",
            "sjmi_parser_set_gpu_walk", "sjmi_set_auto_safe", "sjmi_match_brackets",
-           "sjmi_match_brackets_device", "sjmi_stage1_shard_device"]
+           "sjmi_match_brackets_device", "sjmi_stage1_shard_device",
+           "sjmi_parser_ondemand_init", "sjmi_od_skip_child", "sjmi_od_get_boolean", "sjmi_od_get_long", "sjmi_od_get_double",
+           "sjmi_od_get_string", "sjmi_od_get_field_name", "sjmi_od_start_array", "sjmi_od_next_array_element",
+           "sjmi_od_start_object", "sjmi_od_next_object_field", "sjmi_od_move_to_field_value", "sjmi_od_assert_no_more_values",
+           "sjmi_od_depth", "sjmi_od_peek"]
 
 
 def lib():
@@ -172,6 +176,16 @@ def lib():
             f.argtypes = [C.c_void_p] + extra
         L.sjmi_parser_set_gpu_walk.restype = C.c_int
         L.sjmi_parser_set_gpu_walk.argtypes = [C.c_void_p, C.c_int]
+        P = C.c_void_p
+        for name, args in (("sjmi_parser_ondemand_init", [P, P, C.c_uint64, C.c_int]), ("sjmi_od_skip_child", [P, C.c_int]),
+                           ("sjmi_od_get_boolean", [P, C.c_int, C.c_int, P, P]), ("sjmi_od_get_long", [P, C.c_int, C.c_int, P, P]),
+                           ("sjmi_od_get_double", [P, C.c_int, C.c_int, P, P]), ("sjmi_od_get_string", [P, C.c_int, P, P, P]),
+                           ("sjmi_od_get_field_name", [P, P, P]), ("sjmi_od_start_array", [P, C.c_int, P]),
+                           ("sjmi_od_next_array_element", [P, P]), ("sjmi_od_start_object", [P, C.c_int, P]),
+                           ("sjmi_od_next_object_field", [P, P]), ("sjmi_od_move_to_field_value", [P]),
+                           ("sjmi_od_assert_no_more_values", [P]), ("sjmi_od_depth", [P]), ("sjmi_od_peek", [P])):
+            getattr(L, name).restype = C.c_int
+            getattr(L, name).argtypes = args
         L.sjmi_parse_document.restype = C.c_int
         L.sjmi_parse_document.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                           C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -594,6 +608,18 @@ class SimdJsonParser:
         strings = bytes(np.ctypeslib.as_array(sb_p, shape=(max(sb_len.value, 1),))[:sb_len.value])
         return ParsedDocument(tape, strings)
 
+    def ondemand(self, buffer, length=None, skip_table=True):
+        """The on-demand front end (OnDemandJsonIterator.java; csrc/host/ondemand.h): pad + GPU stage 1 (+ the GPU skip
+        table) + iterator.init -> the cursor.  One cursor per parser at a time, invalidated by the next parse / ondemand."""
+        a = np.frombuffer(bytes(buffer), dtype=np.uint8)
+        n = a.size if length is None else length
+        rc = lib().sjmi_parser_ondemand_init(self._h, a.ctypes.data if a.size else None, n, 1 if skip_table else 0)
+        if rc > 0:
+            raise JsonParsingException(rc, lib().sjmi_parser_last_message(self._h).decode("utf-8"))
+        if rc < 0:
+            raise SjmiError("sjmi_parser_ondemand_init failed (rc=%d): %s" % (rc, lib().sjmi_parser_last_message(self._h).decode()))
+        return OnDemandIterator(self)
+
     def root(self):
         """JsonValue of the last parse() (what SimdJsonParser.parse returns in the reference)."""
         v = _Value()
@@ -636,3 +662,81 @@ class SimdJsonParser:
         strings = bytes(view(sb_p, sb_len.value, np.uint8))
         tapes = [alltape[int(to[k]):int(to[k + 1])] if errors[k] == 0 else None for k in range(n)]
         return tapes, strings, errors
+
+
+class OnDemandIterator:
+    """Python face of the sjmi_od_* entry points: the methods of the reference's OnDemandJsonIterator (names as in
+    oracle/ondemand.py, the checker).  Nullable getters return None where the reference returns null."""
+    EMPTY, NULL, NOT_EMPTY = 0, 1, 2
+
+    def __init__(self, parser):
+        self._p = parser
+
+    def _check(self, rc):
+        if rc > 0:
+            raise JsonParsingException(rc, lib().sjmi_parser_last_message(self._p._h).decode("utf-8"))
+        if rc < 0:
+            raise SjmiError("on-demand call failed (rc=%d): %s" % (rc, lib().sjmi_parser_last_message(self._p._h).decode()))
+
+    def depth_value(self):
+        return lib().sjmi_od_depth(self._p._h)
+
+    def peek_byte(self):
+        return lib().sjmi_od_peek(self._p._h)
+
+    def skip_child(self, parent_depth=None):
+        self._check(lib().sjmi_od_skip_child(self._p._h, -1 if parent_depth is None else parent_depth))
+
+    def get_boolean(self, root=False, nullable=True):
+        n, v = C.c_int(0), C.c_int(0)
+        self._check(lib().sjmi_od_get_boolean(self._p._h, int(root), int(nullable), C.addressof(n), C.addressof(v)))
+        return None if n.value else bool(v.value)
+
+    def get_long(self, root=False, nullable=True):
+        n, v = C.c_int(0), C.c_int64(0)
+        self._check(lib().sjmi_od_get_long(self._p._h, int(root), int(nullable), C.addressof(n), C.addressof(v)))
+        return None if n.value else v.value
+
+    def get_double(self, root=False, nullable=True):
+        n, v = C.c_int(0), C.c_double(0)
+        self._check(lib().sjmi_od_get_double(self._p._h, int(root), int(nullable), C.addressof(n), C.addressof(v)))
+        return None if n.value else v.value
+
+    def _bytes(self, ptr, ln):
+        return C.string_at(ptr.value, ln.value) if ln.value else b""
+
+    def get_string(self, root=False):
+        n, ptr, ln = C.c_int(0), C.c_void_p(), C.c_uint64(0)
+        self._check(lib().sjmi_od_get_string(self._p._h, int(root), C.addressof(n), C.addressof(ptr), C.addressof(ln)))
+        return None if n.value else self._bytes(ptr, ln)
+
+    def get_field_name(self):
+        ptr, ln = C.c_void_p(), C.c_uint64(0)
+        self._check(lib().sjmi_od_get_field_name(self._p._h, C.addressof(ptr), C.addressof(ln)))
+        return self._bytes(ptr, ln)
+
+    def start_iterating_array(self, root=False):
+        r = C.c_int(0)
+        self._check(lib().sjmi_od_start_array(self._p._h, int(root), C.addressof(r)))
+        return r.value
+
+    def next_array_element(self):
+        r = C.c_int(0)
+        self._check(lib().sjmi_od_next_array_element(self._p._h, C.addressof(r)))
+        return bool(r.value)
+
+    def start_iterating_object(self, root=False):
+        r = C.c_int(0)
+        self._check(lib().sjmi_od_start_object(self._p._h, int(root), C.addressof(r)))
+        return r.value
+
+    def next_object_field(self):
+        r = C.c_int(0)
+        self._check(lib().sjmi_od_next_object_field(self._p._h, C.addressof(r)))
+        return bool(r.value)
+
+    def move_to_field_value(self):
+        self._check(lib().sjmi_od_move_to_field_value(self._p._h))
+
+    def assert_no_more_json_values(self):
+        self._check(lib().sjmi_od_assert_no_more_values(self._p._h))

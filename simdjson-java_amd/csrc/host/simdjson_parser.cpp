@@ -2,6 +2,7 @@
 // C ABI, then the reference's sequential stage 2 (JsonIterator + TapeBuilder + Tape + number grammar)
 // re-implemented in C++.  Citations: /root/reference/src/main/java/org/simdjson/<file>:<lines>.
 #include "simdjson_parser.h"
+#include "ondemand.h"
 #include "../sj_number.h"
 
 #include <stdio.h>
@@ -269,6 +270,38 @@ JsonValue SimdJsonParser::parse(const uint8_t* buffer, size_t len) {
     walker_.setStringBuffer(stringBuffer_.data());
     walker_.walkDocument(len);
     return JsonValue(&walker_.tape(), 1, stringBuffer_.data());  // TapeBuilder.createJsonValue :215-217
+}
+
+// The head of the schema-based parse (SimdJsonParser.java:31-33: padIfNeeded, reset, stage1; SchemaBasedJsonIterator.java
+// :29-41: iterator.init): stage 1 alone on the GPU -- the on-demand cursor parses the strings it is asked for itself -- and,
+// on request, the skip table of the document's brackets.
+void SimdJsonParser::onDemandInit(const uint8_t* buffer, size_t len, bool withSkipTable) {
+    onDemandReady_ = false;
+    if (len > (size_t)capacity_) throw fail(E_CAPACITY);
+    memcpy(paddedBuffer_.data(), buffer, len);
+    memset(paddedBuffer_.data() + len, 0, PADDING);
+    walker_.bitIndexes().reset();
+    uint64_t count = 0;
+    uint32_t status = 0;
+    int rc = sjmi_stage1(ctx_, paddedBuffer_.data(), len, indexes_.data(), indexes_.size(), &count, &status);
+    if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_stage1: ") + sjmi_last_error(ctx_));
+    walker_.bitIndexes().setWriteIdx((size_t)count);
+    if (status & SJMI_ST_UTF8) throw fail(E_UTF8);
+    if (status & SJMI_ST_UNCLOSED) throw fail(E_UNCLOSED_STRING);
+    if (status & SJMI_ST_UNESCAPED) throw fail(E_UNESCAPED_CHARS);
+    if (!onDemand_) onDemand_.reset(new OnDemandJsonIterator(&walker_.bitIndexes()));
+    onDemand_->setSkipTable(nullptr, nullptr);
+    if (withSkipTable && count) {
+        if (skipUp_.size() < count + 1) {
+            skipUp_.resize((size_t)count + 1);
+            skipMatch_.resize((size_t)count + 1);
+        }
+        rc = sjmi_match_brackets(ctx_, skipUp_.data(), skipMatch_.data(), skipUp_.size());
+        if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_match_brackets: ") + sjmi_last_error(ctx_));
+        onDemand_->setSkipTable(skipUp_.data(), skipMatch_.data());
+    }
+    onDemand_->init(paddedBuffer_.data(), len);
+    onDemandReady_ = true;
 }
 
 // Batched parse.  The batch is cut into up to eight sub-batches of whole documents (about 8 MB or more each); two feeder threads, each with its
@@ -750,6 +783,25 @@ struct sjmi_parser {
     std::string msg;
 };
 
+// (the on-demand entry points below: one try / catch for all of them)
+namespace {
+template <class F>
+int odCall(sjmi_parser* h, F&& f) {
+    if (!h || !h->p->onDemandReady()) return SJMI_ERR_ARG;
+    h->msg.clear();
+    try {
+        f(h->p->onDemand());
+        return 0;
+    } catch (const org_simdjson::JsonParsingException& e) {
+        h->msg = e.what();
+        return e.code();
+    } catch (const std::exception& e) {
+        h->msg = e.what();
+        return SJMI_ERR_HIP;
+    }
+}
+}  // namespace
+
 extern "C" {
 
 int sjmi_parser_create(sjmi_parser** out, int capacity, int max_depth, int device) {
@@ -953,6 +1005,96 @@ int sjmi_value_next(const sjmi_parser* h, const sjmi_value* container, const sjm
     out->doc = container->doc;
     out->tape_idx = nx;
     return SJMI_OK;
+}
+
+
+// ---- the on-demand front end over the C ABI (ondemand.h) ----
+
+int sjmi_parser_ondemand_init(sjmi_parser* h, const uint8_t* buf, uint64_t len, int with_skip_table) {
+    if (!h || (!buf && len)) return SJMI_ERR_ARG;
+    h->msg.clear();
+    try {
+        h->p->onDemandInit(buf, (size_t)len, with_skip_table != 0);
+        return 0;
+    } catch (const org_simdjson::JsonParsingException& e) {
+        h->msg = e.what();
+        return e.code();
+    } catch (const std::exception& e) {
+        h->msg = e.what();
+        return SJMI_ERR_HIP;
+    }
+}
+int sjmi_od_skip_child(sjmi_parser* h, int parent_depth) {
+    return odCall(h, [&](org_simdjson::OnDemandJsonIterator& it) { if (parent_depth < 0) it.skipChild(); else it.skipChild(parent_depth); });
+}
+int sjmi_od_get_boolean(sjmi_parser* h, int root, int nullable, int* is_null, int* value) {
+    if (!is_null || !value) return SJMI_ERR_ARG;
+    return odCall(h, [&](org_simdjson::OnDemandJsonIterator& it) {
+        bool n = false;
+        *value = it.getBoolean(root != 0, nullable != 0, &n) ? 1 : 0;
+        *is_null = n;
+    });
+}
+int sjmi_od_get_long(sjmi_parser* h, int root, int nullable, int* is_null, int64_t* value) {
+    if (!is_null || !value) return SJMI_ERR_ARG;
+    return odCall(h, [&](org_simdjson::OnDemandJsonIterator& it) {
+        bool n = false;
+        *value = it.getLong(root != 0, nullable != 0, &n);
+        *is_null = n;
+    });
+}
+int sjmi_od_get_double(sjmi_parser* h, int root, int nullable, int* is_null, double* value) {
+    if (!is_null || !value) return SJMI_ERR_ARG;
+    return odCall(h, [&](org_simdjson::OnDemandJsonIterator& it) {
+        bool n = false;
+        *value = it.getDouble(root != 0, nullable != 0, &n);
+        *is_null = n;
+    });
+}
+int sjmi_od_get_string(sjmi_parser* h, int root, int* is_null, const uint8_t** bytes, uint64_t* len) {
+    if (!is_null || !bytes || !len) return SJMI_ERR_ARG;
+    return odCall(h, [&](org_simdjson::OnDemandJsonIterator& it) {
+        bool n = false;
+        const std::vector<uint8_t>& s = it.getString(root != 0, &n);
+        *is_null = n;
+        *bytes = s.data();
+        *len = s.size();
+    });
+}
+int sjmi_od_get_field_name(sjmi_parser* h, const uint8_t** bytes, uint64_t* len) {
+    if (!bytes || !len) return SJMI_ERR_ARG;
+    return odCall(h, [&](org_simdjson::OnDemandJsonIterator& it) {
+        const std::vector<uint8_t>& s = it.getFieldName();
+        *bytes = s.data();
+        *len = s.size();
+    });
+}
+int sjmi_od_start_array(sjmi_parser* h, int root, int* result) {
+    if (!result) return SJMI_ERR_ARG;
+    return odCall(h, [&](org_simdjson::OnDemandJsonIterator& it) { *result = (int)it.startIteratingArray(root != 0); });
+}
+int sjmi_od_next_array_element(sjmi_parser* h, int* has_next) {
+    if (!has_next) return SJMI_ERR_ARG;
+    return odCall(h, [&](org_simdjson::OnDemandJsonIterator& it) { *has_next = it.nextArrayElement() ? 1 : 0; });
+}
+int sjmi_od_start_object(sjmi_parser* h, int root, int* result) {
+    if (!result) return SJMI_ERR_ARG;
+    return odCall(h, [&](org_simdjson::OnDemandJsonIterator& it) { *result = (int)it.startIteratingObject(root != 0); });
+}
+int sjmi_od_next_object_field(sjmi_parser* h, int* has_next) {
+    if (!has_next) return SJMI_ERR_ARG;
+    return odCall(h, [&](org_simdjson::OnDemandJsonIterator& it) { *has_next = it.nextObjectField() ? 1 : 0; });
+}
+int sjmi_od_move_to_field_value(sjmi_parser* h) {
+    return odCall(h, [&](org_simdjson::OnDemandJsonIterator& it) { it.moveToFieldValue(); });
+}
+int sjmi_od_assert_no_more_values(sjmi_parser* h) {
+    return odCall(h, [&](org_simdjson::OnDemandJsonIterator& it) { it.assertNoMoreJsonValues(); });
+}
+int sjmi_od_depth(const sjmi_parser* h) { return (h && h->p->onDemandReady()) ? h->p->onDemand().getDepth() : SJMI_ERR_ARG; }
+int sjmi_od_peek(const sjmi_parser* h) {
+    if (!h || !h->p->onDemandReady()) return SJMI_ERR_ARG;
+    return h->p->bitIndexes().isEnd() || h->p->bitIndexes().isPastEnd() ? SJMI_OD_END : (int)h->p->onDemand().peekByte();
 }
 
 }  // extern "C"

@@ -49,8 +49,12 @@ public:
     void advance() { ++readIdx_; }                                                    // :47-49
     uint32_t getAndAdvance() { return at(readIdx_++); }                               // :51-54
     uint32_t getLast() const { return indexes_[writeIdx_ - 1]; }                      // :56-58
+    uint32_t advanceAndGet() { return at(++readIdx_); }                               // :60-63
     uint32_t peek() const { return at(readIdx_); }                                    // :65-68
+    bool hasNext() const { return writeIdx_ > readIdx_; }                             // :70-72
     bool isEnd() const { return writeIdx_ == readIdx_; }                              // :74-76
+    bool isPastEnd() const { return readIdx_ > writeIdx_; }                           // :78-80
+    void setReadIdx(size_t r) { readIdx_ = r; }   // the on-demand cursor's table-driven skipChild (ondemand.h)
     bool isEmpty() const { return writeIdx_ == base_; }
     size_t readIdx() const { return readIdx_; }
     size_t writeIdx() const { return writeIdx_; }
@@ -191,6 +195,7 @@ private:
 };
 
 class WorkerPool;  // simdjson_parser.cpp: the host threads of parseBatch
+class OnDemandJsonIterator;  // ondemand.h
 
 // SimdJsonParser.java:3-59
 class SimdJsonParser {
@@ -218,6 +223,12 @@ public:
     size_t batchTapeLen() const { return batchTapeLen_; }
     const std::vector<uint64_t>& batchTapeOffsets() const { return batchTapeOffsets_; }
     const std::vector<int32_t>& batchErrors() const { return batchErrors_; }
+
+    // The on-demand front end (ondemand.h): pad + GPU stage 1 (+ the GPU skip table) + iterator.init, i.e. the head of
+    // SimdJsonParser.parse(byte[], int, Class<T>) (SimdJsonParser.java:31-33 / SchemaBasedJsonIterator.java:29-41)
+    void onDemandInit(const uint8_t* buffer, size_t len, bool withSkipTable);
+    OnDemandJsonIterator& onDemand() { return *onDemand_; }
+    bool onDemandReady() const { return onDemandReady_; }
 
     const Tape& tape() const { return walker_.tape(); }
     const std::vector<uint8_t>& stringBuffer() const { return stringBuffer_; }
@@ -256,6 +267,9 @@ private:
     std::vector<uint32_t> docStatus_;
     void* pinned_[3] = {nullptr, nullptr, nullptr};  // page-locked parser buffers (sjmi_host_register)
     std::vector<int32_t> batchErrors_;
+    std::unique_ptr<OnDemandJsonIterator> onDemand_;
+    std::vector<uint32_t> skipUp_, skipMatch_;
+    bool onDemandReady_ = false;
 };
 
 }  // namespace org_simdjson

@@ -169,3 +169,86 @@ def test_nesting_steps_and_unbalanced_documents(ctx):
     doc = ("[" * 70 + "1" + "]" * 70).encode()
     idx, up, match = _tables(ctx, doc)
     assert int(up[69]) == UNKNOWN and int(up[30]) == 29 and int(match[0]) == len(idx) - 1
+
+
+# ---- the on-demand cursor itself (csrc/host/ondemand.h over the C ABI: sjmi_parser_ondemand_init + sjmi_od_*) ----
+from oracle import ondemand as OD  # noqa: E402
+from tests.golden.ondemand_vectors import VECTORS  # noqa: E402
+from tests.ondemand_common import OracleIterator, fuzz_walk, run_oracle, walk_document  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def parser():
+    import simdjson_java_amd as S
+    p = S.SimdJsonParser(capacity=8 * 1024 * 1024)
+    yield p
+    p.close()
+
+
+def _run_parser(parser, doc, length, schema, table):
+    import simdjson_java_amd as S
+    try:
+        return "ok", walk_document(parser.ondemand(doc, length, skip_table=table), schema)
+    except S.JsonParsingException as e:
+        return "error", str(e)
+
+
+@pytest.mark.parametrize("table", [False, True], ids=["scan", "skip-table"])
+def test_reference_schema_vectors_through_the_c_abi(parser, table):
+    """The 200 inputs of tests/golden/ondemand_vectors.py (values / messages asserted by the reference's own
+    *SchemaBasedParsingTest classes) through GPU stage 1 (+ the GPU skip table) and the C ABI cursor."""
+    for (j, length, schema, value, message) in VECTORS:
+        doc = j.encode("utf-8")
+        n = len(doc) if length is None else length
+        kind, got = _run_parser(parser, doc, n, schema, table)
+        if message is not None:
+            assert (kind, got) == ("error", message), (j, schema, got)
+        else:
+            assert kind == "ok" and got == value, (j, schema, got)
+
+
+@pytest.mark.parametrize("table", [False, True], ids=["scan", "skip-table"])
+def test_parse_and_select_twitter_on_demand(parser, table):
+    """BenchmarkCorrectnessTest.java:23-55 (schemaBasedSimdJsonParser): the screen names of the users with default_profile,
+    selected on demand -- 86 of them, the same set the full parse + JsonValue walk finds (tests/test_gpu_parse.py)."""
+    import json
+    doc = load_fixture("twitter.json")
+    schema = ("object", {"statuses": ("array", ("object", {"user": ("object", {"default_profile": "boolean", "screen_name": "String"})}))})
+    kind, got = _run_parser(parser, doc, len(doc), schema, table)
+    assert kind == "ok"
+    names = {u["user"]["screen_name"] for u in got["statuses"] if u["user"]["default_profile"]}
+    assert len(names) == 86
+    assert names == {s["user"]["screen_name"].encode() for s in json.loads(doc)["statuses"] if s["user"]["default_profile"]}
+    idx, _ = O.stage1(doc)
+    assert run_oracle(doc, len(doc), idx, schema) == (kind, got)
+
+
+@pytest.mark.parametrize("table", [False, True], ids=["scan", "skip-table"])
+def test_on_demand_fuzz_traces(parser, table):
+    """Random (often broken) documents, schema-less walk with seeded skips / wrong-typed reads / early exits: the trace of the
+    C ABI cursor (GPU indexes, GPU skip table) equals the trace of the restated reference, exception message included."""
+    import simdjson_java_amd as S
+    from tests.test_host_ondemand import _random_doc
+    rng = random.Random(77)
+    walked = 0
+    for _ in range(1500):
+        doc = _random_doc(rng).encode("utf-8")
+        idx, st = O.stage1(doc)
+        seed = rng.getrandbits(32)
+        want = []
+        try:
+            if st:
+                raise OD.JsonParsingException(O.error_message(1 if st & 1 else (2 if st & 2 else 3)))
+            fuzz_walk(OracleIterator(doc, len(doc), idx), random.Random(seed), want)
+            want.append("done")
+        except OD.JsonParsingException as e:
+            want.append(("raised", str(e)))
+        got = []
+        try:
+            fuzz_walk(parser.ondemand(doc, skip_table=table), random.Random(seed), got)
+            got.append("done")
+        except S.JsonParsingException as e:
+            got.append(("raised", str(e)))
+        assert got == want, (doc, seed, got[-3:], want[-3:])
+        walked += 1
+    assert walked == 1500
