@@ -369,6 +369,19 @@ def bench_single(args):
         # ---- the drop-in call itself: SimdJsonParser.parse(byte[], len) of ONE twitter.json from a host buffer (H2D, all
         #      stages, outputs back on the host), with the reference's stage 2 on the host or all three stages on the GPU ----
         extra["parse_twitter_json"] = parse_single_document(S, doc)
+    if "select" in sections:
+        # ---- the reference's headline benchmark shape (jmh ParseAndSelectBenchmark / SchemaBasedParseAndSelectBenchmark: the
+        #      screen names of twitter.json's users with default_profile), user code in C++ against the public C ABI ----
+        import ondemand_bench
+        sel = ondemand_bench.measure(doc)
+        assert all(v["selected"] == 86 for v in sel.values()), sel  # BenchmarkCorrectnessTest.java:23-55
+        extra["parse_and_select_twitter_json"] = {
+            "config": "twitter.json from a host buffer -> the 86 screen names of users with default_profile, per call: H2D, GPU "
+                      "stage 1 (+ string records and host stage 2 for the full parse; + k_coop_match and its D2H for the skip table), "
+                      "selection on the host through sjmi_value_* / sjmi_od_* (tools/ondemand_bench.cpp)",
+            "unit": "ms per parse-and-select", "value": sel["on_demand_scan"]["ms"], **sel,
+            "reference_readme": "README.md, 512-bit vectors, Xeon Platinum 8375C, one thread: SchemaBasedParseAndSelectBenchmark 3164 ops/s, "
+                                "ParseAndSelectBenchmark 1842 ops/s (other hardware; no JVM here)"}
     line["extra"] = extra
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(doc)
@@ -540,8 +553,8 @@ def main():
     ap.add_argument("--pool", type=int, default=4000, help="unique documents of the configs[3] batch")
     ap.add_argument("--batch-steps", type=int, default=10, help="N=1: timed steps of the configs[3] extra")
     ap.add_argument("--no-extras", action="store_true", help="N=1: only the primary workload")
-    ap.add_argument("--sections", default="x1024,unescape,synth,batch,parse",
-                    help="N=1: which extras to run (comma list of x1024, unescape, synth, batch, parse); the profiling passes run one each")
+    ap.add_argument("--sections", default="x1024,unescape,synth,batch,parse,select",
+                    help="N=1: which extras to run (comma list of x1024, unescape, synth, batch, parse, select); the profiling passes run one each")
     ap.add_argument("--skip-main-timing", action="store_true",
                     help="N=1, profiling passes of an extra only: check the primary workload once, do not time it")
     ap.add_argument("--no-cpu-baseline", action="store_true")

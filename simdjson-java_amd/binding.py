@@ -608,9 +608,10 @@ class SimdJsonParser:
         strings = bytes(np.ctypeslib.as_array(sb_p, shape=(max(sb_len.value, 1),))[:sb_len.value])
         return ParsedDocument(tape, strings)
 
-    def ondemand(self, buffer, length=None, skip_table=True):
+    def ondemand(self, buffer, length=None, skip_table=False):
         """The on-demand front end (OnDemandJsonIterator.java; csrc/host/ondemand.h): pad + GPU stage 1 (+ the GPU skip
-        table) + iterator.init -> the cursor.  One cursor per parser at a time, invalidated by the next parse / ondemand."""
+        table, worth its download only when large subtrees of a large document are skipped) + iterator.init -> the cursor.
+        One cursor per parser at a time, invalidated by the next parse / ondemand."""
         a = np.frombuffer(bytes(buffer), dtype=np.uint8)
         n = a.size if length is None else length
         rc = lib().sjmi_parser_ondemand_init(self._h, a.ctypes.data if a.size else None, n, 1 if skip_table else 0)

@@ -905,8 +905,11 @@ int sjmi_match_brackets(sjmi_ctx* c, uint32_t* up, uint32_t* match, uint64_t cap
     const unsigned long long io[2] = {0ull, count};
     unsigned long long* d_io = (unsigned long long*)c->d_single + 2;
     if (fail(c, "H2D", hipMemcpyAsync(d_io, io, sizeof io, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
-    const int rc = sjmi_match_brackets_device(c, c->d_in, c->d_idx, d_io, 1, c->d_sb, c->d_tape, c->stream);
-    if (rc != SJMI_OK) return rc;
+    // (a large document: chunk-parallel, with the chunk states in the walk workspace)
+    if (!grow(c, &c->d_ws_walk, &c->ws_walk_bytes, sjmi::coop_chunk_workspace_bytes(count), "hipMalloc(ws_walk)")) return SJMI_ERR_HIP;
+    if (fail(c, "match launch", sjmi::coop_match_launch(c->d_in, 1, c->d_idx, d_io, (uint32_t*)c->d_sb, (uint32_t*)c->d_tape, c->stream,
+                                                        c->d_ws_walk, count)))
+        return SJMI_ERR_HIP;
     if (count && (fail(c, "D2H(up)", hipMemcpyAsync(up, c->d_sb, count * 4, hipMemcpyDeviceToHost, c->stream)) ||
                   fail(c, "D2H(match)", hipMemcpyAsync(match, c->d_tape, count * 4, hipMemcpyDeviceToHost, c->stream))))
         return SJMI_ERR_HIP;
