@@ -312,7 +312,7 @@ int sjmi_parser_parse_batch(sjmi_parser* p, const uint8_t* buf, uint64_t total_l
  * containers by k - 1 + 1 table reads instead of scanning every structural in between (:47-81).  The calls below mirror
  * the iterator's methods one to one (root != 0: the Root form; nullable == 0: the NonNull form; *is_null: the method
  * returned null); each returns 0, or > 0 = the SJMI_E_* code of the JsonParsingException the reference throws there
- * (exact text: sjmi_parser_last_message), or < 0.  Not built: the byte / short / int / float / char getters. */
+ * (exact text: sjmi_parser_last_message), or < 0.  Not built: the float / char getters. */
 #define SJMI_E_OD_NOT_ENOUGH_CLOSE 40    /* "Not enough close braces."                                   :80 */
 #define SJMI_E_OD_EXPECTED_CHAR 41       /* "Expected 'x' but got: 'y'."                                 :662 */
 #define SJMI_E_OD_EXPECTED_CHAR_END 42   /* "Expected 'x' but reached end of buffer."                    :660 */
@@ -320,6 +320,9 @@ int sjmi_parser_parse_batch(sjmi_parser* p, const uint8_t* buf, uint64_t total_l
 #define SJMI_E_OD_BOOLEAN_OR_NULL 44     /* "... Expected: 'true', 'false' or 'null'."                   :104,:167 */
 #define SJMI_E_OD_STRING_OR_NULL 45      /* "Invalid value starting at N. Expected either string or 'null'."  :455,:470 */
 #define SJMI_E_OD_FLOAT_PART_MISSING 46  /* "Invalid floating-point number. Fraction or exponent part is missing."  NumberParser.java:303 */
+#define SJMI_E_OD_BYTE_RANGE 47          /* "Number value is out of byte range ([-128, 127])."            NumberParser.java:97 */
+#define SJMI_E_OD_SHORT_RANGE 48         /* "... out of short range ([-32768, 32767])."                   :136 */
+#define SJMI_E_OD_INT_RANGE 49           /* "... out of int range ([-2147483648, 2147483647])."           :175 */
 #define SJMI_OD_EMPTY 0                  /* IteratorResult :672-674 */
 #define SJMI_OD_NULL 1
 #define SJMI_OD_NOT_EMPTY 2
@@ -327,6 +330,8 @@ int sjmi_parser_ondemand_init(sjmi_parser* p, const uint8_t* buf, uint64_t len, 
 int sjmi_od_skip_child(sjmi_parser* p, int parent_depth);             /* skipChild(parentDepth) :47-81; < 0: skipChild() :43-45 */
 int sjmi_od_get_boolean(sjmi_parser* p, int root, int nullable, int* is_null, int* value);     /* :83-109,:147-171 */
 int sjmi_od_get_long(sjmi_parser* p, int root, int nullable, int* is_null, int64_t* value);    /* :321-358 */
+/* the Byte :204-241 / Short :243-280 / Int :282-319 getters: bits = 8, 16, 32 (64 = sjmi_od_get_long) */
+int sjmi_od_get_integral(sjmi_parser* p, int bits, int root, int nullable, int* is_null, int64_t* value);
 int sjmi_od_get_double(sjmi_parser* p, int root, int nullable, int* is_null, double* value);   /* :383-428 */
 /* getRootString / getString :446-472, getFieldName :646-652: the unescaped bytes, valid until the next of these calls */
 int sjmi_od_get_string(sjmi_parser* p, int root, int* is_null, const uint8_t** bytes, uint64_t* len);

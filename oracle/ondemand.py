@@ -3,8 +3,8 @@ org.simdjson.OnDemandJsonIterator (/root/reference/src/main/java/org/simdjson/On
 pieces of NumberParser (NumberParser.java:199-310), StringParser (StringParser.java:25-161) and BitIndexes
 (BitIndexes.java:47-101) it calls -- method for method, message for message.  Only tests/ may import it: it is the checker
 for csrc/host/ondemand.h (the product's C++ mirror, which adds the GPU skip table).  Pure-Python loops: small documents.
-Pinned by tests/test_ondemand_oracle.py against the messages and values the reference's own schema-based tests assert.
-Not restated (as in the product): the byte / short / int / float / char getters."""
+Pinned by tests/test_host_ondemand.py (tests/golden/ondemand_vectors.py: what the reference's own schema-based tests assert).
+Not restated (as in the product): the float / char getters."""
 import struct
 
 
@@ -122,7 +122,8 @@ class OnDemandJsonIterator:
         # only looked at while `currentIdx < len` (NumberParser.java:219,:299)
         return self.buffer[q] if q < self.len else 0x20
 
-    def get_long(self, root=False, nullable=True):
+    def get_long(self, root=False, nullable=True, bits=64):
+        """bits = 8 / 16 / 32: the Byte :204-241, Short :243-280, Int :282-319 getters"""
         self.depth -= 1
         idx = self._get_and_advance()
         if nullable and self.buffer[idx] == ord("n"):
@@ -130,7 +131,7 @@ class OnDemandJsonIterator:
             if root:
                 self.assert_no_more_json_values()
             return None
-        value = self._parse_long(idx)
+        value = self._parse_long(idx, bits)
         if root:
             self.assert_no_more_json_values()
         return value
@@ -148,7 +149,7 @@ class OnDemandJsonIterator:
             self.assert_no_more_json_values()
         return value
 
-    def _parse_long(self, offset):  # NumberParser.parseLong :199-224
+    def _parse_long(self, offset, bits=64):  # NumberParser.parseByte :76-100, parseShort :115-139, parseInt :154-178, parseLong :199-224
         negative = self._byte(offset) == ord("-")
         cur = offset + 1 if negative else offset
         start = cur
@@ -163,8 +164,13 @@ class OnDemandJsonIterator:
             raise JsonParsingException("Invalid number. Leading zeroes are not allowed.")
         if self._byte(cur) not in _STRUCT_OR_WS:
             raise JsonParsingException("Number has to be followed by a structural character or whitespace.")
-        if count > 19 or (count == 19 and not (negative and digits == 1 << 63) and digits >= 1 << 63):  # isOutOfLongRange :313-328
-            raise JsonParsingException("Number value is out of long range ([-9223372036854775808, 9223372036854775807]).")
+        if bits == 64:
+            if count > 19 or (count == 19 and not (negative and digits == 1 << 63) and digits >= 1 << 63):  # isOutOfLongRange :313-328
+                raise JsonParsingException("Number value is out of long range ([-9223372036854775808, 9223372036854775807]).")
+        else:  # isOutOfByteRange :102-113, isOutOfShortRange :141-152, isOutOfIntRange :180-191
+            max_digits, max_abs = {8: 3, 16: 5, 32: 10}[bits], 1 << (bits - 1)
+            if count > max_digits or (count == max_digits and digits > (max_abs if negative else max_abs - 1)):
+                raise JsonParsingException("Number value is out of %s range ([%d, %d])." % ({8: "byte", 16: "short", 32: "int"}[bits], -max_abs, max_abs - 1))
         return -digits if negative else digits
 
     def _parse_double(self, offset):  # NumberParser.parseDouble :268-310

@@ -6,9 +6,9 @@
 // csrc/coop_walk.hip (k_coop_match: up[i] = the opening bracket structural i lies in, match[i] = the partner of a
 // bracket), which turns skipChild's bracket-counting scan (:47-81) -- the bulk of the work when a schema wants a few
 // fields of a large document -- into k - 1 climbs through up[] and one jump through match[].
-// Built: booleans, long, double, String (and their Root / NonNull forms), null handling, arrays, objects, field names,
-// skipChild, assertNoMoreJsonValues.  Not built: the byte / short / int / float / char variants (:204-320,:360-382,
-// :430-444,:474-520: the same cursor moves with narrower range checks) and the reflection-driven schema mapping itself
+// Built: booleans, byte / short / int / long, double, String (and their Root / NonNull forms), null handling, arrays,
+// objects, field names, skipChild, assertNoMoreJsonValues.  Not built: the float and char getters (:360-382,:430-444,
+// :474-520; FloatParser is a binary32 Eisel-Lemire of its own) and the reflection-driven schema mapping itself
 // (SchemaBasedJsonIterator, ClassResolver), which is Java-specific.
 #pragma once
 #include <locale.h>
@@ -32,7 +32,10 @@ enum {  // numbering of include/sjmi.h SJMI_E_OD_*
     E_OD_BOOLEAN = 43,             // "Unrecognized boolean value. Expected: 'true' or 'false'."          :88,:152
     E_OD_BOOLEAN_OR_NULL = 44,     // "Unrecognized boolean value. Expected: 'true', 'false' or 'null'."  :104,:167
     E_OD_STRING_OR_NULL = 45,      // "Invalid value starting at N. Expected either string or 'null'."    :455,:470
-    E_OD_FLOAT_PART_MISSING = 46   // "Invalid floating-point number. Fraction or exponent part is missing."  NumberParser.java:303
+    E_OD_FLOAT_PART_MISSING = 46,  // "Invalid floating-point number. Fraction or exponent part is missing."  NumberParser.java:303
+    E_OD_BYTE_RANGE = 47,          // "Number value is out of byte range ([-128, 127])."                  NumberParser.java:97
+    E_OD_SHORT_RANGE = 48,         // "Number value is out of short range ([-32768, 32767])."             :136
+    E_OD_INT_RANGE = 49            // "Number value is out of int range ([-2147483648, 2147483647])."     :175
 };
 
 class OnDemandJsonIterator {
@@ -112,8 +115,9 @@ public:
         return result;
     }
 
-    // getRootNonNullLong :321-328, getRootLong :330-342, getNonNullLong :344-348, getLong :350-358
-    int64_t getLong(bool root, bool nullable, bool* isNull) {
+    // getRootNonNullLong :321-328, getRootLong :330-342, getNonNullLong :344-348, getLong :350-358; bits = 8 / 16 / 32: the
+    // Byte :204-241, Short :243-280 and Int :282-319 forms (the same cursor moves, narrower range check)
+    int64_t getLong(bool root, bool nullable, bool* isNull, int bits = 64) {
         depth_--;
         const uint32_t idx = indexer_->getAndAdvance();
         *isNull = false;
@@ -123,7 +127,7 @@ public:
             *isNull = true;
             return 0;
         }
-        const int64_t v = parseLong(idx);
+        const int64_t v = parseLong(idx, bits);
         if (root) assertNoMoreJsonValues();
         return v;
     }
@@ -219,6 +223,9 @@ private:
         case E_OD_BOOLEAN_OR_NULL: m = "Unrecognized boolean value. Expected: 'true', 'false' or 'null'."; break;
         case E_OD_STRING_OR_NULL: m = "Invalid value starting at " + std::to_string(pos) + ". Expected either string or 'null'."; break;
         case E_OD_FLOAT_PART_MISSING: m = "Invalid floating-point number. Fraction or exponent part is missing."; break;
+        case E_OD_BYTE_RANGE: m = "Number value is out of byte range ([-128, 127])."; break;
+        case E_OD_SHORT_RANGE: m = "Number value is out of short range ([-32768, 32767])."; break;
+        case E_OD_INT_RANGE: m = "Number value is out of int range ([-2147483648, 2147483647])."; break;
         default: {
             m = errorMessage(code);
             const size_t at = m.find("%d");
@@ -288,7 +295,7 @@ private:
     // `currentIdx < len` before the byte behind any other number (NumberParser.java:219,:299)
     uint32_t byteAt(uint32_t q) const { return q < len_ ? buffer_[q] : 0x20u; }
 
-    int64_t parseLong(uint32_t offset) const {                                    // NumberParser.parseLong :199-224
+    int64_t parseLong(uint32_t offset, int bits) const {                          // NumberParser.parseByte / Short / Int / Long :76-224
         const bool negative = byteAt(offset) == '-';
         uint32_t cur = negative ? offset + 1 : offset;
         const uint32_t digitsStart = cur;
@@ -298,7 +305,14 @@ private:
         if (digitCount == 0) throw error(22 /* E_NUM_MINUS */);
         if (byteAt(digitsStart) == '0' && digitCount > 1) throw error(23 /* E_NUM_LEADING_ZERO */);
         if (!structuralOrWs((uint8_t)byteAt(cur))) throw error(26 /* E_NUM_FOLLOWED */);
-        if (sjmi::sj_out_of_long_range(negative, digits, digitCount)) throw error(27 /* E_NUM_LONG_RANGE */);
+        if (bits == 64) {
+            if (sjmi::sj_out_of_long_range(negative, digits, digitCount)) throw error(27 /* E_NUM_LONG_RANGE */);
+        } else {  // isOutOfByteRange :102-113, isOutOfShortRange :141-152, isOutOfIntRange :180-191
+            const uint32_t maxDigits = bits == 8 ? 3u : (bits == 16 ? 5u : 10u);
+            const unsigned long long maxAbs = 1ull << (bits - 1);
+            const bool out = digitCount > maxDigits || (digitCount == maxDigits && (negative ? digits > maxAbs : digits > maxAbs - 1));
+            if (out) throw error(bits == 8 ? E_OD_BYTE_RANGE : (bits == 16 ? E_OD_SHORT_RANGE : E_OD_INT_RANGE));
+        }
         return (int64_t)(negative ? (~digits + 1) : digits);
     }
 

@@ -1043,6 +1043,14 @@ int sjmi_od_get_long(sjmi_parser* h, int root, int nullable, int* is_null, int64
         *is_null = n;
     });
 }
+int sjmi_od_get_integral(sjmi_parser* h, int bits, int root, int nullable, int* is_null, int64_t* value) {
+    if (!is_null || !value || (bits != 8 && bits != 16 && bits != 32 && bits != 64)) return SJMI_ERR_ARG;
+    return odCall(h, [&](org_simdjson::OnDemandJsonIterator& it) {
+        bool n = false;
+        *value = it.getLong(root != 0, nullable != 0, &n, bits);
+        *is_null = n;
+    });
+}
 int sjmi_od_get_double(sjmi_parser* h, int root, int nullable, int* is_null, double* value) {
     if (!is_null || !value) return SJMI_ERR_ARG;
     return odCall(h, [&](org_simdjson::OnDemandJsonIterator& it) {

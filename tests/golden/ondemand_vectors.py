@@ -46,6 +46,18 @@ for n in ("9223372036854775808", "9999999999999999999", "10000000000000000000", 
           "-10000000000000000000"):
     add(n, "long", message=LONG_RANGE)                    # :342-364 outOfPrimitiveLongRange
     add(n, "Long", message=LONG_RANGE)
+for t, name, lo, hi in (("byte", "byte", -128, 127), ("short", "short", -32768, 32767), ("int", "int", -2147483648, 2147483647)):
+    box = {"byte": "Byte", "short": "Short", "int": "Integer"}[t]
+    for n in ("-9223372036854775809", str(lo - 1), str(hi + 1), "9223372036854775808"):
+        add(n, t, message="Number value is out of %s range ([%d, %d])." % (name, lo, hi))    # :279-341 outOfPrimitive<T>Range
+        add(n, box, message="Number value is out of %s range ([%d, %d])." % (name, lo, hi))
+    add(str(lo), t, lo)
+    add(str(hi), box, hi)
+    add("null", box, None)                                # :69-81
+    add("null", t, message=MINUS)                         # :83-96
+    add("[%d, 1, %d, null]" % (lo, hi), A(box), [lo, 1, hi, None])
+    add("-0", t, 0)                                       # :679-719 minusZeroIsTreatedAs<T>Zero
+    add("1.0", t, message=FOLLOWED)                       # :466-489
 for n in ("01", "-01", "000", "-000"):
     add(n, "long", message="Invalid number. Leading zeroes are not allowed.")  # :366-389
 for n in ("-a123", "--123", "-+123"):

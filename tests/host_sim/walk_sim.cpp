@@ -85,7 +85,7 @@ int sim_od_call(void* h, int op, int a, int b, int64_t* out, double* dout, const
         switch (op) {
         case 0: if (a < 0) s->it.skipChild(); else s->it.skipChild(a); break;
         case 1: *out = s->it.getBoolean(a != 0, b != 0, &isNull) ? 1 : 0; if (isNull) *out = -1; break;
-        case 2: *out = s->it.getLong(a != 0, b != 0, &isNull); if (isNull) *nbytes = 1; break;
+        case 2: *out = s->it.getLong((a & 1) != 0, b != 0, &isNull, (a >> 8) ? (a >> 8) : 64); if (isNull) *nbytes = 1; break;  // a = root | bits << 8
         case 3: *dout = s->it.getDouble(a != 0, b != 0, &isNull); if (isNull) *nbytes = 1; break;
         case 4: { const std::vector<uint8_t>& v = s->it.getString(a != 0, &isNull); *bytes = v.data(); *nbytes = v.size(); if (isNull) *out = -1; break; }
         case 5: { const std::vector<uint8_t>& v = s->it.getFieldName(); *bytes = v.data(); *nbytes = v.size(); break; }

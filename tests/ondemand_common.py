@@ -3,11 +3,13 @@ SchemaBasedJsonIterator makes (SchemaBasedJsonIterator.java:29-132,:229-272,:481
 method names of oracle/ondemand.py, and a schema-less fuzz driver that walks a document by peeking (with seeded random
 skips, wrong-typed reads and early exits) and records every result and exception message as a trace.
 
-Schemas: "boolean" "long" "double" (primitive: the NonNull getters), "Boolean" "Long" "Double" "String" (nullable),
+Schemas: "boolean" "byte" "short" "int" "long" "double" (primitive: the NonNull getters), "Boolean" "Byte" "Short" "Integer" "Long"
+"Double" "String" (nullable),
 ("array", element schema), ("object", {field name: schema})."""
 from oracle import ondemand as OD
 
-PRIMITIVE = {"boolean", "long", "double"}
+PRIMITIVE = {"boolean", "byte", "short", "int", "long", "double"}
+INTEGRAL = {"byte": 8, "Byte": 8, "short": 16, "Short": 16, "int": 32, "Integer": 32}
 
 
 def _scalar(it, schema, root):
@@ -15,6 +17,8 @@ def _scalar(it, schema, root):
         return it.get_boolean(root=root, nullable=schema == "Boolean")
     if schema in ("long", "Long"):
         return it.get_long(root=root, nullable=schema == "Long")
+    if schema in INTEGRAL:
+        return it.get_long(root=root, nullable=schema[0].isupper(), bits=INTEGRAL[schema])
     if schema in ("double", "Double"):
         return it.get_double(root=root, nullable=schema == "Double")
     if schema == "String":

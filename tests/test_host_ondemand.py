@@ -2,7 +2,7 @@
 GPU: the engine ABI is stubbed (tests/host_sim/walk_sim.cpp), the structural indexes come from the oracle's stage 1 and
 the skip table from a plain bracket stack, and a schema driver / a fuzz driver make the same calls on the product's cursor
 and on the Python restatement of the reference (oracle/ondemand.py) -- values, depth bookkeeping and exception messages
-must agree call for call.  The restatement itself is pinned by tests/golden/ondemand_vectors.py: 200 inputs with the
+must agree call for call.  The restatement itself is pinned by tests/golden/ondemand_vectors.py: 245 inputs with the
 values / messages the reference's own *SchemaBasedParsingTest classes assert."""
 import ctypes as C
 import os
@@ -100,8 +100,8 @@ class SimIterator:
         v = self._call(1, int(root), int(nullable))[0]
         return None if v == -1 else bool(v)
 
-    def get_long(self, root=False, nullable=True):
-        v, _, _, isnull = self._call(2, int(root), int(nullable))
+    def get_long(self, root=False, nullable=True, bits=64):
+        v, _, _, isnull = self._call(2, int(root) | (bits << 8 if bits != 64 else 0), int(nullable))
         return None if isnull else v
 
     def get_double(self, root=False, nullable=True):
