@@ -289,9 +289,10 @@ void sjmi_parser_destroy(sjmi_parser* p);
 int sjmi_parser_parse(sjmi_parser* p, const uint8_t* buf, uint64_t len, const uint64_t** tape, uint64_t* tape_len,
                       const uint8_t** strings, uint64_t* strings_len, uint64_t* error_pos);
 const char* sjmi_parser_last_message(const sjmi_parser* p);
-/* Where stage 2 of sjmi_parser_parse runs: 0 (default) = the host walker over the GPU-made indexes and string records,
- * 1 = the cooperative GPU walker (sjmi_parse_document): the tape comes from the device, and only a document that fails
- * or is handed back is walked again on the host (for the exact exception).  Results are identical either way. */
+/* Where stage 2 of sjmi_parser_parse runs: 0 = the host walker over the GPU-made indexes and string records, 1 = the
+ * cooperative GPU walker (sjmi_parse_document): the tape comes from the device, and only a document that fails or is
+ * handed back is walked again on the host (for the exact exception); < 0 (the default) = by size: the GPU walker for
+ * documents of 1 MiB and more, where it is 2-4 x faster end to end, the host walker below.  Identical results. */
 int sjmi_parser_set_gpu_walk(sjmi_parser* p, int on);
 /* Batched parse (BASELINE.json configs[3]/[4]): the batch goes through the GPU (isolated stage 1 + string records)
  * as a pipeline of sub-batches on two streams, the host stage 2 of the documents runs on a pool of threads

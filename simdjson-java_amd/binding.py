@@ -570,14 +570,14 @@ class SimdJsonParser:
     DEFAULT_CAPACITY = 34 * 1024 * 1024
     DEFAULT_MAX_DEPTH = 1024
 
-    def __init__(self, capacity=DEFAULT_CAPACITY, max_depth=DEFAULT_MAX_DEPTH, device=0, gpu_walk=False):
+    def __init__(self, capacity=DEFAULT_CAPACITY, max_depth=DEFAULT_MAX_DEPTH, device=0, gpu_walk=None):
         self._h = C.c_void_p()
         rc = lib().sjmi_parser_create(C.byref(self._h), capacity, max_depth, device)
         if rc != 0:
             self._h = C.c_void_p()
             raise SjmiError("sjmi_parser_create failed (rc=%d): no usable MI355X; there is no CPU fallback" % rc)
-        if gpu_walk:  # stage 2 on the GPU too (the cooperative walker): sjmi_parser_set_gpu_walk
-            lib().sjmi_parser_set_gpu_walk(self._h, 1)
+        if gpu_walk is not None:  # stage 2 on the GPU (True) / on the host (False); None: the library's default, by size
+            lib().sjmi_parser_set_gpu_walk(self._h, 1 if gpu_walk else 0)
 
     def close(self):
         if self._h:

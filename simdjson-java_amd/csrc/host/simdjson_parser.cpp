@@ -250,7 +250,7 @@ JsonValue SimdJsonParser::parse(const uint8_t* buffer, size_t len) {
     // reset (:50-53)
     walker_.bitIndexes().reset();
     walker_.resetForDocument(0, 0);
-    if (gpuWalk_) {
+    if (gpuWalk_ > 0 || (gpuWalk_ < 0 && len >= GPU_WALK_AUTO_BYTES)) {
         // all three stages on the GPU: the tape arrives ready; a document that fails (or that the device hands back) takes
         // the host path below, which raises the reference's exception with its exact message and position
         uint64_t words = 0, sbLen = 0;
@@ -827,7 +827,7 @@ const char* sjmi_parser_last_message(const sjmi_parser* h) { return h ? h->msg.c
 
 int sjmi_parser_set_gpu_walk(sjmi_parser* h, int on) {
     if (!h) return SJMI_ERR_ARG;
-    h->p->setGpuWalk(on != 0);
+    h->p->setGpuWalk(on);
     return SJMI_OK;
 }
 

@@ -212,8 +212,11 @@ public:
     // parse(byte[] buffer, int len) :35-40.  Only buffer[0,len) is read.  The returned JsonValue aliases
     // parser-owned memory and is invalidated by the next parse(), exactly like the reference.
     JsonValue parse(const uint8_t* buffer, size_t len);
-    // stage 2 of parse() on the GPU (the cooperative walker) instead of the host walker; identical results
-    void setGpuWalk(bool on) { gpuWalk_ = on; }
+    // where stage 2 of parse() runs: 1 = on the GPU (the cooperative walker), 0 = the host walker, -1 (default) = by size --
+    // the GPU from GPU_WALK_AUTO_BYTES on, where it is the faster one (tools/single_doc_modes.py: 1.9 x at 1 MiB, 3.7 x at
+    // 4 MiB, 2 x at 64 MiB; equal at twitter.json's 0.6 MiB).  Identical results either way.
+    static constexpr size_t GPU_WALK_AUTO_BYTES = 1u << 20;
+    void setGpuWalk(int mode) { gpuWalk_ = mode < 0 ? -1 : (mode ? 1 : 0); }
 
     // Batched parse: documents packed NDJSON-style at doc_offsets[k] (n+1 entries).  One GPU pass for the batch (isolated
     // stage 1 + string unescape + per-document string offsets), then the host stage 2 of the documents on several
@@ -249,7 +252,7 @@ private:
     std::unique_ptr<uint64_t[]> batchTape_;  // (not a vector: grown without zero-filling, kept between batches)
     size_t batchTapeLen_ = 0, batchTapeRoom_ = 0;
     std::vector<uint64_t> batchTapeOffsets_, indexOffsets_, docStringOffsets_;
-    bool gpuWalk_ = false;
+    int gpuWalk_ = -1;
     int batchThreads_ = 1;  // host threads walking the documents of a batch (SJMI_PARSE_THREADS overrides)
     int batchPipeline_ = 0;  // sub-batches per batch, 0 = by size (SJMI_PARSE_PIPELINE overrides)
     // kept between batches: a walker per batch thread, and per (sub-batch, thread) the slab its tapes are built in

@@ -13,12 +13,13 @@ from tests.golden import vectors as V
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["host_walk", "gpu_walk"])
+@pytest.fixture(scope="module", params=["host_walk", "gpu_walk", "by_size"])
 def parser(request):
-    """Both homes of stage 2: the host walker over GPU-made indexes / strings (default), and the cooperative GPU walker
-    (sjmi_parser_set_gpu_walk: the tape itself comes from the device).  Every test below holds for both, bit for bit."""
+    """The homes of stage 2: the host walker over GPU-made indexes / strings, the cooperative GPU walker
+    (sjmi_parser_set_gpu_walk: the tape itself comes from the device), and the library's default -- by size, the GPU walker
+    from 1 MiB on.  Every test below holds for all of them, bit for bit."""
     import simdjson_java_amd as S
-    p = S.SimdJsonParser(capacity=8 * 1024 * 1024, gpu_walk=request.param == "gpu_walk")
+    p = S.SimdJsonParser(capacity=8 * 1024 * 1024, gpu_walk={"host_walk": False, "gpu_walk": True, "by_size": None}[request.param])
     yield p
     p.close()
 
@@ -208,3 +209,17 @@ def test_json_value_accessors_through_the_c_abi(parser, twitter):
                  '{"k":[{"a":1},{"b":[2,3]}],"é":"€"}']:
         parser.parse(text.encode())
         assert parser.root().to_python() == O.parse(text.encode()).to_python(), text
+
+
+def test_documents_around_the_stage2_placement_threshold(parser):
+    """1 MiB is where the default placement of stage 2 changes (SimdJsonParser::GPU_WALK_AUTO_BYTES): documents just below
+    and above it, valid and broken (a broken one is walked again on the host for the reference's exact message)."""
+    unit = '{"id":%d,"name":"user \\u00e9 %d","tags":["a","b"],"score":%d.5,"ok":true}'
+    for n in (13000, 15500, 40000):
+        body = ",".join(unit % (i, i, i % 97) for i in range(n))
+        assert abs(len(body) - (1 << 20)) < (3 << 20)
+        _same(parser, "[" + body + "]")
+        _same(parser, "[" + body + ",]")
+        _same(parser, "[" + body + "] 1")
+        _same(parser, "[" + body.replace('"ok":true', '"ok":tru', 1) + "]")
+        _same(parser, "[" + body[: len(body) // 2])

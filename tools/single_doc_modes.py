@@ -11,7 +11,16 @@ import simdjson_java_amd as S  # noqa: E402
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 twitter = gzip.open(os.path.join(root, "tests/golden/data/twitter.json.gz")).read()
 big = b"[" + b",".join(b'{"id":%d,"name":"user %d","tags":["a","b"],"score":%d.5,"ok":true}' % (i, i, i % 97) for i in range(900000)) + b"]"
-for name, doc, reps in (("twitter.json", twitter, 200), ("array of 900k objects (%.0f MiB)" % (len(big) / 2 ** 20), big, 5)):
+def array_of(n):
+    return b"[" + b",".join(b'{"id":%d,"name":"user %d","tags":["a","b"],"score":%d.5,"ok":true}' % (i, i, i % 97) for i in range(n)) + b"]"
+
+
+cases = [("twitter.json", twitter, 200)]
+for n, reps in ((14000, 100), (56000, 40), (225000, 15)):
+    d = array_of(n)
+    cases.append(("array of %dk objects (%.1f MiB)" % (n // 1000, len(d) / 2 ** 20), d, reps))
+cases.append(("array of 900k objects (%.0f MiB)" % (len(big) / 2 ** 20), big, 5))
+for name, doc, reps in cases:
     for mode in (False, True):
         p = S.SimdJsonParser(capacity=len(doc) + 64, gpu_walk=mode)
         for _ in range(3):
