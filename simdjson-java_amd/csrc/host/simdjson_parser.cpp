@@ -199,6 +199,8 @@ SimdJsonParser::SimdJsonParser(int capacity, int maxDepth, int device)
     pinned_[0] = sjmi_host_register(ctx_, paddedBuffer_.data(), paddedBuffer_.size()) == SJMI_OK ? paddedBuffer_.data() : nullptr;
     pinned_[1] = sjmi_host_register(ctx_, indexes_.data(), indexes_.size() * sizeof(uint32_t)) == SJMI_OK ? (void*)indexes_.data() : nullptr;
     pinned_[2] = sjmi_host_register(ctx_, stringBuffer_.data(), stringBuffer_.size()) == SJMI_OK ? stringBuffer_.data() : nullptr;
+    // (the tape: the download of the GPU walker's result, sjmi_parse_document)
+    pinned_[3] = sjmi_host_register(ctx_, walker_.tape().raw(), walker_.tape().capacity() * sizeof(uint64_t)) == SJMI_OK ? (void*)walker_.tape().raw() : nullptr;
     unsigned hw = std::thread::hardware_concurrency();
     batchThreads_ = (int)(hw ? (hw > 32 ? 32 : hw) : 1);
     if (const char* e = getenv("SJMI_PARSE_THREADS")) {

@@ -213,9 +213,10 @@ public:
     // parser-owned memory and is invalidated by the next parse(), exactly like the reference.
     JsonValue parse(const uint8_t* buffer, size_t len);
     // where stage 2 of parse() runs: 1 = on the GPU (the cooperative walker), 0 = the host walker, -1 (default) = by size --
-    // the GPU from GPU_WALK_AUTO_BYTES on, where it is the faster one (tools/single_doc_modes.py: 1.9 x at 1 MiB, 3.7 x at
-    // 4 MiB, 2 x at 64 MiB; equal at twitter.json's 0.6 MiB).  Identical results either way.
-    static constexpr size_t GPU_WALK_AUTO_BYTES = 1u << 20;
+    // the GPU from GPU_WALK_AUTO_BYTES on, where it is the faster one (tools/single_doc_modes.py, sjmi_parser_parse timed
+    // from C++: 0.104 vs 0.073 ms at 1 KiB, 0.157 vs 0.165 ms at 136 KiB, 0.19 vs 0.21 ms for twitter.json, 0.29 vs 0.68 ms
+    // at 1 MiB, 1.95 vs 10.0 ms at 16 MiB, 8.3 vs 40.4 ms at 64 MiB).  Identical results either way.
+    static constexpr size_t GPU_WALK_AUTO_BYTES = 128u << 10;
     void setGpuWalk(int mode) { gpuWalk_ = mode < 0 ? -1 : (mode ? 1 : 0); }
 
     // Batched parse: documents packed NDJSON-style at doc_offsets[k] (n+1 entries).  One GPU pass for the batch (isolated
@@ -268,7 +269,7 @@ private:
     std::vector<TapeSlab> pieces_;
     std::unique_ptr<WorkerPool> pool_;  // created by the first parseBatch
     std::vector<uint32_t> docStatus_;
-    void* pinned_[3] = {nullptr, nullptr, nullptr};  // page-locked parser buffers (sjmi_host_register)
+    void* pinned_[4] = {nullptr, nullptr, nullptr, nullptr};  // page-locked parser buffers (sjmi_host_register)
     std::vector<int32_t> batchErrors_;
     std::unique_ptr<OnDemandJsonIterator> onDemand_;
     std::vector<uint32_t> skipUp_, skipMatch_;

@@ -4,6 +4,7 @@
 //   mode 0  full parse (sjmi_parser_parse) + JsonValue walk (sjmi_value_*)
 //   mode 1  on-demand cursor (sjmi_parser_ondemand_init + sjmi_od_*), skipChild scanning like the reference
 //   mode 2  on-demand cursor with the GPU skip table
+//   mode 3  sjmi_parser_parse alone (any document): the binding-free cost of SimdJsonParser.parse
 // Built and loaded by bench.py (section `select`) / tools/ondemand_bench.py; links libsjmi.so.
 #include <stdint.h>
 #include <string.h>
@@ -134,7 +135,17 @@ extern "C" int odb_run(sjmi_parser* p, const uint8_t* buf, uint64_t len, int mod
     for (int i = 0; i < iters; ++i) {
         *selected = 0;
         *bytes = 0;
-        const int rc = mode == 0 ? select_full_parse(p, buf, len, selected, bytes) : select_on_demand(p, buf, len, mode == 2, selected, bytes);
+        int rc;
+        if (mode == 3) {  // the parse alone (any document)
+            const uint64_t* tape;
+            const uint8_t* strings;
+            uint64_t tl, sl, pos;
+            rc = sjmi_parser_parse(p, buf, len, &tape, &tl, &strings, &sl, &pos);
+            *selected = tl;
+            *bytes = sl;
+        } else {
+            rc = mode == 0 ? select_full_parse(p, buf, len, selected, bytes) : select_on_demand(p, buf, len, mode == 2, selected, bytes);
+        }
         if (rc) return rc;
     }
     *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
