@@ -368,7 +368,7 @@ def bench_single(args):
     if "parse" in sections:
         # ---- the drop-in call itself: SimdJsonParser.parse(byte[], len) of ONE twitter.json from a host buffer (H2D, all
         #      stages, outputs back on the host), with the reference's stage 2 on the host or all three stages on the GPU ----
-        extra["parse_twitter_json"] = parse_single_document(S, doc)
+        extra["parse_single_document"] = parse_single_document(S, doc)
     if "select" in sections:
         # ---- the reference's headline benchmark shape (jmh ParseAndSelectBenchmark / SchemaBasedParseAndSelectBenchmark: the
         #      screen names of twitter.json's users with default_profile), user code in C++ against the public C ABI ----
@@ -390,27 +390,37 @@ def bench_single(args):
 
 
 def parse_single_document(S, doc, reps=300):
-    out = {"config": "SimdJsonParser.parse(twitter.json, %d B) from a host buffer, end to end (H2D of the document, stage 1, string "
-                     "records, stage 2, tape + string buffer on the host); tape checked against the oracle once per mode" % len(doc),
-           "unit": "ms per document (through the ctypes binding: includes its copies of the document and of the outputs)"}
+    """SimdJsonParser.parse of ONE document from a host buffer, both placements of stage 2; the call is timed from C++
+    (tools/ondemand_bench.cpp mode 3: sjmi_parser_parse without the Python binding's copies), the tape is checked against the
+    oracle through the binding once per mode.  twitter.json and a 16 MiB array of objects."""
+    import ctypes as C
+    import ondemand_bench
     from oracle import oracle as O
-    want = O.parse(doc)
-    for mode, key in ((False, "host_walker"), (True, "gpu_walker_chunk_parallel")):
-        p = S.SimdJsonParser(capacity=len(doc) + 64, gpu_walk=mode)
-        tape = p.parse(doc).tape
-        if tape.size != want.tape.size or not (tape == want.tape).all():
-            raise SystemExit("parse(twitter.json) tape differs from the oracle's (gpu_walk=%s)" % mode)
-        for _ in range(reps):  # (untimed: ~70 ms of back-to-back parses, see the clock note in DESIGN.md 6.)
-            p.parse(doc)
-        ms = 1e9
-        for _ in range(3):  # best of three timed runs of `reps` parses
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                p.parse(doc)
-            ms = min(ms, (time.perf_counter() - t0) / reps * 1e3)
-        out[key] = {"ms": round(ms, 4), "GB/s": round(len(doc) / ms / 1e6, 3)}
-        p.close()
-    out["value"] = out["gpu_walker_chunk_parallel"]["ms"]
+    L = ondemand_bench.load_bench_lib()
+    big = b"[" + b",".join(b'{"id":%d,"name":"user %d","tags":["a","b"],"score":%d.5,"ok":true}' % (i, i, i % 97) for i in range(225000)) + b"]"
+    out = {"config": "sjmi_parser_parse (= SimdJsonParser.parse(byte[], len)) from a host buffer, end to end per call: H2D of the document, "
+                     "stage 1, string records, stage 2, tape + string buffer on the host; timed from C++, tape checked against the oracle",
+           "unit": "ms per document"}
+    for name, d, n in (("twitter_json", doc, reps), ("array_16mib", big, 20)):
+        want = O.parse(d)
+        buf = (C.c_uint8 * len(d)).from_buffer_copy(d)
+        res = {"bytes": len(d)}
+        for mode, key in ((False, "host_walker"), (True, "gpu_walker")):
+            p = S.SimdJsonParser(capacity=len(d) + 64, gpu_walk=mode)
+            tape = p.parse(d).tape
+            if tape.size != want.tape.size or not (tape == want.tape).all():
+                raise SystemExit("parse(%s) tape differs from the oracle's (gpu_walk=%s)" % (name, mode))
+            secs, a, b = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+            ms = 1e9
+            for rep in range(4):  # (first round untimed: clocks, see DESIGN.md 6.)
+                if L.odb_run(p._h, buf, len(d), 3, n, C.byref(secs), C.byref(a), C.byref(b)):
+                    raise SystemExit("sjmi_parser_parse failed in the parse section")
+                if rep:
+                    ms = min(ms, secs.value / n * 1e3)
+            res[key] = {"ms": round(ms, 4), "GB/s": round(len(d) / ms / 1e6, 3)}
+            p.close()
+        out[name] = res
+    out["value"] = out["twitter_json"]["gpu_walker"]["ms"]
     return out
 
 
