@@ -11,12 +11,20 @@ sys.path.insert(0, ROOT)
 import simdjson_java_amd as S  # noqa: E402
 
 
-def load_bench_lib():
+def build_bench_lib():
+    """g++ only (no GPU needed): built by __graft_entry__.build() so that it travels with the tree; rebuilt here when stale"""
     src = os.path.join(ROOT, "tools", "ondemand_bench.cpp")
     so = os.path.join(ROOT, "tools", "libondemand_bench.so")
     libdir = os.path.join(ROOT, "simdjson-java_amd")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src, "-L" + libdir, "-lsjmi", "-Wl,-rpath," + libdir])
+        # ($ORIGIN-relative rpath: the tree is copied to another place on the GPU box)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src, "-L" + libdir, "-lsjmi",
+                               "-Wl,-rpath,$ORIGIN/../simdjson-java_amd"])
+    return so
+
+
+def load_bench_lib():
+    so = build_bench_lib()
     S.lib()  # libsjmi.so first (with torch's HIP runtime, see binding.lib)
     L = C.CDLL(so)
     L.odb_run.restype = C.c_int
