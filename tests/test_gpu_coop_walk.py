@@ -167,3 +167,28 @@ def test_large_documents_chunk_parallel(ctx):
                 q = rng.randrange(len(base))
                 d = base[:min(p, q)] + base[max(p, q):]
             _single(ctx, d)
+
+
+def test_chunk_and_group_size_boundaries(ctx):
+    """Structural counts around every switch of the chunk-parallel path: 1,024 (single-wave sweep below), multiples of the
+    128- and 512-structural chunks, 262,144 (chunk length 128 -> 512), squares of the group size; and documents whose BOUND
+    asks for chunks (more than 4 KiB) while they hold a handful of structurals (the summary pass hands them back)."""
+    def with_structurals(s):
+        # "[0,0,...,0]" has 2k + 3 structurals; one "[]," in front adds 3
+        even = s % 2 == 0
+        k = (s - 3 - (3 if even else 0)) // 2
+        doc = "[" + ("[]," if even else "") + "0," * k + "0]"
+        return doc.encode()
+    counts = [1021, 1023, 1024, 1025, 1027, 1151, 1152, 1153, 1279, 1280, 1281, 2047, 2048, 2049, 8191, 8192, 8193, 8320, 8321,
+              128 * 64 - 1, 128 * 64, 128 * 64 + 1, 128 * 256 + 1, 262143, 262144, 262145, 262147, 262144 + 511, 262144 + 512, 262144 + 513,
+              512 * 1024 + 1, 512 * 4096 + 5]
+    for s in counts:
+        d = with_structurals(s)
+        idx, st = ctx.stage1(d)
+        assert idx.size == s, (s, idx.size)
+        assert _single(ctx, d) == "ok", s
+        assert _single(ctx, d[:-1]) == "ok", s           # unclosed
+        assert _single(ctx, d + b" 7") == "ok", s         # trailing content in the last chunk
+    for filler in (5000, 70000, 300000):
+        for doc in ('["%s"]' % ("x" * filler), '{"k":"%s","n":[1,2,{"a":null}]}' % ("y" * filler), '"%s"' % ("z" * filler), " " * filler + "[1, 2]"):
+            assert _single(ctx, doc.encode()) == "ok"

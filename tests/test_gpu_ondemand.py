@@ -252,3 +252,49 @@ def test_on_demand_fuzz_traces(parser, table):
         assert got == want, (doc, seed, got[-3:], want[-3:])
         walked += 1
     assert walked == 1500
+
+
+def test_skip_table_chunk_boundaries(ctx):
+    """The chunk-parallel skip table (k_match_summary -> scan kernels -> k_coop_match<true>) against a plain bracket stack
+    at structural counts around its switches (1,024; multiples of 128 and 512; 262,144), with nested brackets across the
+    chunk boundaries, and for documents that never close / close too often (SJMI_MATCH_NONE / _UNKNOWN)."""
+    rng = random.Random(12)
+
+    def nested(n):
+        out, depth = [], 0
+        for i in range(n):
+            r = rng.random()
+            if r < 0.25 and depth < 40:
+                out.append(rng.choice("[{") if False else "[")
+                depth += 1
+            elif r < 0.45 and depth > 0:
+                out.append("]")
+                depth -= 1
+            else:
+                out.append("0")
+        return out, depth
+    for n in (600, 1500, 5000, 70000, 300000):
+        toks, depth = nested(n)
+        body = []
+        for i, t in enumerate(toks):
+            body.append(t)
+            nxt = toks[i + 1] if i + 1 < len(toks) else "]"
+            if t != "[" and nxt != "]":
+                body.append(",")
+        doc = ("[" + "".join(body) + "]" * (depth + 1)).encode()
+        idx, up, match = _tables(ctx, doc)
+        _check_table_against_stack(doc, idx, up, match)
+    for s in (1023, 1025, 1153, 8193, 262145, 262144 + 513):
+        doc = ("[" + "[0]," * ((s - 3) // 4) + "0]").encode()
+        idx, up, match = _tables(ctx, doc)
+        _check_table_against_stack(doc, idx, up, match)
+        # never closed: the root bracket (and the last "[0" cut open) keep SJMI_MATCH_NONE
+        cut = doc[:-3]
+        idx, up, match = _tables(ctx, cut)
+        assert int(match[0]) == NONE
+        # closed too often, far from the start: everything from the stray bracket on is SJMI_MATCH_UNKNOWN
+        stray = doc[:-1] + b"]],[1,2]"   # ... 0 ] ] , [ 1 , 2 ]  : the second "]" has no opening bracket
+        idx, up, match = _tables(ctx, stray)
+        k = len(idx) - 7                  # the stray bracket
+        assert int(match[0]) == k - 1 and int(up[k - 1]) == 0
+        assert all(int(up[i]) == UNKNOWN and int(match[i]) == UNKNOWN for i in range(k, len(idx)))
