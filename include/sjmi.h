@@ -297,7 +297,7 @@ const char* sjmi_parser_last_message(const sjmi_parser* p);
 int sjmi_parser_set_gpu_walk(sjmi_parser* p, int on);
 /* Batched parse (BASELINE.json configs[3]/[4]): the batch goes through the GPU (isolated stage 1 + string records)
  * as a pipeline of sub-batches on two streams, the host stage 2 of the documents runs on a pool of threads
- * (SJMI_PARSE_THREADS, default min(32, cores)) while the GPU works on the next sub-batch.  Document k's tape is
+ * (SJMI_PARSE_THREADS, default min(64, cores)) while the GPU works on the next sub-batch.  Document k's tape is
  * tape[tape_offsets[k] .. tape_offsets[k+1]) (container words relative to its own start, STRING payloads = offsets
  * into the shared `strings` buffer, which has unused gaps between sub-batches) and errors[k] is 0 or document k's
  * own SJMI_E_* error -- stage-1 errors included (isolated batch mode: one broken document never affects another).
