@@ -314,7 +314,7 @@ int sjmi_parser_parse_batch(sjmi_parser* p, const uint8_t* buf, uint64_t total_l
  * containers by k - 1 + 1 table reads instead of scanning every structural in between (:47-81).  The calls below mirror
  * the iterator's methods one to one (root != 0: the Root form; nullable == 0: the NonNull form; *is_null: the method
  * returned null); each returns 0, or > 0 = the SJMI_E_* code of the JsonParsingException the reference throws there
- * (exact text: sjmi_parser_last_message), or < 0.  Not built: the float / char getters. */
+ * (exact text: sjmi_parser_last_message), or < 0.  Not built: the char getters (a Java UTF-16 unit). */
 #define SJMI_E_OD_NOT_ENOUGH_CLOSE 40    /* "Not enough close braces."                                   :80 */
 #define SJMI_E_OD_EXPECTED_CHAR 41       /* "Expected 'x' but got: 'y'."                                 :662 */
 #define SJMI_E_OD_EXPECTED_CHAR_END 42   /* "Expected 'x' but reached end of buffer."                    :660 */
@@ -335,6 +335,7 @@ int sjmi_od_get_long(sjmi_parser* p, int root, int nullable, int* is_null, int64
 /* the Byte :204-241 / Short :243-280 / Int :282-319 getters: bits = 8, 16, 32 (64 = sjmi_od_get_long) */
 int sjmi_od_get_integral(sjmi_parser* p, int bits, int root, int nullable, int* is_null, int64_t* value);
 int sjmi_od_get_double(sjmi_parser* p, int root, int nullable, int* is_null, double* value);   /* :383-428 */
+int sjmi_od_get_float(sjmi_parser* p, int root, int nullable, int* is_null, float* value);     /* :360-381,:430-444 */
 /* getRootString / getString :446-472, getFieldName :646-652: the unescaped bytes, valid until the next of these calls */
 int sjmi_od_get_string(sjmi_parser* p, int root, int* is_null, const uint8_t** bytes, uint64_t* len);
 int sjmi_od_get_field_name(sjmi_parser* p, const uint8_t** bytes, uint64_t* len);

@@ -4,7 +4,7 @@ pieces of NumberParser (NumberParser.java:199-310), StringParser (StringParser.j
 (BitIndexes.java:47-101) it calls -- method for method, message for message.  Only tests/ may import it: it is the checker
 for csrc/host/ondemand.h (the product's C++ mirror, which adds the GPU skip table).  Pure-Python loops: small documents.
 Pinned by tests/test_host_ondemand.py (tests/golden/ondemand_vectors.py: what the reference's own schema-based tests assert).
-Not restated (as in the product): the float / char getters."""
+Not restated (as in the product): the char getters."""
 import struct
 
 
@@ -149,6 +149,21 @@ class OnDemandJsonIterator:
             self.assert_no_more_json_values()
         return value
 
+    def get_float(self, root=False, nullable=True):
+        """getRootNonNullFloat :360-367, getRootFloat :369-381, getNonNullFloat :430-434, getFloat :436-444 -> the binary32
+        value as a Python float (exactly), or None"""
+        self.depth -= 1
+        idx = self._get_and_advance()
+        if nullable and self.buffer[idx] == ord("n"):
+            self._visit_atom(idx, b"null", True)  # (:440)
+            if root:
+                self.assert_no_more_json_values()
+            return None
+        value = self._parse_double(idx, as_float=True)
+        if root:
+            self.assert_no_more_json_values()
+        return value
+
     def _parse_long(self, offset, bits=64):  # NumberParser.parseByte :76-100, parseShort :115-139, parseInt :154-178, parseLong :199-224
         negative = self._byte(offset) == ord("-")
         cur = offset + 1 if negative else offset
@@ -173,7 +188,7 @@ class OnDemandJsonIterator:
                 raise JsonParsingException("Number value is out of %s range ([%d, %d])." % ({8: "byte", 16: "short", 32: "int"}[bits], -max_abs, max_abs - 1))
         return -digits if negative else digits
 
-    def _parse_double(self, offset):  # NumberParser.parseDouble :268-310
+    def _parse_double(self, offset, as_float=False):  # NumberParser.parseDouble :268-310 / parseFloat :226-266 (the same grammar)
         negative = self._byte(offset) == ord("-")
         cur = offset + 1 if negative else offset
         start = cur
@@ -208,6 +223,8 @@ class OnDemandJsonIterator:
         if self._byte(cur) not in _STRUCT_OR_WS:
             raise JsonParsingException("Number has to be followed by a structural character or whitespace.")
         text = bytes(self._byte(q) for q in range(offset, cur)).decode()
+        if as_float:
+            return float32_of(text)  # FloatParser.java:62-330: the correctly rounded binary32
         return float(text)  # correctly rounded, saturating to +-inf / +-0: DoubleParser.java:79-330
 
     # ---- strings: getRootString :446-459, getString :461-472, getFieldName :646-652 ----
@@ -351,6 +368,49 @@ class OnDemandJsonIterator:
     def assert_no_more_json_values(self):  # :666-670
         if self._has_next():
             raise JsonParsingException("More than one JSON value at the root of the document, or extra characters at the end of the JSON!")
+
+
+def float32_of(text):
+    """the binary32 nearest to the decimal literal (ties to even; +-inf beyond the largest finite + half an ulp), computed
+    exactly: candidates around the double-rounded value, compared with rational arithmetic"""
+    from fractions import Fraction
+    neg = text.startswith("-")
+    body = text.lstrip("-").lower()
+    mant, _, e = body.partition("e")
+    exp = max(-100000, min(100000, int(e) if e else 0))
+    ip, _, fp = mant.partition(".")
+    digits = (ip + fp).lstrip("0")
+    if not digits:
+        return -0.0 if neg else 0.0
+    lead = len(ip + fp) - len(digits)
+    e10 = exp - len(fp)
+    if len(digits) + e10 > 60:
+        return float("-inf") if neg else float("inf")
+    if len(digits) + e10 < -60:
+        return -0.0 if neg else 0.0
+    x = Fraction(int(digits)) * (Fraction(10) ** e10)
+    del lead
+
+    def f32(bits):
+        return struct.unpack("<f", struct.pack("<I", bits))[0]
+    lo, hi = 0, 0x7F800000  # positive binary32 bit patterns are ordered like their values
+    while hi - lo > 1:
+        mid = (lo + hi) // 2
+        if Fraction(f32(mid)) <= x:
+            lo = mid
+        else:
+            hi = mid
+    below, above = Fraction(f32(lo)), (Fraction(f32(hi)) if hi < 0x7F800000 else Fraction(2) ** 128)
+    if x - below < above - x or (x - below == above - x and lo % 2 == 0):
+        pick = lo
+    else:
+        pick = hi
+    v = f32(pick)
+    return -v if neg else v
+
+
+def float_bits(v):
+    return struct.unpack("<I", struct.pack("<f", v))[0]
 
 
 def double_bits(v):

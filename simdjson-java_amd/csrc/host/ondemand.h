@@ -6,10 +6,9 @@
 // csrc/coop_walk.hip (k_coop_match: up[i] = the opening bracket structural i lies in, match[i] = the partner of a
 // bracket), which turns skipChild's bracket-counting scan (:47-81) -- the bulk of the work when a schema wants a few
 // fields of a large document -- into k - 1 climbs through up[] and one jump through match[].
-// Built: booleans, byte / short / int / long, double, String (and their Root / NonNull forms), null handling, arrays,
-// objects, field names, skipChild, assertNoMoreJsonValues.  Not built: the float and char getters (:360-382,:430-444,
-// :474-520; FloatParser is a binary32 Eisel-Lemire of its own) and the reflection-driven schema mapping itself
-// (SchemaBasedJsonIterator, ClassResolver), which is Java-specific.
+// Built: booleans, byte / short / int / long, float, double, String (and their Root / NonNull forms), null handling,
+// arrays, objects, field names, skipChild, assertNoMoreJsonValues.  Not built: the char getters (:474-520: a Java UTF-16
+// unit) and the reflection-driven schema mapping itself (SchemaBasedJsonIterator, ClassResolver), which is Java-specific.
 #pragma once
 #include <locale.h>
 #include <stdlib.h>
@@ -144,6 +143,22 @@ public:
             return 0.0;
         }
         const double v = parseDouble(idx);
+        if (root) assertNoMoreJsonValues();
+        return v;
+    }
+
+    // getRootNonNullFloat :360-367, getRootFloat :369-381, getNonNullFloat :430-434, getFloat :436-444
+    float getFloat(bool root, bool nullable, bool* isNull) {
+        depth_--;
+        const uint32_t idx = indexer_->getAndAdvance();
+        *isNull = false;
+        if (nullable && buffer_[idx] == 'n') {
+            visitNullAtom(idx, true);  // (:440: the root form here too)
+            if (root) assertNoMoreJsonValues();
+            *isNull = true;
+            return 0.0f;
+        }
+        const float v = parseFloat(idx);
         if (root) assertNoMoreJsonValues();
         return v;
     }
@@ -332,6 +347,24 @@ private:
             std::string lit;
             for (uint32_t q = offset; !structuralOrWs((uint8_t)byteAt(q)); ++q) lit.push_back((char)byteAt(q));
             v = strtod_l(lit.c_str(), nullptr, c_locale);
+        }
+        return v;
+    }
+
+    float parseFloat(uint32_t offset) const {                                     // NumberParser.parseFloat :226-266
+        const sjmi::SjNumber n = sjmi::sj_scan_number([&](uint32_t q) -> uint32_t { return byteAt(q); }, offset);
+        if (n.code && n.code != 26) throw error(n.code);
+        if (!n.floating) throw error(E_OD_FLOAT_PART_MISSING);
+        if (n.code) throw error(n.code);
+        uint32_t bits;
+        float v;
+        if (sjmi::sj_number_float_bits(n, &bits)) {
+            memcpy(&v, &bits, 4);
+        } else {  // (FloatParser's slow path :203-330 = a correctly rounded conversion)
+            static const locale_t c_locale = newlocale(LC_ALL_MASK, "C", (locale_t)0);
+            std::string lit;
+            for (uint32_t q = offset; !structuralOrWs((uint8_t)byteAt(q)); ++q) lit.push_back((char)byteAt(q));
+            v = strtof_l(lit.c_str(), nullptr, c_locale);
         }
         return v;
     }

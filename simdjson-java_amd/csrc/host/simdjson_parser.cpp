@@ -1061,6 +1061,14 @@ int sjmi_od_get_double(sjmi_parser* h, int root, int nullable, int* is_null, dou
         *is_null = n;
     });
 }
+int sjmi_od_get_float(sjmi_parser* h, int root, int nullable, int* is_null, float* value) {
+    if (!is_null || !value) return SJMI_ERR_ARG;
+    return odCall(h, [&](org_simdjson::OnDemandJsonIterator& it) {
+        bool n = false;
+        *value = it.getFloat(root != 0, nullable != 0, &n);
+        *is_null = n;
+    });
+}
 int sjmi_od_get_string(sjmi_parser* h, int root, int* is_null, const uint8_t** bytes, uint64_t* len) {
     if (!is_null || !bytes || !len) return SJMI_ERR_ARG;
     return odCall(h, [&](org_simdjson::OnDemandJsonIterator& it) {

@@ -8,7 +8,7 @@ Schemas: "boolean" "byte" "short" "int" "long" "double" (primitive: the NonNull 
 ("array", element schema), ("object", {field name: schema})."""
 from oracle import ondemand as OD
 
-PRIMITIVE = {"boolean", "byte", "short", "int", "long", "double"}
+PRIMITIVE = {"boolean", "byte", "short", "int", "long", "float", "double"}
 INTEGRAL = {"byte": 8, "Byte": 8, "short": 16, "Short": 16, "int": 32, "Integer": 32}
 
 
@@ -21,6 +21,8 @@ def _scalar(it, schema, root):
         return it.get_long(root=root, nullable=schema[0].isupper(), bits=INTEGRAL[schema])
     if schema in ("double", "Double"):
         return it.get_double(root=root, nullable=schema == "Double")
+    if schema in ("float", "Float"):
+        return it.get_float(root=root, nullable=schema == "Float")
     if schema == "String":
         return it.get_string(root=root)
     raise ValueError(schema)
@@ -151,7 +153,10 @@ def fuzz_walk(it, rng, trace, root=True, budget=None):
         trace.append(("null", [it.get_boolean, it.get_long, it.get_double][k](root=root, nullable=True) if k < 3 else it.get_string(root=root)))
     else:
         k = rng.randrange(5 if wrong else 2)
-        if k == 0:
+        if k == 1 and rng.random() < 0.3:
+            v = it.get_float(root=root, nullable=rng.random() < 0.5)
+            trace.append(("float", None if v is None else OD.float_bits(v)))
+        elif k == 0:
             trace.append(("long", it.get_long(root=root, nullable=rng.random() < 0.5)))
         elif k == 1:
             v = it.get_double(root=root, nullable=rng.random() < 0.5)

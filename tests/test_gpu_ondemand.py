@@ -298,3 +298,21 @@ def test_skip_table_chunk_boundaries(ctx):
         k = len(idx) - 7                  # the stray bracket
         assert int(match[0]) == k - 1 and int(up[k - 1]) == 0
         assert all(int(up[i]) == UNKNOWN and int(match[i]) == UNKNOWN for i in range(k, len(idx)))
+
+
+def test_reference_float_vectors_through_the_c_abi(parser):
+    """tests/golden/float_vectors.json (the reference's binary32 tests) through GPU stage 1 and sjmi_od_get_float."""
+    import json
+    import os
+    vs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "float_vectors.json")))
+    for v in vs:
+        doc = v["input"].encode()
+        want = OD.float_bits(OD.float32_of(v["input"]))
+        if v["bits"] is not None:
+            assert want == int(v["bits"], 16)
+        for schema in ("float", "Float"):
+            kind, got = _run_parser(parser, doc, len(doc), schema, False)
+            assert kind == "ok" and OD.float_bits(got) == want, (v, got)
+    assert _run_parser(parser, b"null", 4, "Float", False) == ("ok", None)
+    assert _run_parser(parser, b"null", 4, "float", False) == ("error", "Invalid number. Minus has to be followed by a digit.")
+    assert _run_parser(parser, b"12", 2, "float", False) == ("error", "Invalid floating-point number. Fraction or exponent part is missing.")

@@ -108,6 +108,10 @@ class SimIterator:
         _, d, _, isnull = self._call(3, int(root), int(nullable))
         return None if isnull else d
 
+    def get_float(self, root=False, nullable=True):
+        _, d, _, isnull = self._call(12, int(root), int(nullable))
+        return None if isnull else d
+
     def get_string(self, root=False):
         v, _, s, _ = self._call(4, int(root))
         return None if v == -1 else s
@@ -272,3 +276,23 @@ def test_skip_child_by_table_lands_where_the_scan_lands(lib):
                     except SimException as e:
                         out.append(str(e))
                 assert out[0] == out[1], (name, r, k, out)
+
+
+def test_reference_float_vectors(lib):
+    """Every literal of the reference's binary32 tests (FloatingPointNumberSchemaBasedParsingTest: zeros, infinities, min / max
+    normal and subnormal, rounding overflow, ties to even, round up / down -- tests/golden/float_vectors.json, extracted by
+    make_float_vectors.py): the asserted constant where the test names one, else Float.parseFloat = the correctly rounded
+    binary32, which oracle/ondemand.py computes exactly -- on the restatement and on the product's cursor."""
+    import json
+    vs = json.load(open(os.path.join(ROOT, "tests", "golden", "float_vectors.json")))
+    assert len(vs) >= 120
+    for v in vs:
+        doc = v["input"].encode()
+        idx, _ = O.stage1(doc)
+        want = OD.float_bits(OD.float32_of(v["input"]))
+        if v["bits"] is not None:
+            assert want == int(v["bits"], 16), v
+        for schema in ("float", "Float"):
+            assert run_oracle(doc, len(doc), idx, schema) == ("ok", OD.float32_of(v["input"]))
+            kind, got = run_product(lib, doc, len(doc), idx, schema, False)
+            assert kind == "ok" and OD.float_bits(got) == want, (v, got)
