@@ -314,7 +314,7 @@ int sjmi_parser_parse_batch(sjmi_parser* p, const uint8_t* buf, uint64_t total_l
  * containers by k - 1 + 1 table reads instead of scanning every structural in between (:47-81).  The calls below mirror
  * the iterator's methods one to one (root != 0: the Root form; nullable == 0: the NonNull form; *is_null: the method
  * returned null); each returns 0, or > 0 = the SJMI_E_* code of the JsonParsingException the reference throws there
- * (exact text: sjmi_parser_last_message), or < 0.  Not built: the char getters (a Java UTF-16 unit). */
+ * (exact text: sjmi_parser_last_message), or < 0.  Every getter of the class is here. */
 #define SJMI_E_OD_NOT_ENOUGH_CLOSE 40    /* "Not enough close braces."                                   :80 */
 #define SJMI_E_OD_EXPECTED_CHAR 41       /* "Expected 'x' but got: 'y'."                                 :662 */
 #define SJMI_E_OD_EXPECTED_CHAR_END 42   /* "Expected 'x' but reached end of buffer."                    :660 */
@@ -325,6 +325,10 @@ int sjmi_parser_parse_batch(sjmi_parser* p, const uint8_t* buf, uint64_t total_l
 #define SJMI_E_OD_BYTE_RANGE 47          /* "Number value is out of byte range ([-128, 127])."            NumberParser.java:97 */
 #define SJMI_E_OD_SHORT_RANGE 48         /* "... out of short range ([-32768, 32767])."                   :136 */
 #define SJMI_E_OD_INT_RANGE 49           /* "... out of int range ([-2147483648, 2147483647])."           :175 */
+#define SJMI_E_OD_STRING_EXPECTED 50     /* "Invalid value starting at N. Expected string."               :480,:505 */
+#define SJMI_E_OD_CHAR_CODE_POINT 51     /* "Invalid code point. Should be within the range U+0000–U+D777 or U+E000–U+FFFF."  StringParser.java:78 */
+#define SJMI_E_OD_CHAR_NOT_16BIT 52      /* "String cannot be deserialized to a char. Expected a single 16-bit code unit character."  :104 */
+#define SJMI_E_OD_CHAR_NOT_SINGLE 53     /* "... Expected a single-character string."                    :107 */
 #define SJMI_OD_EMPTY 0                  /* IteratorResult :672-674 */
 #define SJMI_OD_NULL 1
 #define SJMI_OD_NOT_EMPTY 2
@@ -336,6 +340,7 @@ int sjmi_od_get_long(sjmi_parser* p, int root, int nullable, int* is_null, int64
 int sjmi_od_get_integral(sjmi_parser* p, int bits, int root, int nullable, int* is_null, int64_t* value);
 int sjmi_od_get_double(sjmi_parser* p, int root, int nullable, int* is_null, double* value);   /* :383-428 */
 int sjmi_od_get_float(sjmi_parser* p, int root, int nullable, int* is_null, float* value);     /* :360-381,:430-444 */
+int sjmi_od_get_char(sjmi_parser* p, int root, int nullable, int* is_null, uint16_t* utf16_unit);  /* :474-520 */
 /* getRootString / getString :446-472, getFieldName :646-652: the unescaped bytes, valid until the next of these calls */
 int sjmi_od_get_string(sjmi_parser* p, int root, int* is_null, const uint8_t** bytes, uint64_t* len);
 int sjmi_od_get_field_name(sjmi_parser* p, const uint8_t** bytes, uint64_t* len);

@@ -4,7 +4,7 @@ pieces of NumberParser (NumberParser.java:199-310), StringParser (StringParser.j
 (BitIndexes.java:47-101) it calls -- method for method, message for message.  Only tests/ may import it: it is the checker
 for csrc/host/ondemand.h (the product's C++ mirror, which adds the GPU skip table).  Pure-Python loops: small documents.
 Pinned by tests/test_host_ondemand.py (tests/golden/ondemand_vectors.py: what the reference's own schema-based tests assert).
-Not restated (as in the product): the char getters."""
+Every getter of the class is restated."""
 import struct
 
 
@@ -242,6 +242,58 @@ class OnDemandJsonIterator:
         if root:
             self.assert_no_more_json_values()
         return out
+
+    def get_char(self, root=False, nullable=True):
+        """getNonNullChar :474-481, getChar :483-494, getRootNonNullChar :496-505, getRootChar :507-520 -> UTF-16 unit or None"""
+        self.depth -= 1
+        idx = self._get_and_advance()
+        ch = self.buffer[idx]
+        if ch == 0x22:
+            out = self._parse_char(idx)
+        elif nullable and ch == ord("n"):
+            self._visit_atom(idx, b"null", root)
+            out = None
+        elif nullable:
+            raise JsonParsingException("Invalid value starting at %d. Expected either string or 'null'." % idx)
+        else:
+            raise JsonParsingException("Invalid value starting at %d. Expected string." % idx)
+        if root:
+            self.assert_no_more_json_values()
+        return out
+
+    def _parse_char(self, start):  # StringParser.parseChar :70-110
+        b = self.buffer
+        i = start + 1
+        if b[i] == 0x5C:
+            e = b[i + 1]
+            if e == ord("u"):
+                cp = self._hex4(b, i + 2)
+                if 0xD800 <= cp <= 0xDFFF:
+                    raise JsonParsingException("Invalid code point. Should be within the range U+0000–U+D777 or U+E000–U+FFFF.")
+                if cp < 0:
+                    raise JsonParsingException("Invalid unicode escape sequence.")
+                ch = cp
+                i += 6
+            else:
+                r = _ESCAPE.get(e) if e < 0x80 else None
+                if r is None:
+                    raise JsonParsingException("Escaped unexpected character: " + _jchar(e))
+                ch = r
+                i += 2
+        elif b[i] < 0x80:
+            ch = b[i]
+            i += 1
+        elif b[i] & 0xE0 == 0xC0:
+            ch = (b[i] & 0x1F) << 6 | (b[i + 1] & 0x3F)
+            i += 2
+        elif b[i] & 0xF0 == 0xE0:
+            ch = (b[i] & 0x0F) << 12 | (b[i + 1] & 0x3F) << 6 | (b[i + 2] & 0x3F)
+            i += 3
+        else:
+            raise JsonParsingException("String cannot be deserialized to a char. Expected a single 16-bit code unit character.")
+        if b[i] != 0x22:
+            raise JsonParsingException("String cannot be deserialized to a char. Expected a single-character string.")
+        return ch & 0xFFFF
 
     def get_field_name(self):
         idx = self._get_and_advance()

@@ -69,7 +69,7 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_value_next", "sjmi_parse_batch_device", "sjmi_parse_document",
            "sjmi_parser_set_gpu_walk", "sjmi_set_auto_safe", "sjmi_match_brackets",
            "sjmi_match_brackets_device", "sjmi_stage1_shard_device",
-           "sjmi_parser_ondemand_init", "sjmi_od_skip_child", "sjmi_od_get_boolean", "sjmi_od_get_long", "sjmi_od_get_integral", "sjmi_od_get_double", "sjmi_od_get_float",
+           "sjmi_parser_ondemand_init", "sjmi_od_skip_child", "sjmi_od_get_boolean", "sjmi_od_get_long", "sjmi_od_get_integral", "sjmi_od_get_double", "sjmi_od_get_float", "sjmi_od_get_char",
            "sjmi_od_get_string", "sjmi_od_get_field_name", "sjmi_od_start_array", "sjmi_od_next_array_element",
            "sjmi_od_start_object", "sjmi_od_next_object_field", "sjmi_od_move_to_field_value", "sjmi_od_assert_no_more_values",
            "sjmi_od_depth", "sjmi_od_peek"]
@@ -179,7 +179,7 @@ def lib():
         P = C.c_void_p
         for name, args in (("sjmi_parser_ondemand_init", [P, P, C.c_uint64, C.c_int]), ("sjmi_od_skip_child", [P, C.c_int]),
                            ("sjmi_od_get_boolean", [P, C.c_int, C.c_int, P, P]), ("sjmi_od_get_long", [P, C.c_int, C.c_int, P, P]),
-                           ("sjmi_od_get_double", [P, C.c_int, C.c_int, P, P]), ("sjmi_od_get_float", [P, C.c_int, C.c_int, P, P]), ("sjmi_od_get_integral", [P, C.c_int, C.c_int, C.c_int, P, P]), ("sjmi_od_get_string", [P, C.c_int, P, P, P]),
+                           ("sjmi_od_get_double", [P, C.c_int, C.c_int, P, P]), ("sjmi_od_get_float", [P, C.c_int, C.c_int, P, P]), ("sjmi_od_get_char", [P, C.c_int, C.c_int, P, P]), ("sjmi_od_get_integral", [P, C.c_int, C.c_int, C.c_int, P, P]), ("sjmi_od_get_string", [P, C.c_int, P, P, P]),
                            ("sjmi_od_get_field_name", [P, P, P]), ("sjmi_od_start_array", [P, C.c_int, P]),
                            ("sjmi_od_next_array_element", [P, P]), ("sjmi_od_start_object", [P, C.c_int, P]),
                            ("sjmi_od_next_object_field", [P, P]), ("sjmi_od_move_to_field_value", [P]),
@@ -709,6 +709,11 @@ class OnDemandIterator:
     def get_float(self, root=False, nullable=True):
         n, v = C.c_int(0), C.c_float(0)
         self._check(lib().sjmi_od_get_float(self._p._h, int(root), int(nullable), C.addressof(n), C.addressof(v)))
+        return None if n.value else v.value
+
+    def get_char(self, root=False, nullable=True):
+        n, v = C.c_int(0), C.c_uint16(0)
+        self._check(lib().sjmi_od_get_char(self._p._h, int(root), int(nullable), C.addressof(n), C.addressof(v)))
         return None if n.value else v.value
 
     def _bytes(self, ptr, ln):

@@ -7,8 +7,8 @@
 // bracket), which turns skipChild's bracket-counting scan (:47-81) -- the bulk of the work when a schema wants a few
 // fields of a large document -- into k - 1 climbs through up[] and one jump through match[].
 // Built: booleans, byte / short / int / long, float, double, String (and their Root / NonNull forms), null handling,
-// arrays, objects, field names, skipChild, assertNoMoreJsonValues.  Not built: the char getters (:474-520: a Java UTF-16
-// unit) and the reflection-driven schema mapping itself (SchemaBasedJsonIterator, ClassResolver), which is Java-specific.
+// arrays, objects, field names, skipChild, assertNoMoreJsonValues, char (a Java UTF-16 unit) -- every method of the class.
+// Not built: the reflection-driven schema mapping itself (SchemaBasedJsonIterator, ClassResolver), which is Java-specific.
 #pragma once
 #include <locale.h>
 #include <stdlib.h>
@@ -34,7 +34,11 @@ enum {  // numbering of include/sjmi.h SJMI_E_OD_*
     E_OD_FLOAT_PART_MISSING = 46,  // "Invalid floating-point number. Fraction or exponent part is missing."  NumberParser.java:303
     E_OD_BYTE_RANGE = 47,          // "Number value is out of byte range ([-128, 127])."                  NumberParser.java:97
     E_OD_SHORT_RANGE = 48,         // "Number value is out of short range ([-32768, 32767])."             :136
-    E_OD_INT_RANGE = 49            // "Number value is out of int range ([-2147483648, 2147483647])."     :175
+    E_OD_INT_RANGE = 49,           // "Number value is out of int range ([-2147483648, 2147483647])."     :175
+    E_OD_STRING_EXPECTED = 50,     // "Invalid value starting at N. Expected string."                      :480,:505
+    E_OD_CHAR_CODE_POINT = 51,     // "Invalid code point. Should be within the range U+0000–U+D777 or U+E000–U+FFFF."  StringParser.java:78
+    E_OD_CHAR_NOT_16BIT = 52,      // "String cannot be deserialized to a char. Expected a single 16-bit code unit character."  :104
+    E_OD_CHAR_NOT_SINGLE = 53      // "String cannot be deserialized to a char. Expected a single-character string."  :107
 };
 
 class OnDemandJsonIterator {
@@ -163,6 +167,24 @@ public:
         return v;
     }
 
+    // getNonNullChar :474-481, getChar :483-494, getRootNonNullChar :496-505, getRootChar :507-520 -> the UTF-16 unit
+    uint16_t getChar(bool root, bool nullable, bool* isNull) {
+        depth_--;
+        const uint32_t idx = indexer_->getAndAdvance();
+        *isNull = false;
+        uint16_t ch = 0;
+        if (buffer_[idx] == '"') {
+            ch = parseChar(idx);
+        } else if (nullable && buffer_[idx] == 'n') {
+            visitNullAtom(idx, root);
+            *isNull = true;
+        } else {
+            throw error(nullable ? E_OD_STRING_OR_NULL : E_OD_STRING_EXPECTED, idx);
+        }
+        if (root) assertNoMoreJsonValues();
+        return ch;
+    }
+
     // getRootString :446-459, getString :461-472: the unescaped bytes (valid until the next string call), or *isNull
     const std::vector<uint8_t>& getString(bool root, bool* isNull) {
         depth_--;
@@ -238,6 +260,10 @@ private:
         case E_OD_BOOLEAN_OR_NULL: m = "Unrecognized boolean value. Expected: 'true', 'false' or 'null'."; break;
         case E_OD_STRING_OR_NULL: m = "Invalid value starting at " + std::to_string(pos) + ". Expected either string or 'null'."; break;
         case E_OD_FLOAT_PART_MISSING: m = "Invalid floating-point number. Fraction or exponent part is missing."; break;
+        case E_OD_STRING_EXPECTED: m = "Invalid value starting at " + std::to_string(pos) + ". Expected string."; break;
+        case E_OD_CHAR_CODE_POINT: m = "Invalid code point. Should be within the range U+0000\xe2\x80\x93U+D777 or U+E000\xe2\x80\x93U+FFFF."; break;
+        case E_OD_CHAR_NOT_16BIT: m = "String cannot be deserialized to a char. Expected a single 16-bit code unit character."; break;
+        case E_OD_CHAR_NOT_SINGLE: m = "String cannot be deserialized to a char. Expected a single-character string."; break;
         case E_OD_BYTE_RANGE: m = "Number value is out of byte range ([-128, 127])."; break;
         case E_OD_SHORT_RANGE: m = "Number value is out of short range ([-32768, 32767])."; break;
         case E_OD_INT_RANGE: m = "Number value is out of int range ([-2147483648, 2147483647])."; break;
@@ -415,6 +441,48 @@ private:
                 src += 2;
             }
         }
+    }
+    uint16_t parseChar(uint32_t startIdx) const {                                 // StringParser.parseChar :70-110
+        const uint8_t* p = buffer_ + startIdx + 1;
+        uint32_t character;
+        if (p[0] == '\\') {
+            const uint8_t e = p[1];
+            if (e == 'u') {
+                const int cp = hex4(p + 2);
+                if (cp >= 0xD800 && cp <= 0xDFFF) throw error(E_OD_CHAR_CODE_POINT);
+                if (cp < 0) throw error(5 /* E_INVALID_UNICODE_ESCAPE */);
+                character = (uint32_t)cp;
+                p += 6;
+            } else {
+                uint8_t r = 0;
+                switch (e) {
+                case '"': r = '"'; break;
+                case '\\': r = '\\'; break;
+                case '/': r = '/'; break;
+                case 'b': r = 0x08; break;
+                case 'f': r = 0x0C; break;
+                case 'n': r = 0x0A; break;
+                case 'r': r = 0x0D; break;
+                case 't': r = 0x09; break;
+                default: throw JsonParsingException(4, std::string(errorMessage(4)) + javaChar(e), (uint64_t)(p - buffer_));
+                }
+                character = r;
+                p += 2;
+            }
+        } else if (p[0] < 0x80) {
+            character = p[0];
+            p += 1;
+        } else if ((p[0] & 0xE0) == 0xC0) {
+            character = (uint32_t)(p[0] & 0x1F) << 6 | (p[1] & 0x3F);
+            p += 2;
+        } else if ((p[0] & 0xF0) == 0xE0) {
+            character = (uint32_t)(p[0] & 0x0F) << 12 | (uint32_t)(p[1] & 0x3F) << 6 | (p[2] & 0x3F);
+            p += 3;
+        } else {
+            throw error(E_OD_CHAR_NOT_16BIT);
+        }
+        if (p[0] != '"') throw error(E_OD_CHAR_NOT_SINGLE);
+        return (uint16_t)character;
     }
     static int hex4(const uint8_t* p) {                                           // CharacterUtils.hexToInt :241-247
         int v = 0;

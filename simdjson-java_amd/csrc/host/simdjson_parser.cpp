@@ -1069,6 +1069,14 @@ int sjmi_od_get_float(sjmi_parser* h, int root, int nullable, int* is_null, floa
         *is_null = n;
     });
 }
+int sjmi_od_get_char(sjmi_parser* h, int root, int nullable, int* is_null, uint16_t* utf16_unit) {
+    if (!is_null || !utf16_unit) return SJMI_ERR_ARG;
+    return odCall(h, [&](org_simdjson::OnDemandJsonIterator& it) {
+        bool n = false;
+        *utf16_unit = it.getChar(root != 0, nullable != 0, &n);
+        *is_null = n;
+    });
+}
 int sjmi_od_get_string(sjmi_parser* h, int root, int* is_null, const uint8_t** bytes, uint64_t* len) {
     if (!is_null || !bytes || !len) return SJMI_ERR_ARG;
     return odCall(h, [&](org_simdjson::OnDemandJsonIterator& it) {

@@ -143,6 +143,25 @@ add('"a\\nb\\u00e9\\uD83D\\uDE00"', "String", "a\nbé\U0001F600".encode())
 add('"abc"', "Boolean", message=BOOL3)                    # :89-108 mismatchedTypeForStringAsRoot
 add('"abc"', "long", message=MINUS)
 
+for ch, want in (("a", 0x61), ("\\n", 10), ("\\u0041", 0x41), ("é", 0xE9), ("€", 0x20AC), ("\\\\", 0x5C), ("\\\"", 0x22)):
+    add('"%s"' % ch, "Character", want)                   # :244-272 characterAtRoot / primitiveCharAtRoot (shape)
+    add('"%s"' % ch, "char", want)
+    add('{"field": "%s"}' % ch, F("char"), {"field": want})  # :334-366
+add("null", "Character", None)                            # :276-287
+add("null", "char", message="Invalid value starting at 0. Expected string.")  # :289-301
+for j in ("true", "false", "1"):
+    add(j, "Character", message="Invalid value starting at 0. Expected either string or 'null'.")  # :303-316
+    add(j, "char", message="Invalid value starting at 0. Expected string.")                       # :318-331
+    add('{"field": %s}' % j, F("Character"), message="Invalid value starting at 10. Expected either string or 'null'.")  # :394-409
+    add('{"field": %s}' % j, F("char"), message="Invalid value starting at 10. Expected string.")                        # :412-427
+add('{"field": null}', F("Character"), {"field": None})   # :349-360
+add('{"field": null}', F("char"), message="Invalid value starting at 10. Expected string.")  # :377-392
+add("a", "Character", message="Invalid value starting at 0. Expected either string or 'null'.")  # :460-471
+add('"ab"', "char", message="String cannot be deserialized to a char. Expected a single-character string.")
+add('"\\uD83D\\uDE00"', "char", message="Invalid code point. Should be within the range U+0000–U+D777 or U+E000–U+FFFF.")
+add('"😀"', "Character", message="String cannot be deserialized to a char. Expected a single 16-bit code unit character.")
+add('"\\u12G4"', "char", message="Invalid unicode escape sequence.")
+
 # ---- ArraySchemaBasedParsingTest.java ----
 add("[]", A("long"), [])                                  # :50-63
 add('{"field": []}', F(A("Long")), {"field": []})         # :65-76

@@ -72,7 +72,7 @@ void sim_od_destroy(void* h) { delete static_cast<SimOnDemand*>(h); }
 const char* sim_od_message(void* h) { return static_cast<SimOnDemand*>(h)->msg.c_str(); }
 // op: 0 skipChild(a) (a < 0: skipChild()), 1 getBoolean(root=a, nullable=b), 2 getLong, 3 getDouble, 4 getString(root=a),
 // 5 getFieldName, 6 startIteratingArray(root=a), 7 nextArrayElement, 8 startIteratingObject(root=a), 9 nextObjectField,
-// 10 moveToFieldValue, 11 assertNoMoreJsonValues, 12 getFloat(root=a, nullable=b).  -> exception code or 0; results in out (int64) / dout / bytes
+// 10 moveToFieldValue, 11 assertNoMoreJsonValues, 12 getFloat(root=a, nullable=b), 13 getChar.  -> exception code or 0; results in out (int64) / dout / bytes
 int sim_od_call(void* h, int op, int a, int b, int64_t* out, double* dout, const uint8_t** bytes, uint64_t* nbytes) {
     SimOnDemand* s = static_cast<SimOnDemand*>(h);
     s->msg.clear();
@@ -87,6 +87,7 @@ int sim_od_call(void* h, int op, int a, int b, int64_t* out, double* dout, const
         case 1: *out = s->it.getBoolean(a != 0, b != 0, &isNull) ? 1 : 0; if (isNull) *out = -1; break;
         case 2: *out = s->it.getLong((a & 1) != 0, b != 0, &isNull, (a >> 8) ? (a >> 8) : 64); if (isNull) *nbytes = 1; break;  // a = root | bits << 8
         case 3: *dout = s->it.getDouble(a != 0, b != 0, &isNull); if (isNull) *nbytes = 1; break;
+        case 13: *out = s->it.getChar(a != 0, b != 0, &isNull); if (isNull) *out = -1; break;
         case 12: *dout = (double)s->it.getFloat(a != 0, b != 0, &isNull); if (isNull) *nbytes = 1; break;  // (float -> double: exact)
         case 4: { const std::vector<uint8_t>& v = s->it.getString(a != 0, &isNull); *bytes = v.data(); *nbytes = v.size(); if (isNull) *out = -1; break; }
         case 5: { const std::vector<uint8_t>& v = s->it.getFieldName(); *bytes = v.data(); *nbytes = v.size(); break; }

@@ -23,6 +23,8 @@ def _scalar(it, schema, root):
         return it.get_double(root=root, nullable=schema == "Double")
     if schema in ("float", "Float"):
         return it.get_float(root=root, nullable=schema == "Float")
+    if schema in ("char", "Character"):
+        return it.get_char(root=root, nullable=schema == "Character")
     if schema == "String":
         return it.get_string(root=root)
     raise ValueError(schema)
@@ -145,7 +147,10 @@ def fuzz_walk(it, rng, trace, root=True, budget=None):
         if root:
             it.assert_no_more_json_values()
     elif b == 0x22 and not wrong:
-        trace.append(("string", it.get_string(root=root)))
+        if rng.random() < 0.2:
+            trace.append(("char", it.get_char(root=root, nullable=rng.random() < 0.5)))
+        else:
+            trace.append(("string", it.get_string(root=root)))
     elif b in b"tf" and not wrong:
         trace.append(("boolean", it.get_boolean(root=root, nullable=rng.random() < 0.5)))
     elif b == 0x6E and not wrong:

@@ -195,7 +195,7 @@ def _run_parser(parser, doc, length, schema, table):
 
 @pytest.mark.parametrize("table", [False, True], ids=["scan", "skip-table"])
 def test_reference_schema_vectors_through_the_c_abi(parser, table):
-    """The 245 inputs of tests/golden/ondemand_vectors.py (values / messages asserted by the reference's own
+    """The 287 inputs of tests/golden/ondemand_vectors.py (values / messages asserted by the reference's own
     *SchemaBasedParsingTest classes) through GPU stage 1 (+ the GPU skip table) and the C ABI cursor."""
     for (j, length, schema, value, message) in VECTORS:
         doc = j.encode("utf-8")

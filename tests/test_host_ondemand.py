@@ -2,7 +2,7 @@
 GPU: the engine ABI is stubbed (tests/host_sim/walk_sim.cpp), the structural indexes come from the oracle's stage 1 and
 the skip table from a plain bracket stack, and a schema driver / a fuzz driver make the same calls on the product's cursor
 and on the Python restatement of the reference (oracle/ondemand.py) -- values, depth bookkeeping and exception messages
-must agree call for call.  The restatement itself is pinned by tests/golden/ondemand_vectors.py: 245 inputs with the
+must agree call for call.  The restatement itself is pinned by tests/golden/ondemand_vectors.py: 287 inputs with the
 values / messages the reference's own *SchemaBasedParsingTest classes assert."""
 import ctypes as C
 import os
@@ -111,6 +111,10 @@ class SimIterator:
     def get_float(self, root=False, nullable=True):
         _, d, _, isnull = self._call(12, int(root), int(nullable))
         return None if isnull else d
+
+    def get_char(self, root=False, nullable=True):
+        v = self._call(13, int(root), int(nullable))[0]
+        return None if v == -1 else v
 
     def get_string(self, root=False):
         v, _, s, _ = self._call(4, int(root))
