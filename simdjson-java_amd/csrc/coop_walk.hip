@@ -257,8 +257,10 @@ struct ChunkWs {
 // (2 words per structural + 2, walk.hip packs the tapes back to back afterwards); sizes / scratch: the per-structural
 // records of the unescape pass (4 + length | flags per '"' structural, 0 otherwise; scratch[open] = code of a failed
 // string).
+// (five waves per SIMD: 96 instead of 123 VGPRs and three spilled dwords, but the kernel is VALU-bound at 70 % issue
+//  utilisation and the fifth wave fills bubbles: 4.91 -> 4.38 ms per million documents; six waves spill 26 dwords: 4.41)
 template <bool CHUNKED>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
 k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restrict__ doc_offsets, uint64_t n_docs,
             const uint32_t* __restrict__ idx, const unsigned long long* __restrict__ index_offsets,
             const uint32_t* __restrict__ doc_status, const uint32_t* __restrict__ sizes, const uint8_t* __restrict__ scratch,
