@@ -300,3 +300,40 @@ def test_reference_float_vectors(lib):
             assert run_oracle(doc, len(doc), idx, schema) == ("ok", OD.float32_of(v["input"]))
             kind, got = run_product(lib, doc, len(doc), idx, schema, False)
             assert kind == "ok" and OD.float_bits(got) == want, (v, got)
+
+
+def test_float_and_double_getters_on_random_literals(lib):
+    """getFloat / getDouble of the product's cursor on random literals -- plain ones, exact midpoints of two adjacent binary32
+    / binary64 values and their neighbours 10^-30 away, subnormal and overflow boundaries -- against exact roundings
+    (binary32: rational arithmetic, oracle/ondemand.py float32_of; binary64: Python's float)."""
+    import struct
+    from decimal import Decimal, getcontext
+    from tests.walk_common import random_number_literal
+    getcontext().prec = 400
+    rng = random.Random(31337)
+    lits = []
+    for _ in range(1500):
+        lit = random_number_literal(rng)
+        if not any(c in lit for c in ".eE"):
+            lit += ".0"
+        lits.append(lit)
+    for _ in range(600):  # binary32 midpoints (and just beside them)
+        bits = rng.getrandbits(23) | (rng.choice([0, 1, 2, 100, 127, 150, 253, 254]) << 23)
+        lo = Decimal(struct.unpack("<f", struct.pack("<I", bits))[0])
+        hi = Decimal(struct.unpack("<f", struct.pack("<I", bits + 1))[0]) if bits + 1 < 0x7F800000 else Decimal(2) ** 128
+        mid = (lo + hi) / 2
+        for nudge in (Decimal(0), Decimal(10) ** (mid.adjusted() - 30), -Decimal(10) ** (mid.adjusted() - 30)):
+            text = format(mid + nudge, "f")
+            lits.append(text if "." in text else text + ".0")
+    checked_f = checked_d = 0
+    for lit in lits:
+        doc = lit.encode()
+        idx, st = O.stage1(doc)
+        assert st == 0
+        kind, got = run_product(lib, doc, len(doc), idx, "float", False)
+        assert kind == "ok" and OD.float_bits(got) == OD.float_bits(OD.float32_of(lit)), (lit, got)
+        checked_f += 1
+        kind, got = run_product(lib, doc, len(doc), idx, "double", False)
+        assert kind == "ok" and OD.double_bits(got) == OD.double_bits(float(lit)), (lit, got)
+        checked_d += 1
+    assert checked_f == checked_d == len(lits) > 3000
