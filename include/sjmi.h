@@ -239,7 +239,10 @@ int sjmi_walk_batch_device(sjmi_ctx* ctx, const void* d_buf, const void* d_doc_o
  * sjmi_stage1_batch_isolated_device -> sjmi_unescape_batch_device -> sjmi_walk_batch_device (string_base 0), the
  * structural count handed from stage to stage on the device.  Outputs as documented for the three calls; index_capacity
  * bounds the structural count (+ sentinel) and sizes the workspaces.  d_result: a device sjmi_batch_result.  This is
- * what one rank of the sharded multi-GPU batch runs per step (sharding.py); asynchronous on `stream`. */
+ * what one rank of the sharded multi-GPU batch runs per step (sharding.py); asynchronous on `stream`.
+ * Stage 1 is first tried as ONE plain launch over the packed batch and accepted on the device when every document ends in
+ * a control-character separator ('\n', '\r', '\t') and the global verdict is clean -- then it is exactly what the
+ * per-document passes give; otherwise those run (queued behind it, they leave at once when it was accepted). */
 typedef struct sjmi_batch_result {
     sjmi_stage1_result stage1;
     sjmi_unescape_result strings;

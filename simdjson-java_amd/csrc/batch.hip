@@ -37,6 +37,66 @@ k_split_docs(const uint32_t* __restrict__ idx, const Stage1Result* __restrict__ 
     index_offsets[k] = lo;
 }
 
+// ---- the optimistic plain pass of the fused batch pipeline (sjmi_parse_batch_device) --------------------------------------
+// A batch whose documents each end in a control-character separator (the '\n' of NDJSON; '\r', '\t') and ALL pass stage 1 is
+// indexed exactly by ONE plain k_stage1 launch over the packed buffer: alignment invariance makes the indexes those of the
+// per-document passes, the separators clear the scalar carry, and a string left open by one document would make the separator
+// behind it an unescaped control character inside a string -- so "two unclosed strings cancelling" cannot hide behind a
+// clean global verdict.  flags[0] = a separator is missing / an offset pair is unusable; flags[1] = accepted: the
+// per-document passes queued behind leave at once.  Any global error bit (or a tripped liveness bound) rejects, and the
+// per-document passes give every document its own verdict as before.
+__global__ void __launch_bounds__(256)
+k_batch_sep_check(const uint8_t* __restrict__ buf, const unsigned long long* __restrict__ doc_offsets, uint64_t n_docs, sj_u64 total_len,
+                  uint32_t* __restrict__ flags) {
+    const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_docs) return;
+    const sj_u64 s = doc_offsets[k], e = doc_offsets[k + 1];
+    bool bad = e < s || e > total_len;
+    if (!bad && k + 1 < n_docs) {  // (the last document ends where the batch ends)
+        const uint8_t c = e > s ? buf[e - 1] : 0xFF;
+        bad = !(c == 0x0A || c == 0x0D || c == 0x09);
+    }
+    if (bad) atomicOr(&flags[0], 1u);
+}
+__global__ void k_batch_plain_accept(const Stage1Result* __restrict__ res, uint32_t* __restrict__ flags) {
+    if (threadIdx.x == 0) flags[1] = (flags[0] == 0 && res->status == 0) ? 1u : 0u;
+}
+// k_split_docs + "every document's status is 0", only if the plain pass was accepted
+__global__ void __launch_bounds__(256)
+k_split_docs_accept(const uint32_t* __restrict__ idx, const Stage1Result* __restrict__ res, const unsigned long long* __restrict__ doc_offsets,
+                    uint64_t n_docs, unsigned long long* __restrict__ index_offsets, uint32_t* __restrict__ doc_status,
+                    const uint32_t* __restrict__ flags) {
+    if (flags[1] == 0) return;
+    const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k > n_docs) return;
+    const unsigned long long count = res->count;
+    const unsigned long long target = doc_offsets[k];
+    unsigned long long lo = 0, hi = count;
+    while (lo < hi) {
+        const unsigned long long mid = (lo + hi) >> 1;
+        if ((unsigned long long)idx[mid] < target) lo = mid + 1;
+        else hi = mid;
+    }
+    index_offsets[k] = lo;
+    if (k < n_docs) doc_status[k] = 0;
+}
+hipError_t batch_plain_check_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint64_t total_len,
+                                    uint32_t* d_flags, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(d_flags, 0, 8, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_batch_sep_check, dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs,
+                       (sj_u64)total_len, d_flags);
+    return hipGetLastError();
+}
+hipError_t batch_plain_accept_launch(const uint32_t* d_idx, const Stage1Result* d_res, const unsigned long long* d_doc_offsets,
+                                     uint64_t n_docs, unsigned long long* d_index_offsets, uint32_t* d_doc_status, uint32_t* d_flags,
+                                     hipStream_t stream) {
+    hipLaunchKernelGGL(k_batch_plain_accept, dim3(1), dim3(64), 0, stream, d_res, d_flags);
+    hipLaunchKernelGGL(k_split_docs_accept, dim3((unsigned)((n_docs + 1 + 255) / 256)), dim3(256), 0, stream, d_idx, d_res, d_doc_offsets,
+                       n_docs, d_index_offsets, d_doc_status, (const uint32_t*)d_flags);
+    return hipGetLastError();
+}
+
 hipError_t split_docs_launch(const uint32_t* d_idx, const Stage1Result* d_res, const unsigned long long* d_doc_offsets,
                              uint64_t n_docs, unsigned long long* d_index_offsets, hipStream_t stream) {
     hipLaunchKernelGGL(k_split_docs, dim3((unsigned)((n_docs + 1 + 255) / 256)), dim3(256), 0, stream, d_idx, d_res,
@@ -65,7 +125,8 @@ __global__ void __launch_bounds__(256)
 k_doc_pass(const uint8_t* __restrict__ buf, const unsigned long long* __restrict__ doc_offsets, uint64_t n_docs,
            uint32_t* __restrict__ counts, uint32_t* __restrict__ doc_status,
            const unsigned long long* __restrict__ index_offsets, uint32_t* __restrict__ out, uint64_t out_cap,
-           sj_u64 total_len) {
+           sj_u64 total_len, const uint32_t* __restrict__ skip) {
+    if (skip && *skip) return;  // (the optimistic plain pass of the fused pipeline was accepted: k_batch_plain_accept)
     const int lane = threadIdx.x & 63;
     const int rl = lane & 15;         // lane inside the row
     const int rshift = lane & ~15;    // first lane of the row
@@ -183,7 +244,8 @@ __device__ __forceinline__ unsigned long long block_excl_scan_1024(unsigned long
 
 __global__ void __launch_bounds__(1024)
 k_doc_chunk_sums(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ doc_status, uint64_t n_docs,
-                 unsigned long long* __restrict__ chunk_sums, uint32_t* __restrict__ status_or) {
+                 unsigned long long* __restrict__ chunk_sums, uint32_t* __restrict__ status_or, const uint32_t* __restrict__ skip) {
+    if (skip && *skip) return;
     __shared__ unsigned long long s_wave[16];
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK;
     unsigned long long sum = 0;
@@ -216,7 +278,8 @@ k_doc_chunk_sums(const uint32_t* __restrict__ counts, const uint32_t* __restrict
 __global__ void __launch_bounds__(1024)
 k_doc_scan(unsigned long long* __restrict__ chunk_sums, uint64_t nchunks, const uint32_t* __restrict__ status_or,
            uint64_t n_docs, unsigned long long* __restrict__ index_offsets, uint32_t* __restrict__ out, uint64_t out_cap,
-           Stage1Result* res) {
+           Stage1Result* res, const uint32_t* __restrict__ skip) {
+    if (skip && *skip) return;
     __shared__ unsigned long long s_wave[16];
     unsigned long long carry = 0;
     for (uint64_t b = 0; b < nchunks; b += 1024) {
@@ -239,7 +302,8 @@ k_doc_scan(unsigned long long* __restrict__ chunk_sums, uint64_t nchunks, const 
 
 __global__ void __launch_bounds__(1024)
 k_doc_offsets(const uint32_t* __restrict__ counts, uint64_t n_docs, const unsigned long long* __restrict__ chunk_base,
-              unsigned long long* __restrict__ index_offsets) {
+              unsigned long long* __restrict__ index_offsets, const uint32_t* __restrict__ skip) {
+    if (skip && *skip) return;
     __shared__ unsigned long long s_wave[16];
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK;
     unsigned long long carry = chunk_base[blockIdx.x];
@@ -263,7 +327,7 @@ size_t batch_isolated_workspace_bytes(uint64_t n_docs) {
 hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs,
                                  uint32_t* d_out, uint64_t out_cap, unsigned long long* d_index_offsets,
                                  uint32_t* d_doc_status, uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream,
-                                 uint64_t total_len) {
+                                 uint64_t total_len, const uint32_t* d_skip) {
     uint8_t* ws = reinterpret_cast<uint8_t*>(d_counts);
     uint32_t* status_or = reinterpret_cast<uint32_t*>(ws + iso_status_offset(n_docs));
     unsigned long long* chunk_sums = reinterpret_cast<unsigned long long*>(ws + iso_chunks_offset(n_docs));
@@ -274,17 +338,17 @@ hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long*
     const unsigned grid = (unsigned)(want < 8192 ? want : 8192);  // grid-stride over the documents
     if (n_docs) {
         hipLaunchKernelGGL(k_doc_pass<false>, dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_counts,
-                           d_doc_status, (const unsigned long long*)nullptr, (uint32_t*)nullptr, (uint64_t)0, (sj_u64)total_len);
+                           d_doc_status, (const unsigned long long*)nullptr, (uint32_t*)nullptr, (uint64_t)0, (sj_u64)total_len, d_skip);
         hipLaunchKernelGGL(k_doc_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, d_counts, d_doc_status, n_docs,
-                           chunk_sums, status_or);
+                           chunk_sums, status_or, d_skip);
     }
     hipLaunchKernelGGL(k_doc_scan, dim3(1), dim3(1024), 0, stream, chunk_sums, nchunks, status_or, n_docs, d_index_offsets,
-                       d_out, out_cap, d_res);
+                       d_out, out_cap, d_res, d_skip);
     if (n_docs) {
         hipLaunchKernelGGL(k_doc_offsets, dim3((unsigned)nchunks), dim3(1024), 0, stream, d_counts, n_docs, chunk_sums,
-                           d_index_offsets);
+                           d_index_offsets, d_skip);
         hipLaunchKernelGGL(k_doc_pass<true>, dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_counts,
-                           d_doc_status, (const unsigned long long*)d_index_offsets, d_out, out_cap, (sj_u64)total_len);
+                           d_doc_status, (const unsigned long long*)d_index_offsets, d_out, out_cap, (sj_u64)total_len, d_skip);
     }
     return hipGetLastError();
 }

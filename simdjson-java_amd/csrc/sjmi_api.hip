@@ -46,6 +46,7 @@ struct sjmi_ctx {
     void* d_ws_masks = nullptr;
     size_t ws_masks_bytes = 0;
     void* d_single = nullptr;                // sjmi_parse_document: delimiters, tape offsets, error and results of ONE document
+    uint32_t* d_batch_flags = nullptr;       // sjmi_parse_batch_device: the two words of the optimistic plain pass
     unsigned long long* d_tape = nullptr;    // ... and its tape, grown on demand
     size_t tape_bytes = 0;
     void* h_single = nullptr;                // pinned copy of the three result records
@@ -164,6 +165,7 @@ void sjmi_destroy(sjmi_ctx* c) {
     if (c->d_docstr) (void)hipFree(c->d_docstr);
     if (c->d_ws_walk) (void)hipFree(c->d_ws_walk);
     if (c->d_single) (void)hipFree(c->d_single);
+    if (c->d_batch_flags) (void)hipFree(c->d_batch_flags);
     if (c->d_tape) (void)hipFree(c->d_tape);
     if (c->h_single) (void)hipHostFree(c->h_single);
     if (c->d_masks) (void)hipFree(c->d_masks);
@@ -656,9 +658,18 @@ int sjmi_stage1_batch(sjmi_ctx* c, const uint8_t* buf, uint64_t total_len, const
     return SJMI_OK;
 }
 
+static int stage1_batch_isolated_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets,
+                                             uint64_t n_docs, void* d_indexes, uint64_t index_capacity, void* d_index_offsets,
+                                             void* d_doc_status, void* d_result, void* stream, const uint32_t* d_skip);
 int sjmi_stage1_batch_isolated_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets,
                                       uint64_t n_docs, void* d_indexes, uint64_t index_capacity, void* d_index_offsets,
                                       void* d_doc_status, void* d_result, void* stream) {
+    return stage1_batch_isolated_device_impl(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets,
+                                             d_doc_status, d_result, stream, nullptr);
+}
+static int stage1_batch_isolated_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets,
+                                             uint64_t n_docs, void* d_indexes, uint64_t index_capacity, void* d_index_offsets,
+                                             void* d_doc_status, void* d_result, void* stream, const uint32_t* d_skip) {
     if (!c || !d_buf || !d_doc_offsets || !d_indexes || !d_index_offsets || !d_doc_status || !d_result) return SJMI_ERR_ARG;
     if (total_len >= (1ull << 32)) return SJMI_ERR_ARG;
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
@@ -668,7 +679,7 @@ int sjmi_stage1_batch_isolated_device(sjmi_ctx* c, const void* d_buf, uint64_t t
     if (fail(c, "isolated batch launch",
              sjmi::batch_isolated_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs,
                                          (uint32_t*)d_indexes, index_capacity, (unsigned long long*)d_index_offsets,
-                                         (uint32_t*)d_doc_status, c->d_doccnt, (sjmi::Stage1Result*)d_result, st, total_len)))
+                                         (uint32_t*)d_doc_status, c->d_doccnt, (sjmi::Stage1Result*)d_result, st, total_len, d_skip)))
         return SJMI_ERR_HIP;
     return SJMI_OK;
 }
@@ -728,9 +739,33 @@ int sjmi_parse_batch_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, 
         return SJMI_ERR_ARG;
     if (total_len >= (1ull << 32)) return SJMI_ERR_ARG;
     sjmi_batch_result* r = (sjmi_batch_result*)d_result;
+    hipStream_t st0 = stream ? (hipStream_t)stream : c->stream;
+    // Optimistic: one plain k_stage1 launch over the packed batch, accepted on the device when every document ends in a
+    // control-character separator and the global verdict is clean (batch.hip); the per-document passes are queued behind it
+    // and leave at once if it was.  (SJMI_BATCH_OPTIMISTIC=0 switches it off.)
+    static const bool optimistic = !(getenv("SJMI_BATCH_OPTIMISTIC") && atoi(getenv("SJMI_BATCH_OPTIMISTIC")) == 0);
+    const uint32_t* d_skip = nullptr;
+    if (optimistic && n_docs && total_len && !((uintptr_t)d_buf & 15) && !((uintptr_t)d_indexes & 15)) {
+        if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+        if (!c->d_batch_flags && fail(c, "hipMalloc(batch flags)", hipMalloc((void**)&c->d_batch_flags, 64))) return SJMI_ERR_HIP;
+        if (fail(c, "separator check", sjmi::batch_plain_check_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets,
+                                                                      n_docs, total_len, c->d_batch_flags, st0)))
+            return SJMI_ERR_HIP;
+        const bool keep_auto_safe = c->auto_safe;
+        c->auto_safe = false;  // (a tripped liveness bound only rejects the plain pass: the per-document passes take over)
+        const int rc0 = stage1_device_impl(c, d_buf, total_len, d_indexes, index_capacity, &r->stage1, stream, 0);
+        c->auto_safe = keep_auto_safe;
+        if (rc0 != SJMI_OK) return rc0;
+        if (fail(c, "plain accept", sjmi::batch_plain_accept_launch((const uint32_t*)d_indexes, (const sjmi::Stage1Result*)&r->stage1,
+                                                                    (const unsigned long long*)d_doc_offsets, n_docs,
+                                                                    (unsigned long long*)d_index_offsets, (uint32_t*)d_doc_status,
+                                                                    c->d_batch_flags, st0)))
+            return SJMI_ERR_HIP;
+        d_skip = c->d_batch_flags + 1;
+    }
     // stage 1 (isolated: per-document verdicts), queued
-    int rc = sjmi_stage1_batch_isolated_device(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity,
-                                               d_index_offsets, d_doc_status, &r->stage1, stream);
+    int rc = stage1_batch_isolated_device_impl(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity,
+                                               d_index_offsets, d_doc_status, &r->stage1, stream, d_skip);
     if (rc != SJMI_OK) return rc;
     // string records: the structural count stays on the device (no host round trip between the stages); workspaces and
     // grids are sized for the bound index_capacity - 1

@@ -112,7 +112,13 @@ hipError_t single_doc_setup_launch(const Stage1Result* d_res, uint64_t len, unsi
 void unescape_records(void* d_ws, uint64_t count_bound, const uint32_t** sizes, const uint8_t** scratch);
 hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint32_t* d_out,
                                  uint64_t out_cap, unsigned long long* d_index_offsets, uint32_t* d_doc_status,
-                                 uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream, uint64_t total_len);
+                                 uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream, uint64_t total_len, const uint32_t* d_skip = nullptr);
+// the optimistic plain pass of the fused batch pipeline (batch.hip)
+hipError_t batch_plain_check_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint64_t total_len,
+                                    uint32_t* d_flags, hipStream_t stream);
+hipError_t batch_plain_accept_launch(const uint32_t* d_idx, const Stage1Result* d_res, const unsigned long long* d_doc_offsets,
+                                     uint64_t n_docs, unsigned long long* d_index_offsets, uint32_t* d_doc_status, uint32_t* d_flags,
+                                     hipStream_t stream);
 // masks.hip: the reference's six per-block masks (6 x u64 per block, len / 64 + 1 blocks)
 size_t masks_workspace_bytes(uint64_t len);
 hipError_t masks_launch(const uint8_t* d_buf, uint64_t len, unsigned long long* d_masks, void* d_ws, hipStream_t stream);

@@ -87,3 +87,60 @@ def test_capacity_shortfall_is_reported_not_overrun(short):
         assert ok.check()["documents"] == len(docs)
     finally:
         ctx.close()
+
+
+def _run_shard(ctx, buf, offs, n):
+    import torch
+    from simdjson_java_amd import sharding
+    shard = sharding.BatchShard(ctx, buf, offs, torch.device("cuda", 0))
+    for _ in range(2):
+        shard.step(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    c = shard.check()
+    to = shard.tape_offsets.cpu().numpy()
+    tape = shard.tape.cpu().numpy().view(np.uint64)
+    err = shard.doc_errors.cpu().numpy()[:n]
+    io = shard.index_offsets.cpu().numpy()[:n + 1]
+    idx = shard.idx.cpu().numpy()[:c["structurals"] + 1]
+    return c, tape, to, err, bytes(shard.sb[:c["string_bytes"]].cpu().numpy()), io, idx
+
+
+@pytest.mark.parametrize("separator", [b"\n", b"\r\n", b"\t", b" ", b""], ids=["lf", "crlf", "tab", "space", "none"])
+def test_optimistic_plain_pass_and_its_rejections(separator, monkeypatch):
+    """sjmi_parse_batch_device indexes a batch with ONE plain k_stage1 launch when every document ends in a control-character
+    separator and the global verdict is clean; anything else (space / no separators, any broken document) falls to the
+    per-document passes.  Either way the outputs equal those of the pipeline with the optimistic pass switched off
+    (SJMI_BATCH_OPTIMISTIC=0 in a fresh process is not needed: the rejected cases ARE the per-document passes) and the
+    oracle's, document by document -- including batches in which two documents leave a string open (which a plain pass
+    without the separator rule would accept)."""
+    import simdjson_java_amd as S
+    rng = random.Random(99)
+    good = [d for d in _small_docs(rng, 3000)]
+    cases = {"all valid": good,
+             "two unclosed strings": good[:700] + [b'["abc'] + good[700:1500] + [b'def"]'] + good[1500:],
+             "one broken": good[:100] + [b"[1 1]"] + good[100:],
+             "utf-8": good[:50] + [bytes([0x5B, 0x22, 0xC3, 0x22, 0x5D])] + good[50:],
+             "empty documents": good[:10] + [b"", b""] + good[10:40]}
+    ctx = S.Context(0, 1 << 20)
+    try:
+        for name, docs in cases.items():
+            if separator == b"" and name == "empty documents":
+                continue
+            buf = b"".join(d + separator for d in docs)
+            offs = np.concatenate([[0], np.cumsum([len(d) + len(separator) for d in docs])]).astype(np.uint64)
+            c, tape, to, err, strings, io, idx = _run_shard(ctx, buf, offs, len(docs))
+            n_bad = 0
+            for k, d in enumerate(docs):
+                # (a document is judged alone: what stands behind it in the batch must not matter -- with space / no
+                #  separators a scalar at the end of one document would otherwise merge with the next)
+                want = O.parse(d + separator) if separator.strip() == b"" and separator else O.parse(d)
+                got = tape[int(to[k]):int(to[k + 1])]
+                assert int(err[k]) == want.error, (name, k, d[:40], int(err[k]), want.error)
+                if want.error:
+                    n_bad += 1
+                    assert got.size == 0
+                else:
+                    assert O.Parsed(got, strings, 0, 0, 0).to_python() == want.to_python(), (name, k)
+            assert c["failed_documents"] == n_bad, name
+    finally:
+        ctx.close()
