@@ -1,8 +1,10 @@
 """ctypes binding of libsjmi.so (C ABI: include/sjmi.h).  No compute happens in Python and nothing
 here falls back to a CPU path: a missing library or GPU raises SjmiError."""
+import atexit
 import ctypes as C
 import os
 import subprocess
+import weakref
 
 import numpy as np
 
@@ -73,6 +75,27 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_od_get_string", "sjmi_od_get_field_name", "sjmi_od_start_array", "sjmi_od_next_array_element",
            "sjmi_od_start_object", "sjmi_od_next_object_field", "sjmi_od_move_to_field_value", "sjmi_od_assert_no_more_values",
            "sjmi_od_depth", "sjmi_od_peek"]
+
+
+# Handles that are still open when the interpreter exits are closed HERE, in an atexit hook -- i.e. while the HIP runtime
+# (PyTorch's instance) is still up.  Left to __del__ during interpreter finalisation they would call hipFree /
+# hipStreamDestroy in an arbitrary order relative to the runtime's own teardown, which can abort the process after the
+# work is done (seen once as a core dump at the end of a GPU test run).
+_live = weakref.WeakSet()
+_exiting = False
+
+
+def _close_all_at_exit():
+    global _exiting
+    for obj in list(_live):
+        try:
+            obj.close()
+        except Exception:
+            pass
+    _exiting = True
+
+
+atexit.register(_close_all_at_exit)
 
 
 def lib():
@@ -209,6 +232,7 @@ class Context:
             self._h = C.c_void_p()
             raise SjmiError("sjmi_create failed (rc=%d): no usable MI355X / HIP device; there is no CPU fallback" % rc)
         self.capacity = capacity
+        _live.add(self)
 
     def close(self):
         if self._h:
@@ -216,6 +240,8 @@ class Context:
             self._h = C.c_void_p()
 
     def __del__(self):
+        if _exiting:
+            return
         try:
             self.close()
         except Exception:
@@ -578,6 +604,7 @@ class SimdJsonParser:
             raise SjmiError("sjmi_parser_create failed (rc=%d): no usable MI355X; there is no CPU fallback" % rc)
         if gpu_walk is not None:  # stage 2 on the GPU (True) / on the host (False); None: the library's default, by size
             lib().sjmi_parser_set_gpu_walk(self._h, 1 if gpu_walk else 0)
+        _live.add(self)
 
     def close(self):
         if self._h:
@@ -585,6 +612,8 @@ class SimdJsonParser:
             self._h = C.c_void_p()
 
     def __del__(self):
+        if _exiting:
+            return
         try:
             self.close()
         except Exception:
