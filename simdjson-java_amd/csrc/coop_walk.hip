@@ -363,7 +363,6 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
             uint32_t prev_cls = K_COMMA;     // class of the structural in front of the step (none at the start)
             bool prev_empty_open = false, prev_is_key = false, root_closed = false;
             uint32_t root_kind = 0, root_c = 0;
-            uint32_t prev_cls_known = K_COMMA;  // (chunked: class of the structural in front of the chunk, for the empty-bracket test)
             if (CHUNKED) {  // start from the chunk's entry state (k_group_replay)
                 H0 = cw.in.H[k];
                 T0 = cw.in.T[k];
@@ -382,12 +381,10 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                     const uint32_t c1 = class_of(buf[idx[wfrom - 1]]);
                     const uint32_t c2 = wfrom - 1 > from ? class_of(buf[idx[wfrom - 2]]) : K_COLON;
                     prev_cls = c1;
-                    prev_cls_known = c1;
                     const bool in_obj = H0 >= 1 && !((arr_mask >> (H0 - 1)) & 1ull);
                     prev_is_key = c1 == K_QUOTE && (c2 == K_OPEN_O || (c2 == K_COMMA && in_obj));
                 }
             }
-            (void)prev_cls_known;
             // positions (and sizes) are requested TWO steps ahead, the 16-byte windows they point at one step ahead: neither
             // round trip is on the step-to-step critical path
             const uint64_t nsteps = (wto - wfrom + 63) / 64;
@@ -695,8 +692,6 @@ k_chunk_summary(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ id
                 out_of_range = true;
                 break;
             }
-            const unsigned long long lt_mask = (1ull << lane) - 1ull;
-            (void)lt_mask;
             for (int L = hmin; L <= hmax; ++L) {
                 const unsigned long long O = __ballot(is_open && h == L);
                 const unsigned long long C = __ballot(valid && cls == K_COMMA && plevel == L);
