@@ -2,7 +2,7 @@
 seeded random corpora far larger than the test-suite's -- adversarial grammar, escape soups (the packed stream of
 unescape.hip), number literals around rounding boundaries, nested documents -- as batches and, for a sample, as single
 documents through sjmi_parse_document (chunk-parallel walker for the large ones).  Run on the GPU box:
-    python tools/soak_pipeline.py [rounds] [docs per round]"""
+    python tools/soak_pipeline.py [rounds] [docs per round] [seed base]"""
 import os
 import random
 import sys
@@ -47,10 +47,11 @@ def value(rng, d):
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
+    seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 7000
     ctx = S.Context(device=0, capacity=256 << 20)
     stats = {"docs": 0, "ok": 0, "errors": 0, "host": 0, "single": 0}
     for rnd in range(rounds):
-        rng = random.Random(7000 + rnd)
+        rng = random.Random(seed0 + rnd)
         docs = _adversarial(rng, n // 4) + [value(rng, 0).encode() for _ in range(3 * n // 4)]
         rng.shuffle(docs)
         docs = [d for d in docs if b"\n" not in d or True]
