@@ -44,6 +44,29 @@ def value(rng, d):
     return "{" + ",".join('"%s":%s' % (soup(rng, rng.randint(1, 12), 0.001), value(rng, d + 1)) for _ in range(rng.randint(0, 6))) + "}"
 
 
+def fused_check(ctx, docs, want_err, want_tapes, stats):
+    import torch
+    from simdjson_java_amd import sharding
+    buf = b"".join(d + b"\n" for d in docs)
+    offs = np.concatenate([[0], np.cumsum([len(d) + 1 for d in docs])]).astype(np.uint64)
+    shard = sharding.BatchShard(ctx, buf, offs, torch.device("cuda", 0))
+    shard.step(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    shard.check()
+    to = shard.tape_offsets.cpu().numpy()
+    tape = shard.tape.cpu().numpy().view(np.uint64)
+    err = shard.doc_errors.cpu().numpy()[:len(docs)]
+    assert np.array_equal(err, np.asarray(want_err, dtype=err.dtype)), "fused pipeline: document verdicts differ"
+    for k in range(len(docs)):
+        if err[k] == 0:
+            got = tape[int(to[k]):int(to[k + 1])]
+            assert got.size == want_tapes[k].size, k
+            # (STRING payloads are offsets into the batch's own string buffer: compare everything else word for word)
+            strings_at = (want_tapes[k] >> np.uint64(56)) == np.uint64(ord('"'))
+            assert np.array_equal(got[~strings_at], want_tapes[k][~strings_at]), k
+    stats["fused"] = stats.get("fused", 0) + len(docs)
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
@@ -64,8 +87,13 @@ def main():
         stats["ok"] += int((errors == 0).sum())
         stats["errors"] += int((errors > 0).sum())
         stats["host"] += len(host_ok)
-        # single documents: a sample of the small ones, and everything concatenated into large arrays (chunk-parallel)
+        # the fused pipeline (sjmi_parse_batch_device): the mixed batch (per-document passes) and the valid documents alone
+        # (newline-separated and clean: the optimistic plain stage 1) must reproduce the three separate calls
         good = [d for k, d in enumerate(docs) if int(errors[k]) == 0]
+        good_tapes = [tapes[k] for k in range(len(docs)) if int(errors[k]) == 0]
+        for batch, want_err, want_tapes in ((docs, errors, tapes), (good, np.zeros(len(good), dtype=np.int32), good_tapes)):
+            fused_check(ctx, batch, want_err, want_tapes, stats)
+        # single documents: a sample of the small ones, and everything concatenated into large arrays (chunk-parallel)
         big = [b"[" + b",".join(good[i::7]) + b"]" for i in range(7)]
         bad = [b"[" + b",".join(docs[i:i + 400]) + b"]" for i in range(0, min(len(docs), 4000), 400)]
         for d in rng.sample(docs, 300) + big + bad:
