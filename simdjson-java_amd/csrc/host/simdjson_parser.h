@@ -214,8 +214,8 @@ public:
     JsonValue parse(const uint8_t* buffer, size_t len);
     // where stage 2 of parse() runs: 1 = on the GPU (the cooperative walker), 0 = the host walker, -1 (default) = by size --
     // the GPU from GPU_WALK_AUTO_BYTES on, where it is the faster one (tools/single_doc_modes.py, sjmi_parser_parse timed
-    // from C++: 0.104 vs 0.073 ms at 1 KiB, 0.157 vs 0.165 ms at 136 KiB, 0.19 vs 0.21 ms for twitter.json, 0.29 vs 0.68 ms
-    // at 1 MiB, 1.95 vs 10.0 ms at 16 MiB, 8.3 vs 40.4 ms at 64 MiB).  Identical results either way.
+    // from C++: 0.104 vs 0.073 ms at 1 KiB, 0.157 vs 0.165 ms at 136 KiB, 0.18 vs 0.21 ms for twitter.json, 0.28 vs 0.68 ms
+    // at 1 MiB, 1.7 vs 10.0 ms at 16 MiB, 7.3 vs 40.4 ms at 64 MiB).  Identical results either way.
     static constexpr size_t GPU_WALK_AUTO_BYTES = 128u << 10;
     void setGpuWalk(int mode) { gpuWalk_ = mode < 0 ? -1 : (mode ? 1 : 0); }
 

@@ -17,6 +17,8 @@ struct sjmi_ctx {
     int device = 0;
     uint64_t capacity = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;       // sjmi_parse_document: downloads the string records while the walker runs
+    hipEvent_t strings_ready = nullptr;
     uint8_t* d_in = nullptr;      // capacity + padding
     uint32_t* d_idx = nullptr;    // capacity + 1 entries (host-buffer path)
     void* d_ws = nullptr;         // tile-state workspace
@@ -175,6 +177,8 @@ void sjmi_destroy(sjmi_ctx* c) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->strings_ready) (void)hipEventDestroy(c->strings_ready);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     g_live_contexts.fetch_sub(1);
@@ -852,7 +856,10 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
         !grow(c, (void**)&c->d_tape, &c->tape_bytes, (2 * (size_t)bound + 16) * sizeof(unsigned long long), "hipMalloc(tape)"))
         return SJMI_ERR_HIP;
     if (!c->d_single && fail(c, "hipMalloc(single)", hipMalloc(&c->d_single, 512))) return SJMI_ERR_HIP;
-    if (!c->h_single && fail(c, "hipHostMalloc(single)", hipHostMalloc(&c->h_single, 256))) return SJMI_ERR_HIP;
+    if (!c->h_single && fail(c, "hipHostMalloc(single)", hipHostMalloc(&c->h_single, 512))) return SJMI_ERR_HIP;
+    if (!c->copy_stream && (fail(c, "hipStreamCreate", hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) ||
+                            fail(c, "hipEventCreate", hipEventCreateWithFlags(&c->strings_ready, hipEventDisableTiming))))
+        return SJMI_ERR_HIP;
     // layout of d_single: doc_offsets[2] | index_offsets[2] | doc_str_offsets[2] | tape_offsets[2] | status | error | results
     unsigned long long* d64 = (unsigned long long*)c->d_single;
     unsigned long long *d_doc = d64, *d_io = d64 + 2, *d_dso = d64 + 4, *d_to = d64 + 6;
@@ -867,23 +874,44 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
     const uint32_t* sizes = nullptr;
     const uint8_t* str_scratch = nullptr;
     sjmi::unescape_records(c->d_ws_str, bound, &sizes, &str_scratch);
+    // The string records are complete long before the tape: their download runs on a second stream while the walker works
+    // (a large document: a tenth of the call).  The size comes from the unescape result, fetched on that stream too.
+    sjmi_unescape_result* h_u_early = (sjmi_unescape_result*)((uint8_t*)c->h_single + 256);
+    bool strings_in_flight = false;
+    const bool early_strings = len >= (256u << 10);  // (below that the second stream's synchronisation costs more than it hides)
     for (int attempt = 0; attempt < 2; ++attempt) {
+        strings_in_flight = false;
         if (fail(c, "launch", sjmi::stage1_launch(c->d_in, len, c->d_idx, c->capacity + 2, c->d_ws, steps, c->stream, nullptr, nullptr,
                                                   launch_flags(c))) ||
             fail(c, "unescape launch", sjmi::unescape_launch(c->d_in, len, c->d_idx, bound, d_res1, c->d_sb, c->sb_bytes, c->d_ws_str,
                                                              d_ures, c->stream)) ||
+            (early_strings && fail(c, "event", hipEventRecord(c->strings_ready, c->stream))) ||
             fail(c, "setup", sjmi::single_doc_setup_launch(d_res1, len, d_doc, d_io, d_st, d_dso, c->stream)) ||
             fail(c, "walk launch",
                  sjmi::walk_launch(c->d_in, d_doc, 1, c->d_idx, bound, d_io, d_st, c->d_sb, d_dso, 0, max_depth, c->d_tape,
                                    2 * bound + 8, d_to, d_err, c->d_ws_walk, d_wres, c->stream, d_res1, d_ures, sizes, str_scratch)) ||
             fail(c, "results", single_doc_results_launch(d_res1, d_ures, d_wres, d_to, d_err,
                                                          (SingleDocResults*)((uint8_t*)c->d_single + 256), c->stream)) ||
-            fail(c, "D2H", hipMemcpyAsync(h, (uint8_t*)c->d_single + 256, sizeof *h, hipMemcpyDeviceToHost, c->stream)) ||
-            fail(c, "sync", hipStreamSynchronize(c->stream)))
+            fail(c, "D2H", hipMemcpyAsync(h, (uint8_t*)c->d_single + 256, sizeof *h, hipMemcpyDeviceToHost, c->stream)))
             return SJMI_ERR_HIP;
+        // (everything of the main stream is queued: now the early look at the string records)
+        if (early_strings) {
+            if (fail(c, "wait", hipStreamWaitEvent(c->copy_stream, c->strings_ready, 0)) ||
+                fail(c, "D2H", hipMemcpyAsync(h_u_early, d_ures, sizeof *h_u_early, hipMemcpyDeviceToHost, c->copy_stream)) ||
+                fail(c, "sync", hipStreamSynchronize(c->copy_stream)))
+                return SJMI_ERR_HIP;
+            if (!(h_u_early->flags & 1u) && h_u_early->total_bytes && h_u_early->total_bytes <= string_capacity) {
+                if (fail(c, "D2H(sb)", hipMemcpyAsync(string_buffer, c->d_sb, h_u_early->total_bytes, hipMemcpyDeviceToHost, c->copy_stream)))
+                    return SJMI_ERR_HIP;
+                strings_in_flight = true;
+            }
+        }
+        if (fail(c, "sync", hipStreamSynchronize(c->stream))) return SJMI_ERR_HIP;
         if (!(h->s1.status & SJMI_ST_INTERNAL) || c->ticket_mode) break;
+        if (strings_in_flight && fail(c, "sync", hipStreamSynchronize(c->copy_stream))) return SJMI_ERR_HIP;
         c->ticket_mode = true;  // fast-mode liveness assumption failed: latch the safe mode and run again
     }
+    if (strings_in_flight && fail(c, "sync", hipStreamSynchronize(c->copy_stream))) return SJMI_ERR_HIP;
     c->last_valid = false;
     c->unesc_idx = nullptr;
     *stage1_status = h->s1.status & 0xFFu;
@@ -902,7 +930,7 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
         return SJMI_ERR_CAPACITY;
     }
     if (fail(c, "D2H(tape)", hipMemcpyAsync(tape, c->d_tape + h->to[0], words * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream)) ||
-        (h->u.total_bytes &&
+        (h->u.total_bytes && !strings_in_flight &&
          fail(c, "D2H(sb)", hipMemcpyAsync(string_buffer, c->d_sb, h->u.total_bytes, hipMemcpyDeviceToHost, c->stream))) ||
         fail(c, "sync", hipStreamSynchronize(c->stream)))
         return SJMI_ERR_HIP;
