@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 def parser(request):
     """The homes of stage 2: the host walker over GPU-made indexes / strings, the cooperative GPU walker
     (sjmi_parser_set_gpu_walk: the tape itself comes from the device), and the library's default -- by size, the GPU walker
-    from 128 KiB on.  Every test below holds for all of them, bit for bit."""
+    from 1 MiB on.  Every test below holds for all of them, bit for bit."""
     import simdjson_java_amd as S
     p = S.SimdJsonParser(capacity=8 * 1024 * 1024, gpu_walk={"host_walk": False, "gpu_walk": True, "by_size": None}[request.param])
     yield p
@@ -212,10 +212,10 @@ def test_json_value_accessors_through_the_c_abi(parser, twitter):
 
 
 def test_documents_around_the_stage2_placement_threshold(parser):
-    """128 KiB is where the default placement of stage 2 changes (SimdJsonParser::GPU_WALK_AUTO_BYTES): documents just below
+    """1 MiB is where the default placement of stage 2 changes (SimdJsonParser::GPU_WALK_AUTO_BYTES): documents just below
     and above it and larger ones, valid and broken (a broken one is walked again on the host for the reference's exact message)."""
     unit = '{"id":%d,"name":"user \\u00e9 %d","tags":["a","b"],"score":%d.5,"ok":true}'
-    for n in (1700, 1900, 15500, 40000):
+    for n in (1800, 13000, 15500, 40000):
         body = ",".join(unit % (i, i, i % 97) for i in range(n))
         _same(parser, "[" + body + "]")
         _same(parser, "[" + body + ",]")

@@ -32,7 +32,7 @@ def load_bench_lib():
     return L
 
 
-def measure(doc, iters=300, gpu_walk=False):
+def measure(doc, iters=300, gpu_walk=None):  # None: the library places stage 2 of the full parse by document size
     """-> {mode: ms per parse-and-select}; asserts the 86 selected users of twitter.json"""
     L = load_bench_lib()
     p = S.SimdJsonParser(capacity=len(doc) + 64, gpu_walk=gpu_walk)
