@@ -134,17 +134,26 @@ int sjmi_stage1_shard_device(sjmi_ctx* ctx, const void* d_buf, uint64_t len, uin
 /* device-side result record of one unescape call */
 typedef struct sjmi_unescape_result {
     uint64_t total_bytes;      /* bytes of [be32 length][unescaped bytes] records written */
-    uint64_t first_error_inv;  /* 0 = every string is fine; else ~((position in indexes[] << 8) | SJMI_E_* code) */
-    uint32_t flags;            /* bit 0: string_buffer capacity exceeded */
-    uint32_t reserved;
+    uint64_t first_error_inv;  /* 0 = every string is fine; else ~((p << 8) | SJMI_E_* code) of the first failing string, p = byte
+                                  offset of the offending escape in the document (sjmi_unescape_device, sjmi_parse_*), or the
+                                  string's position in indexes[] (sjmi_unescape_batch_device) */
+    uint32_t flags;            /* bit 0: string_buffer capacity exceeded; bits 2-3: engine fault (results invalid) */
+    uint32_t n_strings;        /* string literals of the document (sjmi_unescape_device) */
 } sjmi_unescape_result;
 
 /* Batched replacement of the per-string StringParser.parseString calls (StringParser.java:18-68) that
- * the reference's stage 2 makes for every '"' structural (TapeBuilder.java:174-177): for every index i with
- * buf[indexes[i]] == '"', in order, appends [be32 length][unescaped UTF-8 bytes] to string_buffer, so that
- * record k starts at sum_{j<k}(4 + len_j) -- exactly the STRING tape payloads of a valid document.
- * Requires a stage-1 status of 0 for this document (closed strings). Device-resident form, asynchronous on
- * `stream`; d_result is a device sjmi_unescape_result. */
+ * the reference's stage 2 makes for every string (TapeBuilder.java:174-177): for every string literal of the
+ * document, in order, appends [be32 length][unescaped UTF-8 bytes] to string_buffer, so that
+ * record k starts at sum_{j<k}(4 + len_j) -- exactly the STRING tape payloads of a valid document, and byte for byte
+ * the reference's stringBuffer.  One streaming pass over the document (csrc/strings.hip); the index array is not
+ * read (it is part of the signature because the reference's loop is over the '"' structurals: every opening quote of a
+ * document that passes stage 2 is one).  It starts from the in-string parity of every 64-byte block, which the last
+ * sjmi_stage1*_device launch of this context over the same (d_buf, len) left on the device -- the bytes must not have
+ * changed since; without one (another context indexed the document) the call derives them itself with one more pass.
+ * A string StringParser would throw on gets the record header FF FF FF <SJMI_E_* code> (what follows it up to the next
+ * record is unspecified), all other records are still exact and in place; the first such error is also reported in
+ * d_result.  Requires a stage-1 status of 0 for this document (closed strings); string_capacity < 4 GiB.
+ * Device-resident form, asynchronous on `stream`; d_buf 16-byte aligned; d_result is a device sjmi_unescape_result. */
 int sjmi_unescape_device(sjmi_ctx* ctx, const void* d_buf, uint64_t len, const void* d_indexes, uint64_t count,
                          void* d_string_buffer, uint64_t string_capacity, void* d_result, void* stream);
 

@@ -299,20 +299,23 @@ SJ_HD void sj_transpose4x4_bytes(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t
     b[3] = sj_perm(t3, t1, 0x07060302u);
 }
 
+// one 32-byte half: w8 = its 8 dwords -> x[k] = its 32 bits of plane k
+SJ_HD void sj_transpose_half(const uint32_t w8[8], uint32_t x[8]) {
+    // x[r] byte c = byte 8c + r of this half
+    sj_transpose4x4_bytes(w8[0], w8[2], w8[4], w8[6], x);
+    sj_transpose4x4_bytes(w8[1], w8[3], w8[5], w8[7], x + 4);
+    for (int r = 0; r < 4; ++r) sj_bit_swap<4, 0x0F0F0F0Fu>(x[r], x[r + 4]);
+    for (int r = 0; r < 8; r += 4) {
+        sj_bit_swap<2, 0x33333333u>(x[r], x[r + 2]);
+        sj_bit_swap<2, 0x33333333u>(x[r + 1], x[r + 3]);
+    }
+    for (int r = 0; r < 8; r += 2) sj_bit_swap<1, 0x55555555u>(x[r], x[r + 1]);
+    // now x[k] bit (8c + r) = bit k of byte 8c + r
+}
+
 SJ_HD void sj_transpose_butterfly(const uint32_t w[16], sj_u64 p[8]) {
     uint32_t y[2][8];
-    for (int h = 0; h < 2; ++h) {
-        uint32_t* x = y[h];  // x[r] byte c = byte 8c + r of this half
-        sj_transpose4x4_bytes(w[8 * h + 0], w[8 * h + 2], w[8 * h + 4], w[8 * h + 6], x);
-        sj_transpose4x4_bytes(w[8 * h + 1], w[8 * h + 3], w[8 * h + 5], w[8 * h + 7], x + 4);
-        for (int r = 0; r < 4; ++r) sj_bit_swap<4, 0x0F0F0F0Fu>(x[r], x[r + 4]);
-        for (int r = 0; r < 8; r += 4) {
-            sj_bit_swap<2, 0x33333333u>(x[r], x[r + 2]);
-            sj_bit_swap<2, 0x33333333u>(x[r + 1], x[r + 3]);
-        }
-        for (int r = 0; r < 8; r += 2) sj_bit_swap<1, 0x55555555u>(x[r], x[r + 1]);
-        // now x[k] bit (8c + r) = bit k of byte 8c + r
-    }
+    for (int h = 0; h < 2; ++h) sj_transpose_half(w + 8 * h, y[h]);
     for (int k = 0; k < 8; ++k) p[k] = (sj_u64)y[0][k] | ((sj_u64)y[1][k] << 32);
 }
 

@@ -35,6 +35,16 @@ struct sjmi_ctx {
     size_t sb_bytes = 0;
     void* d_ws_str = nullptr;     // unescape workspace, grown on demand
     size_t ws_str_bytes = 0;
+    void* d_ws_strm = nullptr;    // workspace of the streaming string pass (strings.hip), grown on demand
+    size_t ws_strm_bytes = 0;
+    void* d_ws_par = nullptr;     // workspace of a parity-only stage-1 launch (strings of a document this context has not indexed)
+    size_t ws_par_bytes = 0;
+    unsigned long long* d_blkpar = nullptr;  // in-string parity of every 64-byte block, left by the last stage-1 launch
+    size_t blkpar_bytes = 0;                 // ... over (par_buf, par_len): what the string pass starts from
+    const void* par_buf = nullptr;
+    uint64_t par_len = 0;
+    bool par_valid = false;
+    unsigned long long* d_err_index = nullptr;  // host forms: position in indexes[] of the first failing string
     sjmi_unescape_result* d_ures = nullptr;
     unsigned long long* d_docoff = nullptr;  // batch: document offsets + index offsets (+ statuses), grown on demand
     uint32_t* d_doccnt = nullptr;            // isolated batch: per-document index counts
@@ -161,6 +171,10 @@ void sjmi_destroy(sjmi_ctx* c) {
     if (c->d_ws_dev) (void)hipFree(c->d_ws_dev);
     if (c->d_sb) (void)hipFree(c->d_sb);
     if (c->d_ws_str) (void)hipFree(c->d_ws_str);
+    if (c->d_ws_strm) (void)hipFree(c->d_ws_strm);
+    if (c->d_ws_par) (void)hipFree(c->d_ws_par);
+    if (c->d_blkpar) (void)hipFree(c->d_blkpar);
+    if (c->d_err_index) (void)hipFree(c->d_err_index);
     if (c->d_ures) (void)hipFree(c->d_ures);
     if (c->d_docoff) (void)hipFree(c->d_docoff);
     if (c->d_doccnt) (void)hipFree(c->d_doccnt);
@@ -200,6 +214,10 @@ int sjmi_set_tile_steps(sjmi_ctx* c, int steps) {
     return SJMI_OK;
 }
 
+namespace {
+void* parity_out(sjmi_ctx* c, const void* d_buf, uint64_t len);
+}
+
 int sjmi_stage1(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes, uint64_t index_capacity,
                 uint64_t* count, uint32_t* status) {
     if (!c || (!buf && len) || !indexes || !count || !status) return SJMI_ERR_ARG;
@@ -214,9 +232,11 @@ int sjmi_stage1(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes
     const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(len);
     const uint64_t dev_cap = c->capacity + 2 < index_capacity ? c->capacity + 2 : index_capacity;
     note_launch(c, c->stream);
+    sjmi::Stage1Extras ex1;
+    ex1.blkpar = parity_out(c, c->d_in, len);
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (fail(c, "launch", sjmi::stage1_launch(c->d_in, len, c->d_idx, dev_cap, c->d_ws, steps, c->stream, nullptr,
-                                                  nullptr, launch_flags(c))) ||
+                                                  nullptr, launch_flags(c), ex1)) ||
             fail(c, "D2H(result)",
                  hipMemcpyAsync(c->h_res, (uint8_t*)c->d_ws + sjmi::WS_RESULT_OFFSET, sizeof(sjmi_stage1_result),
                                 hipMemcpyDeviceToHost, c->stream)) ||
@@ -264,17 +284,63 @@ bool grow(sjmi_ctx* c, void** p, size_t* have, size_t need, const char* what) {
     *have = need;
     return true;
 }
+// Where a plain stage-1 launch over (d_buf, len) leaves its block parities (null: the allocation failed -- the string pass
+// then makes its own).  Shards and the per-document passes of an isolated batch do not record any.
+void* parity_out(sjmi_ctx* c, const void* d_buf, uint64_t len) {
+    c->par_valid = false;
+    if (!grow(c, (void**)&c->d_blkpar, &c->blkpar_bytes, sjmi::strings_parity_words(len) * sizeof(unsigned long long), "hipMalloc(blkpar)"))
+        return nullptr;
+    c->par_buf = d_buf;
+    c->par_len = len;
+    c->par_valid = true;
+    return c->d_blkpar;
+}
+// The block parities of (d_buf, len) for the string pass: those of the context's last stage-1 launch if it was over the same
+// bytes, else a stage-1 launch that writes nothing but them (no indexes, no sentinel), queued on `st`.
+const unsigned long long* parity_for(sjmi_ctx* c, const void* d_buf, uint64_t len, hipStream_t st) {
+    if (c->par_valid && c->par_buf == d_buf && c->par_len == len) return c->d_blkpar;
+    const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(len);
+    if (!grow(c, &c->d_ws_par, &c->ws_par_bytes, sjmi::stage1_workspace_bytes(len, steps), "hipMalloc(ws_par)")) return nullptr;
+    sjmi::Stage1Extras ex;
+    ex.blkpar = parity_out(c, d_buf, len);
+    if (!ex.blkpar) return nullptr;
+    c->par_valid = false;  // (until the launch is queued)
+    if (fail(c, "parity launch", sjmi::stage1_launch((const uint8_t*)d_buf, len, nullptr, 0, c->d_ws_par, steps, st, nullptr, nullptr,
+                                                     (launch_flags(c) & ~sjmi::DBG_NO_LOOKBACK) | sjmi::DBG_NO_WRITE, ex)))
+        return nullptr;
+    note_launch(c, st);
+    c->par_valid = true;
+    return c->d_blkpar;
+}
 }  // namespace
+
+// the streaming string pass over (d_buf, len); optional: record offsets by ordinal / ordinals by block
+static int strings_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_string_buffer, uint64_t string_capacity,
+                               uint32_t* d_soff, uint64_t soff_cap, uint32_t* d_blk_ord, void* d_result, hipStream_t st) {
+    const unsigned long long* par = parity_for(c, d_buf, len, st);
+    if (!par) return SJMI_ERR_HIP;
+    if (!grow(c, &c->d_ws_strm, &c->ws_strm_bytes, sjmi::strings_workspace_bytes(len), "hipMalloc(ws_strm)")) return SJMI_ERR_HIP;
+    if (fail(c, "memset(result)", hipMemsetAsync(d_result, 0, sizeof(sjmi_unescape_result), st)) ||
+        fail(c, "strings launch",
+             sjmi::strings_launch((const uint8_t*)d_buf, len, par, (uint8_t*)d_string_buffer, string_capacity, d_soff, soff_cap,
+                                  d_blk_ord, c->d_ws_strm, (sjmi::UnescapeResult*)d_result, st)))
+        return SJMI_ERR_HIP;
+    return SJMI_OK;
+}
 
 static int unescape_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, const void* d_indexes, uint64_t count,
                                 void* d_string_buffer, uint64_t string_capacity, void* d_result, void* stream,
                                 const sjmi::UnescapeBatch& batch) {
     if (!c || !d_buf || !d_indexes || !d_string_buffer || !d_result || len >= (1ull << 32)) return SJMI_ERR_ARG;
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
-    if (!grow(c, &c->d_ws_str, &c->ws_str_bytes, sjmi::unescape_workspace_bytes(count, len), "hipMalloc(ws_str)"))
-        return SJMI_ERR_HIP;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     c->unesc_idx = nullptr;
+    if (!batch.d_doc_offsets) {
+        if (((uintptr_t)d_buf & 15)) return SJMI_ERR_ARG;
+        return strings_device_impl(c, d_buf, len, d_string_buffer, string_capacity, nullptr, 0, nullptr, d_result, st);
+    }
+    if (!grow(c, &c->d_ws_str, &c->ws_str_bytes, sjmi::unescape_workspace_bytes(count, len), "hipMalloc(ws_str)"))
+        return SJMI_ERR_HIP;
     if (fail(c, "unescape launch",
              sjmi::unescape_launch((const uint8_t*)d_buf, len, (const uint32_t*)d_indexes, count, nullptr,
                                    (uint8_t*)d_string_buffer, string_capacity, c->d_ws_str,
@@ -326,6 +392,16 @@ static int unescape_host(sjmi_ctx* c, uint8_t* string_buffer, uint64_t string_ca
                                         c->stream, batch);
     if (rc != SJMI_OK) return rc;
     sjmi_unescape_result r;
+    unsigned long long err_index = ~0ull;
+    const bool streamed = !batch.d_doc_offsets;  // (the string pass reports the error's byte position: turn it into the string's index)
+    if (streamed) {
+        if (!c->d_err_index && fail(c, "hipMalloc(err_index)", hipMalloc((void**)&c->d_err_index, sizeof(unsigned long long))))
+            return SJMI_ERR_HIP;
+        if (fail(c, "error index", sjmi::strings_error_index_launch(c->d_idx, c->last_count, nullptr, (const sjmi::UnescapeResult*)c->d_ures,
+                                                                    c->d_err_index, c->stream)) ||
+            fail(c, "D2H(err_index)", hipMemcpyAsync(&err_index, c->d_err_index, sizeof err_index, hipMemcpyDeviceToHost, c->stream)))
+            return SJMI_ERR_HIP;
+    }
     if (fail(c, "D2H(ures)", hipMemcpyAsync(&r, c->d_ures, sizeof r, hipMemcpyDeviceToHost, c->stream)) ||
         (doc_string_offsets &&
          fail(c, "D2H(docstr)", hipMemcpyAsync(doc_string_offsets, c->d_docstr, ob, hipMemcpyDeviceToHost, c->stream))) ||
@@ -334,11 +410,15 @@ static int unescape_host(sjmi_ctx* c, uint8_t* string_buffer, uint64_t string_ca
     *total_bytes = r.total_bytes;
     if (r.first_error_inv) {
         const uint64_t v = ~r.first_error_inv;
-        *first_error_index = v >> 8;
+        *first_error_index = streamed ? err_index : v >> 8;
         *first_error_code = (uint32_t)(v & 0xFF);
     } else {
         *first_error_index = ~0ull;
         *first_error_code = 0;
+    }
+    if (r.flags & 0xCu) {
+        c->err = "string pass: engine fault";
+        return SJMI_ERR_INTERNAL;
     }
     if (r.total_bytes > string_capacity || (r.flags & 1u)) {
         c->err = "string_capacity too small";
@@ -388,9 +468,8 @@ int sjmi_stage1_unescape(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t
     // stage-1 result on the device; grids and workspace are sized for the bound "one structural per byte"
     const uint64_t bound = len + 1;
     const size_t need_sb = (size_t)len + 4 * ((size_t)len / 2 + 2) + 64;  // sum(4+len_k): every string takes >= 2 source bytes
-    if (!grow(c, (void**)&c->d_sb, &c->sb_bytes, need_sb, "hipMalloc(sb)") ||
-        !grow(c, &c->d_ws_str, &c->ws_str_bytes, sjmi::unescape_workspace_bytes(bound, len), "hipMalloc(ws_str)"))
-        return SJMI_ERR_HIP;
+    (void)bound;
+    if (!grow(c, (void**)&c->d_sb, &c->sb_bytes, need_sb, "hipMalloc(sb)")) return SJMI_ERR_HIP;
     if (!c->d_ures && fail(c, "hipMalloc(ures)", hipMalloc((void**)&c->d_ures, sizeof(sjmi_unescape_result))))
         return SJMI_ERR_HIP;
     if (len && fail(c, "H2D", hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
@@ -398,12 +477,20 @@ int sjmi_stage1_unescape(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t
     const uint64_t dev_cap = c->capacity + 2 < index_capacity ? c->capacity + 2 : index_capacity;
     const sjmi::Stage1Result* d_res1 = (const sjmi::Stage1Result*)((uint8_t*)c->d_ws + sjmi::WS_RESULT_OFFSET);
     sjmi_unescape_result r;
+    unsigned long long err_index = ~0ull;
+    if (!c->d_err_index && fail(c, "hipMalloc(err_index)", hipMalloc((void**)&c->d_err_index, sizeof(unsigned long long))))
+        return SJMI_ERR_HIP;
     for (int attempt = 0; attempt < 2; ++attempt) {
+        sjmi::Stage1Extras ex1;
+        ex1.blkpar = parity_out(c, c->d_in, len);
         if (fail(c, "launch", sjmi::stage1_launch(c->d_in, len, c->d_idx, dev_cap, c->d_ws, steps, c->stream, nullptr,
-                                                  nullptr, launch_flags(c))) ||
-            fail(c, "unescape launch",
-                 sjmi::unescape_launch(c->d_in, len, c->d_idx, bound, d_res1, c->d_sb, c->sb_bytes, c->d_ws_str,
-                                       (sjmi::UnescapeResult*)c->d_ures, c->stream)) ||
+                                                  nullptr, launch_flags(c), ex1)))
+            return SJMI_ERR_HIP;
+        const int src = strings_device_impl(c, c->d_in, len, c->d_sb, c->sb_bytes, nullptr, 0, nullptr, c->d_ures, c->stream);
+        if (src != SJMI_OK) return src;
+        if (fail(c, "error index", sjmi::strings_error_index_launch(c->d_idx, 0, d_res1, (const sjmi::UnescapeResult*)c->d_ures,
+                                                                    c->d_err_index, c->stream)) ||
+            fail(c, "D2H(err_index)", hipMemcpyAsync(&err_index, c->d_err_index, sizeof err_index, hipMemcpyDeviceToHost, c->stream)) ||
             fail(c, "D2H(result)", hipMemcpyAsync(c->h_res, d_res1, sizeof(sjmi_stage1_result), hipMemcpyDeviceToHost, c->stream)) ||
             fail(c, "D2H(ures)", hipMemcpyAsync(&r, c->d_ures, sizeof r, hipMemcpyDeviceToHost, c->stream)) ||
             fail(c, "sync", hipStreamSynchronize(c->stream)))
@@ -433,8 +520,12 @@ int sjmi_stage1_unescape(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t
         *total_bytes = r.total_bytes;
         if (r.first_error_inv) {
             const uint64_t v = ~r.first_error_inv;
-            *first_error_index = v >> 8;
+            *first_error_index = err_index;
             *first_error_code = (uint32_t)(v & 0xFF);
+        }
+        if (r.flags & 0xCu) {
+            c->err = "string pass: engine fault";
+            return SJMI_ERR_INTERNAL;
         }
         if (r.total_bytes > string_capacity || (r.flags & 1u)) {
             c->err = "string_capacity too small";
@@ -527,6 +618,8 @@ static int stage1_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, void
     ex.zero_next = (uint8_t*)c->d_ws_dev + (size_t)(1 - h) * half;
     ex.zero_bytes = need;
     ex.result_out = fast ? d_result : nullptr;
+    ex.blkpar = shard_flags ? nullptr : parity_out(c, d_buf, len);
+    if (shard_flags) c->par_valid = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->profiling) {
         if (c->events_used == c->events.size()) {
@@ -634,9 +727,11 @@ int sjmi_stage1_batch(sjmi_ctx* c, const uint8_t* buf, uint64_t total_len, const
         return SJMI_ERR_HIP;
     const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(total_len);
     const uint64_t dev_cap = c->capacity + 2 < index_capacity ? c->capacity + 2 : index_capacity;
+    sjmi::Stage1Extras ex1;
+    ex1.blkpar = parity_out(c, c->d_in, total_len);
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (fail(c, "launch", sjmi::stage1_launch(c->d_in, total_len, c->d_idx, dev_cap, c->d_ws, steps, c->stream, nullptr,
-                                                  nullptr, launch_flags(c))) ||
+                                                  nullptr, launch_flags(c), ex1)) ||
             fail(c, "split", sjmi::split_docs_launch(c->d_idx, (const sjmi::Stage1Result*)d_res, c->d_docoff, n_docs, d_io,
                                                      c->stream)) ||
             fail(c, "D2H(result)", hipMemcpyAsync(c->h_res, d_res, sizeof(sjmi_stage1_result), hipMemcpyDeviceToHost, c->stream)) ||

@@ -19,9 +19,9 @@ static_assert(sizeof(Stage1Result) == sizeof(sjmi_stage1_result), "ABI struct mi
 // device-side result of one unescape call; mirrors sjmi_unescape_result in include/sjmi.h
 struct UnescapeResult {
     unsigned long long total_bytes;      // bytes of [be32 len][bytes] records
-    unsigned long long first_error_inv;  // 0 = no error, else ~((structural position << 8) | SJMI_E_* code)
-    uint32_t flags;                      // bit0: string buffer capacity exceeded
-    uint32_t reserved;
+    unsigned long long first_error_inv;  // 0 = no error, else ~((byte position | structural position << 8) | SJMI_E_* code)
+    uint32_t flags;                      // bit0: string buffer capacity exceeded; bits 2-3: engine fault
+    uint32_t reserved;                   // strings.hip: number of string literals
 };
 static_assert(sizeof(UnescapeResult) == sizeof(sjmi_unescape_result), "ABI struct mismatch");
 
@@ -61,11 +61,21 @@ struct Stage1Extras {
     void* zero_next = nullptr;       // workspace the NEXT launch will use: zeroed by this one (16-byte aligned)
     size_t zero_bytes = 0;           //   ... this many bytes of it (multiple of 16)
     void* result_out = nullptr;      // device sjmi_stage1_result written by the scanner (FAST mode only)
+    void* blkpar = nullptr;          // side output for strings.hip: u64 per 4 KiB of input, bit l = block l is entered inside a
+                                     // string (StructuralIndexer.java:233-234's prevInString, per block); len / 4096 + 4 words
 };
 // ev_start/ev_stop (optional) are attached to the kernel's dispatch (not the workspace memset)
 hipError_t stage1_launch(const uint8_t* d_buf, uint64_t len, uint32_t* d_out, uint64_t out_cap, void* d_ws, int steps,
                          hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg = 0,
                          const Stage1Extras& ex = Stage1Extras());
+// strings.hip: the string buffer of a document in one streaming pass (from the bytes and stage 1's block parities)
+size_t strings_workspace_bytes(uint64_t len);
+size_t strings_parity_words(uint64_t len);
+hipError_t strings_launch(const uint8_t* d_buf, uint64_t len, const unsigned long long* d_blkpar, uint8_t* d_sb, uint64_t sb_cap,
+                          uint32_t* d_soff, uint64_t soff_cap, uint32_t* d_blk_ord, void* d_ws, UnescapeResult* d_res,
+                          hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+hipError_t strings_error_index_launch(const uint32_t* d_idx, uint64_t count, const Stage1Result* dev_count, const UnescapeResult* d_res,
+                                      unsigned long long* d_out, hipStream_t stream);
 size_t unescape_workspace_bytes(uint64_t count, uint64_t len);
 // batches: per-document string-buffer offsets (n_docs + 1 device entries), from the device index offsets
 // The indexes belong to a batch of documents (n_docs + 1 byte offsets / index offsets on the device): the last string

@@ -550,7 +550,7 @@ template <int S, int LDSW, bool SAFE>
 __global__ void __launch_bounds__(256)
 k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out, sj_u64 out_cap,
          sj_u64* gstate, uint32_t* ticket, Stage1Result* res, uint32_t ngran, uint32_t dbg, uint4* zero_ptr,
-         uint32_t zero_chunks, Stage1Result* result_out) {
+         uint32_t zero_chunks, Stage1Result* result_out, sj_u64* __restrict__ blkpar) {
     constexpr int E = S, CAP = LDSW / 4;
     static_assert(S <= 4, "meta packs 14-bit offsets: at most 4 steps per granule");
     __shared__ WaveShared<S, LDSW> sh[4];
@@ -729,7 +729,9 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
                 WP += tot >> 16;
                 const uint32_t ue0 = (fl[s] >> 1) & 1u, ue1 = (fl[s] >> 2) & 1u;  // :252 for entry parity 0 / 1
                 if (fl[s] & 8u) err |= SJMI_ST_UTF8;
-                meta[s] = ex0 | (exp_ << 14) | ((lp ? ue1 : ue0) << 28) | ((lp ? ue0 : ue1) << 29);
+                // ([30]: the block is entered inside a string if the granule is entered outside one -- the side output for
+                //  the string pass, strings.hip, written once the granule's own entry parity is known)
+                meta[s] = ex0 | (exp_ << 14) | ((lp ? ue1 : ue0) << 28) | ((lp ? ue0 : ue1) << 29) | (lp << 30);
                 gerr |= ((fl[s] >> 3) & 1u) | ((meta[s] >> 27) & 6u);  // utf8, unescaped if entered outside / inside
             }
             // the granule's error bits travel with its aggregate (the scanner composes the launch's status from them)
@@ -818,6 +820,10 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
                     const uint32_t o0 = mt & 0x3FFFu, op = (mt >> 14) & 0x3FFFu;
                     pos[e] = (pe ? op - o0 : o0) - gbase;
                     if ((mt >> (28 + pe)) & 1u) err |= SJMI_ST_UNESCAPED;  // :252,:300-302
+                    if (blkpar) {  // (wave-uniform) StructuralIndexer.java:233-234's prevInString, for every block
+                        const sj_u64 pm = __ballot(((mt >> 30) ^ pe) & 1u);
+                        if (lane == 0) blkpar[(sj_u64)prev * S + s] = pm;
+                    }
                 }
                 wave_lds_fence();  // the parked state is in registers now: its LDS becomes the staging buffer
                 // ---- index emission (BitIndexes.write :14-41): expand the masks into the wave's LDS slice at
@@ -970,14 +976,15 @@ static hipError_t launch_mode(const uint8_t* d_buf, uint64_t len, uint32_t* d_ou
     uint4* zp = static_cast<uint4*>(ex.zero_next);
     const uint32_t zc = (uint32_t)(ex.zero_bytes / 16);
     Stage1Result* ro = static_cast<Stage1Result*>(ex.result_out);
+    sj_u64* bp = static_cast<sj_u64*>(ex.blkpar);
     if (ev_start && ev_stop) {
         // the events are attached to the dispatch itself (its start / end timestamps), not recorded around it:
         // hipEventRecord pairs added 10-25 us of queue latency to a 200 us kernel
         hipExtLaunchKernelGGL((k_stage1<S, LDSW, SAFE>), grid, block, 0, stream, ev_start, ev_stop, 0, d_buf, (sj_u64)len,
-                              d_out, (sj_u64)out_cap, gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro);
+                              d_out, (sj_u64)out_cap, gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro, bp);
     } else {
         hipLaunchKernelGGL((k_stage1<S, LDSW, SAFE>), grid, block, 0, stream, d_buf, (sj_u64)len, d_out, (sj_u64)out_cap,
-                           gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro);
+                           gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro, bp);
     }
     return hipGetLastError();
 }

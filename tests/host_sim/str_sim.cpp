@@ -46,9 +46,15 @@ extern "C" int sim_strings(const uint8_t* buf, uint64_t len, uint8_t* sb, uint64
         }
         const SjStrBase s = sj_str_base(p, e_in, parity);
         SjStrHalo halo;
-        for (int k = 0; k < 8; ++k) {
-            halo.hp[k] = 0;
-            for (int t = 0; t < 16; ++t) halo.hp[k] |= (uint32_t)((hb[t] >> k) & 1u) << t;
+        {
+            uint32_t w8[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // the halo as the first 16 bytes of a 32-byte half (as the kernel does)
+            memcpy(w8, hb, 16);
+            sj_transpose_half(w8, halo.hp);
+            for (int k = 0; k < 8; ++k) {
+                uint32_t ref = 0;
+                for (int t = 0; t < 16; ++t) ref |= (uint32_t)((hb[t] >> k) & 1u) << t;
+                if ((halo.hp[k] & 0xFFFFu) != ref) return -5;
+            }
         }
         halo.e_in = 0;
         if (b > 0 && sj_str_halo_unresolved(halo.hp)) halo.e_in = sj_backslash_run_parity(buf, 0, start - 16);
