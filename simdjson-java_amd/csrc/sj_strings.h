@@ -42,18 +42,19 @@ SJ_HD SjStrClasses<T> sj_str_classes(const T p[8], bool want_hex) {
     const T p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4], p5 = p[5], p6 = p[6], p7 = p[7];
     const T a = ~p7 & ~p6, b = ~p7 & p6;
     SjStrClasses<T> c;
-    c.bs = b & ~p5 & p4 & p3 & p2 & ~p1 & ~p0;
-    c.rawquote = a & p5 & ~p4 & ~p3 & ~p2 & p1 & ~p0;
-    const T slash = a & p5 & ~p4 & p3 & p2 & p1 & p0;  // 0x2F
-    const T lo6 = b & p5 & ~p4;                          // 0x60..0x6F
-    const T lo7 = b & p5 & p4;                           // 0x70..0x7F
-    const T cb = lo6 & ~p3 & ~p2 & p1 & ~p0;             // 0x62
-    const T cf = lo6 & ~p3 & p2 & p1 & ~p0;              // 0x66
-    c.cn = lo6 & p3 & p2 & p1 & ~p0;                     // 0x6E
-    c.cr = lo7 & ~p3 & ~p2 & p1 & ~p0;                   // 0x72
-    c.ct = lo7 & ~p3 & p2 & ~p1 & ~p0;                   // 0x74
-    c.isu = lo7 & ~p3 & p2 & ~p1 & p0;                   // 0x75
-    c.cbf = cb | cf;
+    // shared decodes: high nibble 2 / 5 / 6 / 7, low nibble by halves
+    const T h2 = a & p5 & ~p4, h5 = b & ~p5 & p4, h6 = b & p5 & ~p4, h7 = b & p5 & p4;
+    const T n00 = ~p3 & ~p2, n01 = ~p3 & p2, n11 = p3 & p2;
+    const T x00 = ~p1 & ~p0, x01 = ~p1 & p0, x10 = p1 & ~p0;
+    const T l0010 = n00 & x10;
+    c.bs = h5 & n11 & x00;                  // 0x5C
+    c.rawquote = h2 & l0010;                // 0x22
+    const T slash = h2 & n11 & p1 & p0;     // 0x2F
+    c.cn = h6 & n11 & x10;                  // 0x6E
+    c.cr = h7 & l0010;                      // 0x72
+    c.ct = h7 & n01 & x00;                  // 0x74
+    c.isu = h7 & n01 & x01;                 // 0x75
+    c.cbf = h6 & ~p3 & x10;                 // 0x62, 0x66
     c.esc_ok = c.rawquote | slash | c.bs | c.cbf | c.cn | c.cr | c.ct | c.isu;
     c.hv = c.d0 = c.d1 = c.d2 = c.d3 = 0;
     if (want_hex) {

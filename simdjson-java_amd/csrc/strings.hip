@@ -35,6 +35,10 @@
 #include "sj_strings.h"
 #include "stage1.h"
 
+#ifndef SJMI_STR_ABL
+#define SJMI_STR_ABL 0  // ablation experiments only (results invalid): 1 no headers, 2 no copy, 4 no stores
+#endif
+
 namespace sjmi {
 
 constexpr uint32_t STR_NONE = 0xFFFFFFFFu;
@@ -110,7 +114,10 @@ struct StrArgs {
 // the running state is done before it arrives through LDS, and at the workers' frontier a wave publishes whatever
 // is ready lane by lane so that a launch with few resident workgroups cannot deadlock on a half-handed-out window)
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int SSCAN_K = 4;
+#ifndef SJMI_SSCAN_K
+#define SJMI_SSCAN_K 4
+#endif
+constexpr int SSCAN_K = SJMI_SSCAN_K;
 struct StrHand {
     uint32_t seq;  // window whose entry state is in ord / out; 0xFFFFFFFF = a scanner wave gave up
     uint32_t ord;
@@ -266,14 +273,14 @@ __device__ __forceinline__ void str_load_step(StrStep& d, const uint8_t* __restr
 }
 
 __device__ __forceinline__ void tile_or(uint32_t* tile, uint32_t off, uint32_t v) {
-    const uint32_t s = (off & 3u) * 8u;
-    atomicOr(&tile[off >> 2], v << s);
-    atomicOr(&tile[(off >> 2) + 1], (v >> 1) >> (31u - s));
+    const sj_u64 x = (sj_u64)v << ((off & 3u) * 8u);  // (one v_lshlrev_b64: measured 1.6 % faster than two 32-bit shifts)
+    atomicOr(&tile[off >> 2], (uint32_t)x);
+    atomicOr(&tile[(off >> 2) + 1], (uint32_t)(x >> 32));
 }
 __device__ __forceinline__ void tile_xor(uint32_t* tile, uint32_t off, uint32_t v) {
-    const uint32_t s = (off & 3u) * 8u;
-    atomicXor(&tile[off >> 2], v << s);
-    atomicXor(&tile[(off >> 2) + 1], (v >> 1) >> (31u - s));
+    const sj_u64 x = (sj_u64)v << ((off & 3u) * 8u);
+    atomicXor(&tile[off >> 2], (uint32_t)x);
+    atomicXor(&tile[(off >> 2) + 1], (uint32_t)(x >> 32));
 }
 __device__ __forceinline__ bool swar_has_backslash(uint32_t w) {
     const uint32_t z = w ^ 0x5C5C5C5Cu;
@@ -344,6 +351,9 @@ k_strings(const StrArgs a) {
     uint32_t prev_oexcl = 0;  // per lane
     sj_u64 pf = 0, pf_or = 0, pf_pp = 0;  // requested a classification ahead: pfx[prev-1], orec[prev-1], pfx[prev-2]
     uint32_t err_wave = 0;
+#ifdef SJMI_STR_SPINSTAT
+    unsigned long long stat_waits = 0, stat_spins = 0, stat_flushes = 0;
+#endif
 
     for (;;) {
         const bool have = cur < ngran;
@@ -369,19 +379,22 @@ k_strings(const StrArgs a) {
             sj_transpose_butterfly(w, p);
             uint32_t pin = 0, e_in = 0;
             bool unresolved = false;
+            if (cur == ngran - 1) {  // (wave-uniform) the document's end: bytes behind it are spaces, blocks behind it empty
+                if (active) {
+                    const sj_u64 rem = a.len - blk * 64;
+                    sj_mask_tail(p, rem < 64 ? (uint32_t)rem : 64u);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) p[k] = 0;
+                    p[5] = ~0ull;
+                }
+            }
             if (active) {
-                const sj_u64 start = blk * 64;
-                const sj_u64 rem = a.len - start;
-                sj_mask_tail(p, rem < 64 ? (uint32_t)rem : 64u);
                 pin = (uint32_t)(parword >> lane) & 1u;
                 if (blk > 0) {
                     uint32_t p_in;
                     unresolved = !sj_carry_from_halo((sj_u64)hq.z | ((sj_u64)hq.w << 32), &e_in, &p_in);
                 }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) p[k] = 0;
-                p[5] = ~0ull;  // spaces
             }
             if (__ballot(unresolved)) {  // rare: a backslash run longer than the 8 bytes in front of the block
                 if (unresolved) {
@@ -394,10 +407,7 @@ k_strings(const StrArgs a) {
             // reaches into one of its blocks (the previous lane's last 10 positions; lane 0: any backslash in its halo)
             const bool any_esc = __ballot(s.ED != 0) != 0;
             sj_u64 euc = 0;
-            if (any_esc) {
-                const sj_u64 isu = ~p[7] & p[6] & p[5] & p[4] & ~p[3] & p[2] & ~p[1] & p[0];
-                euc = s.ED & isu;
-            }
+            if (any_esc) euc = s.ED & sj_str_classes<sj_u64>(p, false).isu;  // (the same expressions as in sj_str_block: shared)
             const uint32_t euc_hi_prev = (uint32_t)__shfl_up((int)(uint32_t)(euc >> 32), 1);
             const bool halo_bs = blk > 0 && active && (swar_has_backslash(hq.y) | swar_has_backslash(hq.z) | swar_has_backslash(hq.w));
             const bool trig = euc != 0 || (lane > 0 ? (euc_hi_prev >> 22) != 0 : halo_bs);
@@ -488,16 +498,20 @@ k_strings(const StrArgs a) {
         }
         uint32_t nxt = STR_NONE;
         if (have && retire != 0) nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk) * NC + cls;
-        // the next granule's bytes are in flight during everything below
-        StrStep dn;
-        str_load_step(dn, a.buf, (sj_u64)nxt * 64 + lane, nblocks);
 
         // =================== flush granule `prev` ===================
         if (prev != STR_NONE) {
             sj_u64 outbase = 0;
             uint32_t ordbase = 0;
             if (prev != 0) {
+#ifdef SJMI_STR_SPINSTAT
+                if ((pf >> 62) != 2) ++stat_waits;
+                ++stat_flushes;
+#endif
                 for (uint32_t spins = 0; (pf >> 62) != 2; ++spins) {
+#ifdef SJMI_STR_SPINSTAT
+                    ++stat_spins;
+#endif
                     if (spins > STR_SPIN_LIMIT) {  // never expected: the scanner is not running
                         if (lane == 0) {
                             __hip_atomic_fetch_or(&a.wsflags[0], SJMI_ST_INTERNAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -512,32 +526,27 @@ k_strings(const StrArgs a) {
                 ordbase = (uint32_t)(pf >> 32) & 0x3FFFFFFFu;
             }
             const bool fits = (pf >> 62) == 2 || prev == 0 ? (outbase != 0xFFFFFFFFull && outbase + prev_n <= a.sb_cap) : false;
-            if (fits) {
-                const uint32_t al = (uint32_t)outbase & 15u;
-                const uint32_t sh = (16u - al) & 3u;
-                const uint32_t nchunks = (al + prev_n + 15u) >> 4;
-                uint8_t* const gb = a.sb + (outbase - al);
-                for (uint32_t q = (uint32_t)lane; q < nchunks; q += 64) {
-                    const int s0 = (int)(16u * q) - (int)al;
-                    const bool full = s0 >= 0 && (uint32_t)s0 + 16u <= prev_n &&
-                                      !(prev_pend != STR_NONE && (uint32_t)s0 < prev_pend + 4u && (uint32_t)s0 + 16u > prev_pend);
-                    if (full) {
-                        const uint32_t di = (uint32_t)s0 >> 2;
-                        const uint32_t l0 = tile[di], l1 = tile[di + 1], l2 = tile[di + 2], l3 = tile[di + 3], l4 = tile[di + 4];
-                        uint4 o;
-                        o.x = __builtin_amdgcn_alignbyte(l1, l0, sh);
-                        o.y = __builtin_amdgcn_alignbyte(l2, l1, sh);
-                        o.z = __builtin_amdgcn_alignbyte(l3, l2, sh);
-                        o.w = __builtin_amdgcn_alignbyte(l4, l3, sh);
-                        *reinterpret_cast<uint4*>(gb + 16u * q) = o;
-                    } else {
-                        const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
-                        for (int j = 0; j < 16; ++j) {
-                            const int pos = s0 + j;
-                            if (pos >= 0 && (uint32_t)pos < prev_n && !(prev_pend != STR_NONE && (uint32_t)pos >= prev_pend && (uint32_t)pos < prev_pend + 4u))
-                                gb[16u * q + (uint32_t)j] = tb[pos];
-                        }
+            if (fits && !(SJMI_STR_ABL & 4)) {
+                // 16-byte chunks of the tile, stored to byte-granular addresses (gfx950 global memory runs in unaligned access
+                // mode; measured against an LDS funnel shift to 16-byte aligned stores: 3.6 % faster).  The two chunks around a
+                // header that another granule will write, and the tail, go byte by byte, one byte per lane.
+                struct __attribute__((packed, aligned(1))) StrU16B { uint32_t a, b, c, d; };
+                const uint32_t pq = prev_pend != STR_NONE ? prev_pend >> 4 : 0x7FFFFFF0u;
+                for (uint32_t q = (uint32_t)lane; 16u * q + 16u <= prev_n; q += 64) {
+                    if (q - pq > 1u) {
+                        const uint4 v = reinterpret_cast<const uint4*>(tile)[q];
+                        StrU16B o = {v.x, v.y, v.z, v.w};
+                        *reinterpret_cast<StrU16B*>(a.sb + outbase + 16u * q) = o;
                     }
+                }
+                {
+                    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
+                    int pos;
+                    if (lane < 16) pos = (int)((prev_n & ~15u) + (uint32_t)lane);
+                    else if (lane < 32) pos = -1;
+                    else pos = prev_pend != STR_NONE ? (int)(16u * pq + ((uint32_t)lane - 32u)) : -1;
+                    if (pos >= 0 && (uint32_t)pos < prev_n && !(prev_pend != STR_NONE && (uint32_t)pos - prev_pend < 4u))
+                        a.sb[outbase + (uint32_t)pos] = tb[pos];
                 }
             }
             // the string that was open when the granule began: its header lives in an earlier granule
@@ -610,7 +619,7 @@ k_strings(const StrArgs a) {
             const uint32_t Clo = (uint32_t)Kc, Chi = (uint32_t)(Kc >> 32);
             const uint32_t Bhi = B + (uint32_t)__popc(Klo) + 4u * (uint32_t)__popc(Olo);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < ((SJMI_STR_ABL & 2) ? 0 : 16); ++i) {
                 const int sft = 4 * (i & 7);
                 const uint32_t ltm = (1u << sft) - 1u, grp = 0xFu << sft;
                 const uint32_t Kh = i < 8 ? Klo : Khi, Oh = i < 8 ? Olo : Ohi, Sh = i < 8 ? Slo : Shi, Ch = i < 8 ? Clo : Chi;
@@ -624,35 +633,93 @@ k_strings(const StrArgs a) {
                 for (int i = 0; i < 16; ++i)
                     if ((g.bad >> (4 * i + 2)) & 1ull) tile_or(tile, base + sj_str_offset(m, 4u * i + 3u), w[i] >> 24);
             }
+            // the next granule's bytes: requested as soon as this granule's are in the tile, in flight during the headers,
+            // the patches and the first instructions of the next classification (a second register buffer for an earlier
+            // request costs a wave per SIMD)
+            asm volatile("" ::: "memory");
+            str_load_step(d, a.buf, (sj_u64)nxt * 64 + lane, nblocks);
+            asm volatile("" ::: "memory");
             str_lds_fence();
-            // ---- headers, by the closing quotes ----
-            for (sj_u64 cl = m.CL; cl; cl &= cl - 1) {
-                const uint32_t c = (uint32_t)__builtin_ctzll(cl);
-                const sj_u64 lt_c = (1ull << c) - 1ull;
-                const sj_u64 olt = m.O & lt_c;
-                uint32_t Do, err = 0;
-                if (olt) {
-                    const uint32_t o = 63u - (uint32_t)__builtin_clzll(olt);
-                    Do = base + sj_str_offset(m, o);
-                    if (any_err) {
+            // ---- headers, by the closing quotes: length = kept bytes between the quotes (32-bit halves: 64-bit shifts by
+            //      a variable are slow) ----
+            if (SJMI_STR_ABL & 1) {
+            } else if (!any_err) {
+                const uint32_t CLlo = (uint32_t)m.CL, CLhi = (uint32_t)(m.CL >> 32);
+                const uint32_t nKlo = (uint32_t)__popc(Klo);
+                for (uint32_t cl = CLlo; cl; cl &= cl - 1) {
+                    const uint32_t c = (uint32_t)__builtin_ctz(cl);
+                    const uint32_t ltc = (1u << c) - 1u, olt = Olo & ltc;
+                    uint32_t Do, n;
+                    if (olt) {
+                        const uint32_t lto = (1u << (31u - (uint32_t)__builtin_clz(olt))) - 1u;
+                        Do = B + (uint32_t)__popc(Klo & lto) + 4u * (uint32_t)__popc(olt) - 4u;
+                        n = (uint32_t)__popc(Klo & ltc & ~lto);
+                    } else if (prevD) {
+                        Do = prevD - 1u;
+                        n = B + (uint32_t)__popc(Klo & ltc) - Do - 4u;
+                    } else {
+                        continue;  // opened in an earlier granule: the flush writes that header
+                    }
+                    tile_or(tile, Do, __builtin_bswap32(n));
+                }
+                for (uint32_t cl = CLhi; cl; cl &= cl - 1) {
+                    const uint32_t c = (uint32_t)__builtin_ctz(cl);
+                    const uint32_t ltc = (1u << c) - 1u, olt = Ohi & ltc;
+                    uint32_t Do, n;
+                    if (olt) {
+                        const uint32_t lto = (1u << (31u - (uint32_t)__builtin_clz(olt))) - 1u;
+                        Do = Bhi + (uint32_t)__popc(Khi & lto) + 4u * (uint32_t)__popc(olt) - 4u;
+                        n = (uint32_t)__popc(Khi & ltc & ~lto);
+                    } else if (Olo) {
+                        const uint32_t lto = (1u << (31u - (uint32_t)__builtin_clz(Olo))) - 1u;
+                        const uint32_t kb = (uint32_t)__popc(Klo & lto);
+                        Do = B + kb + 4u * (uint32_t)__popc(Olo) - 4u;
+                        n = nKlo - kb + (uint32_t)__popc(Khi & ltc);
+                    } else if (prevD) {
+                        Do = prevD - 1u;
+                        n = Bhi + (uint32_t)__popc(Khi & ltc) - Do - 4u;
+                    } else {
+                        continue;
+                    }
+                    tile_or(tile, Do, __builtin_bswap32(n));
+                }
+            } else {  // (rare: some string of the wave's 4 KiB has a malformed escape)
+                for (sj_u64 cl = m.CL; cl; cl &= cl - 1) {
+                    const uint32_t c = (uint32_t)__builtin_ctzll(cl);
+                    const sj_u64 lt_c = (1ull << c) - 1ull;
+                    const sj_u64 olt = m.O & lt_c;
+                    uint32_t Do, err = 0;
+                    if (olt) {
+                        const uint32_t o = 63u - (uint32_t)__builtin_clzll(olt);
+                        Do = base + sj_str_offset(m, o);
                         uint32_t dummy;
                         err = sj_str_first_error(m, (c == 63 ? ~0ull : ((2ull << c) - 1ull)) & ~((2ull << o) - 1ull), &dummy);
+                    } else if (prevD) {
+                        Do = prevD - 1u;
+                        err = xerr;
+                    } else {
+                        continue;
                     }
-                } else if (prevD) {
-                    Do = prevD - 1u;
-                    err = xerr;
-                } else {
-                    continue;  // opened in an earlier granule: the flush writes that header
+                    const uint32_t n = base + sj_str_offset(m, c) - Do - 4u;
+                    tile_or(tile, Do, err ? (0x00FFFFFFu | (err << 24)) : __builtin_bswap32(n));
                 }
-                const uint32_t n = base + sj_str_offset(m, c) - Do - 4u;
-                tile_or(tile, Do, err ? (0x00FFFFFFu | (err << 24)) : __builtin_bswap32(n));
             }
-            // ---- escapes that change the byte: XOR the difference in ----
-            if (__ballot((m.pn | m.pt | m.pr | m.pbf) != 0)) {
-                for (sj_u64 x = m.pn; x; x &= x - 1) tile_xor(tile, base + sj_str_offset(m, (uint32_t)__builtin_ctzll(x)), 0x6Eu ^ 0x0Au);
-                for (sj_u64 x = m.pt; x; x &= x - 1) tile_xor(tile, base + sj_str_offset(m, (uint32_t)__builtin_ctzll(x)), 0x74u ^ 0x09u);
-                for (sj_u64 x = m.pr; x; x &= x - 1) tile_xor(tile, base + sj_str_offset(m, (uint32_t)__builtin_ctzll(x)), 0x72u ^ 0x0Du);
-                for (sj_u64 x = m.pbf; x; x &= x - 1) tile_xor(tile, base + sj_str_offset(m, (uint32_t)__builtin_ctzll(x)), 0x6Au);
+            // ---- escapes that change the byte: XOR the difference in (n -> 0A, t -> 09, r -> 0D, b -> 08, f -> 0C) ----
+            {
+                const sj_u64 P = m.pn | m.pt | m.pr | m.pbf;
+                if (__ballot(P != 0)) {
+                    const uint32_t Plo = (uint32_t)P, Phi = (uint32_t)(P >> 32);
+                    for (uint32_t x = Plo; x; x &= x - 1) {
+                        const uint32_t bit = x & (0u - x), lt = bit - 1u;
+                        const uint32_t dl = ((uint32_t)m.pn & bit) ? 0x64u : ((uint32_t)m.pt & bit) ? 0x7Du : ((uint32_t)m.pr & bit) ? 0x7Fu : 0x6Au;
+                        tile_xor(tile, B + (uint32_t)__popc(Klo & lt) + 4u * (uint32_t)__popc(Olo & lt), dl);
+                    }
+                    for (uint32_t x = Phi; x; x &= x - 1) {
+                        const uint32_t bit = x & (0u - x), lt = bit - 1u;
+                        const uint32_t dl = ((uint32_t)(m.pn >> 32) & bit) ? 0x64u : ((uint32_t)(m.pt >> 32) & bit) ? 0x7Du : ((uint32_t)(m.pr >> 32) & bit) ? 0x7Fu : 0x6Au;
+                        tile_xor(tile, Bhi + (uint32_t)__popc(Khi & lt) + 4u * (uint32_t)__popc(Ohi & lt), dl);
+                    }
+                }
             }
             const sj_u64 items = m.l1 | m.l2 | m.l3 | m.pair;
             if (__ballot(items != 0)) {  // \uXXXX: the UTF-8 bytes over the last hex digits (StringParser.java:126-153)
@@ -698,9 +765,11 @@ k_strings(const StrArgs a) {
         prev_fclose_err = fclose_err;
         prev_oexcl = oexcl;
         cur = nxt;
-        d = dn;
     }
     (void)err_wave;
+#ifdef SJMI_STR_SPINSTAT  // experiments only: how often and how long the flush waited for its prefix (in the result record)
+    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&a.res->first_error_inv), stat_waits | (stat_spins << 20) | (stat_flushes << 44));
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -7,6 +7,9 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 import simdjson_java_amd as S
+import simdjson_java_amd.binding as B
+if os.environ.get('SJMI_LIB'):
+    B._LIB = os.environ['SJMI_LIB']
 from oracle import oracle as O
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
@@ -67,6 +70,10 @@ with torch.cuda.stream(work):
     e1.record(work)
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / K
+    u = ures.cpu().numpy()
+    if int(u[1]):
+        v = int(u[1]) & 0xFFFFFFFFFFFFFFFF
+        print("spin statistics: flushes %d, of which waited %d, polls %d" % (v >> 44, v & 0xFFFFF, (v >> 20) & 0xFFFFFF))
     print("string pass: %.4f ms per call = %.0f GB/s of document (%d B)" % (ms, n / ms / 1e6, n), flush=True)
     # stage 1 with the parity side output, for comparison with the committed number
     for _ in range(40):
