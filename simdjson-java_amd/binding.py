@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _CSRC = os.path.join(_HERE, "csrc")
 _LIB = os.path.join(_HERE, "libsjmi.so")
-SOURCES = ["stage1.hip", "strings.hip", "unescape.hip", "batch.hip", "walk.hip", "coop_walk.hip", "masks.hip", "sjmi_api.hip", "host/simdjson_parser.cpp"]
+SOURCES = ["stage1.hip", "strings.hip", "batch.hip", "walk.hip", "coop_walk.hip", "masks.hip", "sjmi_api.hip", "host/simdjson_parser.cpp"]
 
 ST_UTF8, ST_UNCLOSED, ST_UNESCAPED, ST_CAPACITY, ST_INTERNAL = 1, 2, 4, 0x100, 0x200
 PADDING = 64

@@ -263,7 +263,7 @@ template <bool CHUNKED>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
 k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restrict__ doc_offsets, uint64_t n_docs,
             const uint32_t* __restrict__ idx, const unsigned long long* __restrict__ index_offsets,
-            const uint32_t* __restrict__ doc_status, const uint32_t* __restrict__ sizes, const uint8_t* __restrict__ scratch,
+            const uint32_t* __restrict__ doc_status, const uint32_t* __restrict__ soff, const uint8_t* __restrict__ sb,
             const unsigned long long* __restrict__ doc_str_offsets, unsigned long long string_base, int max_depth,
             unsigned long long* __restrict__ scratch_tape, uint32_t* __restrict__ tape_lens, int32_t* __restrict__ doc_errors, const Stage1Result* __restrict__ dev_count,
             const UnescapeResult* __restrict__ dev_strings, WalkResult* res, uint32_t abl, ChunkWs cw, const uint32_t* run_only_if) {
@@ -278,7 +278,9 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
     const bool upstream_failed = (dev_count && (dev_count->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL))) ||
-                                 (dev_strings && (dev_strings->flags & 1u));
+                                 (dev_strings && (dev_strings->flags & 0xFu));
+    // some string of the launch has a malformed escape (rare): then every string's record header is looked at
+    const bool string_errors = dev_strings && dev_strings->first_error_inv != 0;
     unsigned long long n_host = 0, n_bad = 0;
     // A document costs three dependent round trips before its first step can run (its delimiters, then the positions of
     // its first structurals, then the bytes there): with ~3 steps per ~1 KB document that chain, not the steps, bounded
@@ -289,7 +291,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
         uint32_t doc_start, doc_end, st;
     };
     struct Head {
-        uint32_t p_n, sz_n, px_n, p_nn, sz_nn, px_nn;
+        uint32_t p_n, px_n, p_nn, px_nn;
     };
     auto load_meta = [&](uint64_t k) {
         Meta m;
@@ -302,25 +304,23 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
         return m;
     };
     // (wfrom, wto) = the structurals this wave walks: the whole document, or one chunk of it
-    auto load_pos = [&](const Meta& m, uint64_t wfrom, uint64_t wto, uint64_t s, uint32_t* p, uint32_t* sz, uint32_t* px) {
+    auto load_pos = [&](const Meta& m, uint64_t wfrom, uint64_t wto, uint64_t s, uint32_t* p, uint32_t* px) {
         const uint64_t i = wfrom + s * 64 + lane;
         *p = i < wto ? idx[i] : m.doc_start;
-        *sz = i < wto ? sizes[i] : 0u;
         const uint64_t ix = wfrom + s * 64 + 64;
         *px = ix < m.to ? idx[ix] : m.doc_start;
     };
     auto load_head = [&](const Meta& m, uint64_t wfrom, uint64_t wto) {
         Head h;
-        load_pos(m, wfrom, wto, 0, &h.p_n, &h.sz_n, &h.px_n);
+        load_pos(m, wfrom, wto, 0, &h.p_n, &h.px_n);
         h.p_nn = m.doc_start;
-        h.sz_nn = 0;
         h.px_nn = m.doc_start;
-        if (wto - wfrom > 64) load_pos(m, wfrom, wto, 1, &h.p_nn, &h.sz_nn, &h.px_nn);
+        if (wto - wfrom > 64) load_pos(m, wfrom, wto, 1, &h.p_nn, &h.px_nn);
         return h;
     };
     uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
     Meta m = {0, 0, 0, 0, 0, 0}, m_next = m;
-    Head hd = {0, 0, 0, 0, 0, 0};
+    Head hd = {0, 0, 0, 0};
     uint64_t n_items = n_docs;
     uint32_t chunk = 0;
     if (CHUNKED) {  // the work items are the chunks of document 0
@@ -358,7 +358,10 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
             // running state (wave-uniform)
             uint32_t H0 = 0;                 // open containers in front of the step
             uint32_t T0 = 1;                 // tape position of the step's first word (0 = the root word)
-            unsigned long long S0 = m.dso;
+            unsigned long long S0 = m.dso;   // ordinal of the first string at or behind the step (the record table soff[] is by ordinal)
+            // a STRING word needs its record's offset, a gather by ordinal: requested in one step, stored in the next
+            uint32_t pq_tpos = 0, pq_off = 0;
+            bool pq_live = false;
             unsigned long long arr_mask = 0; // bit L: the open container of level L is an array
             uint32_t prev_cls = K_COMMA;     // class of the structural in front of the step (none at the start)
             bool prev_empty_open = false, prev_is_key = false, root_closed = false;
@@ -388,20 +391,19 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
             // positions (and sizes) are requested TWO steps ahead, the 16-byte windows they point at one step ahead: neither
             // round trip is on the step-to-step critical path
             const uint64_t nsteps = (wto - wfrom + 63) / 64;
-            uint32_t p_n = hd.p_n, sz_n = hd.sz_n, px_n = hd.px_n, p_nn = hd.p_nn, sz_nn = hd.sz_nn, px_nn = hd.px_nn;
+            uint32_t p_n = hd.p_n, px_n = hd.px_n, p_nn = hd.p_nn, px_nn = hd.px_nn;
             CW16 win_n = *reinterpret_cast<const CW16*>(buf + p_n);
             uint32_t bx_n = buf[px_n];
             for (uint64_t s = 0; s < nsteps && code == 0; ++s) {
-                const uint32_t p = p_n, sz = sz_n, c_extra = bx_n;
+                const uint32_t p = p_n, c_extra = bx_n;
                 const CW16 win = win_n;
                 p_n = p_nn;
-                sz_n = sz_nn;
                 px_n = px_nn;
                 if (s + 1 < nsteps) {
                     win_n = *reinterpret_cast<const CW16*>(buf + p_n);
                     bx_n = buf[px_n];
                 }
-                if (s + 2 < nsteps) load_pos(m, wfrom, wto, s + 2, &p_nn, &sz_nn, &px_nn);
+                if (s + 2 < nsteps) load_pos(m, wfrom, wto, s + 2, &p_nn, &px_nn);
                 const uint64_t i = wfrom + s * 64 + lane;
                 const bool valid = i < wto;
                 const unsigned long long vmask = __ballot(valid);
@@ -437,11 +439,10 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 const uint32_t words = !valid || cls == K_COMMA || cls == K_COLON ? 0u : (is_num ? 2u : 1u);
                 const uint32_t iw = cw_incl_scan(words);
                 const uint32_t tpos = T0 + iw - words;
-                const uint32_t ssz = (valid && cls == K_QUOTE) ? (sz & ~CW_SIZE_SLOW) : 0u;
-                // (the records of one step cover at most 64 strings of < 2^32 bytes in total: 64-bit running offset, 32-bit scan;
-                //  a step whose sizes would overflow 32 bits cannot occur: the document itself is < 4 GiB)
-                const uint32_t is_ = cw_incl_scan(ssz);
-                const unsigned long long soff = S0 + (is_ - ssz);
+                const bool is_str = valid && cls == K_QUOTE;
+                const unsigned long long qm = __ballot(is_str);
+                const unsigned long long sord = S0 + (unsigned long long)__popcll(qm & lt_mask);  // this string's ordinal
+                const uint32_t rec_off = is_str ? soff[sord] : 0u;                                    // (used one step later)
                 // (4) the container of every structural: level loop over the depths present in this step
                 const int plevel = h - 1;  // level of the container this structural sits in
                 int hmin = cw_wave_minmax<false>(valid ? plevel : 0x7FFF), hmax = cw_wave_minmax<true>(valid ? (is_open ? h : plevel) : -0x7FFF);
@@ -521,8 +522,11 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                         if (!ok) err = par_is_array ? SJMI_E_NO_COMMA_ARRAY : SJMI_E_NO_COMMA_OBJECT;  // :131,:189
                     }
                     if (!err && cls == K_QUOTE && (is_key || want_value)) {
-                        // a string the reference's StringParser would have thrown on: size 4 | SLOW, code in scratch[open]
-                        if (sz == (4u | CW_SIZE_SLOW)) err = (int)scratch[p];
+                        // a string the reference's StringParser would have thrown on: record header FF FF FF <code>
+                        if (string_errors) {
+                            const uint8_t* h = sb + rec_off;
+                            if (h[0] == 0xFF && h[1] == 0xFF && h[2] == 0xFF) err = (int)h[3];
+                        }
                     } else if (!err && want_value) {
                         if (cls <= K_OPEN_O) {
                             if (!empty_open) {
@@ -553,9 +557,12 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 if (rc) root_closed = true;
                 // (7) the tape words of this step
                 const bool live = valid && lane <= rc_lane && !(abl & 4u);
+                if (pq_live && pq_tpos < room) T[pq_tpos] = tape_word('"', string_base + pq_off);  // the previous step's strings
+                pq_live = live && cls == K_QUOTE;
+                pq_tpos = tpos;
+                pq_off = rec_off;
                 if (live) {
                     if (cls == K_QUOTE) {
-                        if (tpos < room) T[tpos] = tape_word('"', string_base + soff);
                     } else if (cls == K_PRIM) {
                         if (tpos < room) T[tpos] = tape_word(ptype, 0);
                         if (is_num && tpos + 1 < room) T[tpos + 1] = praw;
@@ -574,12 +581,13 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 const uint32_t live_words = (uint32_t)__builtin_amdgcn_readlane((int)iw, rc_lane < 64 ? rc_lane : 63);
                 H0 = (uint32_t)((int)H0 + (int)cw_last(iu) - (int)cw_last(id));
                 T0 += rc_lane < 64 ? live_words : cw_last(iw);
-                S0 += cw_last(is_);
+                S0 += (unsigned long long)__popcll(qm);
                 const int lastv = 63 - __builtin_clzll(vmask);
                 prev_cls = (uint32_t)__builtin_amdgcn_readlane((int)cls, lastv);
                 prev_empty_open = __builtin_amdgcn_readlane((int)empty_open, lastv) != 0;
                 prev_is_key = __builtin_amdgcn_readlane((int)is_key, lastv) != 0;
             }
+            if (pq_live && pq_tpos < room) T[pq_tpos] = tape_word('"', string_base + pq_off);  // the last step's strings
             if (CHUNKED) {  // the document's verdict is assembled by k_chunk_finish from the chunks' first errors
                 if (lane == 0) {
                     cw.err_pos[k] = code ? err_at : 0xFFFFFFFFu;
@@ -645,7 +653,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
 // ---- the chunk passes around k_coop_walk<true> --------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_chunk_summary(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ idx, const unsigned long long* __restrict__ index_offsets,
-                const uint32_t* __restrict__ sizes, ChunkWs cw) {
+                ChunkWs cw) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
@@ -665,15 +673,11 @@ k_chunk_summary(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ id
         uint32_t T = 0, S = 0;
         bool out_of_range = false;
         uint32_t p_n = wfrom + lane < wto ? idx[wfrom + lane] : 0u;
-        uint32_t sz_n = wfrom + lane < wto ? sizes[wfrom + lane] : 0u;
         for (uint64_t s = 0; s < nsteps; ++s) {
             const uint64_t i = wfrom + s * 64 + lane;
             const bool valid = i < wto;
-            const uint32_t c = buf[p_n], sz = sz_n;
-            if (s + 1 < nsteps) {
-                p_n = i + 64 < wto ? idx[i + 64] : 0u;
-                sz_n = i + 64 < wto ? sizes[i + 64] : 0u;
-            }
+            const uint32_t c = buf[p_n];
+            if (s + 1 < nsteps) p_n = i + 64 < wto ? idx[i + 64] : 0u;
             const uint32_t cls = valid ? class_of(c) : K_COMMA;
             const bool is_open = valid && cls <= K_OPEN_O, is_close = valid && (cls == K_CLOSE_A || cls == K_CLOSE_O);
             const uint32_t up = is_open ? 1u : 0u, down = is_close ? 1u : 0u;
@@ -683,7 +687,7 @@ k_chunk_summary(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ id
             const uint32_t words = !valid || cls == K_COMMA || cls == K_COLON ? 0u : (is_num ? 2u : 1u);
             const uint32_t iw = cw_incl_scan(words);
             const uint32_t tpos = T + iw - words;
-            const uint32_t is_ = cw_incl_scan((valid && cls == K_QUOTE) ? (sz & ~CW_SIZE_SLOW) : 0u);
+            const uint32_t nstr = (uint32_t)__popcll(__ballot(valid && cls == K_QUOTE));  // strings of the step (S counts them)
             const int plevel = h - 1;
             const int after = cw_wave_minmax<false>(valid ? h + (int)up - (int)down : 0x7FFF);
             const int hmin = cw_wave_minmax<false>(valid ? plevel : 0x7FFF), hmax = cw_wave_minmax<true>(valid ? (is_open ? h : plevel) : -0x7FFF);
@@ -717,7 +721,7 @@ k_chunk_summary(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ id
             }
             H += (int)cw_last(iu) - (int)cw_last(id);
             T += cw_last(iw);
-            S += cw_last(is_);
+            S += nstr;
         }
         if (out_of_range && lane == 0) atomicOr(cw.fallback, 1u);
         if (lane == 0) {
@@ -916,7 +920,9 @@ k_chunk_finish(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ idx
     int code = 0;
     uint32_t tlen = 0;
     const bool upstream_failed = (dev_count && (dev_count->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL))) ||
-                                 (dev_strings && (dev_strings->flags & 1u));
+                                 (dev_strings && (dev_strings->flags & 0xFu));
+    // some string of the launch has a malformed escape (rare): then every string's record header is looked at
+    const bool string_errors = dev_strings && dev_strings->first_error_inv != 0;
     if (upstream_failed) code = SJMI_E_CAPACITY;
     else if (st & SJMI_ST_UTF8) code = SJMI_E_UTF8;
     else if (st & SJMI_ST_UNCLOSED) code = SJMI_E_UNCLOSED_STRING;
@@ -1199,8 +1205,8 @@ static ChunkWs chunk_ws(void* ws, uint64_t count_bound) {
 // with the single-wave sweep queued behind it for the (flagged) cases it does not take
 constexpr uint64_t COOP_CHUNK_MIN = 4096;
 hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_idx,
-                            const unsigned long long* d_index_offsets, const uint32_t* d_doc_status, const uint32_t* d_sizes,
-                            const uint8_t* d_scratch, const unsigned long long* d_doc_str_offsets, uint64_t string_base,
+                            const unsigned long long* d_index_offsets, const uint32_t* d_doc_status, const uint32_t* d_soff,
+                            const uint8_t* d_sb, const unsigned long long* d_doc_str_offsets, uint64_t string_base,
                             int max_depth, unsigned long long* d_scratch_tape, uint32_t* d_tape_lens, int32_t* d_doc_errors,
                             const Stage1Result* dev_count, const UnescapeResult* dev_strings, WalkResult* d_res,
                             hipStream_t stream, void* d_chunk_ws, uint64_t count_bound) {
@@ -1217,14 +1223,14 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
         const uint64_t nchunks = chunk_bound(count_bound);
         const uint64_t want = (nchunks + 3) / 4;
         const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
-        hipLaunchKernelGGL(k_chunk_summary, dim3(grid), dim3(256), 0, stream, d_buf, d_idx, d_index_offsets, d_sizes, cw);
+        hipLaunchKernelGGL(k_chunk_summary, dim3(grid), dim3(256), 0, stream, d_buf, d_idx, d_index_offsets, cw);
         const uint64_t gwant = (group_bound(count_bound) + 3) / 4;
         const unsigned ggrid = (unsigned)(gwant < 4096 ? gwant : 4096);
         hipLaunchKernelGGL(k_group_summary, dim3(ggrid), dim3(256), 0, stream, d_index_offsets, cw);
         hipLaunchKernelGGL(k_top_scan, dim3(1), dim3(64), 0, stream, d_index_offsets, d_doc_str_offsets, cw);
         hipLaunchKernelGGL(k_group_replay, dim3(ggrid), dim3(256), 0, stream, d_index_offsets, cw);
         hipLaunchKernelGGL((k_coop_walk<true>), dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets,
-                           d_doc_status, d_sizes, d_scratch, d_doc_str_offsets, (unsigned long long)string_base, max_depth,
+                           d_doc_status, d_soff, d_sb, d_doc_str_offsets, (unsigned long long)string_base, max_depth,
                            d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res, abl, cw, (const uint32_t*)nullptr);
         hipLaunchKernelGGL(k_chunk_finish, dim3(1), dim3(64), 0, stream, d_buf, d_idx, d_index_offsets, d_doc_status, d_scratch_tape,
                            d_tape_lens, d_doc_errors, dev_count, dev_strings, cw);
@@ -1233,7 +1239,7 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
     const uint64_t want = (n_docs + 3) / 4;  // four documents (waves) per workgroup and trip
     const unsigned grid = (unsigned)(want < 16384 ? want : 16384);
     hipLaunchKernelGGL((k_coop_walk<false>), dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets,
-                       d_doc_status, d_sizes, d_scratch, d_doc_str_offsets, (unsigned long long)string_base, max_depth,
+                       d_doc_status, d_soff, d_sb, d_doc_str_offsets, (unsigned long long)string_base, max_depth,
                        d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res, abl, cw, only_if);
     return hipGetLastError();
 }

@@ -33,8 +33,6 @@ struct sjmi_ctx {
     bool last_valid = false;
     uint8_t* d_sb = nullptr;      // string buffer (host path), grown on demand
     size_t sb_bytes = 0;
-    void* d_ws_str = nullptr;     // unescape workspace, grown on demand
-    size_t ws_str_bytes = 0;
     void* d_ws_strm = nullptr;    // workspace of the streaming string pass (strings.hip), grown on demand
     size_t ws_strm_bytes = 0;
     void* d_ws_par = nullptr;     // workspace of a parity-only stage-1 launch (strings of a document this context has not indexed)
@@ -45,6 +43,20 @@ struct sjmi_ctx {
     uint64_t par_len = 0;
     bool par_valid = false;
     unsigned long long* d_err_index = nullptr;  // host forms: position in indexes[] of the first failing string
+    // what the cooperative walker takes from the string pass: offset of every record by string ordinal, the ordinal of the
+    // first string at or behind every 64-byte block, the ordinal of every document's first string
+    uint32_t* d_soff = nullptr;
+    size_t soff_bytes = 0;
+    uint32_t* d_blk_ord = nullptr;
+    size_t blk_ord_bytes = 0;
+    unsigned long long* d_doc_ord = nullptr;
+    size_t doc_ord_bytes = 0;
+    const void* soff_idx = nullptr;  // the index array these belong to (the last batch string pass on this context)
+    sjmi_unescape_result* d_ures_walk = nullptr;  // ... and a copy of that pass's result record (for a walk queued later)
+    uint8_t* d_copy = nullptr;       // isolated batches: the sanitized copy the string pass runs on, and its block parities
+    size_t copy_bytes = 0;
+    unsigned long long* d_blkpar2 = nullptr;
+    size_t blkpar2_bytes = 0;
     sjmi_unescape_result* d_ures = nullptr;
     unsigned long long* d_docoff = nullptr;  // batch: document offsets + index offsets (+ statuses), grown on demand
     uint32_t* d_doccnt = nullptr;            // isolated batch: per-document index counts
@@ -62,8 +74,6 @@ struct sjmi_ctx {
     unsigned long long* d_tape = nullptr;    // ... and its tape, grown on demand
     size_t tape_bytes = 0;
     void* h_single = nullptr;                // pinned copy of the three result records
-    const void* unesc_idx = nullptr;         // index array and count bound of the last unescape launch on this context: its
-    uint64_t unesc_bound = 0;                // per-structural records (sizes, scratch copy) are still in d_ws_str
     uint64_t last_ndocs = 0;                 // documents of the last batch call (their index offsets are still on the device)
     bool last_batch = false;
     size_t docoff_bytes = 0;
@@ -170,11 +180,16 @@ void sjmi_destroy(sjmi_ctx* c) {
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_ws_dev) (void)hipFree(c->d_ws_dev);
     if (c->d_sb) (void)hipFree(c->d_sb);
-    if (c->d_ws_str) (void)hipFree(c->d_ws_str);
     if (c->d_ws_strm) (void)hipFree(c->d_ws_strm);
     if (c->d_ws_par) (void)hipFree(c->d_ws_par);
     if (c->d_blkpar) (void)hipFree(c->d_blkpar);
     if (c->d_err_index) (void)hipFree(c->d_err_index);
+    if (c->d_soff) (void)hipFree(c->d_soff);
+    if (c->d_ures_walk) (void)hipFree(c->d_ures_walk);
+    if (c->d_blk_ord) (void)hipFree(c->d_blk_ord);
+    if (c->d_doc_ord) (void)hipFree(c->d_doc_ord);
+    if (c->d_copy) (void)hipFree(c->d_copy);
+    if (c->d_blkpar2) (void)hipFree(c->d_blkpar2);
     if (c->d_ures) (void)hipFree(c->d_ures);
     if (c->d_docoff) (void)hipFree(c->d_docoff);
     if (c->d_doccnt) (void)hipFree(c->d_doccnt);
@@ -328,27 +343,88 @@ static int strings_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, voi
     return SJMI_OK;
 }
 
+// The string pass of a BATCH with everything the walkers need: the record table (c->d_soff), the ordinal of every document's
+// first string (c->d_doc_ord) and, optionally, the offset of its first record (d_doc_str_offsets, n_docs + 1 entries).
+//   plain     the batch was indexed by one plain stage-1 launch of this context (its block parities are on the device) and
+//             every document passed: the pass runs over the batch itself;
+//   otherwise the documents were indexed one by one (isolated mode): it runs over the sanitized copy (strings.hip), whose
+//             parities come from a stage-1 launch that writes nothing else;
+//   d_accept  the fused pipeline's device flag: != 0 -> plain, == 0 -> the copy; decided on the device, everything is queued.
+static int strings_batch_impl(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_indexes, uint64_t count_bound,
+                              const void* d_doc_offsets, const void* d_index_offsets, uint64_t n_docs, bool plain,
+                              const uint32_t* d_accept, void* d_string_buffer, uint64_t string_capacity, void* d_doc_str_offsets,
+                              void* d_result, hipStream_t st) {
+    const uint64_t soff_cap = count_bound + 64;
+    if (!grow(c, (void**)&c->d_soff, &c->soff_bytes, soff_cap * sizeof(uint32_t), "hipMalloc(soff)") ||
+        !grow(c, (void**)&c->d_blk_ord, &c->blk_ord_bytes, (total_len / 64 + 2) * sizeof(uint32_t), "hipMalloc(blk_ord)") ||
+        !grow(c, (void**)&c->d_doc_ord, &c->doc_ord_bytes, (n_docs + 2) * sizeof(unsigned long long), "hipMalloc(doc_ord)") ||
+        !grow(c, &c->d_ws_strm, &c->ws_strm_bytes, sjmi::strings_workspace_bytes(total_len), "hipMalloc(ws_strm)"))
+        return SJMI_ERR_HIP;
+    c->soff_idx = nullptr;
+    const uint8_t* buf0 = (const uint8_t*)d_buf;
+    const unsigned long long* par0 = nullptr;
+    sjmi::StringsAlt alt;
+    if (plain || d_accept) {
+        if (!(c->par_valid && c->par_buf == d_buf && c->par_len == total_len)) {
+            c->err = "string pass of a plain batch: the block parities of its stage-1 launch are not on this context";
+            return SJMI_ERR_ARG;
+        }
+        par0 = c->d_blkpar;
+    }
+    if (!plain || d_accept) {
+        const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(total_len);
+        if (!grow(c, (void**)&c->d_copy, &c->copy_bytes, total_len + 2 * SJMI_PADDING + 64, "hipMalloc(copy)") ||
+            !grow(c, (void**)&c->d_blkpar2, &c->blkpar2_bytes, sjmi::strings_parity_words(total_len) * sizeof(unsigned long long), "hipMalloc(blkpar2)") ||
+            !grow(c, &c->d_ws_par, &c->ws_par_bytes, sjmi::stage1_workspace_bytes(total_len, steps), "hipMalloc(ws_par)"))
+            return SJMI_ERR_HIP;
+        sjmi::Stage1Extras ex;
+        ex.blkpar = c->d_blkpar2;
+        ex.skip = d_accept;
+        if (fail(c, "sanitize", sjmi::strings_sanitize_launch((const uint8_t*)d_buf, total_len, (const unsigned long long*)d_doc_offsets,
+                                                              (const unsigned long long*)d_index_offsets, n_docs, c->d_copy, d_accept, st)) ||
+            fail(c, "parity launch", sjmi::stage1_launch(c->d_copy, total_len, nullptr, 0, c->d_ws_par, steps, st, nullptr, nullptr,
+                                                         (launch_flags(c) & ~sjmi::DBG_NO_LOOKBACK) | sjmi::DBG_NO_WRITE, ex)))
+            return SJMI_ERR_HIP;
+        note_launch(c, st);
+        if (d_accept) {
+            alt.d_sel = d_accept;
+            alt.d_buf = c->d_copy;
+            alt.d_blkpar = c->d_blkpar2;
+        } else {
+            buf0 = c->d_copy;
+            par0 = c->d_blkpar2;
+        }
+    }
+    if (fail(c, "memset(result)", hipMemsetAsync(d_result, 0, sizeof(sjmi_unescape_result), st)) ||
+        fail(c, "strings launch",
+             sjmi::strings_launch(buf0, total_len, par0, (uint8_t*)d_string_buffer, string_capacity, c->d_soff, soff_cap, c->d_blk_ord,
+                                  c->d_ws_strm, (sjmi::UnescapeResult*)d_result, st, nullptr, nullptr, alt)) ||
+        fail(c, "doc ordinals",
+             sjmi::strings_doc_ordinals_launch(buf0, par0, alt, total_len, (const unsigned long long*)d_doc_offsets, n_docs, c->d_blk_ord,
+                                               c->d_soff, (const sjmi::UnescapeResult*)d_result, c->d_doc_ord,
+                                               (unsigned long long*)d_doc_str_offsets, st)))
+        return SJMI_ERR_HIP;
+    if (!c->d_ures_walk && fail(c, "hipMalloc(ures_walk)", hipMalloc((void**)&c->d_ures_walk, sizeof(sjmi_unescape_result)))) return SJMI_ERR_HIP;
+    if (fail(c, "D2D(ures)", hipMemcpyAsync(c->d_ures_walk, d_result, sizeof(sjmi_unescape_result), hipMemcpyDeviceToDevice, st))) return SJMI_ERR_HIP;
+    c->soff_idx = d_indexes;
+    return SJMI_OK;
+}
+
 static int unescape_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, const void* d_indexes, uint64_t count,
                                 void* d_string_buffer, uint64_t string_capacity, void* d_result, void* stream,
                                 const sjmi::UnescapeBatch& batch) {
     if (!c || !d_buf || !d_indexes || !d_string_buffer || !d_result || len >= (1ull << 32)) return SJMI_ERR_ARG;
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-    c->unesc_idx = nullptr;
     if (!batch.d_doc_offsets) {
         if (((uintptr_t)d_buf & 15)) return SJMI_ERR_ARG;
         return strings_device_impl(c, d_buf, len, d_string_buffer, string_capacity, nullptr, 0, nullptr, d_result, st);
     }
-    if (!grow(c, &c->d_ws_str, &c->ws_str_bytes, sjmi::unescape_workspace_bytes(count, len), "hipMalloc(ws_str)"))
-        return SJMI_ERR_HIP;
-    if (fail(c, "unescape launch",
-             sjmi::unescape_launch((const uint8_t*)d_buf, len, (const uint32_t*)d_indexes, count, nullptr,
-                                   (uint8_t*)d_string_buffer, string_capacity, c->d_ws_str,
-                                   (sjmi::UnescapeResult*)d_result, st, batch)))
-        return SJMI_ERR_HIP;
-    c->unesc_idx = d_indexes;
-    c->unesc_bound = count;
-    return SJMI_OK;
+    // a batch: over the batch itself if this context's last stage-1 launch was the plain pass over it, else (documents indexed
+    // one by one) over the sanitized copy
+    const bool plain = c->par_valid && c->par_buf == d_buf && c->par_len == len;
+    return strings_batch_impl(c, d_buf, len, d_indexes, count, batch.d_doc_offsets, batch.d_index_offsets, batch.n_docs, plain, nullptr,
+                              d_string_buffer, string_capacity, batch.d_doc_str_offsets, d_result, st);
 }
 
 int sjmi_unescape_device(sjmi_ctx* c, const void* d_buf, uint64_t len, const void* d_indexes, uint64_t count,
@@ -393,7 +469,7 @@ static int unescape_host(sjmi_ctx* c, uint8_t* string_buffer, uint64_t string_ca
     if (rc != SJMI_OK) return rc;
     sjmi_unescape_result r;
     unsigned long long err_index = ~0ull;
-    const bool streamed = !batch.d_doc_offsets;  // (the string pass reports the error's byte position: turn it into the string's index)
+    const bool streamed = true;  // (the string pass reports the error's byte position: turn it into the string's index)
     if (streamed) {
         if (!c->d_err_index && fail(c, "hipMalloc(err_index)", hipMalloc((void**)&c->d_err_index, sizeof(unsigned long long))))
             return SJMI_ERR_HIP;
@@ -553,21 +629,19 @@ int sjmi_walk_batch_device(sjmi_ctx* c, const void* d_buf, const void* d_doc_off
     if (!grow(c, &c->d_ws_walk, &c->ws_walk_bytes, sjmi::walk_workspace_bytes(count, n_docs), "hipMalloc(ws_walk)"))
         return SJMI_ERR_HIP;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-    // The cooperative walker (coop_walk.hip) works from the per-structural records the unescape pass of THESE indexes
-    // left on this context; without them (another context made the string buffer) the lane-per-document walker reads
-    // the record headers out of the string buffer instead.  SJMI_WALK=lane forces the latter (A/B measurements).
-    const uint32_t* sizes = nullptr;
-    const uint8_t* str_scratch = nullptr;
-    static const bool force_lane = getenv("SJMI_WALK") && strcmp(getenv("SJMI_WALK"), "lane") == 0;
-    if (!force_lane && c->unesc_idx == d_indexes && c->unesc_idx && c->d_ws_str)
-        sjmi::unescape_records(c->d_ws_str, c->unesc_bound, &sizes, &str_scratch);
+    // The cooperative walker takes the offsets of the string records from the record table the string pass of THESE indexes
+    // left on this context (sjmi_unescape_batch_device), and the ordinal of every document's first string with it.
+    if (!c->soff_idx || c->soff_idx != d_indexes) {
+        c->err = "sjmi_walk_batch_device needs the sjmi_unescape_batch_device call of the same indexes on this context";
+        return SJMI_ERR_ARG;
+    }
     if (fail(c, "walk launch",
              sjmi::walk_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs, (const uint32_t*)d_indexes,
                                count, (const unsigned long long*)d_index_offsets, (const uint32_t*)d_doc_status,
-                               (const uint8_t*)d_string_buffer, (const unsigned long long*)d_doc_string_offsets, string_base,
+                               (const uint8_t*)d_string_buffer, c->d_doc_ord, string_base,
                                max_depth, (unsigned long long*)d_tape, tape_capacity, (unsigned long long*)d_tape_offsets,
-                               (int32_t*)d_doc_errors, c->d_ws_walk, (sjmi::WalkResult*)d_result, st, nullptr, nullptr, sizes,
-                               str_scratch)))
+                               (int32_t*)d_doc_errors, c->d_ws_walk, (sjmi::WalkResult*)d_result, st, nullptr,
+                               (const sjmi::UnescapeResult*)c->d_ures_walk, c->d_soff)))
         return SJMI_ERR_HIP;
     return SJMI_OK;
 }
@@ -866,35 +940,21 @@ int sjmi_parse_batch_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, 
     int rc = stage1_batch_isolated_device_impl(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity,
                                                d_index_offsets, d_doc_status, &r->stage1, stream, d_skip);
     if (rc != SJMI_OK) return rc;
-    // string records: the structural count stays on the device (no host round trip between the stages); workspaces and
-    // grids are sized for the bound index_capacity - 1
+    // string records and the walk: everything queued, nothing comes back to the host in between.  If the optimistic plain
+    // pass was accepted the string pass runs over the batch itself, else over its sanitized copy -- chosen on the device
     const uint64_t bound = index_capacity - 1;
-    if (!grow(c, &c->d_ws_str, &c->ws_str_bytes, sjmi::unescape_workspace_bytes(bound, total_len), "hipMalloc(ws_str)") ||
-        !grow(c, &c->d_ws_walk, &c->ws_walk_bytes, sjmi::walk_workspace_bytes(bound, n_docs), "hipMalloc(ws_walk)"))
-        return SJMI_ERR_HIP;
+    if (!grow(c, &c->d_ws_walk, &c->ws_walk_bytes, sjmi::walk_workspace_bytes(bound, n_docs), "hipMalloc(ws_walk)")) return SJMI_ERR_HIP;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-    sjmi::UnescapeBatch batch;
-    batch.d_doc_offsets = (const unsigned long long*)d_doc_offsets;
-    batch.d_index_offsets = (const unsigned long long*)d_index_offsets;
-    batch.n_docs = n_docs;
-    batch.d_doc_str_offsets = (unsigned long long*)d_doc_string_offsets;
-    const uint32_t* sizes = nullptr;
-    const uint8_t* str_scratch = nullptr;
-    static const bool force_lane = getenv("SJMI_WALK") && strcmp(getenv("SJMI_WALK"), "lane") == 0;
-    if (!force_lane) sjmi::unescape_records(c->d_ws_str, bound, &sizes, &str_scratch);
-    c->unesc_idx = d_indexes;
-    c->unesc_bound = bound;
-    if (fail(c, "unescape launch",
-             sjmi::unescape_launch((const uint8_t*)d_buf, total_len, (const uint32_t*)d_indexes, bound,
-                                   (const sjmi::Stage1Result*)&r->stage1, (uint8_t*)d_string_buffer, string_capacity,
-                                   c->d_ws_str, (sjmi::UnescapeResult*)&r->strings, st, batch)) ||
-        fail(c, "walk launch",
+    rc = strings_batch_impl(c, d_buf, total_len, d_indexes, bound, d_doc_offsets, d_index_offsets, n_docs, false, d_skip, d_string_buffer,
+                            string_capacity, d_doc_string_offsets, &r->strings, st);
+    if (rc != SJMI_OK) return rc;
+    if (fail(c, "walk launch",
              sjmi::walk_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs, (const uint32_t*)d_indexes,
                                bound, (const unsigned long long*)d_index_offsets, (const uint32_t*)d_doc_status,
-                               (const uint8_t*)d_string_buffer, (const unsigned long long*)d_doc_string_offsets, 0, max_depth,
+                               (const uint8_t*)d_string_buffer, c->d_doc_ord, 0, max_depth,
                                (unsigned long long*)d_tape, tape_capacity, (unsigned long long*)d_tape_offsets,
                                (int32_t*)d_doc_errors, c->d_ws_walk, (sjmi::WalkResult*)&r->walk, st,
-                               (const sjmi::Stage1Result*)&r->stage1, (const sjmi::UnescapeResult*)&r->strings, sizes, str_scratch)))
+                               (const sjmi::Stage1Result*)&r->stage1, (const sjmi::UnescapeResult*)&r->strings, c->d_soff)))
         return SJMI_ERR_HIP;
     return SJMI_OK;
 }
@@ -946,7 +1006,7 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
     const uint64_t bound = len + 1;  // structurals: at most one per byte
     const size_t need_sb = (size_t)len + 4 * ((size_t)len / 2 + 2) + 64;
     if (!grow(c, (void**)&c->d_sb, &c->sb_bytes, need_sb, "hipMalloc(sb)") ||
-        !grow(c, &c->d_ws_str, &c->ws_str_bytes, sjmi::unescape_workspace_bytes(bound, len), "hipMalloc(ws_str)") ||
+        !grow(c, (void**)&c->d_soff, &c->soff_bytes, ((size_t)len / 2 + 66) * sizeof(uint32_t), "hipMalloc(soff)") ||
         !grow(c, &c->d_ws_walk, &c->ws_walk_bytes, sjmi::walk_workspace_bytes(bound, 1), "hipMalloc(ws_walk)") ||
         !grow(c, (void**)&c->d_tape, &c->tape_bytes, (2 * (size_t)bound + 16) * sizeof(unsigned long long), "hipMalloc(tape)"))
         return SJMI_ERR_HIP;
@@ -966,9 +1026,7 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
     SingleDocResults* h = (SingleDocResults*)c->h_single;
     const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(len);
     if (len && fail(c, "H2D", hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
-    const uint32_t* sizes = nullptr;
-    const uint8_t* str_scratch = nullptr;
-    sjmi::unescape_records(c->d_ws_str, bound, &sizes, &str_scratch);
+    c->soff_idx = nullptr;
     // The string records are complete long before the tape: their download runs on a second stream while the walker works
     // (a large document: a tenth of the call).  The size comes from the unescape result, fetched on that stream too.
     sjmi_unescape_result* h_u_early = (sjmi_unescape_result*)((uint8_t*)c->h_single + 256);
@@ -976,15 +1034,18 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
     const bool early_strings = len >= (256u << 10);  // (below that the second stream's synchronisation costs more than it hides)
     for (int attempt = 0; attempt < 2; ++attempt) {
         strings_in_flight = false;
+        sjmi::Stage1Extras ex1;
+        ex1.blkpar = parity_out(c, c->d_in, len);
         if (fail(c, "launch", sjmi::stage1_launch(c->d_in, len, c->d_idx, c->capacity + 2, c->d_ws, steps, c->stream, nullptr, nullptr,
-                                                  launch_flags(c))) ||
-            fail(c, "unescape launch", sjmi::unescape_launch(c->d_in, len, c->d_idx, bound, d_res1, c->d_sb, c->sb_bytes, c->d_ws_str,
-                                                             d_ures, c->stream)) ||
-            (early_strings && fail(c, "event", hipEventRecord(c->strings_ready, c->stream))) ||
+                                                  launch_flags(c), ex1)))
+            return SJMI_ERR_HIP;
+        const int src = strings_device_impl(c, c->d_in, len, c->d_sb, c->sb_bytes, c->d_soff, (size_t)len / 2 + 2, nullptr, d_ures, c->stream);
+        if (src != SJMI_OK) return src;
+        if ((early_strings && fail(c, "event", hipEventRecord(c->strings_ready, c->stream))) ||
             fail(c, "setup", sjmi::single_doc_setup_launch(d_res1, len, d_doc, d_io, d_st, d_dso, c->stream)) ||
             fail(c, "walk launch",
                  sjmi::walk_launch(c->d_in, d_doc, 1, c->d_idx, bound, d_io, d_st, c->d_sb, d_dso, 0, max_depth, c->d_tape,
-                                   2 * bound + 8, d_to, d_err, c->d_ws_walk, d_wres, c->stream, d_res1, d_ures, sizes, str_scratch)) ||
+                                   2 * bound + 8, d_to, d_err, c->d_ws_walk, d_wres, c->stream, d_res1, d_ures, c->d_soff)) ||
             fail(c, "results", single_doc_results_launch(d_res1, d_ures, d_wres, d_to, d_err,
                                                          (SingleDocResults*)((uint8_t*)c->d_single + 256), c->stream)) ||
             fail(c, "D2H", hipMemcpyAsync(h, (uint8_t*)c->d_single + 256, sizeof *h, hipMemcpyDeviceToHost, c->stream)))
@@ -1008,7 +1069,6 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
     }
     if (strings_in_flight && fail(c, "sync", hipStreamSynchronize(c->copy_stream))) return SJMI_ERR_HIP;
     c->last_valid = false;
-    c->unesc_idx = nullptr;
     *stage1_status = h->s1.status & 0xFFu;
     *tape_len = 0;
     *strings_len = 0;

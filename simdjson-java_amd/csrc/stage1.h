@@ -61,6 +61,7 @@ struct Stage1Extras {
     void* zero_next = nullptr;       // workspace the NEXT launch will use: zeroed by this one (16-byte aligned)
     size_t zero_bytes = 0;           //   ... this many bytes of it (multiple of 16)
     void* result_out = nullptr;      // device sjmi_stage1_result written by the scanner (FAST mode only)
+    const uint32_t* skip = nullptr;  // device flag: != 0 -> the launch does nothing (fused batch pipeline)
     void* blkpar = nullptr;          // side output for strings.hip: u64 per 4 KiB of input, bit l = block l is entered inside a
                                      // string (StructuralIndexer.java:233-234's prevInString, per block); len / 4096 + 4 words
 };
@@ -71,42 +72,53 @@ hipError_t stage1_launch(const uint8_t* d_buf, uint64_t len, uint32_t* d_out, ui
 // strings.hip: the string buffer of a document in one streaming pass (from the bytes and stage 1's block parities)
 size_t strings_workspace_bytes(uint64_t len);
 size_t strings_parity_words(uint64_t len);
+// the fused batch pipeline decides ON THE DEVICE whether the string pass runs over the batch itself (*d_sel != 0) or over its
+// sanitized copy (d_buf / d_blkpar here)
+struct StringsAlt {
+    const uint32_t* d_sel = nullptr;
+    const uint8_t* d_buf = nullptr;
+    const unsigned long long* d_blkpar = nullptr;
+};
 hipError_t strings_launch(const uint8_t* d_buf, uint64_t len, const unsigned long long* d_blkpar, uint8_t* d_sb, uint64_t sb_cap,
                           uint32_t* d_soff, uint64_t soff_cap, uint32_t* d_blk_ord, void* d_ws, UnescapeResult* d_res,
-                          hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                          hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
+                          const StringsAlt& alt = StringsAlt());
+// batches whose documents were indexed one by one: the copy the string pass runs on (failed documents blanked); d_skip != null
+// and *d_skip != 0: nothing to do (the optimistic plain pass was accepted)
+hipError_t strings_sanitize_launch(const uint8_t* d_buf, uint64_t total_len, const unsigned long long* d_doc_offsets,
+                                   const unsigned long long* d_index_offsets, uint64_t n_docs, uint8_t* d_copy, const uint32_t* d_skip,
+                                   hipStream_t stream);
+// per document: ordinal of its first string in the record table (and, optionally, that record's offset)
+hipError_t strings_doc_ordinals_launch(const uint8_t* d_buf, const unsigned long long* d_blkpar, const StringsAlt& alt, uint64_t len,
+                                       const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_blk_ord,
+                                       const uint32_t* d_soff, const UnescapeResult* d_res, unsigned long long* d_doc_ord,
+                                       unsigned long long* d_doc_str_offsets, hipStream_t stream);
 hipError_t strings_error_index_launch(const uint32_t* d_idx, uint64_t count, const Stage1Result* dev_count, const UnescapeResult* d_res,
                                       unsigned long long* d_out, hipStream_t stream);
-size_t unescape_workspace_bytes(uint64_t count, uint64_t len);
-// batches: per-document string-buffer offsets (n_docs + 1 device entries), from the device index offsets
-// The indexes belong to a batch of documents (n_docs + 1 byte offsets / index offsets on the device): the last string
-// of a document ends inside that document even when the documents behind it were dropped by the isolated mode; with
-// d_doc_str_offsets also the string-buffer offset of every document's first record (n_docs + 1 entries).
+// the string pass of a batch (sjmi_unescape_batch_device): document / index offsets on the device (n_docs + 1 entries each) and,
+// optionally, where the string-buffer offset of every document's first record goes
 struct UnescapeBatch {
     const unsigned long long* d_doc_offsets = nullptr;
     const unsigned long long* d_index_offsets = nullptr;
     uint64_t n_docs = 0;
     unsigned long long* d_doc_str_offsets = nullptr;
 };
-hipError_t unescape_launch(const uint8_t* d_buf, uint64_t len, const uint32_t* d_idx, uint64_t count_bound,
-                           const Stage1Result* dev_count, uint8_t* d_sb, uint64_t sb_cap, void* d_ws, UnescapeResult* d_res,
-                           hipStream_t stream, const UnescapeBatch& batch = UnescapeBatch());
 hipError_t split_docs_launch(const uint32_t* d_idx, const Stage1Result* d_res, const unsigned long long* d_doc_offsets,
                              uint64_t n_docs, unsigned long long* d_index_offsets, hipStream_t stream);
 size_t batch_isolated_workspace_bytes(uint64_t n_docs);
-// walk.hip: stage 2 of every document of a batch, one lane per document
+// walk.hip: stage 2 of every document of a batch (the cooperative walker + packing of the tapes); d_doc_str_ordinals[k] =
+// ordinal of document k's first string in the record table d_soff of the string pass (strings.hip)
 size_t walk_workspace_bytes(uint64_t count, uint64_t n_docs);
 hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_idx,
                        uint64_t count, const unsigned long long* d_index_offsets, const uint32_t* d_doc_status,
-                       const uint8_t* d_sb, const unsigned long long* d_doc_str_offsets, uint64_t string_base, int max_depth,
+                       const uint8_t* d_sb, const unsigned long long* d_doc_str_ordinals, uint64_t string_base, int max_depth,
                        unsigned long long* d_tape, uint64_t tape_capacity, unsigned long long* d_tape_offsets,
                        int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream,
-                       const Stage1Result* dev_count = nullptr, const UnescapeResult* dev_strings = nullptr,
-                       const uint32_t* d_sizes = nullptr, const uint8_t* d_str_scratch = nullptr);
-// coop_walk.hip: the cooperative walker (a wave per document); d_sizes / d_scratch = the per-structural records and the
-// scratch copy of the unescape pass that produced the string buffer (unescape_records below)
+                       const Stage1Result* dev_count, const UnescapeResult* dev_strings, const uint32_t* d_soff);
+// coop_walk.hip: the cooperative walker (a wave per document); d_soff = offset of every string's record in d_sb, by ordinal
 hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_idx,
-                            const unsigned long long* d_index_offsets, const uint32_t* d_doc_status, const uint32_t* d_sizes,
-                            const uint8_t* d_scratch, const unsigned long long* d_doc_str_offsets, uint64_t string_base,
+                            const unsigned long long* d_index_offsets, const uint32_t* d_doc_status, const uint32_t* d_soff,
+                            const uint8_t* d_sb, const unsigned long long* d_doc_str_ordinals, uint64_t string_base,
                             int max_depth, unsigned long long* d_scratch_tape, uint32_t* d_tape_lens, int32_t* d_doc_errors,
                             const Stage1Result* dev_count, const UnescapeResult* dev_strings, WalkResult* d_res,
                             hipStream_t stream, void* d_chunk_ws = nullptr, uint64_t count_bound = 0);
@@ -118,8 +130,6 @@ hipError_t coop_match_launch(const uint8_t* d_buf, uint64_t n_docs, const uint32
 hipError_t single_doc_setup_launch(const Stage1Result* d_res, uint64_t len, unsigned long long* d_doc_offsets,
                                    unsigned long long* d_index_offsets, uint32_t* d_doc_status, unsigned long long* d_doc_str_offsets,
                                    hipStream_t stream);
-// where unescape_launch(count_bound, ...) keeps its per-structural sizes and its scratch copy inside d_ws
-void unescape_records(void* d_ws, uint64_t count_bound, const uint32_t** sizes, const uint8_t** scratch);
 hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint32_t* d_out,
                                  uint64_t out_cap, unsigned long long* d_index_offsets, uint32_t* d_doc_status,
                                  uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream, uint64_t total_len, const uint32_t* d_skip = nullptr);

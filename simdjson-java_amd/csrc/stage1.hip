@@ -550,8 +550,9 @@ template <int S, int LDSW, bool SAFE>
 __global__ void __launch_bounds__(256)
 k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out, sj_u64 out_cap,
          sj_u64* gstate, uint32_t* ticket, Stage1Result* res, uint32_t ngran, uint32_t dbg, uint4* zero_ptr,
-         uint32_t zero_chunks, Stage1Result* result_out, sj_u64* __restrict__ blkpar) {
+         uint32_t zero_chunks, Stage1Result* result_out, sj_u64* __restrict__ blkpar, const uint32_t* __restrict__ skip) {
     constexpr int E = S, CAP = LDSW / 4;
+    if (skip && *skip) return;  // (fused batch pipeline: this pass is not needed; uniform for the whole launch)
     static_assert(S <= 4, "meta packs 14-bit offsets: at most 4 steps per granule");
     __shared__ WaveShared<S, LDSW> sh[4];
     __shared__ ScanHandoff hand;
@@ -981,10 +982,10 @@ static hipError_t launch_mode(const uint8_t* d_buf, uint64_t len, uint32_t* d_ou
         // the events are attached to the dispatch itself (its start / end timestamps), not recorded around it:
         // hipEventRecord pairs added 10-25 us of queue latency to a 200 us kernel
         hipExtLaunchKernelGGL((k_stage1<S, LDSW, SAFE>), grid, block, 0, stream, ev_start, ev_stop, 0, d_buf, (sj_u64)len,
-                              d_out, (sj_u64)out_cap, gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro, bp);
+                              d_out, (sj_u64)out_cap, gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro, bp, ex.skip);
     } else {
         hipLaunchKernelGGL((k_stage1<S, LDSW, SAFE>), grid, block, 0, stream, d_buf, (sj_u64)len, d_out, (sj_u64)out_cap,
-                           gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro, bp);
+                           gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro, bp, ex.skip);
     }
     return hipGetLastError();
 }

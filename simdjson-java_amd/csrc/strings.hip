@@ -106,6 +106,11 @@ struct StrArgs {
     UnescapeResult* res;
     uint32_t ngran;
     uint32_t flags;
+    // fused batch pipeline: *sel != 0 = the optimistic plain stage-1 pass was accepted (the batch itself + its parities);
+    // *sel == 0 = the sanitized copy and the parities of the pass over it (see strings_sanitize_launch)
+    const uint32_t* sel;
+    const uint8_t* buf_alt;
+    const sj_u64* blkpar_alt;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -300,7 +305,12 @@ struct StrWaveLds {
 
 template <bool SOFF>
 __global__ void __launch_bounds__(256)
-k_strings(const StrArgs a) {
+k_strings(const StrArgs a0) {
+    StrArgs a = a0;
+    if (a.sel && *a.sel == 0) {  // (uniform for the whole launch)
+        a.buf = a.buf_alt;
+        a.blkpar = a.blkpar_alt;
+    }
     __shared__ StrWaveLds<SOFF> sh[4];
     __shared__ uint32_t s_lut[16];
     __shared__ StrHand hand;
@@ -808,7 +818,7 @@ static hipError_t str_resident(unsigned* out) {
 // string literal of buf[0, len) go to d_sb; optional: d_soff (offset of record k), d_blk_ord (see StrArgs)
 hipError_t strings_launch(const uint8_t* d_buf, uint64_t len, const unsigned long long* d_blkpar, uint8_t* d_sb, uint64_t sb_cap,
                           uint32_t* d_soff, uint64_t soff_cap, uint32_t* d_blk_ord, void* d_ws, UnescapeResult* d_res,
-                          hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                          hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, const StringsAlt& alt) {
     const uint64_t ngran = str_granules(len);
     hipError_t e = hipMemsetAsync(d_ws, 0, strings_workspace_bytes(len), stream);
     if (e != hipSuccess) return e;
@@ -828,6 +838,9 @@ hipError_t strings_launch(const uint8_t* d_buf, uint64_t len, const unsigned lon
     a.res = d_res;
     a.ngran = (uint32_t)ngran;
     a.flags = 0;
+    a.sel = alt.d_sel;
+    a.buf_alt = alt.d_buf;
+    a.blkpar_alt = reinterpret_cast<const sj_u64*>(alt.d_blkpar);
     const bool soff = d_soff != nullptr || d_blk_ord != nullptr;
     unsigned resident = 0;
     e = soff ? str_resident<true>(&resident) : str_resident<false>(&resident);
@@ -841,6 +854,93 @@ hipError_t strings_launch(const uint8_t* d_buf, uint64_t len, const unsigned lon
         if (soff) hipLaunchKernelGGL((k_strings<true>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((k_strings<false>), grid, block, 0, stream, a);
     }
+    return hipGetLastError();
+}
+
+// ---- batches ------------------------------------------------------------------------------------------------------------
+// The string pass is one stream over the packed batch, so every document has to begin outside a string and behind an even
+// backslash run.  That holds when all documents pass stage 1 and end in white space; a batch whose documents were indexed
+// one by one (isolated mode: a broken document must not touch its neighbours) is therefore run on a SANITIZED COPY: the
+// documents without structurals (the failed ones) blanked, a trailing odd backslash run shortened by one.  What survives is
+// byte-identical to the batch where it matters (inside the strings of the surviving documents), at the same positions.
+__global__ void __launch_bounds__(256)
+k_batch_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t chunks, const uint32_t* __restrict__ skip) {
+    if (skip && *skip) return;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// one wave per document
+__global__ void __launch_bounds__(256)
+k_batch_blank(uint8_t* __restrict__ copy, const unsigned long long* __restrict__ doc_offsets, const unsigned long long* __restrict__ index_offsets,
+              uint64_t n_docs, const uint32_t* __restrict__ skip) {
+    if (skip && *skip) return;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t k = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < n_docs; k += (uint64_t)gridDim.x * 4) {
+        const unsigned long long lo = doc_offsets[k], hi = doc_offsets[k + 1];
+        if (index_offsets[k + 1] == index_offsets[k]) {
+            for (unsigned long long p = lo + lane; p < hi; p += 64) copy[p] = 0x20;
+        } else if (lane == 0 && hi > lo) {
+            unsigned long long p = hi, run = 0;
+            while (p > lo && copy[p - 1] == 0x5C) { --p; ++run; }
+            if (run & 1) copy[hi - 1] = 0x20;
+        }
+    }
+}
+hipError_t strings_sanitize_launch(const uint8_t* d_buf, uint64_t total_len, const unsigned long long* d_doc_offsets,
+                                   const unsigned long long* d_index_offsets, uint64_t n_docs, uint8_t* d_copy, const uint32_t* d_skip,
+                                   hipStream_t stream) {
+    const uint64_t chunks = (total_len + SJMI_PADDING + 15) / 16;
+    const unsigned g1 = (unsigned)((chunks + 255) / 256 < 4096 ? (chunks + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_batch_copy, dim3(g1 ? g1 : 1), dim3(256), 0, stream, reinterpret_cast<const uint4*>(d_buf), reinterpret_cast<uint4*>(d_copy),
+                       chunks, d_skip);
+    const unsigned g2 = (unsigned)((n_docs + 3) / 4 < 8192 ? (n_docs + 3) / 4 : 8192);
+    hipLaunchKernelGGL(k_batch_blank, dim3(g2 ? g2 : 1), dim3(256), 0, stream, d_copy, d_doc_offsets, d_index_offsets, n_docs, d_skip);
+    return hipGetLastError();
+}
+
+// doc_ord[k] (n_docs + 1 entries) = ordinal of the first string opened at or behind document k's first byte: the ordinal of its
+// block (blk_ord, left by the string pass) + the strings opened in that block in front of it (a byte loop over < 64 bytes from
+// the block's entry state); doc_str_offsets[k] (optional) = offset of that string's record, or the total behind the last one.
+__global__ void __launch_bounds__(256)
+k_doc_str_ordinals(const uint8_t* __restrict__ buf0, const uint8_t* __restrict__ buf1, const sj_u64* __restrict__ par0,
+                   const sj_u64* __restrict__ par1, const uint32_t* __restrict__ sel, uint64_t len,
+                   const unsigned long long* __restrict__ doc_offsets, uint64_t n_docs, const uint32_t* __restrict__ blk_ord,
+                   const uint32_t* __restrict__ soff, const UnescapeResult* __restrict__ res, unsigned long long* __restrict__ doc_ord,
+                   unsigned long long* __restrict__ doc_str_offsets) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > n_docs) return;
+    const bool alt = sel && *sel == 0;
+    const uint8_t* buf = alt ? buf1 : buf0;
+    const sj_u64* par = alt ? par1 : par0;
+    const unsigned long long nstr = res->reserved;
+    unsigned long long ord = nstr;
+    unsigned long long pos = doc_offsets[k];
+    if (!(res->flags & 0xEu)) {
+        if (pos > len) pos = len;
+        const unsigned long long b = pos >> 6, start = b * 64;
+        ord = blk_ord[b];
+        uint32_t in_str = (uint32_t)(par[b >> 6] >> (b & 63)) & 1u;
+        uint32_t escaped = b ? sj_backslash_run_parity(buf, 0, start) : 0u;
+        for (unsigned long long p = start; p < pos; ++p) {
+            const uint32_t c = buf[p];
+            if (escaped) escaped = 0;
+            else if (c == 0x5C) escaped = 1;
+            else if (c == 0x22) {
+                ord += in_str ^ 1u;
+                in_str ^= 1u;
+            }
+        }
+        if (ord > nstr) ord = nstr;
+    }
+    doc_ord[k] = ord;
+    if (doc_str_offsets) doc_str_offsets[k] = ord < nstr ? soff[ord] : res->total_bytes;
+}
+hipError_t strings_doc_ordinals_launch(const uint8_t* d_buf, const unsigned long long* d_blkpar, const StringsAlt& alt, uint64_t len,
+                                       const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_blk_ord,
+                                       const uint32_t* d_soff, const UnescapeResult* d_res, unsigned long long* d_doc_ord,
+                                       unsigned long long* d_doc_str_offsets, hipStream_t stream) {
+    hipLaunchKernelGGL(k_doc_str_ordinals, dim3((unsigned)((n_docs + 1 + 255) / 256)), dim3(256), 0, stream, d_buf, alt.d_buf,
+                       reinterpret_cast<const sj_u64*>(d_blkpar), reinterpret_cast<const sj_u64*>(alt.d_blkpar), alt.d_sel, len, d_doc_offsets,
+                       n_docs, d_blk_ord, d_soff, d_res, d_doc_ord, d_doc_str_offsets);
     return hipGetLastError();
 }
 

@@ -1,30 +1,16 @@
 // SPDX-License-Identifier: Apache-2.0
-// Stage 2 on the GPU for batches of small documents: JsonIterator.walkDocument
-// (JsonIterator.java:26-200) driving TapeBuilder (TapeBuilder.java:41-217) -- the same state machine the host mirror
-// runs (csrc/host/simdjson_parser.cpp, DocWalker::walkDocument), one LANE per document.
-//
-// Why a lane per document: the walk of one document is a sequential automaton over its structurals (container stack,
-// element counts, "what may follow what"), but the documents of a batch are independent, and a batch of ~1 KB documents
-// has a million of them.  Every lane reads its document's structurals in order, checks the grammar exactly as the
-// reference does (so the FIRST error of a document is the reference's error), parses atoms and numbers
-// (NumberParser.java:23-74, ExponentParser.java:14-69) and writes tape words (Tape.java:28-47) into its own slot of
-// a scratch tape; k_tape_chunk_sums / k_tape_chunk_scan / k_tape_compact then pack the tapes back to back.  The container stack lives in
-// the lane's private (scratch) memory: WALK_MAX_DEPTH levels.
-//
-// What stays on the host: a document nested deeper than WALK_MAX_DEPTH, and a document with a floating-point literal
-// outside Clinger's exact range (more than 19 significant digits, a significand above 2^53 or |decimal exponent| > 22)
-// -- there one IEEE multiplication or division of two exactly representable operands IS the correctly rounded result
-// the reference's DoubleParser (DoubleParser.java:79-330) computes; outside it a correctly rounded conversion needs
-// wide arithmetic.  Such documents get doc_errors[k] = SJMI_WALK_NEEDS_HOST and no tape; the host walker takes them.
+// Stage 2 on the GPU, host side of the launch: JsonIterator.walkDocument (JsonIterator.java:26-200)
+// driving TapeBuilder (TapeBuilder.java:41-217) is the cooperative walker of coop_walk.hip (a wave per document, chunk-parallel
+// for one large document); this file queues it and packs the documents' tapes back to back (k_tape_chunk_sums /
+// k_tape_chunk_scan / k_tape_compact).  A document the device hands back gets doc_errors[k] = SJMI_WALK_NEEDS_HOST and no tape.
+// (Rounds 1-2 also had a lane-per-document walker here, k_doc_walk + walk_doc.h: superseded by the cooperative walker
+// and removed in round 3.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "stage1.h"
-#include "walk_doc.h"
 
 namespace sjmi {
-
-constexpr int WALK_THREADS = 64;
 
 namespace {
 
@@ -32,57 +18,6 @@ namespace {
 __device__ __forceinline__ unsigned long long scratch_slot(unsigned long long from, uint64_t k) { return 2 * from + 2 * k; }
 
 }  // namespace
-
-// (latency-bound: 64 % of the wave cycles wait for memory, profiles/r1/batch_pmc.txt -- a sixth wave per SIMD, 80
-// instead of 82 VGPRs, is worth 8 %; a seventh needs SGPR spills and adds nothing)
-__global__ void __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
-k_doc_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restrict__ doc_offsets, uint64_t n_docs,
-           const uint32_t* __restrict__ idx, uint32_t ix_entries, const unsigned long long* __restrict__ index_offsets,
-           const uint32_t* __restrict__ doc_status, const uint8_t* __restrict__ sb,
-           const unsigned long long* __restrict__ doc_str_offsets, unsigned long long string_base, int max_depth,
-           unsigned long long* __restrict__ scratch_tape, uint32_t* __restrict__ tape_lens, int32_t* __restrict__ doc_errors,
-           const Stage1Result* __restrict__ dev_count, const UnescapeResult* __restrict__ dev_strings) {
-    const uint64_t k = (uint64_t)blockIdx.x * WALK_THREADS + threadIdx.x;
-    if (k >= n_docs) return;
-    const uint32_t st = doc_status[k];
-    int code = 0;
-    uint32_t len = 0;
-    // fused pipeline (sjmi_parse_batch_device): a stage 1 that ran out of index capacity left the index array
-    // incomplete, a string buffer that was too small holds only part of the records -- nothing of them may be
-    // dereferenced; every document reports SJMI_E_CAPACITY
-    if ((dev_count && (dev_count->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL))) || (dev_strings && (dev_strings->flags & 1u))) {
-        tape_lens[k] = 0;
-        doc_errors[k] = SJMI_E_CAPACITY;
-        return;
-    }
-    // SimdJsonParser.stage1 order: Utf8Validator.validate (:165-167), then StructuralIndexer.index (:297-302)
-    if (st & SJMI_ST_UTF8) code = SJMI_E_UTF8;
-    else if (st & SJMI_ST_UNCLOSED) code = SJMI_E_UNCLOSED_STRING;
-    else if (st & SJMI_ST_UNESCAPED) code = SJMI_E_UNESCAPED_CHARS;
-    else {
-        Lane w;
-        w.buf = buf;
-        w.ix = idx;
-        w.ix_entries = ix_entries;
-        w.iw_base = 0xFFFFFFFFu;  // (never a multiple of four)
-        w.bw_base = 0xFFFFFFF0u;  // p - base >= 16 for every p the lane can ask for
-        w.from = (uint32_t)index_offsets[k];
-        w.to = (uint32_t)index_offsets[k + 1];
-        w.rd = w.from;
-        w.doc_start = (uint32_t)doc_offsets[k];
-        w.doc_end = (uint32_t)doc_offsets[k + 1];
-        w.tape = scratch_tape + scratch_slot(index_offsets[k], k);
-        w.tl = 0;
-        w.sb = sb;
-        w.sc = doc_str_offsets[k];
-        w.sbase = string_base;
-        w.code = 0;
-        if (walk_document(w, max_depth)) len = w.tl;
-        else code = w.code;
-    }
-    tape_lens[k] = len;
-    doc_errors[k] = code;
-}
 
 // ---- packing the tapes ---------------------------------------------------------------------------
 constexpr int PACK_DOCS = 1024;  // documents per workgroup
@@ -185,31 +120,27 @@ size_t walk_workspace_bytes(uint64_t count, uint64_t n_docs) {
 
 hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_idx,
                        uint64_t count, const unsigned long long* d_index_offsets, const uint32_t* d_doc_status,
-                       const uint8_t* d_sb, const unsigned long long* d_doc_str_offsets, uint64_t string_base, int max_depth,
+                       const uint8_t* d_sb, const unsigned long long* d_doc_str_ordinals, uint64_t string_base, int max_depth,
                        unsigned long long* d_tape, uint64_t tape_capacity, unsigned long long* d_tape_offsets,
                        int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream, const Stage1Result* dev_count,
-                       const UnescapeResult* dev_strings, const uint32_t* d_sizes, const uint8_t* d_str_scratch) {
+                       const UnescapeResult* dev_strings, const uint32_t* d_soff) {
+    if (!d_soff) return hipErrorInvalidValue;  // (the record table of the string pass: strings.hip)
     uint8_t* ws = static_cast<uint8_t*>(d_ws);
     unsigned long long* scratch = reinterpret_cast<unsigned long long*>(ws);
     // one document (its index starts at 0) and room for two words per structural: the walker writes the tape in place
-    const bool direct = d_sizes && n_docs == 1 && tape_capacity >= 2 * count + 2;
+    const bool direct = n_docs == 1 && tape_capacity >= 2 * count + 2;
     if (direct) scratch = d_tape;
     uint32_t* lens = reinterpret_cast<uint32_t*>(ws + walk_lens_offset(count, n_docs));
     unsigned long long* sums = reinterpret_cast<unsigned long long*>(ws + walk_sums_offset(count, n_docs));
     hipError_t e = hipMemsetAsync(d_res, 0, sizeof(WalkResult), stream);
     if (e != hipSuccess) return e;
     const uint64_t nchunks = (n_docs + PACK_DOCS - 1) / PACK_DOCS;
-    if (n_docs && d_sizes) {
-        // the cooperative walker (coop_walk.hip): a wave per document over the per-structural records of the unescape pass
-        e = coop_walk_launch(d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets, d_doc_status, d_sizes, d_str_scratch,
-                             d_doc_str_offsets, string_base, max_depth, scratch, lens, d_doc_errors, dev_count, dev_strings, d_res,
+    if (n_docs) {
+        // the cooperative walker (coop_walk.hip): a wave per document; STRING payloads from the string pass's record table
+        e = coop_walk_launch(d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets, d_doc_status, d_soff, d_sb,
+                             d_doc_str_ordinals, string_base, max_depth, scratch, lens, d_doc_errors, dev_count, dev_strings, d_res,
                              stream, n_docs == 1 ? ws + walk_chunks_offset(count, n_docs) : nullptr, count);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_tape_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, lens, d_doc_errors, n_docs, sums, d_res);
-    } else if (n_docs) {
-        hipLaunchKernelGGL(k_doc_walk, dim3((unsigned)((n_docs + WALK_THREADS - 1) / WALK_THREADS)), dim3(WALK_THREADS), 0, stream,
-                           d_buf, d_doc_offsets, n_docs, d_idx, (uint32_t)(count + 1), d_index_offsets, d_doc_status, d_sb, d_doc_str_offsets,
-                           (unsigned long long)string_base, max_depth, scratch, lens, d_doc_errors, dev_count, dev_strings);
         hipLaunchKernelGGL(k_tape_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, lens, d_doc_errors, n_docs, sums, d_res);
     }
     hipLaunchKernelGGL(k_tape_chunk_scan, dim3(1), dim3(1024), 0, stream, sums, nchunks, n_docs, tape_capacity, d_tape_offsets, d_res);
