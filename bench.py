@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable)
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r2")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r3")
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -123,6 +123,8 @@ def roofline(alg_bytes, ms, input_bytes, kernel, launches, traffic=None, **more)
          "avg_kernel_ms": round(ms, 4), "launches": launches, "algorithmic_bytes_per_launch": int(alg_bytes),
          "achieved_all_algorithmic_bytes": round(alg_bytes / s / 1e9, 2),
          "frac_all_algorithmic_bytes": round(alg_bytes / s / 1e9 / HBM_PEAK_GBS, 4)}
+    if traffic is not None:
+        r["traffic_source"] = pmc_source()
     r.update(more)
     return r
 
@@ -134,6 +136,87 @@ def pmc_traffic(key):
             return int(json.load(f)[key]["hbm_traffic_bytes_per_launch"]["total"])
     except (OSError, KeyError, ValueError, TypeError):
         return None
+
+
+def pmc_source():
+    """where `traffic` comes from: NOT measured by this run -- the tracked rocprofv3 --pmc summary and the commit it was taken at"""
+    try:
+        with open(os.path.join(PROFILE_DIR, "pmc_summary.json")) as f:
+            meta = json.load(f).get("_collected", {})
+        return "profiles/r3/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_r3.sh, calibrated: " \
+               "pmc_calibration.json; collected at commit %s)" % meta.get("commit", "unknown")
+    except (OSError, ValueError):
+        return None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU legs of the extras: the reference's path restated in C (oracle/: AVX-512 stage 1 + the scalar stage 2 / StringParser),
+# timed on this box's host cores on a bounded sample, one core and all cores
+# ---------------------------------------------------------------------------------------------------------------
+def _all_cores(make_work, seconds, cores):
+    """`cores` threads, each looping its own work() (a C call that releases the GIL) until the deadline -> calls per second"""
+    import threading
+    works = [make_work() for _ in range(cores)]
+    done = [0] * cores
+    stop = time.perf_counter() + seconds
+
+    def run(k):
+        while time.perf_counter() < stop:
+            works[k]()
+            done[k] += 1
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=run, args=(k,)) for k in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return sum(done) / (time.perf_counter() - t0)
+
+
+def _one_core(work, seconds):
+    work()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        work()
+        n += 1
+    return n / (time.perf_counter() - t0)
+
+
+def cpu_legs(doc, pool_unit, pool_offs):
+    """-> {section: cpu_baseline object}.  parse = SimdJsonParser.parse of twitter.json (ParseBenchmark.java:40-48's shape);
+    strings = every StringParser.parseString of twitter.json; batch = parse of ~1 KB documents."""
+    import numpy as np
+    from oracle import oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avx = oracle.avx512_supported()
+    kind = "AVX-512 stage 1 (oracle/sj_avx512.c) + scalar stage 2 (oracle/sj_oracle.c)" if avx else "scalar port (oracle/sj_oracle.c)"
+    one = np.array([0, len(doc)], dtype=np.uint64)
+    darr = np.frombuffer(doc + b"\0" * 64, dtype=np.uint8)
+    parse1 = _one_core(lambda: oracle.parse_many(darr, one, 1, avx), 1.5)
+    parse_all = _all_cores(lambda: (lambda a=darr.copy(): oracle.parse_many(a, one, 1, avx)), 3.0, cores)
+    idx0, _ = oracle.stage1(doc)
+    sb = np.zeros(len(doc) + 4 * idx0.size + 128, dtype=np.uint8)
+    str1 = _one_core(lambda: oracle.unescape_loop(darr, idx0, 4, sb), 1.0) * 4
+    def mk_str():
+        a, s2 = darr.copy(), sb.copy()
+        return lambda: oracle.unescape_loop(a, idx0, 4, s2)
+    str_all = _all_cores(mk_str, 2.0, cores) * 4
+    parr = np.frombuffer(bytes(pool_unit) + b"\0" * 64, dtype=np.uint8)
+    nd = pool_offs.size - 1
+    batch1 = _one_core(lambda: oracle.parse_many(parr, pool_offs, 1, avx), 1.5) * nd
+    batch_all = _all_cores(lambda: (lambda a=parr.copy(): oracle.parse_many(a, pool_offs, 1, avx)), 3.0, cores) * nd
+    note = "kind 'port': %s; the reference itself needs a JVM: %s" % (kind, probe_java())
+    parse = {"value": round(parse_all, 1), "unit": "parses/s", "cores": cores, "kind": "port", "one_core": round(parse1, 1),
+             "one_core_ms_per_parse": round(1e3 / parse1, 4),
+             "sample": "SimdJsonParser.parse(twitter.json) = stage 1 + stage 2 (JsonIterator + TapeBuilder + StringParser), %d threads x 3 s; %s" % (cores, note)}
+    strings = {"value": round(str_all * len(doc) / 1e9, 3), "unit": "GB/s of document", "cores": cores, "kind": "port",
+               "one_core": round(str1 * len(doc) / 1e9, 3),
+               "sample": "StringParser.parseString for the 18,099 strings of twitter.json over given indexes, %d threads x 2 s; %s" % (cores, note)}
+    batch = {"value": round(batch_all, 1), "unit": "docs/s", "cores": cores, "kind": "port", "one_core": round(batch1, 1),
+             "sample": "stage 1 + stage 2 of %d unique ~1 KB documents (the configs[3] pool), one after the other per thread, %d threads x 3 s; %s" % (nd, cores, note)}
+    return {"parse": parse, "strings": strings, "batch": batch}
+
 
 
 class Stage1Runner:
@@ -336,7 +419,8 @@ def bench_single(args):
             "value": round(n1 / ums / 1e6, 2), "unit": "GB/s of document",
             "roofline": {"bound": "hbm", "achieved": round(ualg / ums / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ualg / ums / 1e6 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("unescape_twitter_x1024"),
-                         "kernel": "k_str_measure + k_scan_sums + k_str_write", "avg_ms_per_call": round(ums, 4),
+                         "traffic_source": pmc_source(),
+                         "kernel": "k_strings (one streaming pass; + the memsets of its chain state and result record)", "avg_ms_per_call": round(ums, 4),
                          "algorithmic_bytes_per_launch": ualg,
                          "algorithmic_bytes": "string bytes incl. quotes read (%d) + 4 B index word per string + records written (%d), per copy"
                                               % (raw0, len(want_sb))}}
@@ -344,9 +428,10 @@ def bench_single(args):
     if "synth" in sections:
         # ---- configs[2]: 4 GiB synthetic ----
         tile = W.synth_tile()
-        tidx, tst = oracle.stage1(tile)
+        tidx, tst, tmasks = oracle.index_blocks(tile, want_masks=True)
         assert tst == 0
-        treps = (1 << 32) // len(tile) - 1
+        tfrac = W.measured_fractions(tile, tmasks)
+        treps = ((1 << 32) - 1) // len(tile)
         tbuf, tn = W.repeat_on_device(tile, treps, dev)
         rs = Stage1Runner(torch, S, dev, work, tbuf, tn, tidx.size * treps)
         rs.launch()
@@ -356,8 +441,10 @@ def bench_single(args):
         assert ok
         c2, s2 = rs.cold_and_settled(args.steps)
         extra["stage1_synthetic_4g"] = {
-            "config": "configs[2]: 4 GiB synthetic JSON (tools/synth.py 4 MiB tile x%d = %d B; ~50 %% string bytes, 10 %% escapes, "
-                      "10 %% non-ASCII), stage 1 + UTF-8 validation, closed-form index check" % (treps, tn),
+            "config": "configs[2]: 4 GiB synthetic JSON per SURVEY.md 8(d) (tools/synth.synth_tile_spec seed 20250824: one %d B tile x%d = "
+                      "%d B), stage 1 + UTF-8 validation, closed-form index check; measured on the tile: %s, %.2f B per structural"
+                      % (len(tile), treps, tn, json.dumps(tfrac), len(tile) / tidx.size),
+            "measured_fractions": tfrac,
             "value": round(tn / s2 / 1e6, 2), "unit": "GB/s",
             "roofline": roofline(tn + 4 * (tidx.size * treps + 1), s2, tn, "k_stage1", args.steps, traffic=pmc_traffic("stage1_synthetic_4g"),
                                  cold={"avg_kernel_ms": round(c2, 4), "frac": round(tn / c2 / 1e6 / HBM_PEAK_GBS, 4)})}
@@ -388,6 +475,30 @@ def bench_single(args):
                                     "3164 ops/s, ParseAndSelectBenchmark 1842 ops/s (other hardware; no JVM here)"}
         except (OSError, subprocess.CalledProcessError) as e:
             extra["parse_and_select_twitter_json"] = {"error": "not measured: %s" % e}
+    if "trees" in sections:
+        # ---- configs[4]: twitter x1024 as 1024 documents from a HOST buffer -> 1024 trees (GPU stage 1 + GPU string records +
+        #      the host stage 2 on a thread pool), timed from C++; every tree then selected on through sjmi_value_* ----
+        try:
+            extra["twitter_x1024_as_1024_trees"] = trees_1024(S, doc)
+        except (OSError, subprocess.CalledProcessError) as e:
+            extra["twitter_x1024_as_1024_trees"] = {"error": "not measured: %s" % e}
+    if not args.no_cpu_baseline:
+        # ---- the CPU beside every section (bounded samples, about 25 s in all) ----
+        pdocs, punit, plens = W.small_doc_pool(args.pool)
+        legs = cpu_legs(doc, punit, W.batch_offsets(plens, 1))
+        for key, leg in (("unescape_twitter_x1024", "strings"), ("batch_1m_docs", "batch"), ("parse_single_document", "parse"),
+                         ("parse_and_select_twitter_json", "parse"), ("twitter_x1024_as_1024_trees", "parse")):
+            if key in extra:
+                extra[key]["cpu_baseline"] = legs[leg]
+        # configs[0]: the reference's own CPU-runnable case (plumbing, no GPU): twitter.json through the CPU restatement,
+        # checked against the survey's counts (S = 55,263 structurals, 86 users with default_profile)
+        want = oracle.parse(doc)
+        _, unique_users = _twitter_default_profile_users(want.to_python())
+        assert want.error == 0 and idx0.size == 55263 and unique_users == 86  # BenchmarkCorrectnessTest.java:19-42
+        extra["configs0_cpu_parse_twitter_json"] = {
+            "config": "configs[0]: twitter.json (631,515 B) single-document parse on the CPU path (no GPU): 55,263 structurals, 86 unique "
+                      "users with default_profile", "value": legs["parse"]["one_core_ms_per_parse"], "unit": "ms per parse (one core)",
+            "cpu_baseline": legs["parse"]}
     line["extra"] = extra
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(doc)
@@ -430,6 +541,54 @@ def parse_single_document(S, doc, reps=300):
     return out
 
 
+def _twitter_default_profile_users(tree):
+    """the oracle's tree (tagged tuples: ("o", size, [(key, value)...]), ("a", size, [...]), ("s", bytes), ("t",) ...) ->
+    (statuses whose user has default_profile, their unique screen names): BenchmarkCorrectnessTest.java:23-42"""
+    def field(obj, name):
+        assert obj[0] == "o"
+        for k, v in obj[2]:
+            if k == name or k == name.encode():
+                return v
+        raise KeyError(name)
+    names = []
+    for st in field(tree, "statuses")[2]:
+        user = field(st, "user")
+        if field(user, "default_profile")[0] == "t":
+            names.append(field(user, "screen_name")[1])
+    return len(names), len(set(names))
+
+
+def trees_1024(S, doc, reps=1024, iters=3):
+    """BASELINE.json configs[4]"""
+    import ctypes as C
+    import numpy as np
+    import ondemand_bench
+    from oracle import oracle as O
+    L = ondemand_bench.load_bench_lib()
+    d1 = doc.rstrip() + b"\n"
+    host = np.frombuffer(d1 * reps, dtype=np.uint8)
+    offs = np.arange(reps + 1, dtype=np.uint64) * np.uint64(len(d1))
+    want_users, _ = _twitter_default_profile_users(O.parse(doc).to_python())
+    p = S.SimdJsonParser(capacity=host.size + 64)
+    secs, ok, umin, umax = C.c_double(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    best = 1e9
+    for rep in range(3):  # (first round: allocations, page-locking, clocks)
+        rc = L.odb_parse_batch(p._h, host.ctypes.data, host.size, offs.ctypes.data, reps, 1 if rep == 0 else iters, C.byref(secs),
+                               C.byref(ok), C.byref(umin), C.byref(umax))
+        if rc:
+            raise SystemExit("sjmi_parser_parse_batch failed in the trees section: %d" % rc)
+        if rep:
+            best = min(best, secs.value / iters * 1e3)
+    assert ok.value == reps and umin.value == umax.value == want_users, (ok.value, umin.value, umax.value, want_users)
+    p.close()
+    return {"config": "configs[4]: twitter.json x%d as %d documents (%d B) from a host buffer -> %d trees: H2D, GPU stage 1 (per-document "
+                      "verdicts) + GPU string records, D2H, host stage 2 (JsonIterator / TapeBuilder mirror) on a thread pool, pipelined "
+                      "over sub-batches (sjmi_parser_parse_batch, timed from C++); every tree walked through sjmi_value_*: %d statuses "
+                      "with default_profile each (the oracle's count); word-for-word tree equality: tests/test_gpu_fullscale.py"
+                      % (reps, reps, host.size, reps, want_users),
+            "value": round(best, 3), "unit": "ms per batch", "docs_per_s": round(reps / best * 1e3, 1), "GB_per_s": round(host.size / best / 1e6, 3)}
+
+
 def batch_single_gpu(torch, S, W, dev, work, args, with_h2d=True):
     docs, unit, lens = W.small_doc_pool(args.pool)
     reps = max(1, args.docs // len(docs))
@@ -445,12 +604,15 @@ def batch_single_gpu(torch, S, W, dev, work, args, with_h2d=True):
     el = wall_steps(torch, lambda: shard.step(st), args.batch_steps)
     ms = el / args.batch_steps * 1e3
     alg = batch_algorithmic_bytes(shard.n, c)
-    out = {"config": "configs[3] on one GPU: %d documents (%d unique ~1 KB documents x%d, %d B), device-resident: isolated stage 1 "
-                     "(per-document verdicts) -> string records -> GPU walk (tapes), sjmi_parse_batch_device" % (n_docs, len(docs), reps, shard.n),
+    out = {"config": "configs[3] on one GPU: %d documents (%d unique ~1 KB documents x%d, %d B), device-resident: stage 1 (per-document "
+                     "verdicts) -> string records -> GPU walk (tapes), sjmi_parse_batch_device" % (n_docs, len(docs), reps, shard.n),
            "value": round(n_docs / (ms / 1e3), 1), "unit": "docs/s", "ms_per_batch": round(ms, 3), "counts": c,
            "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("batch_1m_docs"),
-                        "kernel": "k_doc_pass x2 + k_str_measure + k_str_write + k_doc_walk + k_tape_compact (+ small scans)",
+                        "traffic_source": pmc_source(),
+                        "kernel": "k_batch_sep_check + k_stage1 (one plain pass, accepted on the device) + k_split_docs_accept + k_strings + "
+                                  "k_doc_str_ordinals + k_coop_walk + k_tape_chunk_sums / _scan + k_tape_compact (the per-document passes "
+                                  "and the sanitized-copy string pass are queued behind the plain pass and leave at once)",
                         "algorithmic_bytes_per_launch": alg,
                         "algorithmic_bytes": "input read once + uint32 indexes + string records + tape words written once"}}
     if with_h2d:
@@ -569,7 +731,7 @@ def main():
     ap.add_argument("--pool", type=int, default=4000, help="unique documents of the configs[3] batch")
     ap.add_argument("--batch-steps", type=int, default=10, help="N=1: timed steps of the configs[3] extra")
     ap.add_argument("--no-extras", action="store_true", help="N=1: only the primary workload")
-    ap.add_argument("--sections", default="x1024,unescape,synth,batch,parse,select",
+    ap.add_argument("--sections", default="x1024,unescape,synth,batch,parse,select,trees",
                     help="N=1: which extras to run (comma list of x1024, unescape, synth, batch, parse, select); the profiling passes run one each")
     ap.add_argument("--skip-main-timing", action="store_true",
                     help="N=1, profiling passes of an extra only: check the primary workload once, do not time it")

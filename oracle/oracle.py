@@ -157,12 +157,7 @@ def avx512_supported():
 def stage1_avx512(data, length=None, out=None):
     """The AVX-512 restatement of the reference's two stage-1 passes (oracle/sj_avx512.c; the CPU timing baseline):
     -> (indexes, status).  Only on hosts where avx512_supported()."""
-    global _avx
-    if _avx is None:
-        assert avx512_supported(), "this host CPU has no AVX-512 F+BW"
-        _avx = C.CDLL(_AVX_PATH)
-        _avx.sjo_stage1_avx512.restype = C.c_int
-        _avx.sjo_stage1_avx512.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    _avx_lib()
     a = _as_u8(data)
     n = a.size if length is None else length
     cap = n + 66
@@ -173,6 +168,42 @@ def stage1_avx512(data, length=None, out=None):
     r = _avx.sjo_stage1_avx512(_ptr(a), n, idx.ctypes.data, cap, C.addressof(cnt), C.addressof(st))
     assert r == 0
     return idx[:cnt.value], st.value
+
+
+def _avx_lib():
+    global _avx
+    if _avx is None:
+        assert avx512_supported(), "this host CPU has no AVX-512 F+BW"
+        _avx = C.CDLL(_AVX_PATH)
+        _avx.sjo_stage1_avx512.restype = C.c_int
+        _avx.sjo_stage1_avx512.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    return _avx
+
+
+def parse_many(packed, offsets, loops=1, avx=False, max_depth=1024):
+    """Timing loop of bench.py's CPU legs: every document packed[offsets[k]:offsets[k+1]] through stage 1 (scalar port, or
+    the AVX-512 restatement) + stage 2, `loops` times, in C.  -> (documents without error, tape words, string bytes)."""
+    a = np.frombuffer(bytes(packed) + b"\0" * 64, dtype=np.uint8) if not isinstance(packed, np.ndarray) else packed
+    offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+    L = lib()
+    L.sjo_parse_many.restype = C.c_uint64
+    L.sjo_parse_many.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn = C.cast(_avx_lib().sjo_stage1_avx512, C.c_void_p) if avx else None
+    tw, sbytes = C.c_uint64(0), C.c_uint64(0)
+    ok = L.sjo_parse_many(_ptr(a), offs.ctypes.data, offs.size - 1, max_depth, loops, fn, C.byref(tw), C.byref(sbytes))
+    return int(ok), tw.value, sbytes.value
+
+
+def unescape_loop(padded, indexes, loops=1, sb=None):
+    """Timing loop: StringParser.parseString for every string of one indexed document, `loops` times, in C -> record bytes."""
+    a = _as_u8(padded)
+    ix = np.ascontiguousarray(indexes, dtype=np.uint32)
+    if sb is None:
+        sb = np.zeros(a.size + 4 * ix.size + 128, dtype=np.uint8)
+    L = lib()
+    L.sjo_unescape_loop.restype = C.c_uint64
+    L.sjo_unescape_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int]
+    return int(L.sjo_unescape_loop(_ptr(a), _ptr(ix), ix.size, sb.ctypes.data, sb.size, loops))
 
 
 def fnv1a64_u32(arr):

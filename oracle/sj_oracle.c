@@ -811,6 +811,54 @@ int sjo_parse(const uint8_t *buf, uint64_t len, int max_depth, sjo_doc *out) {
     return out->error;
 }
 
+/* bench.py's CPU legs (timing only): the documents buf[offsets[k], offsets[k + 1]) parsed one after the other, `loops`
+ * times, with the scalar stage 1 above or with the one handed in (the AVX-512 restatement lives in its own library).
+ * The buffer needs 64 readable bytes behind its end.  Returns the documents of the last loop that parsed without error;
+ * *tape_words / *string_bytes = their totals. */
+uint64_t sjo_parse_many(const uint8_t *buf, const uint64_t *offsets, uint64_t n, int max_depth, int loops, sjo_stage1_fn stage1,
+                        uint64_t *tape_words, uint64_t *string_bytes) {
+    uint64_t maxlen = 0, ok = 0;
+    for (uint64_t k = 0; k < n; k++)
+        if (offsets[k + 1] - offsets[k] > maxlen) maxlen = offsets[k + 1] - offsets[k];
+    uint32_t *ix = (uint32_t *)malloc((maxlen + 2 + 64) * 4);
+    uint8_t *padded = (uint8_t *)calloc(maxlen + 128, 1);
+    for (int l = 0; l < loops; l++) {
+        ok = 0;
+        *tape_words = 0;
+        *string_bytes = 0;
+        for (uint64_t k = 0; k < n; k++) {
+            const uint64_t len = offsets[k + 1] - offsets[k];
+            /* padIfNeeded (SimdJsonParser.java:42-48): a document inside a batch has its neighbours, not padding, behind it */
+            memcpy(padded, buf + offsets[k], len);
+            memset(padded + len, 0, 64);
+            uint64_t count = 0;
+            uint32_t st = 0;
+            sjo_doc d;
+            memset(&d, 0, sizeof d);
+            if (stage1) stage1(padded, len, ix, maxlen + 2 + 64, &count, &st);
+            else sjo_stage1(padded, len, ix, maxlen + 2, &count, &st);
+            if (st == 0 && sjo_stage2(padded, len, ix, count, max_depth, &d) == 0) {
+                ok++;
+                *tape_words += d.tape_len;
+                *string_bytes += d.string_len;
+            }
+            sjo_doc_free(&d);
+        }
+    }
+    free(ix);
+    free(padded);
+    return ok;
+}
+
+/* ... and StringParser.parseString for every string of one indexed document, `loops` times; returns the bytes of records */
+uint64_t sjo_unescape_loop(const uint8_t *padded, const uint32_t *indexes, uint64_t count, uint8_t *sb, uint64_t cap, int loops) {
+    uint64_t total = 0, ns = 0;
+    int64_t feo = 0;
+    int fec = 0;
+    for (int l = 0; l < loops; l++) total = sjo_unescape_all(padded, indexes, count, sb, cap, NULL, &ns, &feo, &fec);
+    return total;
+}
+
 void sjo_doc_free(sjo_doc *d) {
     free(d->tape);
     free(d->string_buffer);

@@ -131,6 +131,13 @@ typedef struct sjo_doc {
 int sjo_parse(const uint8_t *buf, uint64_t len, int max_depth, sjo_doc *out);
 void sjo_doc_free(sjo_doc *d);
 
+/* timing loops for bench.py's CPU legs (see sj_oracle.c) */
+typedef int (*sjo_stage1_fn)(const uint8_t *buf, uint64_t len, uint32_t *indexes, uint64_t index_capacity, uint64_t *count,
+                             uint32_t *status);
+uint64_t sjo_parse_many(const uint8_t *buf, const uint64_t *offsets, uint64_t n, int max_depth, int loops, sjo_stage1_fn stage1,
+                        uint64_t *tape_words, uint64_t *string_bytes);
+uint64_t sjo_unescape_loop(const uint8_t *padded, const uint32_t *indexes, uint64_t count, uint8_t *sb, uint64_t cap, int loops);
+
 /* Stage 2 only, over given structural indexes (used to check the GPU stage-1 output
  * end to end).  padded_buf must have 64 bytes of padding after len. */
 int sjo_stage2(const uint8_t *padded_buf, uint64_t len, const uint32_t *indexes, uint64_t count,

@@ -508,6 +508,23 @@ k_strings(const StrArgs a0) {
         }
         uint32_t nxt = STR_NONE;
         if (have && retire != 0) nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk) * NC + cls;
+        // \uXXXX: the hex digits of a lane's first two sequences are requested now and used behind the flush and the copy
+        // (a request per trip of the loop there costs a memory round trip per trip)
+        uint32_t it_lo[2] = {0, 0}, it_hi[2] = {0, 0};
+        const sj_u64 items = have ? (m.l1 | m.l2 | m.l3 | m.pair) : 0ull;
+        const bool any_items = __ballot(items != 0) != 0;
+        if (any_items) {
+            sj_u64 x = items;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (x) {
+                    const uint8_t* src = a.buf + blk * 64 + (uint32_t)__builtin_ctzll(x);
+                    it_lo[t] = reinterpret_cast<const StrU4B*>(src - 3)->a;
+                    if (m.pair & x & (0 - x)) it_hi[t] = reinterpret_cast<const StrU4B*>(src - 9)->a;
+                    x &= x - 1;
+                }
+            }
+        }
 
         // =================== flush granule `prev` ===================
         if (prev != STR_NONE) {
@@ -731,17 +748,25 @@ k_strings(const StrArgs a0) {
                     }
                 }
             }
-            const sj_u64 items = m.l1 | m.l2 | m.l3 | m.pair;
-            if (__ballot(items != 0)) {  // \uXXXX: the UTF-8 bytes over the last hex digits (StringParser.java:126-153)
-                for (sj_u64 x = items; x; x &= x - 1) {
+            if (any_items) {  // \uXXXX: the UTF-8 bytes over the last hex digits (StringParser.java:126-153)
+                int t = 0;
+                for (sj_u64 x = items; x; x &= x - 1, ++t) {
                     const uint32_t e = (uint32_t)__builtin_ctzll(x);
                     const uint8_t* src = a.buf + blk * 64 + e;
-                    const uint32_t lo = reinterpret_cast<const StrU4B*>(src - 3)->a;
-                    uint32_t cp = (uint32_t)sj_hex4_word(lo);
-                    if ((m.pair >> e) & 1ull) {
-                        const uint32_t hi = reinterpret_cast<const StrU4B*>(src - 9)->a;
-                        cp = ((((uint32_t)sj_hex4_word(hi) - 0xD800u) << 10) | (cp - 0xDC00u)) + 0x10000u;
+                    const bool is_pair = (m.pair >> e) & 1ull;
+                    uint32_t lo, hi = 0;
+                    if (t == 0) {
+                        lo = it_lo[0];
+                        hi = it_hi[0];
+                    } else if (t == 1) {
+                        lo = it_lo[1];
+                        hi = it_hi[1];
+                    } else {
+                        lo = reinterpret_cast<const StrU4B*>(src - 3)->a;
+                        if (is_pair) hi = reinterpret_cast<const StrU4B*>(src - 9)->a;
                     }
+                    uint32_t cp = (uint32_t)sj_hex4_word(lo);
+                    if (is_pair) cp = ((((uint32_t)sj_hex4_word(hi) - 0xD800u) << 10) | (cp - 0xDC00u)) + 0x10000u;
                     uint32_t L;
                     const uint32_t nb = sj_utf8_bytes(cp, &L);
                     uint32_t old = L == 4 ? lo : (lo >> (8u * (4u - L)));
@@ -918,16 +943,31 @@ k_doc_str_ordinals(const uint8_t* __restrict__ buf0, const uint8_t* __restrict__
         if (pos > len) pos = len;
         const unsigned long long b = pos >> 6, start = b * 64;
         ord = blk_ord[b];
-        uint32_t in_str = (uint32_t)(par[b >> 6] >> (b & 63)) & 1u;
-        uint32_t escaped = b ? sj_backslash_run_parity(buf, 0, start) : 0u;
-        for (unsigned long long p = start; p < pos; ++p) {
-            const uint32_t c = buf[p];
-            if (escaped) escaped = 0;
-            else if (c == 0x5C) escaped = 1;
-            else if (c == 0x22) {
-                ord += in_str ^ 1u;
-                in_str ^= 1u;
+        if (pos > start) {
+            // the strings opened in [start, pos): quotes and backslashes of the block as 64-bit masks (SWAR compare per dword, a
+            // multiply gathers the four flag bits), then StructuralIndexer.java:211-234 on them
+            const uint32_t in_str = (uint32_t)(par[b >> 6] >> (b & 63)) & 1u;
+            const uint32_t e_in = b ? sj_backslash_run_parity(buf, 0, start) : 0u;
+            sj_u64 qm = 0, bm = 0;
+            const uint4* src = reinterpret_cast<const uint4*>(buf + start);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 v = src[q];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint32_t zq = w[t] ^ 0x22222222u, zb = w[t] ^ 0x5C5C5C5Cu;
+                    const uint32_t fq = ~(((zq & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | zq) & 0x80808080u;  // 0x80 where the byte matches
+                    const uint32_t fb = ~(((zb & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | zb) & 0x80808080u;
+                    const sj_u64 nq = (((fq >> 7) * 0x00204081u) >> 21) & 0xFu, nb = (((fb >> 7) * 0x00204081u) >> 21) & 0xFu;
+                    qm |= nq << (16 * q + 4 * t);
+                    bm |= nb << (16 * q + 4 * t);
+                }
             }
+            const sj_u64 quote = qm & ~sj_escaped_mask<sj_u64>(bm, e_in);
+            const sj_u64 in0 = sj_prefix_xor(quote);
+            const sj_u64 opens = quote & (in_str ? ~in0 : in0);
+            ord += (unsigned long long)__popcll(opens & ((1ull << (pos - start)) - 1ull));
         }
         if (ord > nstr) ord = nstr;
     }

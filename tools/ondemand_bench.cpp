@@ -129,6 +129,43 @@ int select_full_parse(sjmi_parser* p, const uint8_t* buf, uint64_t len, uint64_t
 }
 }  // namespace
 
+// BASELINE.json configs[4]: a batch of documents from a host buffer -> one tree per document (sjmi_parser_parse_batch: GPU
+// stage 1 + GPU string records + the host stage 2 on a thread pool), timed here; then, untimed, BenchmarkCorrectnessTest's
+// selection (:23-55) on EVERY tree through sjmi_value_*: *users_min / *users_max over the documents.
+extern "C" int odb_parse_batch(sjmi_parser* p, const uint8_t* buf, uint64_t total_len, const uint64_t* offsets, uint64_t n_docs, int iters,
+                               double* seconds, uint64_t* ok_docs, uint64_t* users_min, uint64_t* users_max) {
+    const uint64_t *tape, *tape_offsets;
+    const uint8_t* strings;
+    const int32_t* errors;
+    uint64_t sl = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < iters; ++i) {
+        const int rc = sjmi_parser_parse_batch(p, buf, total_len, offsets, n_docs, &tape, &tape_offsets, &strings, &sl, &errors);
+        if (rc) return rc;
+    }
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *ok_docs = 0;
+    *users_min = ~0ull;
+    *users_max = 0;
+    for (uint64_t k = 0; k < n_docs; ++k) {
+        if (errors[k]) continue;
+        ++*ok_docs;
+        sjmi_value root, statuses, st, user, v;
+        if (sjmi_parser_batch_root(p, k, &root) || sjmi_value_get(p, &root, (const uint8_t*)"statuses", 8, &statuses)) return -100;
+        uint64_t users = 0;
+        for (int more = sjmi_value_first(p, &statuses, &st); more == 0; more = sjmi_value_next(p, &statuses, &st, &st)) {
+            int dflt = 0;
+            if (sjmi_value_get(p, &st, (const uint8_t*)"user", 4, &user) ||
+                sjmi_value_get(p, &user, (const uint8_t*)"default_profile", 15, &v) || sjmi_value_as_boolean(p, &v, &dflt))
+                return -101;
+            users += dflt != 0;
+        }
+        if (users < *users_min) *users_min = users;
+        if (users > *users_max) *users_max = users;
+    }
+    return 0;
+}
+
 extern "C" int odb_run(sjmi_parser* p, const uint8_t* buf, uint64_t len, int mode, int iters, double* seconds, uint64_t* selected,
                        uint64_t* bytes) {
     const auto t0 = std::chrono::steady_clock::now();

@@ -29,6 +29,9 @@ def load_bench_lib():
     L = C.CDLL(so)
     L.odb_run.restype = C.c_int
     L.odb_run.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.odb_parse_batch.restype = C.c_int
+    L.odb_parse_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]
     return L
 
 

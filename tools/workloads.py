@@ -2,7 +2,8 @@
 
   configs[1]  twitter.json x reps byte-concatenated (x1024 = 646,671,360 B; x6801 = 4,294,933,515 B, the north-star
               "4 GiB concatenated twitter.json": the largest multiple that keeps uint32 indexes)
-  configs[2]  4 GiB synthetic JSON (tools/synth.py tile repeated: ~50 % string bytes, 10 % escapes, non-ASCII)
+  configs[2]  4 GiB synthetic JSON (tools/synth.synth_tile_spec: a 16 MiB tile x255; 50 % of the bytes in string literals, 10 % of
+              the string characters escapes, 10 % non-ASCII -- SURVEY.md 8(d); the measured shares are printed with the number)
   configs[3]  1,000,000 ~1 KB documents packed NDJSON-style (a pool of unique documents from tools/synth.small_docs,
               repeated in order), with their u64 offsets table
 Every builder returns what a closed-form parity check needs (the oracle's result for ONE tile / ONE pool)."""
@@ -49,9 +50,20 @@ def closed_form_ok(out, idx0, n0, reps, chunk=64):
     return True, -1
 
 
-def synth_tile(target_bytes=4 << 20):
+def synth_tile(target_bytes=16 << 20):
+    """the configs[2] tile as SURVEY.md 8(d) specifies it (16 MiB, 50 % of the bytes inside string literals)"""
     import synth
-    return synth.synth_tile(target_bytes=target_bytes)
+    return synth.synth_tile_spec(target_bytes=target_bytes)
+
+
+def measured_fractions(tile, masks):
+    """what the tile really is (from the oracle's masks): share of bytes inside string literals, of escape sequences among
+    the string characters, of non-ASCII bytes"""
+    a = np.frombuffer(tile, dtype=np.uint8)
+    in_str = int(sum(bin(int(x)).count("1") for x in masks[:, 2]))
+    esc = int(sum(bin(int(x)).count("1") for x in masks[:, 0]))  # escaped characters = escape sequences
+    return {"bytes_in_string_literals": round(in_str / len(tile), 4), "escape_sequences_per_string_byte": round(esc / max(in_str, 1), 4),
+            "non_ascii_bytes": round(float((a >= 0x80).mean()), 4)}
 
 
 def small_doc_pool(unique=4000, same_schema=False):
