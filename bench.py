@@ -669,7 +669,8 @@ def bench_sharded(args, world):
 
     def step():
         nonlocal gathered
-        gathered = sharding.sharded_step(shard, st)  # kernels of the shard + the count gather (the only collective)
+        # kernels of the shard + the count gather (the only collective; issued in a group of one rank as well)
+        gathered = sharding.sharded_step(shard, st, always_gather=True)
 
     for _ in range(max(args.warmup, 3)):
         step()
@@ -704,6 +705,7 @@ def bench_sharded(args, world):
                        "documents": n_docs, "bytes": total_bytes, "documents_per_rank": [int(x) for x in g[:, 0]],
                        "structurals_per_rank": [int(x) for x in g[:, 1]], "sharding": "by document, contiguous, byte-balanced",
                        "collective": "all_gather_into_tensor of {docs, structurals, string bytes, failed docs} per rank"},
+            "backend": backend + (" (RCCL)" if backend == "nccl" else ""),
             "single_gpu_same_run": single,
             "speedup_vs_single_gpu_same_run": round(value / single["value"], 3) if single else None,
             "roofline": {"bound": "hbm", "achieved": round(batch_algorithmic_bytes(total_bytes, {"structurals": int(g[:, 1].sum()),
@@ -736,12 +738,27 @@ def main():
     ap.add_argument("--skip-main-timing", action="store_true",
                     help="N=1, profiling passes of an extra only: check the primary workload once, do not time it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded", action="store_true",
+                    help="N=1: take the sharded branch anyway -- init_process_group('nccl'), the batch on one rank, the count gather as a "
+                         "real RCCL all_gather_into_tensor in a group of one (prints the SCALE-style line instead of the BENCH line)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         print("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus), file=sys.stderr)
     if world > 1:
         bench_sharded(args, world)
+    elif args.sharded:
+        # a process group of ONE rank over RCCL: what torch.distributed.run would have put into the environment
+        import socket
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("LOCAL_RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        bench_sharded(args, 1)
     else:
         bench_single(args)
 

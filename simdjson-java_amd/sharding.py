@@ -113,9 +113,10 @@ class BatchShard:
                 "host_documents": int(r[6]), "failed_documents": int(r[7]), "stage1_status": st1 & 0xFF}
 
 
-def sharded_step(shard, stream=0):
+def sharded_step(shard, stream=0, always_gather=False):
     """One step of the multi-GPU batched path on this rank: the shard's kernels, then the count gather (the ONLY
-    collective, north_star).  -> gathered [world, 4] int64 tensor on the shard's device."""
+    collective, north_star).  -> gathered [world, 4] int64 tensor on the shard's device.  always_gather: issue the
+    collective even in a group of one rank (bench.py --sharded: the RCCL call path on a single GPU)."""
     import torch
     import torch.distributed as dist
     shard.step(stream)
@@ -125,7 +126,7 @@ def sharded_step(shard, stream=0):
         # handle of the torch stream they are on (bench.py does).
         torch.cuda.synchronize()
     row = shard.counts_tensor()
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not always_gather):
         return row[None, :]
     out = torch.empty(dist.get_world_size() * 4, dtype=torch.int64, device=shard.device)
     dist.all_gather_into_tensor(out, row)
