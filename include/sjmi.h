@@ -32,6 +32,8 @@ extern "C" {
 #define SJMI_ST_UNESCAPED 4u  /* "Unescaped characters. Within strings, ..."         StructuralIndexer.java:300-302 */
 #define SJMI_ST_CAPACITY 0x100u /* index_capacity < count+1 (the reference throws AIOOBE here) */
 #define SJMI_ST_INTERNAL 0x200u /* engine fault (look-back timeout); results invalid */
+#define SJMI_ST_HALO 0x400u     /* sjmi_stage1_shard_device / sjmi_stream_push: a backslash run fills the whole left halo, so whether the
+                                   byte behind it is escaped cannot be told from what is readable; results invalid -- give more halo */
 
 /* return codes */
 #define SJMI_OK 0
@@ -123,13 +125,18 @@ int sjmi_stage1_masks_device(sjmi_ctx* ctx, const void* d_buf, uint64_t len, voi
  * aligned), with halo_bytes (a multiple of 64, >= 64 unless the shard starts the document) of the document's preceding
  * bytes readable right in front of it: everything stage 1 carries from block to block except the in-string parity is
  * re-derived from those bytes (escape run, previous scalar, UTF-8 continuation -- a backslash run that fills the whole
- * halo is the only thing it cannot see through).  is_last = 0: the shard ends on a 64-byte boundary (len % 64 == 0) and has
+ * halo is the only thing it cannot see through: the call then reports SJMI_ST_HALO and the caller repeats it with a larger
+ * halo).  is_last = 0: the shard ends on a 64-byte boundary (len % 64 == 0) and has
  * no tail block -- what straddles the boundary is validated by the next shard.  entry_parity = 1: the shard starts
  * inside a string.  Indexes are relative to d_buf; result.status bit SJMI_ST_UNCLOSED = the parity AFTER the shard.
  * Protocol (sharding.py DocumentSplit): run every shard with entry_parity 0; exchange the parities (1 bit per shard: the
  * first collective); a shard whose true entry parity is 1 runs again with entry_parity 1; exchange the counts. */
 int sjmi_stage1_shard_device(sjmi_ctx* ctx, const void* d_buf, uint64_t len, uint64_t halo_bytes, int is_last, int entry_parity,
                              void* d_indexes, uint64_t index_capacity, void* d_result, void* stream);
+/* the same with one more fact: halo_from_document_start != 0 = the halo begins at the document's first byte (nothing is in
+ * front of it, so a backslash run that fills it is complete and SJMI_ST_HALO is never reported) */
+int sjmi_stage1_shard_device2(sjmi_ctx* ctx, const void* d_buf, uint64_t len, uint64_t halo_bytes, int halo_from_document_start,
+                              int is_last, int entry_parity, void* d_indexes, uint64_t index_capacity, void* d_result, void* stream);
 
 /* device-side result record of one unescape call */
 typedef struct sjmi_unescape_result {

@@ -70,7 +70,7 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_value_as_boolean", "sjmi_value_as_string", "sjmi_value_get", "sjmi_value_size", "sjmi_value_first",
            "sjmi_value_next", "sjmi_parse_batch_device", "sjmi_parse_document",
            "sjmi_parser_set_gpu_walk", "sjmi_set_auto_safe", "sjmi_match_brackets",
-           "sjmi_match_brackets_device", "sjmi_stage1_shard_device",
+           "sjmi_match_brackets_device", "sjmi_stage1_shard_device", "sjmi_stage1_shard_device2",
            "sjmi_parser_ondemand_init", "sjmi_od_skip_child", "sjmi_od_get_boolean", "sjmi_od_get_long", "sjmi_od_get_integral", "sjmi_od_get_double", "sjmi_od_get_float", "sjmi_od_get_char",
            "sjmi_od_get_string", "sjmi_od_get_field_name", "sjmi_od_start_array", "sjmi_od_next_array_element",
            "sjmi_od_start_object", "sjmi_od_next_object_field", "sjmi_od_move_to_field_value", "sjmi_od_assert_no_more_values",
@@ -179,6 +179,9 @@ def lib():
         L.sjmi_stage1_shard_device.restype = C.c_int
         L.sjmi_stage1_shard_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_uint64,
                                                C.c_void_p, C.c_void_p]
+        L.sjmi_stage1_shard_device2.restype = C.c_int
+        L.sjmi_stage1_shard_device2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                C.c_uint64, C.c_void_p, C.c_void_p]
         L.sjmi_set_auto_safe.restype = C.c_int
         L.sjmi_set_auto_safe.argtypes = [C.c_void_p, C.c_int]
         L.sjmi_set_tile_mode.restype = C.c_int
@@ -430,10 +433,12 @@ class Context:
         self._check(lib().sjmi_stage1_device(self._h, d_buf, length, d_indexes, index_capacity, d_result, stream),
                     "sjmi_stage1_device")
 
-    def stage1_shard_device(self, d_buf, length, halo_bytes, is_last, entry_parity, d_indexes, index_capacity, d_result, stream=0):
-        """One shard / stream chunk of a longer document (sjmi_stage1_shard_device)."""
-        self._check(lib().sjmi_stage1_shard_device(self._h, d_buf, length, halo_bytes, 1 if is_last else 0, 1 if entry_parity else 0,
-                                                   d_indexes, index_capacity, d_result, stream), "sjmi_stage1_shard_device")
+    def stage1_shard_device(self, d_buf, length, halo_bytes, is_last, entry_parity, d_indexes, index_capacity, d_result, stream=0,
+                            halo_from_start=False):
+        """One shard / stream chunk of a longer document (sjmi_stage1_shard_device2)."""
+        self._check(lib().sjmi_stage1_shard_device2(self._h, d_buf, length, halo_bytes, 1 if halo_from_start else 0,
+                                                    1 if is_last else 0, 1 if entry_parity else 0,
+                                                    d_indexes, index_capacity, d_result, stream), "sjmi_stage1_shard_device2")
 
     def set_auto_safe(self, on):
         self._check(lib().sjmi_set_auto_safe(self._h, 1 if on else 0), "sjmi_set_auto_safe")

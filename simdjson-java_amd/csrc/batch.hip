@@ -52,6 +52,10 @@ k_batch_sep_check(const uint8_t* __restrict__ buf, const unsigned long long* __r
     if (k >= n_docs) return;
     const sj_u64 s = doc_offsets[k], e = doc_offsets[k + 1];
     bool bad = e < s || e > total_len;
+    // the plain pass scans [0, total_len): bytes in front of the first or behind the last document would feed their in-string /
+    // scalar / UTF-8 state into the documents (and their structurals into the count)
+    if (k == 0 && s != 0) bad = true;
+    if (k + 1 == n_docs && e != total_len) bad = true;
     if (!bad && k + 1 < n_docs) {  // (the last document ends where the batch ends)
         const uint8_t c = e > s ? buf[e - 1] : 0xFF;
         bad = !(c == 0x0A || c == 0x0D || c == 0x09);

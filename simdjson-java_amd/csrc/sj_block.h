@@ -250,6 +250,13 @@ SJ_HD uint32_t sj_backslash_run_parity(const uint8_t* buf, sj_u64 lo, sj_u64 pos
     return par;
 }
 
+// does the backslash run that ends right before buf[pos] reach down to buf[lo] (so that it may go on in front of what is
+// readable: a shard's / stream chunk's left halo)?
+SJ_HD bool sj_backslash_run_reaches(const uint8_t* buf, sj_u64 lo, sj_u64 pos) {
+    while (pos > lo && buf[pos - 1] == 0x5C) --pos;
+    return pos == lo && lo < (sj_u64)-1 && buf[lo] == 0x5C;
+}
+
 SJ_HD void sj_carry_slow(const uint8_t* buf, sj_u64 doc_lo, sj_u64 start, uint32_t* e_in, uint32_t* p_in) {
     const uint32_t h1 = buf[start - 1];
     if (h1 == 0x5C) {

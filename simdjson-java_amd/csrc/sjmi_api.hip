@@ -81,8 +81,8 @@ struct sjmi_ctx {
     uint32_t dbg = 0;  // ablation flags (sjmi_debug_set_flags)
     bool ticket_mode = false;  // safe tile assignment (latched on after a look-back timeout in fast mode)
     bool auto_safe = false;    // sjmi_set_auto_safe: the *_device stage-1 entry point synchronises, checks and re-runs in SAFE mode
-    hipStream_t last_launch_stream = nullptr;  // stream of this context's last stage-1 launch (is it still running?)
-    bool launched = false;
+    hipEvent_t busy_event = nullptr;  // recorded behind this context's last stage-1 launch (is it still running?)
+    std::atomic<bool> launched{false};
     bool profiling = false;  // bracket every stage-1 kernel with HIP events (bench.py roofline)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
@@ -105,15 +105,25 @@ bool another_context_busy(const sjmi_ctx* self) {
     if (g_live_contexts.load() <= 1) return false;
     std::lock_guard<std::mutex> g(g_registry_mutex);
     for (sjmi_ctx* o : g_registry)
-        if (o != self && o->launched && o->device == self->device && hipStreamQuery(o->last_launch_stream) == hipErrorNotReady) return true;
+        if (o != self && o->launched.load(std::memory_order_acquire) && o->device == self->device &&
+            hipEventQuery(o->busy_event) == hipErrorNotReady) {
+            (void)hipGetLastError();  // (hipErrorNotReady is an answer, not an error to leave behind)
+            return true;
+        }
     return false;
 }
 uint32_t launch_flags(const sjmi_ctx* c) {
     return c->dbg | (c->ticket_mode ? sjmi::FLAG_SAFE : 0u) | (another_context_busy(c) ? sjmi::FLAG_ALL_TICKETS : 0u);
 }
+// called right behind a stage-1 launch: a library-owned event on the launch stream is what other contexts poll (never a
+// stream they do not own, which may be gone by then); under the registry lock, like the poll and like sjmi_destroy
 void note_launch(sjmi_ctx* c, hipStream_t st) {
-    c->last_launch_stream = st;
-    c->launched = true;
+    std::lock_guard<std::mutex> g(g_registry_mutex);
+    if (!c->busy_event && hipEventCreateWithFlags(&c->busy_event, hipEventDisableTiming) != hipSuccess) {
+        c->busy_event = nullptr;
+        return;
+    }
+    if (hipEventRecord(c->busy_event, st) == hipSuccess) c->launched.store(true, std::memory_order_release);
 }
 
 bool fail(sjmi_ctx* c, const char* what, hipError_t e) {
@@ -175,6 +185,7 @@ void sjmi_destroy(sjmi_ctx* c) {
     }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->busy_event) (void)hipEventDestroy(c->busy_event);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_idx) (void)hipFree(c->d_idx);
     if (c->d_ws) (void)hipFree(c->d_ws);
@@ -246,13 +257,14 @@ int sjmi_stage1(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes
     if (len && fail(c, "H2D", hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
     const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(len);
     const uint64_t dev_cap = c->capacity + 2 < index_capacity ? c->capacity + 2 : index_capacity;
-    note_launch(c, c->stream);
     sjmi::Stage1Extras ex1;
     ex1.blkpar = parity_out(c, c->d_in, len);
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (fail(c, "launch", sjmi::stage1_launch(c->d_in, len, c->d_idx, dev_cap, c->d_ws, steps, c->stream, nullptr,
-                                                  nullptr, launch_flags(c), ex1)) ||
-            fail(c, "D2H(result)",
+                                                  nullptr, launch_flags(c), ex1)))
+            return SJMI_ERR_HIP;
+        note_launch(c, c->stream);
+        if (fail(c, "D2H(result)",
                  hipMemcpyAsync(c->h_res, (uint8_t*)c->d_ws + sjmi::WS_RESULT_OFFSET, sizeof(sjmi_stage1_result),
                                 hipMemcpyDeviceToHost, c->stream)) ||
             fail(c, "sync", hipStreamSynchronize(c->stream)))
@@ -562,6 +574,7 @@ int sjmi_stage1_unescape(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t
         if (fail(c, "launch", sjmi::stage1_launch(c->d_in, len, c->d_idx, dev_cap, c->d_ws, steps, c->stream, nullptr,
                                                   nullptr, launch_flags(c), ex1)))
             return SJMI_ERR_HIP;
+        note_launch(c, c->stream);
         const int src = strings_device_impl(c, c->d_in, len, c->d_sb, c->sb_bytes, nullptr, 0, nullptr, c->d_ures, c->stream);
         if (src != SJMI_OK) return src;
         if (fail(c, "error index", sjmi::strings_error_index_launch(c->d_idx, 0, d_res1, (const sjmi::UnescapeResult*)c->d_ures,
@@ -654,13 +667,20 @@ int sjmi_stage1_device(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_ind
     return stage1_device_impl(c, d_buf, len, d_indexes, index_capacity, d_result, stream, 0);
 }
 
+int sjmi_stage1_shard_device2(sjmi_ctx* c, const void* d_buf, uint64_t len, uint64_t halo_bytes, int halo_from_document_start,
+                              int is_last, int entry_parity, void* d_indexes, uint64_t index_capacity, void* d_result, void* stream);
 int sjmi_stage1_shard_device(sjmi_ctx* c, const void* d_buf, uint64_t len, uint64_t halo_bytes, int is_last, int entry_parity,
                              void* d_indexes, uint64_t index_capacity, void* d_result, void* stream) {
+    return sjmi_stage1_shard_device2(c, d_buf, len, halo_bytes, 0, is_last, entry_parity, d_indexes, index_capacity, d_result, stream);
+}
+
+int sjmi_stage1_shard_device2(sjmi_ctx* c, const void* d_buf, uint64_t len, uint64_t halo_bytes, int halo_from_document_start,
+                              int is_last, int entry_parity, void* d_indexes, uint64_t index_capacity, void* d_result, void* stream) {
     // a shard that is not the last one ends on a block boundary (its successor owns what straddles it); the halo is
     // whole blocks so that the shard itself stays 16-byte aligned
     if ((halo_bytes & 63) || halo_bytes > 65535ull * 64 || (!is_last && (len & 63)) || (!is_last && len == 0)) return SJMI_ERR_ARG;
     const uint32_t flags = ((uint32_t)(halo_bytes / 64) << 16) | (is_last ? 0u : sjmi::FLAG_NO_TAIL) |
-                           (entry_parity ? sjmi::FLAG_ENTRY_PARITY : 0u);
+                           (entry_parity ? sjmi::FLAG_ENTRY_PARITY : 0u) | (halo_from_document_start ? sjmi::FLAG_HALO_FROM_START : 0u);
     return stage1_device_impl(c, d_buf, len, d_indexes, index_capacity, d_result, stream, flags);
 }
 
@@ -1039,13 +1059,14 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
         if (fail(c, "launch", sjmi::stage1_launch(c->d_in, len, c->d_idx, c->capacity + 2, c->d_ws, steps, c->stream, nullptr, nullptr,
                                                   launch_flags(c), ex1)))
             return SJMI_ERR_HIP;
+        note_launch(c, c->stream);
         const int src = strings_device_impl(c, c->d_in, len, c->d_sb, c->sb_bytes, c->d_soff, (size_t)len / 2 + 2, nullptr, d_ures, c->stream);
         if (src != SJMI_OK) return src;
         if ((early_strings && fail(c, "event", hipEventRecord(c->strings_ready, c->stream))) ||
             fail(c, "setup", sjmi::single_doc_setup_launch(d_res1, len, d_doc, d_io, d_st, d_dso, c->stream)) ||
             fail(c, "walk launch",
                  sjmi::walk_launch(c->d_in, d_doc, 1, c->d_idx, bound, d_io, d_st, c->d_sb, d_dso, 0, max_depth, c->d_tape,
-                                   2 * bound + 8, d_to, d_err, c->d_ws_walk, d_wres, c->stream, d_res1, d_ures, c->d_soff)) ||
+                                   2 * bound + 8, d_to, d_err, c->d_ws_walk, d_wres, c->stream, d_res1, d_ures, c->d_soff, true)) ||
             fail(c, "results", single_doc_results_launch(d_res1, d_ures, d_wres, d_to, d_err,
                                                          (SingleDocResults*)((uint8_t*)c->d_single + 256), c->stream)) ||
             fail(c, "D2H", hipMemcpyAsync(h, (uint8_t*)c->d_single + 256, sizeof *h, hipMemcpyDeviceToHost, c->stream)))

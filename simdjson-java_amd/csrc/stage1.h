@@ -44,6 +44,8 @@ constexpr uint32_t FLAG_SAFE = 0x100;
 // last shard (no tail block); bits 16..31 = readable 64-byte blocks in front of the buffer (left halo)
 constexpr uint32_t FLAG_ENTRY_PARITY = 0x1000;
 constexpr uint32_t FLAG_NO_TAIL = 0x4000;
+// the shard's left halo begins at the document's first byte (a backslash run that fills it is complete)
+constexpr uint32_t FLAG_HALO_FROM_START = 0x2000;
 // kernel flag: FAST mode without static first granules (several contexts may be launching concurrently)
 constexpr uint32_t FLAG_ALL_TICKETS = 0x800;
 
@@ -114,7 +116,8 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
                        const uint8_t* d_sb, const unsigned long long* d_doc_str_ordinals, uint64_t string_base, int max_depth,
                        unsigned long long* d_tape, uint64_t tape_capacity, unsigned long long* d_tape_offsets,
                        int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream,
-                       const Stage1Result* dev_count, const UnescapeResult* dev_strings, const uint32_t* d_soff);
+                       const Stage1Result* dev_count, const UnescapeResult* dev_strings, const uint32_t* d_soff,
+                       bool index_from_zero = false);
 // coop_walk.hip: the cooperative walker (a wave per document); d_soff = offset of every string's record in d_sb, by ordinal
 hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_idx,
                             const unsigned long long* d_index_offsets, const uint32_t* d_doc_status, const uint32_t* d_soff,

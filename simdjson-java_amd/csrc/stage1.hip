@@ -132,7 +132,8 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 //   bits 63..62 : 0 = nothing yet, 1 = AGGREGATE, 2 = INCLUSIVE PREFIX
 //   AGGREGATE   : [19:0] structurals if the granule is entered with parity 0, [39:20] with parity 1,
 //                 [40] quote parity of the granule, [41] UTF-8 error in the granule, [42] / [43] unescaped control
-//                 character inside a string if the granule is entered with parity 0 / 1
+//                 character inside a string if the granule is entered with parity 0 / 1, [44] a shard's left halo was too
+//                 short to resolve a backslash run
 //   PREFIX      : [39:0] structurals in granules 0..t, [40] in-string parity after granule t
 // A granule is one naturally aligned 8-byte relaxed agent-scope store/load: the data is the flag
 // (cdna_hip_programming.md Guideline 16, form R2), so no fences are needed.
@@ -291,6 +292,7 @@ __device__ __forceinline__ uint32_t scanner_errors(const sj_u64 v[SCAN_K], uint3
 #pragma unroll
     for (int j = 0; j < SCAN_K; ++j) {
         if ((v[j] >> 41) & 1u) e |= SJMI_ST_UTF8;
+        if ((v[j] >> 44) & 1u) e |= SJMI_ST_HALO;
         if ((v[j] >> (42 + q)) & 1u) e |= SJMI_ST_UNESCAPED;
         q ^= (uint32_t)(v[j] >> 40) & 1u;
     }
@@ -645,6 +647,7 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
             sj_u64 sm[S];
             uint32_t fl[S];     // bit0 quote parity, bit1 ue0, bit2 ue1, bit3 utf8 error
             uint32_t slow = 0;  // steps whose carries the halo could not resolve (long backslash run)
+            bool halo_short = false;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 // software pipeline with ONE buffer: step s was loaded during the algebra of step s-1 (step 0 before
@@ -702,6 +705,11 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
                     uint32_t e_in = 0, p_in = 0;
                     // (a shard: the run may reach into the left halo, whose first byte bounds the walk)
                     sj_carry_slow(buf - (sj_u64)halo_blocks * 64, 0, start + (sj_u64)halo_blocks * 64, &e_in, &p_in);
+                    if (left_halo && !(dbg & FLAG_HALO_FROM_START)) {  // the run must begin inside the halo, or its parity is not known
+                        const uint8_t* hb = buf - (sj_u64)halo_blocks * 64;
+                        const sj_u64 hs = start + (sj_u64)halo_blocks * 64;
+                        if (sj_backslash_run_reaches(hb, 0, hb[hs - 1] == 0x22 ? hs - 1 : hs)) halo_short = true;
+                    }
                     sj_u64 p[8];
                     sj_transpose_butterfly(w, p);
                     const sj_u64 rem = len - start;
@@ -736,7 +744,11 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
                 gerr |= ((fl[s] >> 3) & 1u) | ((meta[s] >> 27) & 6u);  // utf8, unescaped if entered outside / inside
             }
             // the granule's error bits travel with its aggregate (the scanner composes the launch's status from them)
-            const uint32_t gbits = (__ballot(gerr & 1u) ? 1u : 0u) | (__ballot(gerr & 2u) ? 2u : 0u) | (__ballot(gerr & 4u) ? 4u : 0u);
+            uint32_t gbits = (__ballot(gerr & 1u) ? 1u : 0u) | (__ballot(gerr & 2u) ? 2u : 0u) | (__ballot(gerr & 4u) ? 4u : 0u);
+            if (left_halo && __ballot(halo_short)) {
+                gbits |= 8u;
+                err |= SJMI_ST_HALO;
+            }
             if (lane == 0 && !(dbg & DBG_NO_LOOKBACK)) {
                 if (safe && cur == 0) publish_prefix(agg, 0, wpar ^ entry_par, (sj_u64)(entry_par ? WP - W0 : W0));  // nothing to look back at
                 else publish_aggregate(agg, cur, W0, WP - W0, wpar, gbits);

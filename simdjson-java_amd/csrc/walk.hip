@@ -123,12 +123,13 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
                        const uint8_t* d_sb, const unsigned long long* d_doc_str_ordinals, uint64_t string_base, int max_depth,
                        unsigned long long* d_tape, uint64_t tape_capacity, unsigned long long* d_tape_offsets,
                        int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream, const Stage1Result* dev_count,
-                       const UnescapeResult* dev_strings, const uint32_t* d_soff) {
+                       const UnescapeResult* dev_strings, const uint32_t* d_soff, bool index_from_zero) {
     if (!d_soff) return hipErrorInvalidValue;  // (the record table of the string pass: strings.hip)
     uint8_t* ws = static_cast<uint8_t*>(d_ws);
     unsigned long long* scratch = reinterpret_cast<unsigned long long*>(ws);
-    // one document (its index starts at 0) and room for two words per structural: the walker writes the tape in place
-    const bool direct = n_docs == 1 && tape_capacity >= 2 * count + 2;
+    // one document whose index range starts at 0 (only sjmi_parse_document knows that: the walker's slot for document 0 is
+    // T = tape + 2 * index_offsets[0]) and room for two words per structural: the walker writes the tape in place
+    const bool direct = index_from_zero && n_docs == 1 && tape_capacity >= 2 * count + 2;
     if (direct) scratch = d_tape;
     uint32_t* lens = reinterpret_cast<uint32_t*>(ws + walk_lens_offset(count, n_docs));
     unsigned long long* sums = reinterpret_cast<unsigned long long*>(ws + walk_sums_offset(count, n_docs));

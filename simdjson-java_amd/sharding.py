@@ -147,14 +147,19 @@ def split_points(n_bytes, parts, align=64):
     return [(bounds[r], bounds[r + 1]) for r in range(parts)]
 
 
+class HaloTooShort(RuntimeError):
+    """SJMI_ST_HALO: a backslash run fills the whole left halo of a shard / chunk -- repeat with a larger one"""
+
+
 class DocumentShard:
     """One rank's shard [a, b) of a document, resident on its device together with `halo` bytes of the document in front
     of it (the carries stage 1 needs are re-derived from them; only the in-string parity has to come from the ranks in
     front).  `data` = the document's bytes [a - halo, b) (bytes or a uint8 tensor)."""
 
-    def __init__(self, engine, data, halo, is_last, device, index_ratio=1):
+    def __init__(self, engine, data, halo, is_last, device, index_ratio=1, halo_from_start=False):
         import torch
         self.engine, self.device, self.halo, self.is_last = engine, device, int(halo), bool(is_last)
+        self.halo_from_start = bool(halo_from_start)  # the halo begins at the document's first byte
         total = int(data.numel()) if hasattr(data, "numel") else len(data)
         self.length = total - self.halo
         assert self.halo % 64 == 0 and (self.is_last or self.length % 64 == 0)
@@ -168,7 +173,8 @@ class DocumentShard:
     def run(self, entry_parity, stream=0):
         self.entry_parity = int(entry_parity)
         self.engine.stage1_shard_device(self.buf.data_ptr() + self.halo, self.length, self.halo, self.is_last, self.entry_parity,
-                                        self.idx.data_ptr(), self.capacity, self.result.data_ptr(), stream)
+                                        self.idx.data_ptr(), self.capacity, self.result.data_ptr(), stream,
+                                        halo_from_start=self.halo_from_start)
 
     def outcome(self):
         """(synchronise first) -> (count, status bits without UNCLOSED, parity after the shard)"""
@@ -176,6 +182,8 @@ class DocumentShard:
         st = int(r[1]) & 0xFFFFFFFF
         if st & 0x300:
             raise RuntimeError("stage 1 of the shard: capacity / internal error (status 0x%x)" % st)
+        if st & 0x400:
+            raise HaloTooShort("a backslash run fills the %d bytes of halo in front of the shard" % self.halo)
         return int(r[0]), st & 0xFD, (st >> 1) & 1
 
 
@@ -229,17 +237,27 @@ def stream_document(engine, device, chunks, halo=64):
     import numpy as np
     import torch
     out, status, parity, base, tail = [], 0, 0, 0, b""
+    keep = max(halo, 4096)  # bytes of the stream kept for the halo (a chunk is repeated with more of them on SJMI_ST_HALO)
     for k, ch in enumerate(chunks):
         last = k == len(chunks) - 1
-        h = min(halo, len(tail)) // 64 * 64
-        sh = DocumentShard(engine, tail[len(tail) - h:] + ch if h else ch, h, last, device)
-        sh.run(parity)
-        torch.cuda.synchronize()
-        count, st, parity = sh.outcome()
+        want = halo
+        while True:
+            h = min(want, len(tail)) // 64 * 64
+            sh = DocumentShard(engine, tail[len(tail) - h:] + ch if h else ch, h, last, device, halo_from_start=(h == base))
+            sh.run(parity)
+            torch.cuda.synchronize()
+            try:
+                count, st, after = sh.outcome()
+                break
+            except HaloTooShort:
+                if h >= len(tail) // 64 * 64:
+                    raise  # (everything that is kept of the stream is backslashes)
+                want *= 4
+        parity = after
         status |= st
         out.append((base, sh.idx[:count].cpu().numpy().view(np.uint32).copy()))
         base += len(ch)
-        tail = (tail + ch)[-max(halo, 64):]
+        tail = (tail + ch)[-keep:]
     if parity:
         status |= 2
     return out, status

@@ -30,7 +30,7 @@ def _run_split(ctx, doc, bounds, halo=64):
     shards = []
     for r, (a, b) in enumerate(bounds):
         h = min(halo, a) // 64 * 64
-        shards.append(sharding.DocumentShard(ctx, doc[a - h:b], h, r == len(bounds) - 1, dev))
+        shards.append(sharding.DocumentShard(ctx, doc[a - h:b], h, r == len(bounds) - 1, dev, halo_from_start=(h == a)))
     for s in shards:
         s.run(0)
     torch.cuda.synchronize()
@@ -50,6 +50,11 @@ def _run_split(ctx, doc, bounds, halo=64):
     if after:
         status |= O.ST_UNCLOSED
     return (np.concatenate(idx) if idx else np.zeros(0, np.int64)), status, reran
+
+
+def sharding_mod():
+    from simdjson_java_amd import sharding
+    return sharding
 
 
 def _check(ctx, doc, bounds):
@@ -83,8 +88,11 @@ def test_every_boundary_of_small_hazard_documents(ctx):
         for cut in range(64, len(d) // 64 * 64 + 1, 64):
             if cut >= len(d):
                 break
-            if d.startswith(b"\\\\") and cut > 64:
-                continue  # a backslash run that fills the whole halo is the documented limit: only the first boundary is exact
+            if d.startswith(b"\\\\") and 64 < cut <= 640:
+                # a backslash run that fills the whole halo: the call says so (SJMI_ST_HALO) instead of guessing
+                with pytest.raises(sharding_mod().HaloTooShort):
+                    _check(ctx, d, [(0, cut), (cut, len(d))])
+                continue
             _check(ctx, d, [(0, cut), (cut, len(d))])
     # with a halo that covers the run, long backslash runs are exact everywhere
     d = b"\\" * 700 + b'"x" [1,2,3]'
@@ -116,3 +124,41 @@ def test_document_stream_mode(ctx, twitter):
     parts, st = sharding.stream_document(ctx, torch.device("cuda", 0), chunks)
     got = np.concatenate([ix.astype(np.int64) + base for base, ix in parts])
     assert st == want_st and np.array_equal(got, want_idx.astype(np.int64))
+
+
+def test_backslash_run_that_fills_the_halo_is_reported(ctx):
+    """a backslash run of 64 or more bytes in front of a shard / chunk boundary hides the escape carry behind
+    the halo.  The call must say so (SJMI_ST_HALO) instead of deriving the parity from the visible part; with more halo the
+    result is the whole document's, and the stream mode repeats the chunk with more halo by itself."""
+    import torch
+    from simdjson_java_amd import sharding
+    dev = torch.device("cuda", 0)
+    for run in (64, 65, 127, 128, 129, 200):
+        # the run ends exactly at the boundary (a multiple of 64): an odd run escapes the quote behind it, an even one does not
+        pre = b'["' + b"a" * (256 - 2 - run) + b"\\" * run
+        assert len(pre) == 256
+        doc = pre + b'","x"]       '
+        want_idx, want_st = O.stage1(doc)
+        # one halo block: the run (>= 64 backslashes) fills it
+        sh = sharding.DocumentShard(ctx, doc[192:], 64, True, dev)
+        sh.run(1)  # (the boundary lies inside the first string)
+        torch.cuda.synchronize()
+        with pytest.raises(sharding.HaloTooShort):
+            sh.outcome()
+        # enough halo to see where the run begins
+        sh = sharding.DocumentShard(ctx, doc, 256, True, dev)
+        sh.run(1)
+        torch.cuda.synchronize()
+        count, st, after = sh.outcome()
+        first = sharding.DocumentShard(ctx, doc[:256], 0, False, dev)
+        first.run(0)
+        torch.cuda.synchronize()
+        c0, st0, flip0 = first.outcome()
+        assert flip0 == 1
+        got = np.concatenate([first.idx[:c0].cpu().numpy().view(np.uint32), sh.idx[:count].cpu().numpy().view(np.uint32) + 256])
+        assert np.array_equal(got, want_idx), run
+        assert (st0 | st | (2 if after else 0)) == want_st, run
+        # the stream mode with the default halo of 64 bytes repeats the second chunk with more halo
+        parts, status = sharding.stream_document(ctx, dev, [doc[:256], doc[256:]], halo=64)
+        got = np.concatenate([idx + base for base, idx in parts])
+        assert np.array_equal(got, want_idx) and status == want_st, run

@@ -121,7 +121,7 @@ class _StubShardEngine:
     """binding.Context.stage1_shard_device for the CPU test: the per-byte form of stage 1 (SURVEY.md 8(a) a3') over the left
     halo (for the escape / previous-scalar carries only) and then over the shard, entered with the given parity."""
 
-    def stage1_shard_device(self, d_buf, length, halo, is_last, entry_parity, d_indexes, cap, d_result, stream=0):
+    def stage1_shard_device(self, d_buf, length, halo, is_last, entry_parity, d_indexes, cap, d_result, stream=0, halo_from_start=False):
         import ctypes as C
         raw = bytes((C.c_uint8 * (halo + length)).from_address(d_buf - halo))
         out = (C.c_uint32 * cap).from_address(d_indexes)
