@@ -34,13 +34,15 @@
 #include <stdlib.h>
 
 #include "sj_number.h"
+#include "sj_bigdec.h"
 #include "stage1.h"
 
 namespace sjmi {
 
 namespace {
 
-constexpr int CW_LEVELS = 64;              // levels of the per-wave stack (a non-empty container at depth 63 is handed back)
+constexpr int CW_LEVELS = 64;              // levels of the per-wave stack in registers
+constexpr int CW_OVF_LEVELS = 960;         // deeper levels, in global memory (together: the reference's default maxDepth of 1024)
 constexpr uint32_t CW_SIZE_SLOW = 0x80000000u;  // unescape.hip: sizes[] flag "this string had escapes / failed"
 
 enum : uint32_t { K_OPEN_A = 0, K_OPEN_O = 1, K_CLOSE_A = 2, K_CLOSE_O = 3, K_COMMA = 4, K_COLON = 5, K_QUOTE = 6, K_PRIM = 7 };
@@ -109,6 +111,9 @@ struct CwBytes {
 };
 
 constexpr uint32_t CW_TRUE = 0x65757274u, CW_FALS = 0x736c6166u, CW_NULL = 0x6c6c756eu;
+// internal: a floating literal of more than 19 significant digits whose two 19-digit neighbours round to different doubles;
+// the walker writes the lower candidate and lists the literal for k_slow_doubles (the exact comparison of sj_bigdec.h)
+constexpr int CW_SLOW_DOUBLE = -2;
 
 // TapeBuilder.visitPrimitive (TapeBuilder.java:70-79) / visitRootPrimitive (:59-68) for one lane; win = the 16 bytes at idx.
 // -> 0 and (type, raw second word for numbers) or the SJMI_E_* / SJMI_WALK_NEEDS_HOST code
@@ -176,8 +181,8 @@ __device__ int cw_primitive(const uint8_t* buf, const CW16& win, uint32_t idx, b
         const SjNumber n = sj_scan_number([&](uint32_t q) -> uint32_t { return q < limit ? w.at(q) : 0x20u; }, idx);
         if (n.code) return n.code;
         if (n.floating) {
-            if (!sj_number_double_bits(n, raw)) return SJMI_WALK_NEEDS_HOST;  // DoubleParser's slow path (:205-330)
             *type = 'd';
+            if (!sj_number_double_bits(n, raw)) return CW_SLOW_DOUBLE;  // DoubleParser's slow path (:205-330): decided behind the walk
         } else {
             if (sj_out_of_long_range(n.negative, n.digits, n.digit_count)) return SJMI_E_NUM_LONG_RANGE;
             *type = 'l';
@@ -252,6 +257,34 @@ struct ChunkWs {
     uint32_t* fin;           // [0] final depth, [1] final tape position, [2] kind of the innermost open container (1 = array)
 };
 
+// the literals the walk could not decide (see CW_SLOW_DOUBLE): count, then per literal {address of the tape word that holds the
+// lower candidate, position of the literal | limit of the readable bytes << 32}
+struct SlowList {
+    unsigned long long* count;
+    unsigned long long* rec;
+    unsigned long long cap;
+};
+constexpr unsigned long long CW_SLOW_CAP = 1ull << 16;
+
+// One literal per workgroup, one thread of it at work (big-integer loops over two arrays in LDS): the rarest path there is.
+__global__ void __launch_bounds__(64)
+k_slow_doubles(const uint8_t* __restrict__ buf, SlowList sl) {
+    __shared__ uint32_t wa[SJ_BIG_WORDS], wb[SJ_BIG_WORDS];
+    unsigned long long n = *sl.count;
+    if (n > sl.cap) n = sl.cap;
+    if (threadIdx.x != 0) return;
+    for (unsigned long long r = blockIdx.x; r < n; r += gridDim.x) {
+        unsigned long long* const slot = reinterpret_cast<unsigned long long*>(sl.rec[2 * r]);
+        const uint32_t p = (uint32_t)sl.rec[2 * r + 1], limit = (uint32_t)(sl.rec[2 * r + 1] >> 32);
+        const unsigned long long cand = *slot;
+        const bool neg = buf[p] == '-';
+        const unsigned long long mag =
+            sj_decide_double([&](uint32_t q) -> uint32_t { return q < limit ? (uint32_t)buf[q] : 0x20u; }, p + (neg ? 1u : 0u),
+                             cand & ~(1ull << 63), wa, wb);
+        *slot = mag | (neg ? 1ull << 63 : 0ull);
+    }
+}
+
 // One wave per document (grid-stride over the documents).  Documents are delimited by index_offsets (n_docs + 1 entries)
 // and doc_offsets; a single document is the batch of one.  Document k's tape is built in its slot of the scratch tape
 // (2 words per structural + 2, walk.hip packs the tapes back to back afterwards); sizes / scratch: the per-structural
@@ -266,7 +299,8 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
             const uint32_t* __restrict__ doc_status, const uint32_t* __restrict__ soff, const uint8_t* __restrict__ sb,
             const unsigned long long* __restrict__ doc_str_offsets, unsigned long long string_base, int max_depth,
             unsigned long long* __restrict__ scratch_tape, uint32_t* __restrict__ tape_lens, int32_t* __restrict__ doc_errors, const Stage1Result* __restrict__ dev_count,
-            const UnescapeResult* __restrict__ dev_strings, WalkResult* res, uint32_t abl, ChunkWs cw, const uint32_t* run_only_if) {
+            const UnescapeResult* __restrict__ dev_strings, WalkResult* res, uint32_t abl, ChunkWs cw, const uint32_t* run_only_if,
+            unsigned long long* __restrict__ ovf, SlowList slow) {
     if (run_only_if && *run_only_if == 0) return;   // (the single-wave sweep behind a chunked launch: only on fall-back)
     if (CHUNKED && *cw.fallback != 0) return;
     const int lane = threadIdx.x & 63;
@@ -277,6 +311,23 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
     uint32_t st_tpos = 0, st_cnt = 0;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    // Levels CW_LEVELS and deeper (SimdJsonParser.java:7: the default maxDepth is 1024) live in global memory, one record per
+    // level and wave: {commas so far | kind << 31, tape position of the opening word}.  Rare, so nothing about it is fast;
+    // lane 0 writes and reads them (one thread, one address: program order), the value is broadcast.
+    unsigned long long* const my_ovf = ovf ? ovf + ((uint64_t)blockIdx.x * 4 + wv) * CW_OVF_LEVELS : nullptr;
+    const int level_cap = my_ovf ? CW_LEVELS + CW_OVF_LEVELS : CW_LEVELS;
+    auto ovf_read = [&](int L) -> unsigned long long {
+        unsigned long long v = 0;
+        if (lane == 0) v = __hip_atomic_load(&my_ovf[L - CW_LEVELS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    auto ovf_write = [&](int L, uint32_t tpos_, uint32_t cnt_, bool arr_) {
+        if (lane == 0)
+            __hip_atomic_store(&my_ovf[L - CW_LEVELS], ((unsigned long long)tpos_ << 32) | (cnt_ & 0x7FFFFFFFu) | (arr_ ? 0x80000000u : 0u),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     const bool upstream_failed = (dev_count && (dev_count->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL))) ||
                                  (dev_strings && (dev_strings->flags & 0xFu));
     // some string of the launch has a malformed escape (rare): then every string's record header is looked at
@@ -457,20 +508,30 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 const int key = valid ? (is_open ? h : plevel) : -1;
                 // (deeper than the device stack: the non-empty open at depth 63 is handed back below, at a lower position
                 //  than anything that would need a level beyond the stack)
-                if (hmax >= CW_LEVELS) hmax = CW_LEVELS - 1;
+                if (hmax >= level_cap) hmax = level_cap - 1;
                 if (abl & 2u) hmax = hmin - 1;
                 for (int L = hmin; L <= hmax; ++L) {
                     const unsigned long long O = __ballot(is_open && h == L);                 // opens of level L
                     const unsigned long long C = __ballot(valid && cls == K_COMMA && plevel == L);  // commas directly inside level L
                     const unsigned long long Z = __ballot(is_close && plevel == L);            // closes of level-L containers
-                    const uint32_t sk_tpos = (uint32_t)__builtin_amdgcn_readlane((int)st_tpos, L);
-                    const uint32_t sk_cnt = (uint32_t)__builtin_amdgcn_readlane((int)st_cnt, L);
+                    uint32_t sk_tpos, sk_cnt;
+                    bool lv_arr;
+                    if (L < CW_LEVELS) {
+                        sk_tpos = (uint32_t)__builtin_amdgcn_readlane((int)st_tpos, L);
+                        sk_cnt = (uint32_t)__builtin_amdgcn_readlane((int)st_cnt, L);
+                        lv_arr = ((arr_mask >> L) & 1ull) != 0;
+                    } else {  // (wave-uniform) a level beyond the stack registers
+                        const unsigned long long v = ovf_read(L);
+                        sk_tpos = (uint32_t)(v >> 32);
+                        sk_cnt = (uint32_t)v & 0x7FFFFFFFu;
+                        lv_arr = ((uint32_t)v >> 31) != 0;
+                    }
                     if (key == L) kc = (uint32_t)__popcll(C & lt_mask);
                     if (valid && plevel == L) {
                         par_lane = highest_bit_below(O, lt_mask);
                         sk_t = sk_tpos;
                         sk_c = sk_cnt;
-                        sk_arr = ((arr_mask >> L) & 1ull) != 0;
+                        sk_arr = lv_arr;
                     }
                     // stack update for the next steps (wave-uniform)
                     if (O) {
@@ -479,12 +540,17 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                         if (!(Z & above)) {  // still open at the end of the step
                             const uint32_t tp = (uint32_t)__builtin_amdgcn_readlane((int)tpos, al);
                             const uint32_t kc_ = (uint32_t)__builtin_amdgcn_readlane((int)cls, al);
-                            st_tpos = lane == L ? tp : st_tpos;
-                            st_cnt = lane == L ? (uint32_t)__popcll(C & above) : st_cnt;
-                            arr_mask = kc_ == K_OPEN_A ? (arr_mask | (1ull << L)) : (arr_mask & ~(1ull << L));
+                            if (L < CW_LEVELS) {
+                                st_tpos = lane == L ? tp : st_tpos;
+                                st_cnt = lane == L ? (uint32_t)__popcll(C & above) : st_cnt;
+                                arr_mask = kc_ == K_OPEN_A ? (arr_mask | (1ull << L)) : (arr_mask & ~(1ull << L));
+                            } else {
+                                ovf_write(L, tp, (uint32_t)__popcll(C & above), kc_ == K_OPEN_A);
+                            }
                         }
                     } else if (!Z && C) {
-                        st_cnt = lane == L ? sk_cnt + (uint32_t)__popcll(C) : st_cnt;
+                        if (L < CW_LEVELS) st_cnt = lane == L ? sk_cnt + (uint32_t)__popcll(C) : st_cnt;
+                        else ovf_write(L, sk_tpos, sk_cnt + (uint32_t)__popcll(C), lv_arr);
                     }
                 }
                 const bool par_in_wave = par_lane >= 0;
@@ -531,11 +597,21 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                         if (cls <= K_OPEN_O) {
                             if (!empty_open) {
                                 if (h + 1 >= max_depth) err = SJMI_E_DEPTH;                  // JsonIterator.java:69-70
-                                else if (h + 1 >= CW_LEVELS) err = SJMI_WALK_NEEDS_HOST;     // deeper than the device stack
+                                else if (h + 1 >= level_cap) err = SJMI_WALK_NEEDS_HOST;     // deeper than the device stack
                             }
                         } else if (cls != K_QUOTE) {
                             if (!(abl & 1u)) err = cw_primitive(buf, win, p, i == from, doc_end, &ptype, &praw);
                             else ptype = 'n';
+                            if (err == CW_SLOW_DOUBLE) {  // (rare) listed for k_slow_doubles, which overwrites the candidate
+                                err = 0;
+                                const unsigned long long slot = atomicAdd(slow.count, 1ull);
+                                if (slot < slow.cap && tpos + 1 < room) {
+                                    slow.rec[2 * slot] = reinterpret_cast<unsigned long long>(T + tpos + 1);
+                                    slow.rec[2 * slot + 1] = (unsigned long long)p | ((unsigned long long)(i == from ? doc_end : 0xFFFFFFFFu) << 32);
+                                } else {
+                                    err = SJMI_WALK_NEEDS_HOST;  // (more than 65,536 such literals in one launch)
+                                }
+                            }
                         }
                     }
                 }
@@ -613,7 +689,9 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 // the walker reads on past the last structural: BitIndexes' sentinel = the document's first byte, an opening
                 // bracket where a separator is due (BitIndexes.java:82-96, JsonIterator.java:131,:189)
                 const int top = (int)H0 - 1;
-                code = (top >= 0 && top < CW_LEVELS && ((arr_mask >> top) & 1ull)) ? SJMI_E_NO_COMMA_ARRAY : SJMI_E_NO_COMMA_OBJECT;
+                bool top_arr = top >= 0 && top < CW_LEVELS && ((arr_mask >> top) & 1ull);
+                if (top >= CW_LEVELS && top < level_cap) top_arr = ((uint32_t)ovf_read(top) >> 31) != 0;
+                code = top_arr ? SJMI_E_NO_COMMA_ARRAY : SJMI_E_NO_COMMA_OBJECT;
             }
             if (code == 0) {
                 tlen = T0 + 1;  // + the closing root word
@@ -1204,13 +1282,30 @@ static ChunkWs chunk_ws(void* ws, uint64_t count_bound) {
 // d_chunk_ws != nullptr and one document of more than COOP_CHUNK_MIN structurals (by its bound): the chunk-parallel path,
 // with the single-wave sweep queued behind it for the (flagged) cases it does not take
 constexpr uint64_t COOP_CHUNK_MIN = 4096;
+constexpr uint64_t COOP_WALK_MAX_GRID = 8192;  // workgroups of the wave-per-document kernel (grid-stride over the documents)
+static size_t coop_slow_bytes() { return 64 + (size_t)CW_SLOW_CAP * 16; }
+// the list of undecided literals + the deep levels of every wave of that kernel (see k_coop_walk)
+size_t coop_deep_workspace_bytes(uint64_t n_docs) {
+    const uint64_t want = (n_docs + 3) / 4;
+    return coop_slow_bytes() + (size_t)(want < COOP_WALK_MAX_GRID ? want : COOP_WALK_MAX_GRID) * 4 * CW_OVF_LEVELS * sizeof(unsigned long long);
+}
 hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_idx,
                             const unsigned long long* d_index_offsets, const uint32_t* d_doc_status, const uint32_t* d_soff,
                             const uint8_t* d_sb, const unsigned long long* d_doc_str_offsets, uint64_t string_base,
                             int max_depth, unsigned long long* d_scratch_tape, uint32_t* d_tape_lens, int32_t* d_doc_errors,
                             const Stage1Result* dev_count, const UnescapeResult* dev_strings, WalkResult* d_res,
-                            hipStream_t stream, void* d_chunk_ws, uint64_t count_bound) {
+                            hipStream_t stream, void* d_chunk_ws, uint64_t count_bound, void* d_deep_ws) {
     if (!n_docs) return hipSuccess;
+    // (the deep-level workspace begins with the list of undecided literals)
+    SlowList slow;
+    slow.count = static_cast<unsigned long long*>(d_deep_ws);
+    slow.rec = slow.count + 8;
+    slow.cap = CW_SLOW_CAP;
+    d_deep_ws = static_cast<uint8_t*>(d_deep_ws) + coop_slow_bytes();
+    {
+        hipError_t e0 = hipMemsetAsync(slow.count, 0, 64, stream);
+        if (e0 != hipSuccess) return e0;
+    }
     const uint32_t abl = (uint32_t)(getenv("SJMI_COOP_ABLATE") ? atoi(getenv("SJMI_COOP_ABLATE")) : 0);
     ChunkWs cw = {};
     static const bool no_chunks = getenv("SJMI_COOP_CHUNKS") && atoi(getenv("SJMI_COOP_CHUNKS")) == 0;
@@ -1231,16 +1326,19 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
         hipLaunchKernelGGL(k_group_replay, dim3(ggrid), dim3(256), 0, stream, d_index_offsets, cw);
         hipLaunchKernelGGL((k_coop_walk<true>), dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets,
                            d_doc_status, d_soff, d_sb, d_doc_str_offsets, (unsigned long long)string_base, max_depth,
-                           d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res, abl, cw, (const uint32_t*)nullptr);
+                           d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res, abl, cw, (const uint32_t*)nullptr,
+                           (unsigned long long*)nullptr, slow);
         hipLaunchKernelGGL(k_chunk_finish, dim3(1), dim3(64), 0, stream, d_buf, d_idx, d_index_offsets, d_doc_status, d_scratch_tape,
                            d_tape_lens, d_doc_errors, dev_count, dev_strings, cw);
         only_if = cw.fallback;
     }
     const uint64_t want = (n_docs + 3) / 4;  // four documents (waves) per workgroup and trip
-    const unsigned grid = (unsigned)(want < 16384 ? want : 16384);
+    const unsigned grid = (unsigned)(want < COOP_WALK_MAX_GRID ? want : COOP_WALK_MAX_GRID);
     hipLaunchKernelGGL((k_coop_walk<false>), dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets,
                        d_doc_status, d_soff, d_sb, d_doc_str_offsets, (unsigned long long)string_base, max_depth,
-                       d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res, abl, cw, only_if);
+                       d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res, abl, cw, only_if,
+                       static_cast<unsigned long long*>(d_deep_ws), slow);
+    hipLaunchKernelGGL(k_slow_doubles, dim3(256), dim3(64), 0, stream, d_buf, slow);  // (nothing listed: 256 waves that leave at once)
     return hipGetLastError();
 }
 

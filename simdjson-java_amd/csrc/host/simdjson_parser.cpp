@@ -4,6 +4,8 @@
 #include "simdjson_parser.h"
 #include "ondemand.h"
 #include "../sj_number.h"
+#include "../sj_bigdec.h"
+#include "../sj_bigdec.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -555,12 +557,7 @@ static inline bool isNull(const uint8_t* b) { return b[0] == 'n' && b[1] == 'u' 
 
 // NumberParser.parseNumber (NumberParser.java:23-74), ExponentParser.parse (ExponentParser.java:14-69),
 // isOutOfLongRange (NumberParser.java:313-328).  Doubles: the reference's DoubleParser is a correctly rounded,
-// saturating decimal->binary64 conversion (DoubleParser.java:79-330); strtod has the same contract.
-static locale_t cLocale() {
-    static const locale_t c = newlocale(LC_ALL_MASK, "C", (locale_t)0);
-    return c;
-}
-
+// saturating decimal->binary64 conversion (DoubleParser.java:79-330).
 void DocWalker::parseNumber(const uint8_t* p) {
     // grammar + Clinger / Eisel-Lemire conversion shared with the device walkers (csrc/sj_number.h): locale-independent,
     // no allocation, the literal is scanned in place (the buffer is padded and the literal ends at a structural or
@@ -571,10 +568,16 @@ void DocWalker::parseNumber(const uint8_t* p) {
         unsigned long long bits;
         if (!sjmi::sj_number_double_bits(n, &bits)) {
             // more than 19 significant digits AND within 10^-19 of a rounding boundary: the reference's slow path
-            // (DoubleParser.java:205-330), a correctly rounded saturating conversion -- strtod_l in the "C" locale has
-            // the same contract.  Never plain strtod: a JVM host process calls setlocale(LC_ALL, ""), and under a comma
-            // locale strtod("1.5") returns 1.0.
-            tape_.appendDouble(strtod_l(reinterpret_cast<const char*>(p), nullptr, cLocale()));
+            // (DoubleParser.java:205-330) -- here the exact comparison with the midpoint of the two candidates (sj_bigdec.h:
+            // big integers on the stack, no libc: a JVM host's locale cannot touch it)
+            uint32_t wa[sjmi::SJ_BIG_WORDS], wb[sjmi::SJ_BIG_WORDS];
+            const uint32_t start = n.negative ? 1u : 0u;
+            const unsigned long long mag =
+                sjmi::sj_decide_double([&](uint32_t q) -> uint32_t { return p[q]; }, start, bits & ~(1ull << 63), wa, wb);
+            bits = mag | (n.negative ? 1ull << 63 : 0ull);
+            double v;
+            memcpy(&v, &bits, 8);
+            tape_.appendDouble(v);
         } else {
             double v;
             memcpy(&v, &bits, 8);

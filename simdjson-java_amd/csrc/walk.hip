@@ -113,9 +113,12 @@ static size_t walk_sums_offset(uint64_t count, uint64_t n_docs) { return walk_le
 static size_t walk_chunks_offset(uint64_t count, uint64_t n_docs) {
     return (walk_sums_offset(count, n_docs) + ((n_docs + PACK_DOCS - 1) / PACK_DOCS + 2) * sizeof(unsigned long long) + 64 + 255) / 256 * 256;
 }
+static size_t walk_deep_offset(uint64_t count, uint64_t n_docs) {
+    return (walk_chunks_offset(count, n_docs) + (n_docs == 1 ? coop_chunk_workspace_bytes(count) : 0) + 255) / 256 * 256;
+}
 size_t walk_workspace_bytes(uint64_t count, uint64_t n_docs) {
-    // (+ the chunk states of the chunk-parallel path for one large document)
-    return walk_chunks_offset(count, n_docs) + (n_docs == 1 ? coop_chunk_workspace_bytes(count) : 0);
+    // (+ the chunk states of the chunk-parallel path for one large document, + the deep nesting levels of every wave)
+    return walk_deep_offset(count, n_docs) + coop_deep_workspace_bytes(n_docs);
 }
 
 hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_idx,
@@ -140,7 +143,8 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
         // the cooperative walker (coop_walk.hip): a wave per document; STRING payloads from the string pass's record table
         e = coop_walk_launch(d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets, d_doc_status, d_soff, d_sb,
                              d_doc_str_ordinals, string_base, max_depth, scratch, lens, d_doc_errors, dev_count, dev_strings, d_res,
-                             stream, n_docs == 1 ? ws + walk_chunks_offset(count, n_docs) : nullptr, count);
+                             stream, n_docs == 1 ? ws + walk_chunks_offset(count, n_docs) : nullptr, count,
+                             ws + walk_deep_offset(count, n_docs));
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_tape_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, lens, d_doc_errors, n_docs, sums, d_res);
     }

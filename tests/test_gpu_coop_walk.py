@@ -105,12 +105,36 @@ def test_documents_spanning_many_steps(ctx):
         assert _single(ctx, d) == "ok", d[:60]
     tapes, strings, errors = gpu_walk(ctx, docs)
     check_against_oracle(docs, tapes, strings, errors)
-    # handed back: a non-empty container at depth 63
-    tape, strings, err, st = ctx.parse_document(b"[" * 64 + b"1" + b"]" * 64)
-    assert err == NEEDS_HOST and tape is None
-    # the same document with a depth limit below the device stack: the reference's depth error instead
+    # deeper than the 64 levels the walker keeps in registers: levels 64 .. 1023 live in global memory -- the tape is still the
+    # oracle's, word for word, up to the reference's default maxDepth (SimdJsonParser.java:7, JsonIterator.java:20-23)
+    rng = random.Random(78)
+    deep = [b"[" * d + b"1" + b"]" * d for d in (64, 65, 100, 500, 1000, 1022, 1023)]
+    deep += [b'{"a":' * d + b"[1,2,{}]" + b"}" * d for d in (64, 200, 1020)]
+    deep.append(b"[" * 300 + b",".join(b"[" * 70 + b'"x",2' + b"]" * 70 for _ in range(5)) + b"]" * 300)  # up and down across level 64 .. 370
+    kinds = [rng.choice("[{") for _ in range(900)]  # arrays and objects alternating at random, 900 deep
+    deep.append(("".join("[" if k == "[" else '{"k":' for k in kinds) + "0" + "".join("]" if k == "[" else "}" for k in reversed(kinds))).encode())
+    for d in deep:
+        assert _single(ctx, d) == "ok", (len(d), d[:20])
+    tapes, strings, errors = gpu_walk(ctx, deep)
+    import sys
+    limit = sys.getrecursionlimit()
+    sys.setrecursionlimit(20000)  # (the tree comparison of the checker recurses per level)
+    try:
+        check_against_oracle(deep, tapes, strings, errors)
+    finally:
+        sys.setrecursionlimit(limit)
+    # commas and counts of containers that live in the overflow levels; errors there
+    for d in (b"[" * 100 + b"1,2,3" + b"]" * 100, b"[" * 100 + b"1 2" + b"]" * 100, b"[" * 100 + b"1" + b"]" * 99, b"[" * 99 + b"1" + b"]" * 100,
+              b'{"a":' * 80 + b'"v", "b":1' + b"}" * 80, b"[" * 80 + b"[],[]" + b"]" * 80, b"[" * 80 + b"1," + b"]" * 80):
+        assert _single(ctx, d) == "ok", d[:20]
+    # the reference's depth error at its default limit, and at a limit below the register levels
+    tape, strings, err, st = ctx.parse_document(b"[" * 1024 + b"1" + b"]" * 1024)
+    assert err == 28
     tape, strings, err, st = ctx.parse_document(b"[" * 64 + b"1" + b"]" * 64, max_depth=20)
     assert err == 28
+    # handed back: a depth limit above the 1024 levels the device keeps
+    tape, strings, err, st = ctx.parse_document(b"[" * 1030 + b"1" + b"]" * 1030, max_depth=4096)
+    assert err == NEEDS_HOST and tape is None
 
 
 def test_large_array_count_saturates(ctx):
@@ -151,7 +175,7 @@ def test_large_documents_chunk_parallel(ctx):
     handed = 0
     for d in docs:
         handed += _single(ctx, d.encode()) == "host"
-    assert handed == 1  # the 70-level staircase
+    assert handed == 0  # (the 70-level staircase too: the single-wave sweep keeps levels 64 .. 1023 in global memory)
     for name in ("twitter.json", "github_events.json"):
         base = load_fixture(name)
         for _ in range(60):

@@ -118,3 +118,40 @@ def test_reference_number_vectors(walk):
         doc = v["input"].encode("utf-8")[:v.get("length")]
         n += _check(walk, doc)
     assert n >= 150
+
+
+def test_literals_at_rounding_boundaries_are_decided_exactly(walk):
+    """DoubleParser.slowlyParseDouble (DoubleParser.java:216-330): more than 19 significant digits, within 10^-19 of the
+    midpoint of two doubles -- the exact comparison of csrc/sj_bigdec.h (big integers, no libc) against the oracle's strtod:
+    exact midpoints (ties to even), midpoints nudged up / down far behind the 19th digit, more than 800 digits (the digits
+    left out only count as "something more"), subnormals, the neighbourhood of the largest double and of zero."""
+    import struct
+    from decimal import Decimal, getcontext
+    from tests.walk_common import AMBIGUOUS
+    getcontext().prec = 2400
+    rng = random.Random(2026)
+    lits = list(AMBIGUOUS)
+    for exp in [0, 1, 2, 52, 500, 1000, 1021, 1022, 1023, 1024, 1076, 1500, 2044, 2045, 2046]:
+        for _ in range(12):
+            bits = (rng.getrandbits(52) if exp else rng.randrange(0, 1 << 52)) | (exp << 52)
+            if exp == 2046:
+                bits = (exp << 52) | ((1 << 52) - 1)  # the largest double: its "successor" is infinity
+            lo = Decimal(struct.unpack("<d", struct.pack("<Q", bits))[0])
+            hi = Decimal(struct.unpack("<d", struct.pack("<Q", bits + 1))[0]) if exp != 2046 else Decimal(2) ** 1024
+            text = format((lo + hi) / 2, "f")
+            if "." not in text:
+                text += ".0"
+            lits.append(text)                                   # the tie itself
+            lits.append(text + "0" * rng.choice([1, 30, 900]) + "1")  # a hair above (also: far behind the 800th digit)
+            t = text.rstrip("0")
+            if t[-1] != ".":
+                lits.append(t[:-1] + str(int(t[-1]) - 1) + "9" * rng.choice([12, 60, 1000]))  # a hair below
+            if exp > 1100:  # the same with an exponent instead of leading digits
+                mant, _, frac = text.partition(".")
+                lits.append(mant[0] + "." + mant[1:] + frac + "e%d" % (len(mant) - 1))
+    checked = 0
+    for lit in lits:
+        for sign in ("", "-"):
+            checked += _check(walk, ("[" + sign + lit + "]").encode())
+            checked += _check(walk, (sign + lit).encode())  # as a root value (TapeBuilder.java:183-189: the padded copy)
+    assert checked == 4 * len(lits) and len(lits) > 500
