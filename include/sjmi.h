@@ -138,6 +138,34 @@ int sjmi_stage1_shard_device(sjmi_ctx* ctx, const void* d_buf, uint64_t len, uin
 int sjmi_stage1_shard_device2(sjmi_ctx* ctx, const void* d_buf, uint64_t len, uint64_t halo_bytes, int halo_from_document_start,
                               int is_last, int entry_parity, void* d_indexes, uint64_t index_capacity, void* d_result, void* stream);
 
+/* The same as a PRODUCT feature, with the protocol's state kept in C (no per-chunk allocation, nothing for a binding to
+ * re-implement): ONE document as a stream of chunks on one GPU -- a document of any length (the 4 GiB - 1 of uint32 indexes
+ * and the 2 GiB of a Java byte[] apply to a chunk, not to the stream).  sjmi_stream_open sizes the device buffers once
+ * (max_chunk_bytes per push; halo_bytes, a multiple of 64, 0 = 64: how much of the stream in front of a chunk stage 1 looks
+ * at; up to 4 KiB of the stream are kept on the device, and a chunk whose halo proves too short -- SJMI_ST_HALO -- is
+ * repeated with more of them by the call itself).  sjmi_stream_push: chunk = host bytes, every chunk but the last a non-zero
+ * multiple of 64 long; indexes[0..*count] = the chunk's structurals RELATIVE to the chunk (+ the sentinel), *base = the
+ * chunk's offset in the stream; *status = the document's verdict so far (SJMI_ST_UNCLOSED only behind the last chunk).
+ * The in-string parity is carried from chunk to chunk, so every chunk is scanned exactly once. */
+typedef struct sjmi_stream sjmi_stream;
+int sjmi_stream_open(sjmi_ctx* ctx, uint64_t max_chunk_bytes, uint64_t halo_bytes, sjmi_stream** out);
+int sjmi_stream_push(sjmi_stream* s, const uint8_t* chunk, uint64_t len, int is_last, uint32_t* indexes, uint64_t index_capacity,
+                     uint64_t* count, uint64_t* base, uint32_t* status);
+void sjmi_stream_close(sjmi_stream* s);
+/* ... and one rank's shard of a document split over several GPUs (arguments as sjmi_stage1_shard_device2; everything stays
+ * on the device).  sjmi_split_scan: the shard as if it began outside a string; *flips_parity = does it flip the in-string
+ * parity -- all_gather that bit (the first collective).  sjmi_split_resolve(entry_parity = XOR of the flips of the ranks in
+ * front): scans again ONLY if the entry parity is 1; -> the shard's count / status bits / parity behind it -- all_gather
+ * those (the second collective): global index offsets = prefix sums of the counts, the document is unclosed iff the LAST
+ * shard's parity_after is 1.  (A shard entered inside a string costs a second scan: both polarities in one pass would double
+ * the index stores of the hot kernel for everybody) */
+typedef struct sjmi_split sjmi_split;
+int sjmi_split_open(sjmi_ctx* ctx, const void* d_shard, uint64_t len, uint64_t halo_bytes, int halo_from_document_start, int is_last,
+                    void* d_indexes, uint64_t index_capacity, sjmi_split** out);
+int sjmi_split_scan(sjmi_split* s, void* stream, int* flips_parity, uint32_t* status);
+int sjmi_split_resolve(sjmi_split* s, int entry_parity, void* stream, uint64_t* count, uint32_t* status, int* parity_after);
+void sjmi_split_close(sjmi_split* s);
+
 /* device-side result record of one unescape call */
 typedef struct sjmi_unescape_result {
     uint64_t total_bytes;      /* bytes of [be32 length][unescaped bytes] records written */

@@ -71,6 +71,7 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_value_next", "sjmi_parse_batch_device", "sjmi_parse_document",
            "sjmi_parser_set_gpu_walk", "sjmi_set_auto_safe", "sjmi_match_brackets",
            "sjmi_match_brackets_device", "sjmi_stage1_shard_device", "sjmi_stage1_shard_device2",
+           "sjmi_stream_open", "sjmi_stream_push", "sjmi_stream_close", "sjmi_split_open", "sjmi_split_scan", "sjmi_split_resolve", "sjmi_split_close",
            "sjmi_parser_ondemand_init", "sjmi_od_skip_child", "sjmi_od_get_boolean", "sjmi_od_get_long", "sjmi_od_get_integral", "sjmi_od_get_double", "sjmi_od_get_float", "sjmi_od_get_char",
            "sjmi_od_get_string", "sjmi_od_get_field_name", "sjmi_od_start_array", "sjmi_od_next_array_element",
            "sjmi_od_start_object", "sjmi_od_next_object_field", "sjmi_od_move_to_field_value", "sjmi_od_assert_no_more_values",
@@ -440,6 +441,14 @@ class Context:
                                                     1 if is_last else 0, 1 if entry_parity else 0,
                                                     d_indexes, index_capacity, d_result, stream), "sjmi_stage1_shard_device2")
 
+    def stream(self, max_chunk_bytes, halo_bytes=0):
+        """sjmi_stream_open: one document as a stream of chunks -> a Stream (push(chunk, is_last), close())."""
+        return Stream(self, max_chunk_bytes, halo_bytes)
+
+    def split(self, d_shard, length, halo_bytes, halo_from_start, is_last, d_indexes, index_capacity):
+        """sjmi_split_open: one rank's shard of a document split over GPUs -> a Split (scan(), resolve(entry_parity), close())."""
+        return Split(self, d_shard, length, halo_bytes, halo_from_start, is_last, d_indexes, index_capacity)
+
     def set_auto_safe(self, on):
         self._check(lib().sjmi_set_auto_safe(self._h, 1 if on else 0), "sjmi_set_auto_safe")
 
@@ -697,6 +706,72 @@ class SimdJsonParser:
         strings = bytes(view(sb_p, sb_len.value, np.uint8))
         tapes = [alltape[int(to[k]):int(to[k + 1])] if errors[k] == 0 else None for k in range(n)]
         return tapes, strings, errors
+
+
+class Stream:
+    """sjmi_stream_*: chunks of one document, scanned once each; push -> (base offset, indexes relative to the chunk, status so far)"""
+
+    def __init__(self, ctx, max_chunk_bytes, halo_bytes=0):
+        L = lib()
+        L.sjmi_stream_open.restype = C.c_int
+        L.sjmi_stream_open.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
+        L.sjmi_stream_push.restype = C.c_int
+        L.sjmi_stream_push.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sjmi_stream_close.restype = None
+        L.sjmi_stream_close.argtypes = [C.c_void_p]
+        self._ctx, self._max = ctx, int(max_chunk_bytes)
+        h = C.c_void_p()
+        ctx._check(L.sjmi_stream_open(ctx._h, self._max, halo_bytes, C.byref(h)), "sjmi_stream_open")
+        self._h = h
+        self._idx = np.empty(self._max + 70, dtype=np.uint32)
+
+    def push(self, chunk, is_last):
+        a = np.frombuffer(bytes(chunk), dtype=np.uint8)
+        count, base, st = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+        self._ctx._check(lib().sjmi_stream_push(self._h, a.ctypes.data if a.size else None, a.size, 1 if is_last else 0, self._idx.ctypes.data,
+                                                self._idx.size, C.byref(count), C.byref(base), C.byref(st)), "sjmi_stream_push")
+        return base.value, self._idx[:count.value].copy(), st.value
+
+    def close(self):
+        if self._h:
+            lib().sjmi_stream_close(self._h)
+            self._h = None
+
+
+class Split:
+    """sjmi_split_*: scan() -> (flips the parity?, status bits); resolve(entry_parity) -> (count, status bits, parity behind the shard)"""
+
+    def __init__(self, ctx, d_shard, length, halo_bytes, halo_from_start, is_last, d_indexes, index_capacity):
+        L = lib()
+        L.sjmi_split_open.restype = C.c_int
+        L.sjmi_split_open.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+        L.sjmi_split_scan.restype = C.c_int
+        L.sjmi_split_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sjmi_split_resolve.restype = C.c_int
+        L.sjmi_split_resolve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sjmi_split_close.restype = None
+        L.sjmi_split_close.argtypes = [C.c_void_p]
+        self._ctx = ctx
+        h = C.c_void_p()
+        ctx._check(L.sjmi_split_open(ctx._h, d_shard, length, halo_bytes, 1 if halo_from_start else 0, 1 if is_last else 0, d_indexes,
+                                     index_capacity, C.byref(h)), "sjmi_split_open")
+        self._h = h
+
+    def scan(self, stream=0):
+        flips, st = C.c_int(0), C.c_uint32(0)
+        self._ctx._check(lib().sjmi_split_scan(self._h, stream, C.byref(flips), C.byref(st)), "sjmi_split_scan")
+        return flips.value, st.value
+
+    def resolve(self, entry_parity, stream=0):
+        count, st, after = C.c_uint64(0), C.c_uint32(0), C.c_int(0)
+        self._ctx._check(lib().sjmi_split_resolve(self._h, 1 if entry_parity else 0, stream, C.byref(count), C.byref(st), C.byref(after)),
+                         "sjmi_split_resolve")
+        return count.value, st.value, after.value
+
+    def close(self):
+        if self._h:
+            lib().sjmi_split_close(self._h)
+            self._h = None
 
 
 class OnDemandIterator:

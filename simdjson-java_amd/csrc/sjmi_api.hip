@@ -1209,6 +1209,192 @@ int sjmi_kernel_time(sjmi_ctx* c, double* sum_ms, uint32_t* launches) {
     return SJMI_OK;
 }
 
+// ---- one document as a stream of chunks / one shard of a document split over GPUs: the protocol state in C ----------------
+// (the reference has one byte[] per parse and no counterpart)
+struct sjmi_stream {
+    sjmi_ctx* c = nullptr;
+    uint8_t* d_buf = nullptr;       // [keep bytes of the stream in front of the chunk | the chunk | padding]
+    uint32_t* d_idx = nullptr;
+    sjmi_stage1_result* d_res = nullptr;
+    uint64_t max_chunk = 0, keep = 0, halo = 0;
+    uint64_t have = 0;              // bytes of the stream kept in front of the next chunk (<= keep, the END of [0, keep))
+    uint64_t offset = 0;            // stream offset of the next chunk
+    int parity = 0;                 // in-string parity after the chunks so far
+    uint32_t status = 0;
+    bool finished = false;
+};
+
+int sjmi_stream_open(sjmi_ctx* c, uint64_t max_chunk_bytes, uint64_t halo_bytes, sjmi_stream** out) {
+    if (!c || !out || !max_chunk_bytes || max_chunk_bytes >= (1ull << 32) || (halo_bytes & 63)) return SJMI_ERR_ARG;
+    *out = nullptr;
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    sjmi_stream* s = new (std::nothrow) sjmi_stream();
+    if (!s) return SJMI_ERR_ARG;
+    s->c = c;
+    s->max_chunk = (max_chunk_bytes + 63) / 64 * 64;
+    s->halo = halo_bytes ? halo_bytes : 64;
+    s->keep = s->halo > 4096 ? s->halo : 4096;  // what a chunk can be repeated with when its halo proves too short
+    if (fail(c, "hipMalloc(stream)", hipMalloc((void**)&s->d_buf, s->keep + s->max_chunk + 2 * SJMI_PADDING)) ||
+        fail(c, "hipMalloc(stream idx)", hipMalloc((void**)&s->d_idx, (s->max_chunk + 66) * sizeof(uint32_t) + s->keep)) ||
+        fail(c, "hipMalloc(stream res)", hipMalloc((void**)&s->d_res, sizeof(sjmi_stage1_result)))) {
+        sjmi_stream_close(s);
+        return SJMI_ERR_HIP;
+    }
+    *out = s;
+    return SJMI_OK;
+}
+
+void sjmi_stream_close(sjmi_stream* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->c->device);
+    (void)hipStreamSynchronize(s->c->stream);
+    if (s->d_buf) (void)hipFree(s->d_buf);
+    if (s->d_idx) (void)hipFree(s->d_idx);
+    if (s->d_res) (void)hipFree(s->d_res);
+    delete s;
+}
+
+int sjmi_stream_push(sjmi_stream* s, const uint8_t* chunk, uint64_t len, int is_last, uint32_t* indexes, uint64_t index_capacity,
+                     uint64_t* count, uint64_t* base, uint32_t* status) {
+    if (!s || (!chunk && len) || !indexes || !count || !base || !status || s->finished) return SJMI_ERR_ARG;
+    if (len > s->max_chunk || (!is_last && ((len & 63) || len == 0))) return SJMI_ERR_ARG;
+    sjmi_ctx* c = s->c;
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    uint8_t* d_chunk = s->d_buf + s->keep;
+    if (len && fail(c, "H2D(chunk)", hipMemcpyAsync(d_chunk, chunk, len, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
+    const uint64_t dev_cap = s->max_chunk + 66 < index_capacity ? s->max_chunk + 66 : index_capacity;
+    sjmi_stage1_result r;
+    for (uint64_t want = s->halo;;) {
+        const uint64_t h = (want < s->have ? want : s->have) / 64 * 64;
+        const bool from_start = h == s->offset;  // the halo reaches back to the stream's first byte
+        const int rc = sjmi_stage1_shard_device2(c, d_chunk, len, h, from_start ? 1 : 0, is_last ? 1 : 0, s->parity, s->d_idx, dev_cap, s->d_res,
+                                                 nullptr);
+        if (rc != SJMI_OK) return rc;
+        if (fail(c, "D2H(result)", hipMemcpyAsync(&r, s->d_res, sizeof r, hipMemcpyDeviceToHost, c->stream)) ||
+            fail(c, "sync", hipStreamSynchronize(c->stream)))
+            return SJMI_ERR_HIP;
+        if ((r.status & SJMI_ST_INTERNAL) && !c->ticket_mode) {
+            c->ticket_mode = true;  // fast-mode liveness assumption failed: latch the safe mode and run again
+            continue;
+        }
+        if (!(r.status & SJMI_ST_HALO)) break;
+        if (h >= s->have / 64 * 64) {  // everything that is kept of the stream is one backslash run
+            c->err = "sjmi_stream_push: a backslash run longer than the bytes kept of the stream";
+            return SJMI_ERR_CAPACITY;
+        }
+        want *= 4;
+    }
+    if (r.status & SJMI_ST_INTERNAL) return SJMI_ERR_INTERNAL;
+    if (r.status & SJMI_ST_CAPACITY) return SJMI_ERR_CAPACITY;
+    if (r.count + 1 > index_capacity) return SJMI_ERR_CAPACITY;
+    if (fail(c, "D2H(indexes)", hipMemcpyAsync(indexes, s->d_idx, (r.count + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)))
+        return SJMI_ERR_HIP;
+    // keep the end of the stream so far in front of the next chunk: [keep - have', keep)
+    if (!is_last) {
+        const uint64_t total = s->have + len, nh = total < s->keep ? total : s->keep;
+        // source: the last nh bytes of [keep - have, keep + len); destination: [keep - nh, keep) -- they may overlap: move
+        // through the free space behind the chunk when they do (nh <= keep <= max(halo, 4096): small)
+        const uint8_t* src = s->d_buf + s->keep + len - nh;
+        uint8_t* dst = s->d_buf + s->keep - nh;
+        if (src >= dst + nh || src + nh <= dst) {
+            if (fail(c, "D2D(keep)", hipMemcpyAsync(dst, src, nh, hipMemcpyDeviceToDevice, c->stream))) return SJMI_ERR_HIP;
+        } else {
+            uint8_t* bounce = reinterpret_cast<uint8_t*>(s->d_idx + s->max_chunk + 66);  // (`keep` spare bytes behind the index array)
+            if (fail(c, "D2D(keep)", hipMemcpyAsync(bounce, src, nh, hipMemcpyDeviceToDevice, c->stream)) ||
+                fail(c, "D2D(keep)", hipMemcpyAsync(dst, bounce, nh, hipMemcpyDeviceToDevice, c->stream)))
+                return SJMI_ERR_HIP;
+        }
+        s->have = nh;
+    }
+    if (fail(c, "sync", hipStreamSynchronize(c->stream))) return SJMI_ERR_HIP;
+    *count = r.count;
+    *base = s->offset;
+    s->parity = (r.status & SJMI_ST_UNCLOSED) ? 1 : 0;  // (a shard's UNCLOSED bit = the parity behind it)
+    s->status |= r.status & (SJMI_ST_UTF8 | SJMI_ST_UNESCAPED);
+    s->offset += len;
+    if (is_last) {
+        s->finished = true;
+        if (s->parity) s->status |= SJMI_ST_UNCLOSED;  // StructuralIndexer.java:297-299
+    }
+    *status = s->status;
+    c->par_valid = false;
+    c->last_valid = false;
+    return SJMI_OK;
+}
+
+// One rank's shard of a document split over GPUs (sjmi_stage1_shard_device2 with the protocol's bookkeeping): scan as if the
+// shard began outside a string; exchange sjmi_split_flips() with the other ranks (one bit per rank: the first collective);
+// sjmi_split_resolve(entry parity = XOR of the flips in front) scans again ONLY if that parity is 1; exchange the counts.
+struct sjmi_split {
+    sjmi_ctx* c = nullptr;
+    const void* d_shard = nullptr;
+    uint64_t len = 0, halo = 0, index_capacity = 0;
+    int halo_from_start = 0, is_last = 0, entry = 0, scans = 0;
+    void* d_indexes = nullptr;
+    sjmi_stage1_result* d_res = nullptr;
+    sjmi_stage1_result r{};
+};
+
+int sjmi_split_open(sjmi_ctx* c, const void* d_shard, uint64_t len, uint64_t halo_bytes, int halo_from_document_start, int is_last,
+                    void* d_indexes, uint64_t index_capacity, sjmi_split** out) {
+    if (!c || !d_shard || !d_indexes || !out) return SJMI_ERR_ARG;
+    *out = nullptr;
+    sjmi_split* s = new (std::nothrow) sjmi_split();
+    if (!s) return SJMI_ERR_ARG;
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device)) || fail(c, "hipMalloc(split res)", hipMalloc((void**)&s->d_res, sizeof(sjmi_stage1_result)))) {
+        delete s;
+        return SJMI_ERR_HIP;
+    }
+    s->c = c;
+    s->d_shard = d_shard;
+    s->len = len;
+    s->halo = halo_bytes;
+    s->halo_from_start = halo_from_document_start;
+    s->is_last = is_last;
+    s->d_indexes = d_indexes;
+    s->index_capacity = index_capacity;
+    *out = s;
+    return SJMI_OK;
+}
+void sjmi_split_close(sjmi_split* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->c->device);
+    if (s->d_res) (void)hipFree(s->d_res);
+    delete s;
+}
+static int split_scan(sjmi_split* s, int entry_parity, void* stream) {
+    sjmi_ctx* c = s->c;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    const int rc = sjmi_stage1_shard_device2(c, s->d_shard, s->len, s->halo, s->halo_from_start, s->is_last, entry_parity, s->d_indexes,
+                                             s->index_capacity, s->d_res, stream);
+    if (rc != SJMI_OK) return rc;
+    if (fail(c, "D2H(result)", hipMemcpyAsync(&s->r, s->d_res, sizeof s->r, hipMemcpyDeviceToHost, st)) || fail(c, "sync", hipStreamSynchronize(st)))
+        return SJMI_ERR_HIP;
+    s->entry = entry_parity;
+    ++s->scans;
+    if (s->r.status & SJMI_ST_INTERNAL) return SJMI_ERR_INTERNAL;
+    if (s->r.status & SJMI_ST_CAPACITY) return SJMI_ERR_CAPACITY;
+    return SJMI_OK;
+}
+int sjmi_split_scan(sjmi_split* s, void* stream, int* flips_parity, uint32_t* status) {
+    if (!s || !flips_parity || !status) return SJMI_ERR_ARG;
+    const int rc = split_scan(s, 0, stream);
+    *flips_parity = (s->r.status & SJMI_ST_UNCLOSED) ? 1 : 0;  // entered outside a string: the parity behind the shard IS the flip
+    *status = s->r.status & (SJMI_ST_UTF8 | SJMI_ST_UNESCAPED | SJMI_ST_HALO);
+    return rc;
+}
+int sjmi_split_resolve(sjmi_split* s, int entry_parity, void* stream, uint64_t* count, uint32_t* status, int* parity_after) {
+    if (!s || !count || !status || !parity_after || !s->scans) return SJMI_ERR_ARG;
+    if ((entry_parity != 0) != (s->entry != 0)) {
+        const int rc = split_scan(s, entry_parity ? 1 : 0, stream);
+        if (rc != SJMI_OK) return rc;
+    }
+    *count = s->r.count;
+    *status = s->r.status & (SJMI_ST_UTF8 | SJMI_ST_UNESCAPED | SJMI_ST_HALO);
+    *parity_after = (s->r.status & SJMI_ST_UNCLOSED) ? 1 : 0;
+    return SJMI_OK;
+}
+
 int sjmi_selftest(sjmi_ctx* c, uint32_t* mismatches) {
     if (!c || !mismatches) return SJMI_ERR_ARG;
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;

@@ -162,3 +162,64 @@ def test_backslash_run_that_fills_the_halo_is_reported(ctx):
         parts, status = sharding.stream_document(ctx, dev, [doc[:256], doc[256:]], halo=64)
         got = np.concatenate([idx + base for base, idx in parts])
         assert np.array_equal(got, want_idx) and status == want_st, run
+
+
+def test_stream_and_split_through_the_c_abi(ctx, twitter):
+    """sjmi_stream_* / sjmi_split_*: the protocol's state lives in C (include/sjmi.h), no chunk is scanned twice in stream mode,
+    an odd-parity shard exactly twice in split mode."""
+    import torch
+    dev = torch.device("cuda", 0)
+    # ---- stream: twitter x4 in uneven chunks, and the backslash run that fills the default halo ----
+    doc = twitter * 4
+    want_idx, want_st = O.stage1(doc)
+    cuts = [0, 65536, 65536 * 3, 1 << 20, (1 << 20) + 64, len(doc)]
+    s = ctx.stream(max(b - a for a, b in zip(cuts, cuts[1:])))
+    got, st = [], 0
+    for a, b in zip(cuts, cuts[1:]):
+        base, idx, st = s.push(doc[a:b], b == len(doc))
+        assert base == a
+        got.append(idx.astype(np.int64) + base)
+    s.close()
+    assert st == want_st and np.array_equal(np.concatenate(got), want_idx.astype(np.int64))
+    for run in (64, 65, 129, 1000, 1001):
+        pre = b'["' + b"a" * (2048 - 2 - run) + b"\\" * run
+        d = pre + b'","x"]       ' + b'"unclosed'
+        want_idx, want_st = O.stage1(d)
+        s = ctx.stream(4096)
+        b0, i0, _ = s.push(d[:2048], False)
+        b1, i1, st = s.push(d[2048:], True)
+        s.close()
+        assert st == want_st and np.array_equal(np.concatenate([i0.astype(np.int64), i1.astype(np.int64) + 2048]), want_idx.astype(np.int64)), run
+    # a run longer than everything the stream keeps (4 KiB): reported, not guessed
+    import simdjson_java_amd as S
+    s = ctx.stream(8192)
+    s.push(b'["' + b"\\" * 8190, False)
+    with pytest.raises(S.SjmiError):
+        s.push(b'\\"x"]' + b" " * 59, True)
+    s.close()
+    # ---- split: twitter x16 over 5 virtual ranks ----
+    from simdjson_java_amd import sharding
+    doc = twitter * 16
+    want_idx, want_st = O.stage1(doc)
+    bounds = sharding.split_points(len(doc), 8)
+    bufs, idxs, sp = [], [], []
+    for r, (a, b) in enumerate(bounds):
+        h = min(64, a)
+        t = torch.zeros(h + (b - a) + 128, dtype=torch.uint8, device=dev)
+        t[:h + b - a] = torch.frombuffer(bytearray(doc[a - h:b]), dtype=torch.uint8).to(dev)
+        ix = torch.empty(b - a + 66, dtype=torch.int32, device=dev)
+        bufs.append(t)
+        idxs.append(ix)
+        sp.append(ctx.split(t.data_ptr() + h, b - a, h, h == a, r == len(bounds) - 1, ix.data_ptr(), ix.numel()))
+    flips = [x.scan()[0] for x in sp]
+    out, status, rescans = [], 0, 0
+    for r, x in enumerate(sp):
+        entry = sum(flips[:r]) & 1
+        rescans += entry
+        count, st, after = x.resolve(entry)
+        status |= st
+        out.append(idxs[r][:count].cpu().numpy().view(np.uint32).astype(np.int64) + bounds[r][0])
+        x.close()
+    if after:
+        status |= O.ST_UNCLOSED
+    assert status == want_st and np.array_equal(np.concatenate(out), want_idx.astype(np.int64)), rescans
