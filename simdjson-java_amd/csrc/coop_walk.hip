@@ -285,6 +285,34 @@ k_slow_doubles(const uint8_t* __restrict__ buf, SlowList sl) {
     }
 }
 
+// ONE document whose tape was written in place: the listed literals, and what k_tape_chunk_sums + k_tape_chunk_scan (walk.hip)
+// would compute for it, in one launch of one wave
+__global__ void __launch_bounds__(64)
+k_single_finish(const uint8_t* __restrict__ buf, SlowList sl, const uint32_t* __restrict__ tape_lens, const int32_t* __restrict__ doc_errors,
+                uint64_t tape_capacity, unsigned long long* __restrict__ tape_offsets, WalkResult* res) {
+    __shared__ uint32_t wa[SJ_BIG_WORDS], wb[SJ_BIG_WORDS];
+    if (threadIdx.x != 0) return;
+    unsigned long long n = *sl.count;
+    if (n > sl.cap) n = sl.cap;
+    for (unsigned long long r = 0; r < n; ++r) {
+        unsigned long long* const slot = reinterpret_cast<unsigned long long*>(sl.rec[2 * r]);
+        const uint32_t p = (uint32_t)sl.rec[2 * r + 1], limit = (uint32_t)(sl.rec[2 * r + 1] >> 32);
+        const bool neg = buf[p] == '-';
+        const unsigned long long mag =
+            sj_decide_double([&](uint32_t q) -> uint32_t { return q < limit ? (uint32_t)buf[q] : 0x20u; }, p + (neg ? 1u : 0u),
+                             *slot & ~(1ull << 63), wa, wb);
+        *slot = mag | (neg ? 1ull << 63 : 0ull);
+    }
+    const unsigned long long words = tape_lens[0];
+    const int e = doc_errors[0];
+    tape_offsets[0] = 0;
+    tape_offsets[1] = words;
+    res->tape_words = words;
+    res->host_documents = e == SJMI_WALK_NEEDS_HOST ? 1 : 0;
+    res->failed_documents = e > 0 ? 1 : 0;
+    if (words > tape_capacity) res->flags |= 1u;
+}
+
 // One wave per document (grid-stride over the documents).  Documents are delimited by index_offsets (n_docs + 1 entries)
 // and doc_offsets; a single document is the batch of one.  Document k's tape is built in its slot of the scratch tape
 // (2 words per structural + 2, walk.hip packs the tapes back to back afterwards); sizes / scratch: the per-structural
@@ -1238,14 +1266,14 @@ static size_t chunk_bound(uint64_t count_bound) {  // n <= CW_SMALL_N: chunks of
 }
 static size_t group_bound(uint64_t count_bound) { return chunk_bound(count_bound) / 8 + 2; }
 size_t coop_chunk_workspace_bytes(uint64_t count_bound) {
-    return (chunk_bound(count_bound) + group_bound(count_bound)) * (4 * 64 * sizeof(uint32_t) + 24 * sizeof(unsigned long long)) + 4096;
+    return (chunk_bound(count_bound) + group_bound(count_bound)) * (4 * 64 * sizeof(uint32_t) + 24 * sizeof(unsigned long long)) + 4096 + 64;
 }
 
-static ChunkWs chunk_ws(void* ws, uint64_t count_bound) {
+static ChunkWs chunk_ws(void* ws, uint64_t count_bound, uint32_t* flags) {
     uint8_t* p = static_cast<uint8_t*>(ws);
     ChunkWs c;
     auto take = [&](size_t bytes) { uint8_t* r = p; p += (bytes + 63) / 64 * 64; return r; };
-    c.fallback = reinterpret_cast<uint32_t*>(take(64));
+    c.fallback = flags;  // (in the header of the undecided-literal list: one memset per launch covers both)
     c.fin = c.fallback + 4;
     auto sums = [&](size_t n) {
         ChunkSum q;
@@ -1294,7 +1322,8 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
                             const uint8_t* d_sb, const unsigned long long* d_doc_str_offsets, uint64_t string_base,
                             int max_depth, unsigned long long* d_scratch_tape, uint32_t* d_tape_lens, int32_t* d_doc_errors,
                             const Stage1Result* dev_count, const UnescapeResult* dev_strings, WalkResult* d_res,
-                            hipStream_t stream, void* d_chunk_ws, uint64_t count_bound, void* d_deep_ws) {
+                            hipStream_t stream, void* d_chunk_ws, uint64_t count_bound, void* d_deep_ws,
+                            unsigned long long* d_single_tape_offsets, uint64_t tape_capacity) {
     if (!n_docs) return hipSuccess;
     // (the deep-level workspace begins with the list of undecided literals)
     SlowList slow;
@@ -1312,9 +1341,7 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
     const bool chunked = d_chunk_ws && n_docs == 1 && count_bound > COOP_CHUNK_MIN && !no_chunks;
     const uint32_t* only_if = nullptr;
     if (chunked) {
-        cw = chunk_ws(d_chunk_ws, count_bound);
-        hipError_t e = hipMemsetAsync(cw.fallback, 0, 64, stream);
-        if (e != hipSuccess) return e;
+        cw = chunk_ws(d_chunk_ws, count_bound, reinterpret_cast<uint32_t*>(slow.count) + 8);  // (zeroed with the list's count above)
         const uint64_t nchunks = chunk_bound(count_bound);
         const uint64_t want = (nchunks + 3) / 4;
         const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
@@ -1338,7 +1365,11 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
                        d_doc_status, d_soff, d_sb, d_doc_str_offsets, (unsigned long long)string_base, max_depth,
                        d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res, abl, cw, only_if,
                        static_cast<unsigned long long*>(d_deep_ws), slow);
-    hipLaunchKernelGGL(k_slow_doubles, dim3(256), dim3(64), 0, stream, d_buf, slow);  // (nothing listed: 256 waves that leave at once)
+    if (d_single_tape_offsets)
+        hipLaunchKernelGGL(k_single_finish, dim3(1), dim3(64), 0, stream, d_buf, slow, d_tape_lens, d_doc_errors, tape_capacity,
+                           d_single_tape_offsets, d_res);
+    else
+        hipLaunchKernelGGL(k_slow_doubles, dim3(256), dim3(64), 0, stream, d_buf, slow);  // (nothing listed: 256 waves that leave at once)
     return hipGetLastError();
 }
 
@@ -1351,7 +1382,8 @@ hipError_t coop_match_launch(const uint8_t* d_buf, uint64_t n_docs, const uint32
     if (d_chunk_ws && n_docs == 1 && count_bound > COOP_CHUNK_MIN && !no_chunks) {
         // one large document: chunks by different waves (k_match_summary -> the walker's scan kernels -> k_coop_match<true>),
         // the single-wave kernel behind it for the flagged cases
-        cw = chunk_ws(d_chunk_ws, count_bound);
+        // (the flags of this path live in the first 64 bytes of the chunk workspace; the states behind them)
+        cw = chunk_ws(static_cast<uint8_t*>(d_chunk_ws) + 64, count_bound, static_cast<uint32_t*>(d_chunk_ws));
         hipError_t e = hipMemsetAsync(cw.fallback, 0, 64, stream);
         if (e != hipSuccess) return e;
         const uint64_t want = (chunk_bound(count_bound) + 3) / 4;

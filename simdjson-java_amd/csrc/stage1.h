@@ -124,7 +124,8 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
                             const uint8_t* d_sb, const unsigned long long* d_doc_str_ordinals, uint64_t string_base,
                             int max_depth, unsigned long long* d_scratch_tape, uint32_t* d_tape_lens, int32_t* d_doc_errors,
                             const Stage1Result* dev_count, const UnescapeResult* dev_strings, WalkResult* d_res,
-                            hipStream_t stream, void* d_chunk_ws = nullptr, uint64_t count_bound = 0, void* d_deep_ws = nullptr);
+                            hipStream_t stream, void* d_chunk_ws = nullptr, uint64_t count_bound = 0, void* d_deep_ws = nullptr,
+                            unsigned long long* d_single_tape_offsets = nullptr, uint64_t tape_capacity = 0);
 // nesting levels 64 .. 1023 of the wave-per-document walker live in global memory: bytes for a batch of n_docs documents
 size_t coop_deep_workspace_bytes(uint64_t n_docs);
 // workspace of the chunk-parallel path for one large document (coop_walk.hip)

@@ -141,11 +141,14 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
     const uint64_t nchunks = (n_docs + PACK_DOCS - 1) / PACK_DOCS;
     if (n_docs) {
         // the cooperative walker (coop_walk.hip): a wave per document; STRING payloads from the string pass's record table
+        // (direct = one document written in place: the walker's last launch also decides the listed literals and writes the
+        //  tape offsets and counters -- three small launches fewer on the single-document latency path)
         e = coop_walk_launch(d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets, d_doc_status, d_soff, d_sb,
                              d_doc_str_ordinals, string_base, max_depth, scratch, lens, d_doc_errors, dev_count, dev_strings, d_res,
                              stream, n_docs == 1 ? ws + walk_chunks_offset(count, n_docs) : nullptr, count,
-                             ws + walk_deep_offset(count, n_docs));
+                             ws + walk_deep_offset(count, n_docs), direct ? d_tape_offsets : nullptr, tape_capacity);
         if (e != hipSuccess) return e;
+        if (direct) return hipGetLastError();
         hipLaunchKernelGGL(k_tape_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, lens, d_doc_errors, n_docs, sums, d_res);
     }
     hipLaunchKernelGGL(k_tape_chunk_scan, dim3(1), dim3(1024), 0, stream, sums, nchunks, n_docs, tape_capacity, d_tape_offsets, d_res);
