@@ -49,39 +49,38 @@ enum : uint32_t { K_OPEN_A = 0, K_OPEN_O = 1, K_CLOSE_A = 2, K_CLOSE_O = 3, K_CO
 
 struct __attribute__((packed, aligned(1))) CW16 { uint32_t a, b, c, d; };
 
+// class of a structural from its first byte: (c * 25 >> 4) & 7 is a perfect hash of the seven structural characters
+// ('{' 0, ']' 1, ':' 2, '}' 3, ',' 4, '"' 5, '[' 6); two byte-table lookups (v_perm_b32) and one compare instead of seven
 __device__ __forceinline__ uint32_t class_of(uint32_t c) {
-    return c == '[' ? K_OPEN_A : c == '{' ? K_OPEN_O : c == ']' ? K_CLOSE_A : c == '}' ? K_CLOSE_O
-           : c == ',' ? K_COMMA : c == ':' ? K_COLON : c == '"' ? K_QUOTE : K_PRIM;
+    const uint32_t h = ((c * 25u) >> 4) & 7u;
+    const uint32_t sel = h | 0x0C0C0C00u;  // (selector 0x0C = constant zero byte)
+    const uint32_t want = __builtin_amdgcn_perm(0x7B5B222Cu, 0x7D3A5D7Bu, sel);   // bytes 0..7: { ] : } , " [ {
+    const uint32_t cls = __builtin_amdgcn_perm(0x07000604u, 0x03050201u, sel);    //             1 2 5 3 4 6 0 7
+    return c == want ? cls : K_PRIM;
 }
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t cw_dpp_add(uint32_t v) {
-    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
-}
+// The wave-wide ladders (inclusive sum, minimum, maximum) as ONE instruction per rung: the VOP2 form with a DPP source
+// operand, written in place -- a lane whose source lane does not exist (bound_ctrl 0) or whose row is masked out is not
+// written, i.e. keeps its own value, which is what every rung wants.  The compiler's own selection splits each rung into a
+// v_mov_b32_dpp plus the operation (25 moves per step of the walker); "s_nop 1" = the two wait states a DPP read of a VGPR
+// needs behind the VALU write of that VGPR.
+#define CW_DPP_LADDER(OP)                                                         \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"       \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"       \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"       \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"       \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"    \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
 __device__ __forceinline__ uint32_t cw_incl_scan(uint32_t v) {
-    v = cw_dpp_add<0x111, 0xF>(v);
-    v = cw_dpp_add<0x112, 0xF>(v);
-    v = cw_dpp_add<0x114, 0xF>(v);
-    v = cw_dpp_add<0x118, 0xF>(v);
-    v = cw_dpp_add<0x142, 0xA>(v);
-    v = cw_dpp_add<0x143, 0xC>(v);
+    asm volatile(CW_DPP_LADDER("v_add_u32_dpp") : "+v"(v));
     return v;
 }
-// wave-wide minimum / maximum of a signed value, uniform result: the same DPP ladder with min / max (lanes without a source
-// keep their own value), the full reduction arrives in lane 63 -- no LDS-crossbar shuffles on the step's dependency chain
-template <int CTRL, int ROW_MASK, bool IS_MAX>
-__device__ __forceinline__ int cw_dpp_minmax(int v) {
-    const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
-    return IS_MAX ? (o > v ? o : v) : (o < v ? o : v);
-}
+// wave-wide minimum / maximum of a signed value, uniform result: the full reduction arrives in lane 63 -- no LDS-crossbar
+// shuffles on the step's dependency chain
 template <bool IS_MAX>
 __device__ __forceinline__ int cw_wave_minmax(int v) {
-    v = cw_dpp_minmax<0x111, 0xF, IS_MAX>(v);
-    v = cw_dpp_minmax<0x112, 0xF, IS_MAX>(v);
-    v = cw_dpp_minmax<0x114, 0xF, IS_MAX>(v);
-    v = cw_dpp_minmax<0x118, 0xF, IS_MAX>(v);
-    v = cw_dpp_minmax<0x142, 0xA, IS_MAX>(v);
-    v = cw_dpp_minmax<0x143, 0xC, IS_MAX>(v);
+    if (IS_MAX) asm volatile(CW_DPP_LADDER("v_max_i32_dpp") : "+v"(v));
+    else asm volatile(CW_DPP_LADDER("v_min_i32_dpp") : "+v"(v));
     return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ uint32_t cw_last(uint32_t incl) { return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63); }
@@ -137,40 +136,41 @@ __device__ int cw_primitive(const uint8_t* buf, const CW16& win, uint32_t idx, b
     }
     if (c == '-' || c - '0' <= 9u) {
         // ---- fast path: an integer of at most 15 digits whose terminator is inside the window (most numbers of most
-        //      documents): branch-free SWAR -- digit run length from a "byte > 9" mask, eight digits per multiply chain ----
+        //      documents), branch-free and in 32-bit operations: digit-run length from a "byte > 9" mask; the digits are moved
+        //      to the top of a 16-byte field (zeros = leading zeros below them, terminator and whatever follows shifted out)
+        //      with dword selects + v_alignbyte_b32; four digits = two v_mad_u32_u24 (full rate; a 64-bit multiply chain costs
+        //      a dozen quarter-rate v_mul_lo/hi_u32) ----
         if (!root) {
-            unsigned long long x = (unsigned long long)win.a | ((unsigned long long)win.b << 32);
-            unsigned long long y = (unsigned long long)win.c | ((unsigned long long)win.d << 32);
-            const bool neg = c == '-';
-            if (neg) {
-                x = (x >> 8) | (y << 56);
-                y >>= 8;  // (the vacated top byte is 0: not a digit)
-            }
-            const unsigned long long M30 = 0x3030303030303030ull, M76 = 0x7676767676767676ull, H = 0x8080808080808080ull;
-            const unsigned long long tx = x ^ M30, ty = y ^ M30;  // digits become 0x00..0x09
-            const unsigned long long ndx = ((tx + M76) | tx) & H, ndy = ((ty + M76) | ty) & H;  // 0x80 where the byte is no digit
-            const uint32_t nd = ndx ? (uint32_t)__builtin_ctzll(ndx) >> 3 : 8u + (ndy ? (uint32_t)__builtin_ctzll(ndy) >> 3 : 8u);
+            const uint32_t sgn = c == '-' ? 1u : 0u;  // a negative number: the digits start one byte up (the vacated top byte is 0)
+            const uint32_t x0 = __builtin_amdgcn_alignbyte(win.b, win.a, sgn), x1 = __builtin_amdgcn_alignbyte(win.c, win.b, sgn),
+                           x2 = __builtin_amdgcn_alignbyte(win.d, win.c, sgn), x3 = __builtin_amdgcn_alignbyte(0u, win.d, sgn);
+            const uint32_t t0 = x0 ^ 0x30303030u, t1 = x1 ^ 0x30303030u, t2 = x2 ^ 0x30303030u, t3 = x3 ^ 0x30303030u;  // digits: 0..9
+            auto nondigit = [](uint32_t t) -> uint32_t { return ((t + 0x76767676u) | t) & 0x80808080u; };  // 0x80 in the first byte that is no digit
+            const unsigned long long fx = (unsigned long long)nondigit(t0) | ((unsigned long long)nondigit(t1) << 32);
+            const unsigned long long fy = (unsigned long long)nondigit(t2) | ((unsigned long long)nondigit(t3) << 32);
+            const uint32_t nd = fx ? (uint32_t)__builtin_ctzll(fx) >> 3 : 8u + (fy ? (uint32_t)__builtin_ctzll(fy) >> 3 : 8u);
             if (nd >= 1u && nd <= 15u) {
-                const uint32_t term = (uint32_t)((nd < 8u ? x >> (8u * nd) : y >> (8u * (nd - 8u))) & 0xFFu);
-                const bool leading_zero = (x & 0xFFu) == '0' && nd > 1u;
+                const uint32_t j = nd >> 2, bs = nd & 3u;
+                const uint32_t xs = j == 0u ? x0 : j == 1u ? x1 : j == 2u ? x2 : x3;  // the dword that holds the terminator
+                const uint32_t term = (xs >> (8u * bs)) & 0xFFu;
+                const bool leading_zero = (x0 & 0xFFu) == '0' && nd > 1u;
                 if (sjn_is_structural_or_ws(term) && !leading_zero) {
-                    // eight little-endian ASCII digits (first digit in the low byte, 0x00..0x09 each) -> their value
-                    auto eight = [](unsigned long long v) -> unsigned long long {
-                        v = (v * 2561ull) >> 8;
-                        v = ((v & 0x00FF00FF00FF00FFull) * 6553601ull) >> 16;
-                        return ((v & 0x0000FFFF0000FFFFull) * 42949672960001ull) >> 32;
+                    // the 32 bytes {zeros, digits...} shifted down by nd bytes: the last digit lands in byte 15
+                    const uint32_t a4 = xs ^ 0x30303030u;
+                    const uint32_t a3 = j == 0u ? 0u : j == 1u ? t0 : j == 2u ? t1 : t2;
+                    const uint32_t a2 = j < 2u ? 0u : j == 2u ? t0 : t1;
+                    const uint32_t a1 = j == 3u ? t0 : 0u;
+                    const uint32_t r3 = __builtin_amdgcn_alignbyte(a4, a3, bs), r2 = __builtin_amdgcn_alignbyte(a3, a2, bs),
+                                   r1 = __builtin_amdgcn_alignbyte(a2, a1, bs), r0 = __builtin_amdgcn_alignbyte(a1, 0u, bs);
+                    // four digits (0..9 per byte, the first in the low byte) -> their value
+                    auto four = [](uint32_t w) -> uint32_t {
+                        const uint32_t pairs = __umul24(w & 0x00FF00FFu, 10u) + ((w >> 8) & 0x00FF00FFu);  // 10 d0 + d1 | (10 d2 + d3) << 16
+                        return __umul24(pairs & 0xFFFFu, 100u) + (pairs >> 16);
                     };
-                    // the algorithm wants the LAST digit in byte 7: fewer than eight digits are shifted up, zeros below them
-                    unsigned long long value;
-                    if (nd <= 8u) {
-                        value = eight(nd == 8u ? tx : (tx & ((1ull << (8u * nd)) - 1ull)) << (8u * (8u - nd)));
-                    } else {
-                        const uint32_t r = nd - 8u;  // 1..7 digits in the second half
-                        const unsigned long long P10[8] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull};
-                        value = eight(tx) * P10[r] + eight((ty & ((1ull << (8u * r)) - 1ull)) << (8u * (8u - r)));
-                    }
+                    const uint32_t hi8 = __umul24(four(r0), 10000u) + four(r1), lo8 = __umul24(four(r2), 10000u) + four(r3);
+                    const unsigned long long value = (unsigned long long)hi8 * 100000000ull + lo8;
                     *type = 'l';
-                    *raw = neg ? (~value + 1) : value;
+                    *raw = sgn ? (~value + 1) : value;
                     return 0;
                 }
             }
@@ -510,13 +510,14 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 if (lane == 0) eo_prev = prev_empty_open;
                 const bool empty_close = valid && is_close && eo_prev && i > from;
                 // (2) depth in front of every structural
+                // ((2) and (3) share one ladder: opens <= 64, closes <= 64 and words <= 128 in the fields of one dword)
                 const uint32_t up = is_open ? 1u : 0u, down = is_close ? 1u : 0u;
-                const uint32_t iu = cw_incl_scan(up), id = cw_incl_scan(down);
-                const int h = (int)H0 + (int)(iu - up) - (int)(id - down);  // may go negative behind the root's end: never used there
-                // (3) tape positions and string offsets
                 const bool is_num = valid && cls == K_PRIM && (c == '-' || c - '0' <= 9u);
                 const uint32_t words = !valid || cls == K_COMMA || cls == K_COLON ? 0u : (is_num ? 2u : 1u);
-                const uint32_t iw = cw_incl_scan(words);
+                const uint32_t scan3 = cw_incl_scan(up | (down << 8) | (words << 16));
+                const uint32_t iu = scan3 & 0xFFu, id = (scan3 >> 8) & 0xFFu, iw = scan3 >> 16;
+                const int h = (int)H0 + (int)(iu - up) - (int)(id - down);  // may go negative behind the root's end: never used there
+                // (3) tape positions and string offsets
                 const uint32_t tpos = T0 + iw - words;
                 const bool is_str = valid && cls == K_QUOTE;
                 const unsigned long long qm = __ballot(is_str);
@@ -683,8 +684,9 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 }
                 // (8) carries
                 const uint32_t live_words = (uint32_t)__builtin_amdgcn_readlane((int)iw, rc_lane < 64 ? rc_lane : 63);
-                H0 = (uint32_t)((int)H0 + (int)cw_last(iu) - (int)cw_last(id));
-                T0 += rc_lane < 64 ? live_words : cw_last(iw);
+                const uint32_t tot3 = cw_last(scan3);
+                H0 = (uint32_t)((int)H0 + (int)(tot3 & 0xFFu) - (int)((tot3 >> 8) & 0xFFu));
+                T0 += rc_lane < 64 ? live_words : tot3 >> 16;
                 S0 += (unsigned long long)__popcll(qm);
                 const int lastv = 63 - __builtin_clzll(vmask);
                 prev_cls = (uint32_t)__builtin_amdgcn_readlane((int)cls, lastv);
