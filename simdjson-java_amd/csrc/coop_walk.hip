@@ -116,65 +116,76 @@ constexpr int CW_SLOW_DOUBLE = -2;
 
 // TapeBuilder.visitPrimitive (TapeBuilder.java:70-79) / visitRootPrimitive (:59-68) for one lane; win = the 16 bytes at idx.
 // -> 0 and (type, raw second word for numbers) or the SJMI_E_* / SJMI_WALK_NEEDS_HOST code
+//
+// The walker is VALU-bound and every lane of a step executes every path some lane takes, so the atoms and the common
+// integers share ONE branch-free path out of the window registers (a step of 64 structurals nearly always has all of them):
+//   * the digit run's length from a "byte > 9" mask (numbers: the digits start one byte up behind a '-');
+//   * one terminator test for all: byte 4 of true / null, byte 5 of false, the byte behind the digits of a number;
+//   * an integer of at most 15 digits: the digits are moved to the top of a 16-byte field (zeros = leading zeros below them,
+//     the terminator and whatever follows shifted out) with dword selects + v_alignbyte_b32; two digits = one v_dot4_u32_u8,
+//     the rest 24-bit multiply-adds (a 64-bit multiply chain costs a dozen quarter-rate v_mul_lo/hi_u32).
+// Everything else (the root value, which must also end at the document's end; floats, exponents, longer integers, anything
+// malformed) takes the scanner of sj_number.h behind a branch no lane of most steps enters.
 __device__ int cw_primitive(const uint8_t* buf, const CW16& win, uint32_t idx, bool root, uint32_t end, uint32_t* type,
                             unsigned long long* raw) {
     const uint32_t c = win.a & 0xFFu;
-    if (c == 't' || c == 'n') {  // the atom and the byte behind it are in the window's first five bytes
-        const bool word_ok = win.a == (c == 't' ? CW_TRUE : CW_NULL);
-        const bool ok = root ? (idx + 4 <= end && word_ok && (idx + 4 == end || sjn_is_structural_or_ws(win.b & 0xFFu)))
-                             : (word_ok && sjn_is_structural_or_ws(win.b & 0xFFu));
-        *type = c;
-        return ok ? 0 : (c == 't' ? SJMI_E_INVALID_TRUE : SJMI_E_INVALID_NULL);
-    }
-    if (c == 'f') {
-        const bool word_ok = win.a == CW_FALS && (win.b & 0xFFu) == 'e';
-        const uint32_t behind = (win.b >> 8) & 0xFFu;
-        const bool ok = root ? (idx + 5 <= end && word_ok && (idx + 5 == end || sjn_is_structural_or_ws(behind)))
-                             : (word_ok && sjn_is_structural_or_ws(behind));
-        *type = 'f';
-        return ok ? 0 : SJMI_E_INVALID_FALSE;
-    }
-    if (c == '-' || c - '0' <= 9u) {
-        // ---- fast path: an integer of at most 15 digits whose terminator is inside the window (most numbers of most
-        //      documents), branch-free and in 32-bit operations: digit-run length from a "byte > 9" mask; the digits are moved
-        //      to the top of a 16-byte field (zeros = leading zeros below them, terminator and whatever follows shifted out)
-        //      with dword selects + v_alignbyte_b32; four digits = two v_mad_u32_u24 (full rate; a 64-bit multiply chain costs
-        //      a dozen quarter-rate v_mul_lo/hi_u32) ----
-        if (!root) {
-            const uint32_t sgn = c == '-' ? 1u : 0u;  // a negative number: the digits start one byte up (the vacated top byte is 0)
-            const uint32_t x0 = __builtin_amdgcn_alignbyte(win.b, win.a, sgn), x1 = __builtin_amdgcn_alignbyte(win.c, win.b, sgn),
-                           x2 = __builtin_amdgcn_alignbyte(win.d, win.c, sgn), x3 = __builtin_amdgcn_alignbyte(0u, win.d, sgn);
-            const uint32_t t0 = x0 ^ 0x30303030u, t1 = x1 ^ 0x30303030u, t2 = x2 ^ 0x30303030u, t3 = x3 ^ 0x30303030u;  // digits: 0..9
-            auto nondigit = [](uint32_t t) -> uint32_t { return ((t + 0x76767676u) | t) & 0x80808080u; };  // 0x80 in the first byte that is no digit
-            const unsigned long long fx = (unsigned long long)nondigit(t0) | ((unsigned long long)nondigit(t1) << 32);
-            const unsigned long long fy = (unsigned long long)nondigit(t2) | ((unsigned long long)nondigit(t3) << 32);
-            const uint32_t nd = fx ? (uint32_t)__builtin_ctzll(fx) >> 3 : 8u + (fy ? (uint32_t)__builtin_ctzll(fy) >> 3 : 8u);
-            if (nd >= 1u && nd <= 15u) {
-                const uint32_t j = nd >> 2, bs = nd & 3u;
-                const uint32_t xs = j == 0u ? x0 : j == 1u ? x1 : j == 2u ? x2 : x3;  // the dword that holds the terminator
-                const uint32_t term = (xs >> (8u * bs)) & 0xFFu;
-                const bool leading_zero = (x0 & 0xFFu) == '0' && nd > 1u;
-                if (sjn_is_structural_or_ws(term) && !leading_zero) {
-                    // the 32 bytes {zeros, digits...} shifted down by nd bytes: the last digit lands in byte 15
-                    const uint32_t a4 = xs ^ 0x30303030u;
-                    const uint32_t a3 = j == 0u ? 0u : j == 1u ? t0 : j == 2u ? t1 : t2;
-                    const uint32_t a2 = j < 2u ? 0u : j == 2u ? t0 : t1;
-                    const uint32_t a1 = j == 3u ? t0 : 0u;
-                    const uint32_t r3 = __builtin_amdgcn_alignbyte(a4, a3, bs), r2 = __builtin_amdgcn_alignbyte(a3, a2, bs),
-                                   r1 = __builtin_amdgcn_alignbyte(a2, a1, bs), r0 = __builtin_amdgcn_alignbyte(a1, 0u, bs);
-                    // four digits (0..9 per byte, the first in the low byte) -> their value
-                    auto four = [](uint32_t w) -> uint32_t {
-                        const uint32_t pairs = __umul24(w & 0x00FF00FFu, 10u) + ((w >> 8) & 0x00FF00FFu);  // 10 d0 + d1 | (10 d2 + d3) << 16
-                        return __umul24(pairs & 0xFFFFu, 100u) + (pairs >> 16);
-                    };
-                    const uint32_t hi8 = __umul24(four(r0), 10000u) + four(r1), lo8 = __umul24(four(r2), 10000u) + four(r3);
-                    const unsigned long long value = (unsigned long long)hi8 * 100000000ull + lo8;
-                    *type = 'l';
-                    *raw = sgn ? (~value + 1) : value;
-                    return 0;
-                }
-            }
+    const bool is_t = c == 't', is_n = c == 'n', is_f = c == 'f';
+    const bool is_atom = is_t || is_n || is_f, is_num = c == '-' || c - '0' <= 9u;
+    int code = SJMI_E_UNRECOGNIZED_PRIMITIVE;
+    bool slow_number = is_num;
+    if (!root) {
+        const uint32_t sgn = c == '-' ? 1u : 0u;  // (the vacated top byte of a negative number is 0: not a digit)
+        const uint32_t x0 = __builtin_amdgcn_alignbyte(win.b, win.a, sgn), x1 = __builtin_amdgcn_alignbyte(win.c, win.b, sgn),
+                       x2 = __builtin_amdgcn_alignbyte(win.d, win.c, sgn), x3 = __builtin_amdgcn_alignbyte(0u, win.d, sgn);
+        const uint32_t t0 = x0 ^ 0x30303030u, t1 = x1 ^ 0x30303030u, t2 = x2 ^ 0x30303030u, t3 = x3 ^ 0x30303030u;  // digits: 0..9
+        auto nondigit = [](uint32_t t) -> uint32_t { return ((t + 0x76767676u) | t) & 0x80808080u; };  // 0x80 in every byte > 9 up to the first
+        auto ffbl = [](uint32_t v) -> uint32_t { return v ? (uint32_t)__builtin_ctz(v) : 0xFFFFFFFFu; };
+        uint32_t z = ffbl(nondigit(t0));
+        const uint32_t z1 = ffbl(nondigit(t1)) | 32u, z2 = ffbl(nondigit(t2)) | 64u, z3 = ffbl(nondigit(t3)) | 96u;
+        z = z < z1 ? z : z1;
+        z = z < z2 ? z : z2;
+        z = z < z3 ? z : z3;
+        const uint32_t nd = z >> 3;  // digits in front of the first non-digit (>= 16: none in the window)
+        const uint32_t ti = is_num ? nd : (is_f ? 5u : 4u);  // where the terminator sits
+        const uint32_t j = ti >> 2, bs = ti & 3u;
+        const uint32_t xs = j == 0u ? x0 : j == 1u ? x1 : j == 2u ? x2 : x3;
+        const bool sep = sjn_is_structural_or_ws((xs >> (8u * bs)) & 0xFFu);
+        const bool atom_ok = win.a == (is_t ? CW_TRUE : is_n ? CW_NULL : CW_FALS) && (!is_f || (win.b & 0xFFu) == 'e') && sep;
+        const bool leading_zero = (x0 & 0xFFu) == '0' && nd > 1u;
+        const bool fast_number = is_num && nd >= 1u && nd <= 15u && sep && !leading_zero;
+        // the 32 bytes {zeros, digits...} shifted down by nd bytes: the last digit lands in byte 15
+        const uint32_t a4 = xs ^ 0x30303030u;
+        const uint32_t a3 = j == 0u ? 0u : j == 1u ? t0 : j == 2u ? t1 : t2;
+        const uint32_t a2 = j < 2u ? 0u : j == 2u ? t0 : t1;
+        const uint32_t a1 = j == 3u ? t0 : 0u;
+        const uint32_t r3 = __builtin_amdgcn_alignbyte(a4, a3, bs), r2 = __builtin_amdgcn_alignbyte(a3, a2, bs),
+                       r1 = __builtin_amdgcn_alignbyte(a2, a1, bs), r0 = __builtin_amdgcn_alignbyte(a1, 0u, bs);
+        // eight digits (0..9 per byte, the first in the low byte of the first dword) -> their value
+        auto eight = [](uint32_t w0, uint32_t w1) -> uint32_t {
+            uint32_t v = __builtin_amdgcn_udot4(w0, 0x0000010Au, 0u, false);          // 10 d0 + d1
+            v = __builtin_amdgcn_udot4(w0, 0x010A0000u, __umul24(v, 100u), false);    // ... d3
+            v = __builtin_amdgcn_udot4(w1, 0x0000010Au, __umul24(v, 100u), false);
+            return __builtin_amdgcn_udot4(w1, 0x010A0000u, __umul24(v, 100u), false);  // < 10^8
+        };
+        const unsigned long long value = (unsigned long long)eight(r0, r1) * 100000000ull + eight(r2, r3);
+        if (fast_number) {
+            *type = 'l';
+            *raw = sgn ? (~value + 1) : value;
+            code = 0;
+            slow_number = false;
+        } else if (is_atom) {
+            *type = c;
+            code = atom_ok ? 0 : (is_t ? SJMI_E_INVALID_TRUE : is_n ? SJMI_E_INVALID_NULL : SJMI_E_INVALID_FALSE);
         }
+    } else if (is_atom) {  // (rare) the document is one atom: it must also end where the document ends
+        const uint32_t len = is_f ? 5u : 4u;
+        const uint32_t behind = is_f ? (win.b >> 8) & 0xFFu : win.b & 0xFFu;
+        const bool word_ok = win.a == (is_t ? CW_TRUE : is_n ? CW_NULL : CW_FALS) && (!is_f || (win.b & 0xFFu) == 'e');
+        const bool ok = idx + len <= end && word_ok && (idx + len == end || sjn_is_structural_or_ws(behind));
+        *type = c;
+        code = ok ? 0 : (is_t ? SJMI_E_INVALID_TRUE : is_n ? SJMI_E_INVALID_NULL : SJMI_E_INVALID_FALSE);
+    }
+    if (slow_number) {
         CwBytes w = {buf, idx, (unsigned long long)win.a | ((unsigned long long)win.b << 32),
                      (unsigned long long)win.c | ((unsigned long long)win.d << 32), 0ull, 0ull, false};
         const uint32_t limit = root ? end : 0xFFFFFFFFu;  // the root number's padded copy (TapeBuilder.java:183-189)
@@ -190,7 +201,7 @@ __device__ int cw_primitive(const uint8_t* buf, const CW16& win, uint32_t idx, b
         }
         return 0;
     }
-    return SJMI_E_UNRECOGNIZED_PRIMITIVE;
+    return code;
 }
 
 __device__ __forceinline__ unsigned long long tape_word(uint32_t type, unsigned long long payload) {
@@ -338,7 +349,9 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
     // step-to-step dependency chain
     uint32_t st_tpos = 0, st_cnt = 0;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    // (everything that indexes structurals is 32-bit: a launch has fewer than 2^32 of them -- its bytes are addressed by 32-bit
+    //  indexes -- and a document of more than 2^31 - 256 is handed back below, so neither a position nor a tape offset wraps)
+    const uint32_t nwaves = gridDim.x * 4u;
     // Levels CW_LEVELS and deeper (SimdJsonParser.java:7: the default maxDepth is 1024) live in global memory, one record per
     // level and wave: {commas so far | kind << 31, tape position of the opening word}.  Rare, so nothing about it is fast;
     // lane 0 writes and reads them (one thread, one address: program order), the value is broadcast.
@@ -366,30 +379,30 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
     // the kernel.  So the delimiters of the wave's NEXT document are requested when the current one starts, and the
     // positions of its first two steps when the current one ends.
     struct Meta {
-        unsigned long long from, to, dso;
+        uint32_t from, to, dso;
         uint32_t doc_start, doc_end, st;
     };
     struct Head {
         uint32_t p_n, px_n, p_nn, px_nn;
     };
-    auto load_meta = [&](uint64_t k) {
+    auto load_meta = [&](uint32_t k) {
         Meta m;
-        m.from = index_offsets[k];
-        m.to = index_offsets[k + 1];
-        m.dso = doc_str_offsets[k];
+        m.from = (uint32_t)index_offsets[k];
+        m.to = (uint32_t)index_offsets[k + 1];
+        m.dso = (uint32_t)doc_str_offsets[k];
         m.doc_start = (uint32_t)doc_offsets[k];
         m.doc_end = (uint32_t)doc_offsets[k + 1];
         m.st = doc_status ? doc_status[k] : 0u;
         return m;
     };
     // (wfrom, wto) = the structurals this wave walks: the whole document, or one chunk of it
-    auto load_pos = [&](const Meta& m, uint64_t wfrom, uint64_t wto, uint64_t s, uint32_t* p, uint32_t* px) {
-        const uint64_t i = wfrom + s * 64 + lane;
+    auto load_pos = [&](const Meta& m, uint32_t wfrom, uint32_t wto, uint32_t s, uint32_t* p, uint32_t* px) {
+        const uint32_t i = wfrom + s * 64u + (uint32_t)lane;
         *p = i < wto ? idx[i] : m.doc_start;
-        const uint64_t ix = wfrom + s * 64 + 64;
+        const uint32_t ix = wfrom + s * 64u + 64u;
         *px = ix < m.to ? idx[ix] : m.doc_start;
     };
-    auto load_head = [&](const Meta& m, uint64_t wfrom, uint64_t wto) {
+    auto load_head = [&](const Meta& m, uint32_t wfrom, uint32_t wto) {
         Head h;
         load_pos(m, wfrom, wto, 0, &h.p_n, &h.px_n);
         h.p_nn = m.doc_start;
@@ -397,47 +410,50 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
         if (wto - wfrom > 64) load_pos(m, wfrom, wto, 1, &h.p_nn, &h.px_nn);
         return h;
     };
-    uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
+    uint32_t k = blockIdx.x * 4u + (uint32_t)wv;
     Meta m = {0, 0, 0, 0, 0, 0}, m_next = m;
     Head hd = {0, 0, 0, 0};
-    uint64_t n_items = n_docs;
+    uint32_t n_items = (uint32_t)n_docs;
     uint32_t chunk = 0;
     if (CHUNKED) {  // the work items are the chunks of document 0
         m = load_meta(0);
         chunk = cw_chunk_of(m.to - m.from);
-        n_items = (m.to - m.from + chunk - 1) / chunk;
+        n_items = (m.to - m.from + chunk - 1u) / chunk;
         if (k < n_items) {
-            const uint64_t a = m.from + k * chunk, b = a + chunk < m.to ? a + chunk : m.to;
+            const uint32_t a = m.from + k * chunk, b = m.to - a > chunk ? a + chunk : m.to;
             hd = load_head(m, a, b);
         }
-    } else if (k < n_docs) {
+    } else if (k < n_items) {
         m = load_meta(k);
         hd = load_head(m, m.from, m.to);
     }
-    for (; k < n_items; k += nwaves) {
-        if (!CHUNKED && k + nwaves < n_docs) m_next = load_meta(k + nwaves);
+    bool more = false;
+    for (; k < n_items; k = more ? k + nwaves : n_items) {
+        more = n_items - k > nwaves;  // (k + nwaves < n_items, without a sum that could wrap)
+        if (!CHUNKED && more) m_next = load_meta(k + nwaves);
         int code = 0;
         uint32_t tlen = 0, err_at = 0xFFFFFFFFu;
         const uint32_t st = m.st;
-        const unsigned long long from = m.from, to = m.to;
-        const unsigned long long wfrom = CHUNKED ? from + k * chunk : from;
-        const unsigned long long wto = CHUNKED ? (wfrom + chunk < to ? wfrom + chunk : to) : to;
-        const uint64_t kdoc = CHUNKED ? 0 : k;
+        const uint32_t from = m.from, to = m.to;
+        const uint32_t wfrom = CHUNKED ? from + k * chunk : from;
+        const uint32_t wto = CHUNKED ? (to - wfrom > chunk ? wfrom + chunk : to) : to;
+        const uint32_t kdoc = CHUNKED ? 0u : k;
         // SimdJsonParser.stage1 order: Utf8Validator.validate (:165-167), then StructuralIndexer.index (:297-302)
         if (upstream_failed) code = SJMI_E_CAPACITY;
         else if (st & SJMI_ST_UTF8) code = SJMI_E_UTF8;
         else if (st & SJMI_ST_UNCLOSED) code = SJMI_E_UNCLOSED_STRING;
         else if (st & SJMI_ST_UNESCAPED) code = SJMI_E_UNESCAPED_CHARS;
         else if (from == to) code = SJMI_E_NO_STRUCTURAL;  // JsonIterator.java:27-29
+        else if (to - from > 0x7FFFFF00u || to > 0xFFFFFF00u) code = SJMI_WALK_NEEDS_HOST;  // (tape offsets are 32-bit here)
         if (code == 0) {
             const uint32_t doc_start = m.doc_start, doc_end = m.doc_end;
-            const uint64_t n = to - from;
-            unsigned long long* const T = scratch_tape + 2 * from + 2 * kdoc;  // this document's slot (word 0 = root)
-            const uint64_t room = 2 * n + 2;                                // a structural makes at most two words
+            const uint32_t n = to - from;
+            unsigned long long* const T = scratch_tape + 2ull * from + 2ull * kdoc;  // this document's slot (word 0 = root)
+            const uint32_t room = 2u * n + 2u;                              // a structural makes at most two words
             // running state (wave-uniform)
             uint32_t H0 = 0;                 // open containers in front of the step
             uint32_t T0 = 1;                 // tape position of the step's first word (0 = the root word)
-            unsigned long long S0 = m.dso;   // ordinal of the first string at or behind the step (the record table soff[] is by ordinal)
+            uint32_t S0 = m.dso;             // ordinal of the first string at or behind the step (the record table soff[] is by ordinal)
             // a STRING word needs its record's offset, a gather by ordinal: requested in one step, stored in the next
             uint32_t pq_tpos = 0, pq_off = 0;
             bool pq_live = false;
@@ -448,7 +464,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
             if (CHUNKED) {  // start from the chunk's entry state (k_group_replay)
                 H0 = cw.in.H[k];
                 T0 = cw.in.T[k];
-                S0 = cw.in.S[k];
+                S0 = (uint32_t)cw.in.S[k];
                 st_tpos = cw.in.tpos[k * 64 + lane];
                 st_cnt = cw.in.cnt[k * 64 + lane];
                 arr_mask = cw.in.arr[k];
@@ -469,11 +485,11 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
             }
             // positions (and sizes) are requested TWO steps ahead, the 16-byte windows they point at one step ahead: neither
             // round trip is on the step-to-step critical path
-            const uint64_t nsteps = (wto - wfrom + 63) / 64;
+            const uint32_t nsteps = (wto - wfrom + 63u) / 64u;
             uint32_t p_n = hd.p_n, px_n = hd.px_n, p_nn = hd.p_nn, px_nn = hd.px_nn;
             CW16 win_n = *reinterpret_cast<const CW16*>(buf + p_n);
             uint32_t bx_n = buf[px_n];
-            for (uint64_t s = 0; s < nsteps && code == 0; ++s) {
+            for (uint32_t s = 0; s < nsteps && code == 0; ++s) {
                 const uint32_t p = p_n, c_extra = bx_n;
                 const CW16 win = win_n;
                 p_n = p_nn;
@@ -483,12 +499,12 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                     bx_n = buf[px_n];
                 }
                 if (s + 2 < nsteps) load_pos(m, wfrom, wto, s + 2, &p_nn, &px_nn);
-                const uint64_t i = wfrom + s * 64 + lane;
+                const uint32_t i = wfrom + s * 64u + (uint32_t)lane;
                 const bool valid = i < wto;
                 const unsigned long long vmask = __ballot(valid);
                 if (root_closed) {  // JsonIterator.java:196-198: something follows the root value
                     code = SJMI_E_TRAILING_CONTENT;
-                    err_at = (uint32_t)(wfrom + s * 64);
+                    err_at = wfrom + s * 64u;
                     break;
                 }
                 const uint32_t c = win.a & 0xFFu;
@@ -521,7 +537,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 const uint32_t tpos = T0 + iw - words;
                 const bool is_str = valid && cls == K_QUOTE;
                 const unsigned long long qm = __ballot(is_str);
-                const unsigned long long sord = S0 + (unsigned long long)__popcll(qm & lt_mask);  // this string's ordinal
+                const uint32_t sord = S0 + (uint32_t)__popcll(qm & lt_mask);  // this string's ordinal
                 const uint32_t rec_off = is_str ? soff[sord] : 0u;                                    // (used one step later)
                 // (4) the container of every structural: level loop over the depths present in this step
                 const int plevel = h - 1;  // level of the container this structural sits in
@@ -656,7 +672,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 const unsigned long long em = __ballot(err != 0 && lane <= rc_lane + 1);
                 if (em) {
                     code = __builtin_amdgcn_readlane(err, __builtin_ctzll(em));
-                    err_at = (uint32_t)(wfrom + s * 64 + __builtin_ctzll(em));
+                    err_at = wfrom + s * 64u + (uint32_t)__builtin_ctzll(em);
                     break;
                 }
                 if (rc) root_closed = true;
@@ -687,7 +703,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 const uint32_t tot3 = cw_last(scan3);
                 H0 = (uint32_t)((int)H0 + (int)(tot3 & 0xFFu) - (int)((tot3 >> 8) & 0xFFu));
                 T0 += rc_lane < 64 ? live_words : tot3 >> 16;
-                S0 += (unsigned long long)__popcll(qm);
+                S0 += (uint32_t)__popcll(qm);
                 const int lastv = 63 - __builtin_clzll(vmask);
                 prev_cls = (uint32_t)__builtin_amdgcn_readlane((int)cls, lastv);
                 prev_empty_open = __builtin_amdgcn_readlane((int)empty_open, lastv) != 0;
@@ -699,8 +715,8 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                     cw.err_pos[k] = code ? err_at : 0xFFFFFFFFu;
                     cw.err_code[k] = code;
                 }
-                if (k + nwaves < n_items) {
-                    const uint64_t a = from + (k + nwaves) * chunk, b = a + chunk < to ? a + chunk : to;
+                if (more) {
+                    const uint32_t a = from + (k + nwaves) * chunk, b = to - a > chunk ? a + chunk : to;
                     hd = load_head(m, a, b);
                 }
                 continue;
@@ -751,7 +767,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
         n_host += code == SJMI_WALK_NEEDS_HOST;
         n_bad += code > 0;
         m = m_next;
-        if (k + nwaves < n_docs) hd = load_head(m, m.from, m.to);
+        if (more) hd = load_head(m, m.from, m.to);
     }
     (void)res;
     (void)n_host;
