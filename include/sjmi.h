@@ -255,14 +255,17 @@ int sjmi_unescape_batch_device(sjmi_ctx* ctx, const void* d_buf, uint64_t total_
 
 /* ---- stage 2 on the GPU for batches ---------------------------------------------------------
  * JsonIterator.walkDocument + TapeBuilder (JsonIterator.java:26-200, TapeBuilder.java:41-217) for every document of a
- * batch, one GPU lane per document, from the outputs of sjmi_stage1_batch_isolated_device and
- * sjmi_unescape_batch_device (all device pointers).  Produces the tapes back to back in d_tape (Tape.java:5-47 word
- * layout; document k: words [tape_offsets[k], tape_offsets[k+1]), its container words relative to its own start,
- * STRING payloads = string_base + offset of the record in d_string_buffer) and doc_errors[k] (int32): 0, or the
- * SJMI_E_* code of the document's first error (stage-1 verdicts included) with an empty tape, or SJMI_WALK_NEEDS_HOST
- * with an empty tape: the document nests deeper than 64 levels or holds a floating-point literal outside the range in
- * which one IEEE operation is the correctly rounded result (more than 19 significant digits, significand > 2^53,
- * |decimal exponent| > 22) -- the host walker (sjmi_parser_*) takes those.  d_result: sjmi_walk_result, bit 0 of flags =
+ * batch, one GPU wave per document (csrc/coop_walk.hip), from the outputs of sjmi_stage1_batch_isolated_device and
+ * sjmi_unescape_batch_device (all device pointers; the string pass also leaves a table of record offsets by string
+ * ordinal on the context, so both calls must come from this context, for the same d_indexes).  Produces the tapes back to
+ * back in d_tape (Tape.java:5-47 word layout; document k: words [tape_offsets[k], tape_offsets[k+1]), its container words
+ * relative to its own start, STRING payloads = string_base + offset of the record in d_string_buffer) and doc_errors[k]
+ * (int32): 0, or the SJMI_E_* code of the document's first error (stage-1 verdicts and malformed escapes included) with an
+ * empty tape, or SJMI_WALK_NEEDS_HOST with an empty tape.  The device decides everything the reference's defaults admit:
+ * nesting up to 1024 open containers (SimdJsonParser.java:7) and every number literal, including floating-point literals
+ * of more than 19 significant digits at a rounding boundary (exact big-integer comparison with the midpoint, DoubleParser.
+ * java:205-330).  Handed back only: max_depth > 1024 and a document that uses it, more than 65,536 such boundary literals
+ * in one launch, a single document of more than 2^31 - 256 structurals.  d_result: sjmi_walk_result, bit 0 of flags =
  * tape_capacity exceeded (offsets valid, tapes not written).  d_buf needs 64 readable bytes after the batch (the
  * reference's padding, SimdJsonParser.java:42-48).  Asynchronous on `stream`. */
 #define SJMI_WALK_NEEDS_HOST (-1)
@@ -301,8 +304,8 @@ int sjmi_parse_batch_device(sjmi_ctx* ctx, const void* d_buf, uint64_t total_len
 /* One document, ALL stages on the GPU: stage 1, string records and the cooperative walker (csrc/coop_walk.hip: JsonIterator.
  * walkDocument + TapeBuilder as scans, JsonIterator.java:26-200, TapeBuilder.java:41-217); only the tape (Tape.java:5-47 word
  * layout, tape[0] = root) and the string buffer come back -- the structural indexes stay on the device.  *error = 0, or the
- * document's SJMI_E_* code (stage-1 verdicts included; no tape), or SJMI_WALK_NEEDS_HOST (nesting beyond 63 levels, a
- * floating-point literal of more than 19 significant digits: walk it on the host, sjmi_parser_parse does). */
+ * document's SJMI_E_* code (stage-1 verdicts included; no tape), or SJMI_WALK_NEEDS_HOST (see sjmi_walk_batch_device: not
+ * for anything the reference's default limits admit; sjmi_parser_parse walks such a document on the host). */
 int sjmi_parse_document(sjmi_ctx* ctx, const uint8_t* buf, uint64_t len, int max_depth, uint64_t* tape, uint64_t tape_capacity,
                         uint64_t* tape_len, uint8_t* string_buffer, uint64_t string_capacity, uint64_t* strings_len,
                         int32_t* error, uint32_t* stage1_status);

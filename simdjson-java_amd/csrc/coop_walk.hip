@@ -7,28 +7,35 @@
 // every ~1 KB document of a batch (3 steps).  Per step, everything the sequential walker carries in its state is
 // recovered with wave primitives (the formulation was validated first as a Python model against the oracle,
 // tools/coop_walk_model.py):
-//   * class of each structural from its first byte; coalesced loads of the indexes and of the record sizes, one
-//     16-byte window of the document per structural (consecutive lanes share cache lines: the document is read once);
+//   * class of each structural from its first byte (a perfect hash + two byte-table lookups); coalesced loads of the
+//     indexes, one 16-byte window of the document per structural (consecutive lanes share cache lines: the document is
+//     read once);
 //   * depth before each structural = running depth + exclusive DPP scan of (+1 open, -1 close);
 //   * the container a structural sits in ("bracket matching") = the last opening bracket in front of it whose depth is
 //     one less: found among the wave's own 64 structurals with one ballot per depth level present in the step, else in
-//     a small per-wave stack in LDS (tape position, comma count and kind of the open container of every level), which
-//     the step then updates -- the only state carried from step to step besides four running sums;
+//     a small per-wave stack (two VGPRs: lane L = level L: tape position, comma count; a 64-bit kind mask), which
+//     the step then updates -- the only state carried from step to step besides four running sums; levels 64..1023
+//     (the reference's default maxDepth is 1024) live in a per-wave overflow stack in global memory;
 //   * the role of a structural (value / key / colon / separator) is a function of its predecessor's class, of whether
 //     the predecessor was a key, and of the kind of its container: every grammar test of JsonIterator.java:68-193
 //     becomes a local predicate, and the document's error is the failing predicate at the LOWEST position -- exactly
 //     where the sequential walker stops;
 //   * tape positions = running position + exclusive scan of words per structural (bracket / string / atom 1, number 2,
-//     comma / colon 0); STRING payloads = running offset + exclusive scan of the record sizes the unescape pass left
-//     per structural; a closing bracket writes both container words (its own and the opening one, TapeBuilder.java:
-//     197-203: element count = commas directly inside + 1, saturated at 0xFFFFFF; empty-container quirk :205-208);
-//   * atoms and numbers are parsed by the lane that owns them (sj_number.h: Clinger / Eisel-Lemire on the device).
+//     comma / colon 0; the same ladder as the depth scan, three fields of one dword); STRING payloads = the record offsets
+//     the string pass (strings.hip) leaves BY STRING ORDINAL: ordinal = running count + popcount of the step's quotes in
+//     front of the lane, one 4-byte gather, requested in one step and stored in the next; a closing bracket writes both
+//     container words (its own and the opening one, TapeBuilder.java:197-203: element count = commas directly inside
+//     + 1, saturated at 0xFFFFFF; empty-container quirk :205-208);
+//   * atoms and numbers are parsed by the lane that owns them: atoms and integers of up to 15 digits branch-free out of
+//     the window registers (cw_primitive), everything else through sj_number.h (Clinger / Eisel-Lemire on the device).
+//     A floating literal of more than 19 significant digits whose two 19-digit neighbours round differently is listed
+//     and decided behind the walk by an exact big-integer comparison with the midpoint (sj_bigdec.h, k_slow_doubles).
 // Tape words leave as 8-byte stores at consecutive addresses across the lanes (whole lines per step); nothing is
-// re-read: FETCH ~ document + 8 B per structural, WRITE ~ tape.
+// re-read: FETCH ~ document + 4 B per structural + 4 B per string, WRITE ~ tape.
 //
-// Handed back to the host walker (doc_errors[k] = SJMI_WALK_NEEDS_HOST), as with the lane-per-document kernel it
-// replaces (walk.hip): a document nested deeper than 63 open containers, a floating-point literal of more than 19
-// significant digits.
+// Handed back to the host walker (doc_errors[k] = SJMI_WALK_NEEDS_HOST) only beyond the reference's defaults: more than
+// 1024 open containers (when the caller raised max_depth), more than 65,536 listed literals in one launch, a document of
+// more than 2^31 - 256 structurals.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -43,7 +50,6 @@ namespace {
 
 constexpr int CW_LEVELS = 64;              // levels of the per-wave stack in registers
 constexpr int CW_OVF_LEVELS = 960;         // deeper levels, in global memory (together: the reference's default maxDepth of 1024)
-constexpr uint32_t CW_SIZE_SLOW = 0x80000000u;  // unescape.hip: sizes[] flag "this string had escapes / failed"
 
 enum : uint32_t { K_OPEN_A = 0, K_OPEN_O = 1, K_CLOSE_A = 2, K_CLOSE_O = 3, K_COMMA = 4, K_COLON = 5, K_QUOTE = 6, K_PRIM = 7 };
 
@@ -326,9 +332,9 @@ k_single_finish(const uint8_t* __restrict__ buf, SlowList sl, const uint32_t* __
 
 // One wave per document (grid-stride over the documents).  Documents are delimited by index_offsets (n_docs + 1 entries)
 // and doc_offsets; a single document is the batch of one.  Document k's tape is built in its slot of the scratch tape
-// (2 words per structural + 2, walk.hip packs the tapes back to back afterwards); sizes / scratch: the per-structural
-// records of the unescape pass (4 + length | flags per '"' structural, 0 otherwise; scratch[open] = code of a failed
-// string).
+// (2 words per structural + 2, walk.hip packs the tapes back to back afterwards); soff[] = the string pass's record offsets
+// by string ordinal, doc_str_offsets[k] = ordinal of document k's first string, sb = the string buffer (only looked at when
+// the pass reported a malformed escape: the failing record's header is FF FF FF <code>).
 // (five waves per SIMD: 96 instead of 123 VGPRs and three spilled dwords, but the kernel is VALU-bound at 70 % issue
 //  utilisation and the fifth wave fills bubbles: 4.91 -> 4.38 ms per million documents; six waves spill 26 dwords: 4.41)
 template <bool CHUNKED>
