@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../sj_number.h"
+#include "../sj_bigdec.h"
 #include "simdjson_parser.h"
 
 namespace org_simdjson {
@@ -368,11 +369,14 @@ private:
         if (sjmi::sj_number_double_bits(n, &bits)) {
             memcpy(&v, &bits, 8);
         } else {
-            // (within 10^-19 of a rounding boundary: DoubleParser's slow path :205-330 = a correctly rounded conversion)
-            static const locale_t c_locale = newlocale(LC_ALL_MASK, "C", (locale_t)0);
-            std::string lit;
-            for (uint32_t q = offset; !structuralOrWs((uint8_t)byteAt(q)); ++q) lit.push_back((char)byteAt(q));
-            v = strtod_l(lit.c_str(), nullptr, c_locale);
+            // (within 10^-19 of a rounding boundary: DoubleParser's slow path :205-330 = the exact comparison of the literal with
+            //  the midpoint of its two candidates, sj_bigdec.h -- the same routine as both walkers)
+            std::vector<uint32_t> wa(sjmi::SJ_BIG_WORDS), wb(sjmi::SJ_BIG_WORDS);
+            const uint32_t start = offset + (n.negative ? 1u : 0u);
+            const unsigned long long mag =
+                sjmi::sj_decide_double([&](uint32_t q) -> uint32_t { return byteAt(q); }, start, bits & ~(1ull << 63), wa.data(), wb.data());
+            bits = mag | (n.negative ? 1ull << 63 : 0ull);
+            memcpy(&v, &bits, 8);
         }
         return v;
     }
