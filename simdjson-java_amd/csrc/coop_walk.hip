@@ -1264,7 +1264,11 @@ k_coop_match(const uint8_t* __restrict__ buf, uint64_t n_docs, const uint32_t* _
 
 // single document: the delimiters the batch kernels expect, from the stage-1 record that is still on the device
 __global__ void k_single_doc_setup(const Stage1Result* __restrict__ res, unsigned long long len, unsigned long long* doc_offsets,
-                                   unsigned long long* index_offsets, uint32_t* doc_status, unsigned long long* doc_str_offsets) {
+                                   unsigned long long* index_offsets, uint32_t* doc_status, unsigned long long* doc_str_offsets,
+                                   uint32_t* walk_result, uint32_t* slow_header) {
+    // (also what two memsets would do on the latency path: the walk's result record and the header of its literal list / flags)
+    if (walk_result && threadIdx.x < sizeof(WalkResult) / 4) walk_result[threadIdx.x] = 0;
+    if (slow_header && threadIdx.x < 16) slow_header[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         doc_offsets[0] = 0;
         doc_offsets[1] = len;
@@ -1278,9 +1282,9 @@ __global__ void k_single_doc_setup(const Stage1Result* __restrict__ res, unsigne
 
 hipError_t single_doc_setup_launch(const Stage1Result* d_res, uint64_t len, unsigned long long* d_doc_offsets,
                                    unsigned long long* d_index_offsets, uint32_t* d_doc_status, unsigned long long* d_doc_str_offsets,
-                                   hipStream_t stream) {
+                                   hipStream_t stream, WalkResult* d_walk_result, void* d_slow_header) {
     hipLaunchKernelGGL(k_single_doc_setup, dim3(1), dim3(64), 0, stream, d_res, (unsigned long long)len, d_doc_offsets, d_index_offsets,
-                       d_doc_status, d_doc_str_offsets);
+                       d_doc_status, d_doc_str_offsets, reinterpret_cast<uint32_t*>(d_walk_result), static_cast<uint32_t*>(d_slow_header));
     return hipGetLastError();
 }
 
@@ -1347,7 +1351,7 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
                             int max_depth, unsigned long long* d_scratch_tape, uint32_t* d_tape_lens, int32_t* d_doc_errors,
                             const Stage1Result* dev_count, const UnescapeResult* dev_strings, WalkResult* d_res,
                             hipStream_t stream, void* d_chunk_ws, uint64_t count_bound, void* d_deep_ws,
-                            unsigned long long* d_single_tape_offsets, uint64_t tape_capacity) {
+                            unsigned long long* d_single_tape_offsets, uint64_t tape_capacity, bool header_zeroed) {
     if (!n_docs) return hipSuccess;
     // (the deep-level workspace begins with the list of undecided literals)
     SlowList slow;
@@ -1355,7 +1359,7 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
     slow.rec = slow.count + 8;
     slow.cap = CW_SLOW_CAP;
     d_deep_ws = static_cast<uint8_t*>(d_deep_ws) + coop_slow_bytes();
-    {
+    if (!header_zeroed) {  // (64 bytes: the list's count and the chunk path's flags)
         hipError_t e0 = hipMemsetAsync(slow.count, 0, 64, stream);
         if (e0 != hipSuccess) return e0;
     }

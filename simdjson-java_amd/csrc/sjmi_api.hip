@@ -29,6 +29,9 @@ struct sjmi_ctx {
     int ws_dev_next = 0;              // half the next launch uses
     void* ws_dev_last = nullptr;      // half the last launch used (debug read-back)
     sjmi_stage1_result* h_res = nullptr;  // pinned
+    void* h_pack = nullptr;               // pinned: {error index, stage-1 record, string record} of sjmi_stage1_unescape
+    void* d_pack = nullptr;
+    void* d_res_tmp = nullptr;            // device stage-1 record of the same call
     uint64_t last_len = 0, last_count = 0;  // document of the last sjmi_stage1 call (still on the device)
     bool last_valid = false;
     uint8_t* d_sb = nullptr;      // string buffer (host path), grown on demand
@@ -213,6 +216,9 @@ void sjmi_destroy(sjmi_ctx* c) {
     if (c->d_masks) (void)hipFree(c->d_masks);
     if (c->d_ws_masks) (void)hipFree(c->d_ws_masks);
     if (c->h_res) (void)hipHostFree(c->h_res);
+    if (c->h_pack) (void)hipHostFree(c->h_pack);
+    if (c->d_pack) (void)hipFree(c->d_pack);
+    if (c->d_res_tmp) (void)hipFree(c->d_res_tmp);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -342,12 +348,17 @@ const unsigned long long* parity_for(sjmi_ctx* c, const void* d_buf, uint64_t le
 }  // namespace
 
 // the streaming string pass over (d_buf, len); optional: record offsets by ordinal / ordinals by block
+// d_result == nullptr: the record inside the pass's workspace (zeroed with it: no memset of its own), returned in *used
 static int strings_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_string_buffer, uint64_t string_capacity,
-                               uint32_t* d_soff, uint64_t soff_cap, uint32_t* d_blk_ord, void* d_result, hipStream_t st) {
+                               uint32_t* d_soff, uint64_t soff_cap, uint32_t* d_blk_ord, void* d_result, hipStream_t st,
+                               sjmi::UnescapeResult** used = nullptr) {
     const unsigned long long* par = parity_for(c, d_buf, len, st);
     if (!par) return SJMI_ERR_HIP;
     if (!grow(c, &c->d_ws_strm, &c->ws_strm_bytes, sjmi::strings_workspace_bytes(len), "hipMalloc(ws_strm)")) return SJMI_ERR_HIP;
-    if (fail(c, "memset(result)", hipMemsetAsync(d_result, 0, sizeof(sjmi_unescape_result), st)) ||
+    const bool own = d_result == nullptr;
+    if (own) d_result = sjmi::strings_workspace_result(c->d_ws_strm);
+    if (used) *used = (sjmi::UnescapeResult*)d_result;
+    if ((!own && fail(c, "memset(result)", hipMemsetAsync(d_result, 0, sizeof(sjmi_unescape_result), st))) ||
         fail(c, "strings launch",
              sjmi::strings_launch((const uint8_t*)d_buf, len, par, (uint8_t*)d_string_buffer, string_capacity, d_soff, soff_cap,
                                   d_blk_ord, c->d_ws_strm, (sjmi::UnescapeResult*)d_result, st)))
@@ -540,6 +551,15 @@ int sjmi_unescape_batch(sjmi_ctx* c, uint8_t* string_buffer, uint64_t string_cap
     return unescape_host(c, string_buffer, string_capacity, doc_string_offsets, total_bytes, first_error_index, first_error_code);
 }
 
+// sjmi_set_auto_safe's per-launch check switched off for the lifetime of the object (a call that re-runs in SAFE mode itself)
+struct AutoSafeOff {
+    sjmi_ctx* c;
+    bool keep;
+    explicit AutoSafeOff(sjmi_ctx* ctx) : c(ctx), keep(ctx->auto_safe) { ctx->auto_safe = false; }
+    ~AutoSafeOff() { c->auto_safe = keep; }
+};
+static int stage1_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_indexes, uint64_t index_capacity,
+                              void* d_result, void* stream, uint32_t shard_flags);
 int sjmi_stage1_unescape(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes, uint64_t index_capacity,
                          uint64_t* count, uint32_t* status, uint8_t* string_buffer, uint64_t string_capacity,
                          uint64_t* total_bytes, uint64_t* first_error_index, uint32_t* first_error_code) {
@@ -564,29 +584,42 @@ int sjmi_stage1_unescape(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t
     const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(len);
     const uint64_t dev_cap = c->capacity + 2 < index_capacity ? c->capacity + 2 : index_capacity;
     const sjmi::Stage1Result* d_res1 = (const sjmi::Stage1Result*)((uint8_t*)c->d_ws + sjmi::WS_RESULT_OFFSET);
+    // Latency path of the drop-in call: besides the two kernels only what cannot be avoided is queued -- stage 1 through the
+    // device entry point (double-buffered workspace: no memset, the scanner writes the record), the string pass's record
+    // inside its own workspace (zeroed with it), one 48-byte D2H of {error index, both records} instead of three copies.
     sjmi_unescape_result r;
     unsigned long long err_index = ~0ull;
-    if (!c->d_err_index && fail(c, "hipMalloc(err_index)", hipMalloc((void**)&c->d_err_index, sizeof(unsigned long long))))
-        return SJMI_ERR_HIP;
+    struct Pack {
+        unsigned long long err_index;
+        sjmi_stage1_result s1;
+        sjmi_unescape_result u;
+    };
+    static_assert(sizeof(Pack) == 48, "ParsePack layout");
+    if (sjmi::strings_parse_pack_bytes() != sizeof(Pack)) return SJMI_ERR_INTERNAL;
+    if (!c->d_pack && fail(c, "hipMalloc(pack)", hipMalloc(&c->d_pack, 64))) return SJMI_ERR_HIP;
+    if (!c->h_pack && fail(c, "hipHostMalloc(pack)", hipHostMalloc(&c->h_pack, 64))) return SJMI_ERR_HIP;
+    if (!c->d_res_tmp && fail(c, "hipMalloc(result)", hipMalloc((void**)&c->d_res_tmp, 64))) return SJMI_ERR_HIP;
+    const AutoSafeOff own_retry(c);  // (the retry below is this call's own)
     for (int attempt = 0; attempt < 2; ++attempt) {
-        sjmi::Stage1Extras ex1;
-        ex1.blkpar = parity_out(c, c->d_in, len);
-        if (fail(c, "launch", sjmi::stage1_launch(c->d_in, len, c->d_idx, dev_cap, c->d_ws, steps, c->stream, nullptr,
-                                                  nullptr, launch_flags(c), ex1)))
-            return SJMI_ERR_HIP;
-        note_launch(c, c->stream);
-        const int src = strings_device_impl(c, c->d_in, len, c->d_sb, c->sb_bytes, nullptr, 0, nullptr, c->d_ures, c->stream);
-        if (src != SJMI_OK) return src;
-        if (fail(c, "error index", sjmi::strings_error_index_launch(c->d_idx, 0, d_res1, (const sjmi::UnescapeResult*)c->d_ures,
-                                                                    c->d_err_index, c->stream)) ||
-            fail(c, "D2H(err_index)", hipMemcpyAsync(&err_index, c->d_err_index, sizeof err_index, hipMemcpyDeviceToHost, c->stream)) ||
-            fail(c, "D2H(result)", hipMemcpyAsync(c->h_res, d_res1, sizeof(sjmi_stage1_result), hipMemcpyDeviceToHost, c->stream)) ||
-            fail(c, "D2H(ures)", hipMemcpyAsync(&r, c->d_ures, sizeof r, hipMemcpyDeviceToHost, c->stream)) ||
+        const int s1rc = stage1_device_impl(c, c->d_in, len, c->d_idx, dev_cap, c->d_res_tmp, c->stream, 0);
+        if (s1rc != SJMI_OK) return s1rc;
+        if (!grow(c, &c->d_ws_strm, &c->ws_strm_bytes, sjmi::strings_workspace_bytes(len), "hipMalloc(ws_strm)")) return SJMI_ERR_HIP;
+        const unsigned long long* par = parity_for(c, c->d_in, len, c->stream);
+        if (!par) return SJMI_ERR_HIP;
+        sjmi::UnescapeResult* d_u = sjmi::strings_workspace_result(c->d_ws_strm);
+        if (fail(c, "strings launch", sjmi::strings_launch(c->d_in, len, par, c->d_sb, c->sb_bytes, nullptr, 0, nullptr, c->d_ws_strm, d_u, c->stream)) ||
+            fail(c, "error index", sjmi::strings_error_index_pack_launch(c->d_idx, (const sjmi::Stage1Result*)c->d_res_tmp, d_u, c->d_pack, c->stream)) ||
+            fail(c, "D2H(results)", hipMemcpyAsync(c->h_pack, c->d_pack, sizeof(Pack), hipMemcpyDeviceToHost, c->stream)) ||
             fail(c, "sync", hipStreamSynchronize(c->stream)))
             return SJMI_ERR_HIP;
+        const Pack* hp = static_cast<const Pack*>(c->h_pack);
+        *c->h_res = hp->s1;
+        r = hp->u;
+        err_index = hp->err_index;
         if (!(c->h_res->status & SJMI_ST_INTERNAL) || c->ticket_mode) break;
         c->ticket_mode = true;  // fast-mode liveness assumption failed: latch the safe mode and run again
     }
+    (void)d_res1;
     *status = c->h_res->status & 0xFFu;
     *count = c->h_res->count;
     *total_bytes = 0;
@@ -1040,9 +1073,9 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
     unsigned long long *d_doc = d64, *d_io = d64 + 2, *d_dso = d64 + 4, *d_to = d64 + 6;
     uint32_t* d_st = (uint32_t*)(d64 + 8);
     int32_t* d_err = (int32_t*)(d64 + 9);
-    sjmi::UnescapeResult* d_ures = (sjmi::UnescapeResult*)(d64 + 10);
+    sjmi::UnescapeResult* d_ures = nullptr;  // (inside the string pass's workspace, zeroed with it)
     sjmi::WalkResult* d_wres = (sjmi::WalkResult*)(d64 + 13);
-    const sjmi::Stage1Result* d_res1 = (const sjmi::Stage1Result*)((uint8_t*)c->d_ws + sjmi::WS_RESULT_OFFSET);
+    sjmi::Stage1Result* d_res1 = (sjmi::Stage1Result*)(d64 + 20);
     SingleDocResults* h = (SingleDocResults*)c->h_single;
     const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(len);
     if (len && fail(c, "H2D", hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
@@ -1052,21 +1085,23 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
     sjmi_unescape_result* h_u_early = (sjmi_unescape_result*)((uint8_t*)c->h_single + 256);
     bool strings_in_flight = false;
     const bool early_strings = len >= (256u << 10);  // (below that the second stream's synchronisation costs more than it hides)
+    // Latency: besides the kernels only ONE memset is queued (the string pass's workspace, which also holds its record) --
+    // stage 1 through the device entry point (double-buffered workspace, the scanner writes the record), the walk's record and
+    // list header zeroed by the setup kernel.
+    (void)steps;
+    const AutoSafeOff own_retry(c);  // (the retry below is this call's own)
     for (int attempt = 0; attempt < 2; ++attempt) {
         strings_in_flight = false;
-        sjmi::Stage1Extras ex1;
-        ex1.blkpar = parity_out(c, c->d_in, len);
-        if (fail(c, "launch", sjmi::stage1_launch(c->d_in, len, c->d_idx, c->capacity + 2, c->d_ws, steps, c->stream, nullptr, nullptr,
-                                                  launch_flags(c), ex1)))
-            return SJMI_ERR_HIP;
-        note_launch(c, c->stream);
-        const int src = strings_device_impl(c, c->d_in, len, c->d_sb, c->sb_bytes, c->d_soff, (size_t)len / 2 + 2, nullptr, d_ures, c->stream);
+        const int s1rc = stage1_device_impl(c, c->d_in, len, c->d_idx, c->capacity + 2, d_res1, c->stream, 0);
+        if (s1rc != SJMI_OK) return s1rc;
+        const int src = strings_device_impl(c, c->d_in, len, c->d_sb, c->sb_bytes, c->d_soff, (size_t)len / 2 + 2, nullptr, nullptr, c->stream, &d_ures);
         if (src != SJMI_OK) return src;
         if ((early_strings && fail(c, "event", hipEventRecord(c->strings_ready, c->stream))) ||
-            fail(c, "setup", sjmi::single_doc_setup_launch(d_res1, len, d_doc, d_io, d_st, d_dso, c->stream)) ||
+            fail(c, "setup", sjmi::single_doc_setup_launch(d_res1, len, d_doc, d_io, d_st, d_dso, c->stream, d_wres,
+                                                           sjmi::walk_slow_header(c->d_ws_walk, bound, 1))) ||
             fail(c, "walk launch",
                  sjmi::walk_launch(c->d_in, d_doc, 1, c->d_idx, bound, d_io, d_st, c->d_sb, d_dso, 0, max_depth, c->d_tape,
-                                   2 * bound + 8, d_to, d_err, c->d_ws_walk, d_wres, c->stream, d_res1, d_ures, c->d_soff, true)) ||
+                                   2 * bound + 8, d_to, d_err, c->d_ws_walk, d_wres, c->stream, d_res1, d_ures, c->d_soff, true, true)) ||
             fail(c, "results", single_doc_results_launch(d_res1, d_ures, d_wres, d_to, d_err,
                                                          (SingleDocResults*)((uint8_t*)c->d_single + 256), c->stream)) ||
             fail(c, "D2H", hipMemcpyAsync(h, (uint8_t*)c->d_single + 256, sizeof *h, hipMemcpyDeviceToHost, c->stream)))

@@ -95,6 +95,10 @@ hipError_t strings_doc_ordinals_launch(const uint8_t* d_buf, const unsigned long
                                        const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_blk_ord,
                                        const uint32_t* d_soff, const UnescapeResult* d_res, unsigned long long* d_doc_ord,
                                        unsigned long long* d_doc_str_offsets, hipStream_t stream);
+size_t strings_parse_pack_bytes();
+hipError_t strings_error_index_pack_launch(const uint32_t* d_idx, const Stage1Result* dev_count, const UnescapeResult* d_res, void* d_pack,
+                                           hipStream_t stream);
+UnescapeResult* strings_workspace_result(void* d_ws);
 hipError_t strings_error_index_launch(const uint32_t* d_idx, uint64_t count, const Stage1Result* dev_count, const UnescapeResult* d_res,
                                       unsigned long long* d_out, hipStream_t stream);
 // the string pass of a batch (sjmi_unescape_batch_device): document / index offsets on the device (n_docs + 1 entries each) and,
@@ -117,7 +121,7 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
                        unsigned long long* d_tape, uint64_t tape_capacity, unsigned long long* d_tape_offsets,
                        int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream,
                        const Stage1Result* dev_count, const UnescapeResult* dev_strings, const uint32_t* d_soff,
-                       bool index_from_zero = false);
+                       bool index_from_zero = false, bool results_zeroed = false);
 // coop_walk.hip: the cooperative walker (a wave per document); d_soff = offset of every string's record in d_sb, by ordinal
 hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_idx,
                             const unsigned long long* d_index_offsets, const uint32_t* d_doc_status, const uint32_t* d_soff,
@@ -125,7 +129,7 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
                             int max_depth, unsigned long long* d_scratch_tape, uint32_t* d_tape_lens, int32_t* d_doc_errors,
                             const Stage1Result* dev_count, const UnescapeResult* dev_strings, WalkResult* d_res,
                             hipStream_t stream, void* d_chunk_ws = nullptr, uint64_t count_bound = 0, void* d_deep_ws = nullptr,
-                            unsigned long long* d_single_tape_offsets = nullptr, uint64_t tape_capacity = 0);
+                            unsigned long long* d_single_tape_offsets = nullptr, uint64_t tape_capacity = 0, bool header_zeroed = false);
 // nesting levels 64 .. 1023 of the wave-per-document walker live in global memory: bytes for a batch of n_docs documents
 size_t coop_deep_workspace_bytes(uint64_t n_docs);
 // workspace of the chunk-parallel path for one large document (coop_walk.hip)
@@ -135,7 +139,10 @@ hipError_t coop_match_launch(const uint8_t* d_buf, uint64_t n_docs, const uint32
                              uint32_t* d_up, uint32_t* d_match, hipStream_t stream, void* d_chunk_ws = nullptr, uint64_t count_bound = 0);
 hipError_t single_doc_setup_launch(const Stage1Result* d_res, uint64_t len, unsigned long long* d_doc_offsets,
                                    unsigned long long* d_index_offsets, uint32_t* d_doc_status, unsigned long long* d_doc_str_offsets,
-                                   hipStream_t stream);
+                                   hipStream_t stream, WalkResult* d_walk_result = nullptr, void* d_slow_header = nullptr);
+// the 64 bytes at the head of the walk workspace's literal list (count + the chunk path's flags): walk_launch zeroes them unless
+// the caller did (results_zeroed: single_doc_setup_launch on the latency path, together with *d_res)
+void* walk_slow_header(void* d_ws, uint64_t count, uint64_t n_docs);
 hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint32_t* d_out,
                                  uint64_t out_cap, unsigned long long* d_index_offsets, uint32_t* d_doc_status,
                                  uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream, uint64_t total_len, const uint32_t* d_skip = nullptr);

@@ -811,12 +811,15 @@ k_strings(const StrArgs a0) {
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr size_t STR_WS_FLAGS_OFFSET = 0;     // u32 status, u32 scanner CU
+constexpr size_t STR_WS_RESULT_OFFSET = 32;   // a result record zeroed with the workspace (strings_workspace_result)
 constexpr size_t STR_WS_TICKET_OFFSET = 64;   // 8 counters, 64 bytes apart
 constexpr size_t STR_WS_STATE_OFFSET = 640;
 
 static uint64_t str_granules(uint64_t len) { return (len / 64 + 1 + 63) / 64; }
 size_t strings_workspace_bytes(uint64_t len) { return STR_WS_STATE_OFFSET + 3 * (size_t)str_granules(len) * sizeof(sj_u64) + 64; }
 size_t strings_parity_words(uint64_t len) { return (size_t)str_granules(len) + 4; }
+// a result record inside the workspace: strings_launch zeroes it with the rest (one memset less on the latency path)
+UnescapeResult* strings_workspace_result(void* d_ws) { return reinterpret_cast<UnescapeResult*>(static_cast<uint8_t*>(d_ws) + STR_WS_RESULT_OFFSET); }
 
 template <bool SOFF>
 static hipError_t str_resident(unsigned* out) {
@@ -1001,6 +1004,38 @@ __global__ void k_error_index(const uint32_t* __restrict__ idx, uint64_t count, 
         if (lo > 0) r = lo - 1;
     }
     *out = r;
+}
+// the same, plus the two result records behind the index: {index, stage-1 record, string record} in one place = ONE D2H for the
+// drop-in call on a small document instead of three
+struct __attribute__((aligned(8))) ParsePack {
+    unsigned long long err_index;
+    Stage1Result s1;
+    UnescapeResult u;
+};
+__global__ void k_error_index_pack(const uint32_t* __restrict__ idx, const Stage1Result* __restrict__ dev_count,
+                                   const UnescapeResult* __restrict__ res, ParsePack* __restrict__ out) {
+    unsigned long long r = ~0ull;
+    const Stage1Result s1 = *dev_count;
+    const UnescapeResult u = *res;
+    if (u.first_error_inv) {
+        const uint64_t count = (s1.status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL)) ? 0 : s1.count;
+        const unsigned long long pos = (~u.first_error_inv) >> 8;
+        uint64_t lo = 0, hi = count;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (idx[mid] <= pos) lo = mid + 1; else hi = mid;
+        }
+        if (lo > 0) r = lo - 1;
+    }
+    out->err_index = r;
+    out->s1 = s1;
+    out->u = u;
+}
+size_t strings_parse_pack_bytes() { return sizeof(ParsePack); }
+hipError_t strings_error_index_pack_launch(const uint32_t* d_idx, const Stage1Result* dev_count, const UnescapeResult* d_res, void* d_pack,
+                                           hipStream_t stream) {
+    hipLaunchKernelGGL(k_error_index_pack, dim3(1), dim3(1), 0, stream, d_idx, dev_count, d_res, static_cast<ParsePack*>(d_pack));
+    return hipGetLastError();
 }
 hipError_t strings_error_index_launch(const uint32_t* d_idx, uint64_t count, const Stage1Result* dev_count, const UnescapeResult* d_res,
                                       unsigned long long* d_out, hipStream_t stream) {

@@ -121,12 +121,14 @@ size_t walk_workspace_bytes(uint64_t count, uint64_t n_docs) {
     return walk_deep_offset(count, n_docs) + coop_deep_workspace_bytes(n_docs);
 }
 
+void* walk_slow_header(void* d_ws, uint64_t count, uint64_t n_docs) { return static_cast<uint8_t*>(d_ws) + walk_deep_offset(count, n_docs); }
+
 hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_idx,
                        uint64_t count, const unsigned long long* d_index_offsets, const uint32_t* d_doc_status,
                        const uint8_t* d_sb, const unsigned long long* d_doc_str_ordinals, uint64_t string_base, int max_depth,
                        unsigned long long* d_tape, uint64_t tape_capacity, unsigned long long* d_tape_offsets,
                        int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream, const Stage1Result* dev_count,
-                       const UnescapeResult* dev_strings, const uint32_t* d_soff, bool index_from_zero) {
+                       const UnescapeResult* dev_strings, const uint32_t* d_soff, bool index_from_zero, bool results_zeroed) {
     if (!d_soff) return hipErrorInvalidValue;  // (the record table of the string pass: strings.hip)
     uint8_t* ws = static_cast<uint8_t*>(d_ws);
     unsigned long long* scratch = reinterpret_cast<unsigned long long*>(ws);
@@ -136,7 +138,7 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
     if (direct) scratch = d_tape;
     uint32_t* lens = reinterpret_cast<uint32_t*>(ws + walk_lens_offset(count, n_docs));
     unsigned long long* sums = reinterpret_cast<unsigned long long*>(ws + walk_sums_offset(count, n_docs));
-    hipError_t e = hipMemsetAsync(d_res, 0, sizeof(WalkResult), stream);
+    hipError_t e = results_zeroed ? hipSuccess : hipMemsetAsync(d_res, 0, sizeof(WalkResult), stream);
     if (e != hipSuccess) return e;
     const uint64_t nchunks = (n_docs + PACK_DOCS - 1) / PACK_DOCS;
     if (n_docs) {
@@ -146,7 +148,7 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
         e = coop_walk_launch(d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets, d_doc_status, d_soff, d_sb,
                              d_doc_str_ordinals, string_base, max_depth, scratch, lens, d_doc_errors, dev_count, dev_strings, d_res,
                              stream, n_docs == 1 ? ws + walk_chunks_offset(count, n_docs) : nullptr, count,
-                             ws + walk_deep_offset(count, n_docs), direct ? d_tape_offsets : nullptr, tape_capacity);
+                             ws + walk_deep_offset(count, n_docs), direct ? d_tape_offsets : nullptr, tape_capacity, results_zeroed);
         if (e != hipSuccess) return e;
         if (direct) return hipGetLastError();
         hipLaunchKernelGGL(k_tape_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, lens, d_doc_errors, n_docs, sums, d_res);
