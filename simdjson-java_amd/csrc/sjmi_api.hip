@@ -250,6 +250,15 @@ namespace {
 void* parity_out(sjmi_ctx* c, const void* d_buf, uint64_t len);
 }
 
+// sjmi_set_auto_safe's per-launch check switched off for the lifetime of the object (a call that re-runs in SAFE mode itself)
+struct AutoSafeOff {
+    sjmi_ctx* c;
+    bool keep;
+    explicit AutoSafeOff(sjmi_ctx* ctx) : c(ctx), keep(ctx->auto_safe) { ctx->auto_safe = false; }
+    ~AutoSafeOff() { c->auto_safe = keep; }
+};
+static int stage1_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_indexes, uint64_t index_capacity,
+                              void* d_result, void* stream, uint32_t shard_flags);
 int sjmi_stage1(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes, uint64_t index_capacity,
                 uint64_t* count, uint32_t* status) {
     if (!c || (!buf && len) || !indexes || !count || !status) return SJMI_ERR_ARG;
@@ -261,18 +270,14 @@ int sjmi_stage1(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
     // padIfNeeded (SimdJsonParser.java:42-48): only buf[0,len) is ever read from the caller
     if (len && fail(c, "H2D", hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
-    const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(len);
     const uint64_t dev_cap = c->capacity + 2 < index_capacity ? c->capacity + 2 : index_capacity;
-    sjmi::Stage1Extras ex1;
-    ex1.blkpar = parity_out(c, c->d_in, len);
+    if (!c->d_res_tmp && fail(c, "hipMalloc(result)", hipMalloc((void**)&c->d_res_tmp, 64))) return SJMI_ERR_HIP;
+    const AutoSafeOff own_retry(c);  // (the retry below is this call's own)
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (fail(c, "launch", sjmi::stage1_launch(c->d_in, len, c->d_idx, dev_cap, c->d_ws, steps, c->stream, nullptr,
-                                                  nullptr, launch_flags(c), ex1)))
-            return SJMI_ERR_HIP;
-        note_launch(c, c->stream);
-        if (fail(c, "D2H(result)",
-                 hipMemcpyAsync(c->h_res, (uint8_t*)c->d_ws + sjmi::WS_RESULT_OFFSET, sizeof(sjmi_stage1_result),
-                                hipMemcpyDeviceToHost, c->stream)) ||
+        // (the device entry point: double-buffered workspace, nothing but the kernel is queued once the context is warm)
+        const int rc = stage1_device_impl(c, c->d_in, len, c->d_idx, dev_cap, c->d_res_tmp, c->stream, 0);
+        if (rc != SJMI_OK) return rc;
+        if (fail(c, "D2H(result)", hipMemcpyAsync(c->h_res, c->d_res_tmp, sizeof(sjmi_stage1_result), hipMemcpyDeviceToHost, c->stream)) ||
             fail(c, "sync", hipStreamSynchronize(c->stream)))
             return SJMI_ERR_HIP;
         if (!(c->h_res->status & SJMI_ST_INTERNAL) || c->ticket_mode) break;
@@ -551,15 +556,6 @@ int sjmi_unescape_batch(sjmi_ctx* c, uint8_t* string_buffer, uint64_t string_cap
     return unescape_host(c, string_buffer, string_capacity, doc_string_offsets, total_bytes, first_error_index, first_error_code);
 }
 
-// sjmi_set_auto_safe's per-launch check switched off for the lifetime of the object (a call that re-runs in SAFE mode itself)
-struct AutoSafeOff {
-    sjmi_ctx* c;
-    bool keep;
-    explicit AutoSafeOff(sjmi_ctx* ctx) : c(ctx), keep(ctx->auto_safe) { ctx->auto_safe = false; }
-    ~AutoSafeOff() { c->auto_safe = keep; }
-};
-static int stage1_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_indexes, uint64_t index_capacity,
-                              void* d_result, void* stream, uint32_t shard_flags);
 int sjmi_stage1_unescape(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes, uint64_t index_capacity,
                          uint64_t* count, uint32_t* status, uint8_t* string_buffer, uint64_t string_capacity,
                          uint64_t* total_bytes, uint64_t* first_error_index, uint32_t* first_error_code) {
