@@ -288,8 +288,10 @@ int sjmi_walk_batch_device(sjmi_ctx* ctx, const void* d_buf, const void* d_doc_o
  * bounds the structural count (+ sentinel) and sizes the workspaces.  d_result: a device sjmi_batch_result.  This is
  * what one rank of the sharded multi-GPU batch runs per step (sharding.py); asynchronous on `stream`.
  * Stage 1 is first tried as ONE plain launch over the packed batch and accepted on the device when every document ends in
- * a control-character separator ('\n', '\r', '\t') and the global verdict is clean -- then it is exactly what the
- * per-document passes give; otherwise those run (queued behind it, they leave at once when it was accepted). */
+ * a control-character separator ('\n', '\r', '\t'), the documents cover the buffer exactly (doc_offsets[0] == 0 and
+ * doc_offsets[n_docs] == total_len: bytes outside the documents would feed state into them) and the global verdict is
+ * clean -- then it is exactly what the per-document passes give; otherwise those run (queued behind it, they leave at once
+ * when it was accepted). */
 typedef struct sjmi_batch_result {
     sjmi_stage1_result stage1;
     sjmi_unescape_result strings;

@@ -101,7 +101,7 @@ struct StrArgs {
     sj_u64 soff_cap;
     uint32_t* blk_ord;     // optional: ordinal of the first string opened at or behind every block's first byte
     sj_u64* gstate;        // aggregates[ngran] | prefixes[ngran] | open records[ngran]
-    uint32_t* ticket;      // 8 counters, 64 bytes apart
+    uint32_t* ticket;      // STR_TICKET_CLASSES counters, 64 bytes apart
     uint32_t* wsflags;     // [0] status bits (SJMI_ST_INTERNAL), [1] the scanner's CU
     UnescapeResult* res;
     uint32_t ngran;
@@ -115,12 +115,14 @@ struct StrArgs {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // the scanner: workgroup 0 turns the workers' aggregates, in order, into inclusive prefixes (see stage1.hip's scanner for
-// why it is built like this: four waves take windows of 256 granules round-robin, everything that does not depend on
+// why it is built like this: four waves take windows of 64 * SSCAN_K granules round-robin, everything that does not depend on
 // the running state is done before it arrives through LDS, and at the workers' frontier a wave publishes whatever
 // is ready lane by lane so that a launch with few resident workgroups cannot deadlock on a half-handed-out window)
 // ---------------------------------------------------------------------------------------------------------------------
+// (windows of 128 granules: twitter x1024 0.400 ms against 0.406 with 256, 0.75 with 512 -- the frontier window is never
+//  complete and goes lane by lane; 64: 0.60)
 #ifndef SJMI_SSCAN_K
-#define SJMI_SSCAN_K 4
+#define SJMI_SSCAN_K 2
 #endif
 constexpr int SSCAN_K = SJMI_SSCAN_K;
 struct StrHand {
@@ -293,7 +295,13 @@ __device__ __forceinline__ bool swar_has_backslash(uint32_t w) {
 }
 struct __attribute__((packed, aligned(1))) StrU4B { uint32_t a; };
 
-constexpr uint32_t STR_TICKET_CLASSES = 8;
+// ticket counters: class c = worker mod N owns the granules = c mod N.  A 4 KiB granule needs a ticket four times as often as
+// stage 1's 16 KiB granule, and one counter saturates: twitter x1024 0.596 ms with 4 counters, 0.400 with 8, 0.385 with 16,
+// 0.387 with 32
+#ifndef SJMI_STR_CLASSES
+#define SJMI_STR_CLASSES 16
+#endif
+constexpr uint32_t STR_TICKET_CLASSES = SJMI_STR_CLASSES;
 
 template <bool SOFF>
 struct StrWaveLds {
@@ -546,7 +554,7 @@ k_strings(const StrArgs a0) {
                         }
                         break;
                     }
-                    if (spins) __builtin_amdgcn_s_sleep(1);
+                    if (spins) __builtin_amdgcn_s_sleep(1);  // (no sleep: 0.407 ms instead of 0.389 -- the polls compete with the stores; 2 .. 8: no change)
                     pf = sg_load(&pfx[prev - 1]);
                 }
                 outbase = pf & 0xFFFFFFFFull;
@@ -812,8 +820,8 @@ k_strings(const StrArgs a0) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr size_t STR_WS_FLAGS_OFFSET = 0;     // u32 status, u32 scanner CU
 constexpr size_t STR_WS_RESULT_OFFSET = 32;   // a result record zeroed with the workspace (strings_workspace_result)
-constexpr size_t STR_WS_TICKET_OFFSET = 64;   // 8 counters, 64 bytes apart
-constexpr size_t STR_WS_STATE_OFFSET = 640;
+constexpr size_t STR_WS_TICKET_OFFSET = 64;   // the ticket counters, 64 bytes apart
+constexpr size_t STR_WS_STATE_OFFSET = 64 + 32 * 64;  // (room for 32 ticket counters)
 
 static uint64_t str_granules(uint64_t len) { return (len / 64 + 1 + 63) / 64; }
 size_t strings_workspace_bytes(uint64_t len) { return STR_WS_STATE_OFFSET + 3 * (size_t)str_granules(len) * sizeof(sj_u64) + 64; }

@@ -58,7 +58,7 @@ class BatchShard:
         self.device = device
         self.n = int(shard_bytes.numel()) if hasattr(shard_bytes, "numel") else len(shard_bytes)
         offs = np.ascontiguousarray(local_offsets, dtype=np.uint64)
-        assert offs[0] == 0 and int(offs[-1]) <= self.n
+        assert offs[0] == 0 and int(offs[-1]) == self.n  # (the documents cover the shard exactly: include/sjmi.h, sjmi_parse_batch_device)
         self.n_docs = offs.size - 1
         if hasattr(shard_bytes, "numel"):
             self.buf = torch.zeros(self.n + 128, dtype=torch.uint8, device=device)
