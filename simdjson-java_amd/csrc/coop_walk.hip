@@ -302,32 +302,56 @@ k_slow_doubles(const uint8_t* __restrict__ buf, SlowList sl) {
     }
 }
 
-// ONE document whose tape was written in place: the listed literals, and what k_tape_chunk_sums + k_tape_chunk_scan (walk.hip)
-// would compute for it, in one launch of one wave
-__global__ void __launch_bounds__(64)
-k_single_finish(const uint8_t* __restrict__ buf, SlowList sl, const uint32_t* __restrict__ tape_lens, const int32_t* __restrict__ doc_errors,
-                uint64_t tape_capacity, unsigned long long* __restrict__ tape_offsets, WalkResult* res) {
-    __shared__ uint32_t wa[SJ_BIG_WORDS], wb[SJ_BIG_WORDS];
-    if (threadIdx.x != 0) return;
-    unsigned long long n = *sl.count;
-    if (n > sl.cap) n = sl.cap;
+// ONE document whose tape was written in place, executed by thread 0 of the walk's last launch: the listed literals, what
+// k_tape_chunk_sums + k_tape_chunk_scan (walk.hip) would compute for it, and (sjmi_parse_document) the three stages' result
+// records packed for one D2H
+struct SingleFinish {
+    SlowList slow;
+    const uint32_t* tape_lens;
+    const int32_t* doc_errors;
+    uint64_t tape_capacity;
+    unsigned long long* tape_offsets;
+    WalkResult* res;
+    const Stage1Result* s1;
+    const UnescapeResult* u;
+    SingleDocPack* pack;
+};
+__device__ void cw_single_finish(const uint8_t* __restrict__ buf, const SingleFinish& f, uint32_t tlen, int code, uint32_t* wa, uint32_t* wb) {
+    unsigned long long n = *f.slow.count;
+    if (n > f.slow.cap) n = f.slow.cap;
     for (unsigned long long r = 0; r < n; ++r) {
-        unsigned long long* const slot = reinterpret_cast<unsigned long long*>(sl.rec[2 * r]);
-        const uint32_t p = (uint32_t)sl.rec[2 * r + 1], limit = (uint32_t)(sl.rec[2 * r + 1] >> 32);
+        unsigned long long* const slot = reinterpret_cast<unsigned long long*>(f.slow.rec[2 * r]);
+        const uint32_t p = (uint32_t)f.slow.rec[2 * r + 1], limit = (uint32_t)(f.slow.rec[2 * r + 1] >> 32);
         const bool neg = buf[p] == '-';
         const unsigned long long mag =
             sj_decide_double([&](uint32_t q) -> uint32_t { return q < limit ? (uint32_t)buf[q] : 0x20u; }, p + (neg ? 1u : 0u),
                              *slot & ~(1ull << 63), wa, wb);
         *slot = mag | (neg ? 1ull << 63 : 0ull);
     }
-    const unsigned long long words = tape_lens[0];
-    const int e = doc_errors[0];
-    tape_offsets[0] = 0;
-    tape_offsets[1] = words;
-    res->tape_words = words;
-    res->host_documents = e == SJMI_WALK_NEEDS_HOST ? 1 : 0;
-    res->failed_documents = e > 0 ? 1 : 0;
-    if (words > tape_capacity) res->flags |= 1u;
+    WalkResult w;
+    w.tape_words = tlen;
+    w.host_documents = code == SJMI_WALK_NEEDS_HOST ? 1 : 0;
+    w.failed_documents = code > 0 ? 1 : 0;
+    w.flags = f.res->flags | (tlen > f.tape_capacity ? 1u : 0u);
+    w.reserved = 0;
+    f.tape_offsets[0] = 0;
+    f.tape_offsets[1] = tlen;
+    *f.res = w;
+    if (f.pack) {
+        f.pack->s1 = *f.s1;
+        f.pack->u = *f.u;
+        f.pack->w = w;
+        f.pack->to[0] = 0;
+        f.pack->to[1] = tlen;
+        f.pack->err = code;
+        f.pack->fallback = 0;
+    }
+}
+__global__ void __launch_bounds__(64)
+k_single_finish(const uint8_t* __restrict__ buf, SingleFinish f) {
+    __shared__ uint32_t wa[SJ_BIG_WORDS], wb[SJ_BIG_WORDS];
+    if (threadIdx.x != 0) return;
+    cw_single_finish(buf, f, f.tape_lens[0], f.doc_errors[0], wa, wb);
 }
 
 // One wave per document (grid-stride over the documents).  Documents are delimited by index_offsets (n_docs + 1 entries)
@@ -1040,8 +1064,12 @@ __global__ void __launch_bounds__(64)
 k_chunk_finish(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ idx, const unsigned long long* __restrict__ index_offsets,
                const uint32_t* __restrict__ doc_status, unsigned long long* __restrict__ scratch_tape, uint32_t* __restrict__ tape_lens,
                int32_t* __restrict__ doc_errors, const Stage1Result* __restrict__ dev_count, const UnescapeResult* __restrict__ dev_strings,
-               ChunkWs cw) {
-    if (*cw.fallback != 0) return;  // the single-wave sweep writes the document's result
+               ChunkWs cw, SingleFinish fin, uint32_t with_tail) {
+    __shared__ uint32_t wa[SJ_BIG_WORDS], wb[SJ_BIG_WORDS];
+    if (*cw.fallback != 0) {  // the single-wave sweep writes the document's result
+        if (with_tail && fin.pack && threadIdx.x == 0) fin.pack->fallback = 1;  // (optimistic tail: the caller queues that sweep)
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const unsigned long long from = index_offsets[0], to = index_offsets[1];
     const uint32_t chunk = cw_chunk_of(to - from);
@@ -1091,6 +1119,7 @@ k_chunk_finish(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ idx
     if (lane == 0) {
         tape_lens[0] = tlen;
         doc_errors[0] = code;
+        if (with_tail) cw_single_finish(buf, fin, tlen, code, wa, wb);  // (nothing else is queued behind this launch)
     }
 }
 
@@ -1351,7 +1380,8 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
                             int max_depth, unsigned long long* d_scratch_tape, uint32_t* d_tape_lens, int32_t* d_doc_errors,
                             const Stage1Result* dev_count, const UnescapeResult* dev_strings, WalkResult* d_res,
                             hipStream_t stream, void* d_chunk_ws, uint64_t count_bound, void* d_deep_ws,
-                            unsigned long long* d_single_tape_offsets, uint64_t tape_capacity, bool header_zeroed) {
+                            unsigned long long* d_single_tape_offsets, uint64_t tape_capacity, bool header_zeroed,
+                            const SingleDocTail& tail) {
     if (!n_docs) return hipSuccess;
     // (the deep-level workspace begins with the list of undecided literals)
     SlowList slow;
@@ -1366,7 +1396,9 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
     const uint32_t abl = (uint32_t)(getenv("SJMI_COOP_ABLATE") ? atoi(getenv("SJMI_COOP_ABLATE")) : 0);
     ChunkWs cw = {};
     static const bool no_chunks = getenv("SJMI_COOP_CHUNKS") && atoi(getenv("SJMI_COOP_CHUNKS")) == 0;
-    const bool chunked = d_chunk_ws && n_docs == 1 && count_bound > COOP_CHUNK_MIN && !no_chunks;
+    const bool chunked = d_chunk_ws && n_docs == 1 && count_bound > COOP_CHUNK_MIN && !no_chunks && !tail.no_chunks;
+    SingleFinish fin = {slow, d_tape_lens, d_doc_errors, tape_capacity, d_single_tape_offsets, d_res, tail.s1, tail.u, tail.pack};
+    const bool optimistic = chunked && d_single_tape_offsets && tail.optimistic && tail.pack;
     const uint32_t* only_if = nullptr;
     if (chunked) {
         cw = chunk_ws(d_chunk_ws, count_bound, reinterpret_cast<uint32_t*>(slow.count) + 8);  // (zeroed with the list's count above)
@@ -1384,7 +1416,8 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
                            d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res, abl, cw, (const uint32_t*)nullptr,
                            (unsigned long long*)nullptr, slow);
         hipLaunchKernelGGL(k_chunk_finish, dim3(1), dim3(64), 0, stream, d_buf, d_idx, d_index_offsets, d_doc_status, d_scratch_tape,
-                           d_tape_lens, d_doc_errors, dev_count, dev_strings, cw);
+                           d_tape_lens, d_doc_errors, dev_count, dev_strings, cw, fin, optimistic ? 1u : 0u);
+        if (optimistic) return hipGetLastError();  // (three launches fewer on the single-document latency path)
         only_if = cw.fallback;
     }
     const uint64_t want = (n_docs + 3) / 4;  // four documents (waves) per workgroup and trip
@@ -1394,8 +1427,7 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
                        d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res, abl, cw, only_if,
                        static_cast<unsigned long long*>(d_deep_ws), slow);
     if (d_single_tape_offsets)
-        hipLaunchKernelGGL(k_single_finish, dim3(1), dim3(64), 0, stream, d_buf, slow, d_tape_lens, d_doc_errors, tape_capacity,
-                           d_single_tape_offsets, d_res);
+        hipLaunchKernelGGL(k_single_finish, dim3(1), dim3(64), 0, stream, d_buf, fin);
     else
         hipLaunchKernelGGL(k_slow_doubles, dim3(256), dim3(64), 0, stream, d_buf, slow);  // (nothing listed: 256 waves that leave at once)
     return hipGetLastError();

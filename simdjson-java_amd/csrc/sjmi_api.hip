@@ -1008,36 +1008,10 @@ int sjmi_parse_batch_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, 
     return SJMI_OK;
 }
 
-// the result records of the three stages in one place: one D2H instead of five
-struct SingleDocResults {
-    sjmi_stage1_result s1;
-    sjmi_unescape_result u;
-    sjmi_walk_result w;
-    unsigned long long to[2];
-    int32_t err;
-};
-static_assert(sizeof(SingleDocResults) <= 256, "d_single / h_single hold 256 bytes of results");
+// (the result records of the three stages come back in one place, sjmi::SingleDocPack, written by the walk's last launch)
+using SingleDocResults = sjmi::SingleDocPack;
 static_assert(sizeof(sjmi_stage1_result) == sizeof(sjmi::Stage1Result) && sizeof(sjmi_unescape_result) == sizeof(sjmi::UnescapeResult) &&
               sizeof(sjmi_walk_result) == sizeof(sjmi::WalkResult), "C ABI records mirror the device records");
-__global__ void k_single_doc_results(const sjmi::Stage1Result* s1, const sjmi::UnescapeResult* u, const sjmi::WalkResult* w,
-                                     const unsigned long long* to, const int32_t* err, SingleDocResults* out) {
-    // (every record is a multiple of four bytes: one dword per lane and record)
-    const uint32_t t = threadIdx.x;
-    auto copy = [&](void* dst, const void* src, size_t bytes) {
-        if (t < bytes / 4) reinterpret_cast<uint32_t*>(dst)[t] = reinterpret_cast<const uint32_t*>(src)[t];
-    };
-    copy(&out->s1, s1, sizeof out->s1);
-    copy(&out->u, u, sizeof out->u);
-    copy(&out->w, w, sizeof out->w);
-    copy(out->to, to, sizeof out->to);
-    copy(&out->err, err, sizeof out->err);
-}
-
-static hipError_t single_doc_results_launch(const sjmi::Stage1Result* s1, const sjmi::UnescapeResult* u, const sjmi::WalkResult* w,
-                                            const unsigned long long* to, const int32_t* err, SingleDocResults* out, hipStream_t stream) {
-    hipLaunchKernelGGL(k_single_doc_results, dim3(1), dim3(64), 0, stream, s1, u, w, to, err, out);
-    return hipGetLastError();
-}
 
 // SimdJsonParser.parse(byte[], int) with ALL THREE stages on the GPU (SimdJsonParser.java:35-40): H2D of the document,
 // stage 1, string records, the cooperative walker, D2H of the tape and the string buffer -- the structural indexes never
@@ -1092,15 +1066,18 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
         if (s1rc != SJMI_OK) return s1rc;
         const int src = strings_device_impl(c, c->d_in, len, c->d_sb, c->sb_bytes, c->d_soff, (size_t)len / 2 + 2, nullptr, nullptr, c->stream, &d_ures);
         if (src != SJMI_OK) return src;
+        sjmi::SingleDocTail tail;
+        tail.s1 = d_res1;
+        tail.u = d_ures;
+        tail.pack = (sjmi::SingleDocPack*)((uint8_t*)c->d_single + 256);
+        tail.optimistic = true;  // (a large document's chunk path ends in k_chunk_finish: a document it declines comes back flagged)
         if ((early_strings && fail(c, "event", hipEventRecord(c->strings_ready, c->stream))) ||
             fail(c, "setup", sjmi::single_doc_setup_launch(d_res1, len, d_doc, d_io, d_st, d_dso, c->stream, d_wres,
                                                            sjmi::walk_slow_header(c->d_ws_walk, bound, 1))) ||
             fail(c, "walk launch",
                  sjmi::walk_launch(c->d_in, d_doc, 1, c->d_idx, bound, d_io, d_st, c->d_sb, d_dso, 0, max_depth, c->d_tape,
-                                   2 * bound + 8, d_to, d_err, c->d_ws_walk, d_wres, c->stream, d_res1, d_ures, c->d_soff, true, true)) ||
-            fail(c, "results", single_doc_results_launch(d_res1, d_ures, d_wres, d_to, d_err,
-                                                         (SingleDocResults*)((uint8_t*)c->d_single + 256), c->stream)) ||
-            fail(c, "D2H", hipMemcpyAsync(h, (uint8_t*)c->d_single + 256, sizeof *h, hipMemcpyDeviceToHost, c->stream)))
+                                   2 * bound + 8, d_to, d_err, c->d_ws_walk, d_wres, c->stream, d_res1, d_ures, c->d_soff, true, true, tail)) ||
+            fail(c, "D2H", hipMemcpyAsync(h, tail.pack, sizeof *h, hipMemcpyDeviceToHost, c->stream)))
             return SJMI_ERR_HIP;
         // (everything of the main stream is queued: now the early look at the string records)
         if (early_strings) {
@@ -1115,6 +1092,20 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
             }
         }
         if (fail(c, "sync", hipStreamSynchronize(c->stream))) return SJMI_ERR_HIP;
+        if (h->fallback && !(h->s1.status & SJMI_ST_INTERNAL)) {
+            // (rare) the chunk path declined the document (a depth swing beyond its relative levels, more than 64 levels): the
+            // single-wave sweep, queued only now
+            tail.optimistic = false;
+            tail.no_chunks = true;
+            if (fail(c, "setup", sjmi::single_doc_setup_launch(d_res1, len, d_doc, d_io, d_st, d_dso, c->stream, d_wres,
+                                                               sjmi::walk_slow_header(c->d_ws_walk, bound, 1))) ||
+                fail(c, "walk launch",
+                     sjmi::walk_launch(c->d_in, d_doc, 1, c->d_idx, bound, d_io, d_st, c->d_sb, d_dso, 0, max_depth, c->d_tape,
+                                       2 * bound + 8, d_to, d_err, c->d_ws_walk, d_wres, c->stream, d_res1, d_ures, c->d_soff, true, true, tail)) ||
+                fail(c, "D2H", hipMemcpyAsync(h, tail.pack, sizeof *h, hipMemcpyDeviceToHost, c->stream)) ||
+                fail(c, "sync", hipStreamSynchronize(c->stream)))
+                return SJMI_ERR_HIP;
+        }
         if (!(h->s1.status & SJMI_ST_INTERNAL) || c->ticket_mode) break;
         if (strings_in_flight && fail(c, "sync", hipStreamSynchronize(c->copy_stream))) return SJMI_ERR_HIP;
         c->ticket_mode = true;  // fast-mode liveness assumption failed: latch the safe mode and run again

@@ -25,12 +25,33 @@ struct UnescapeResult {
 };
 static_assert(sizeof(UnescapeResult) == sizeof(sjmi_unescape_result), "ABI struct mismatch");
 
+// sjmi_parse_document: the result records of the three stages in one place (one D2H), written by the walk's LAST launch
+struct WalkResult;
+struct SingleDocPack;
+struct SingleDocTail {          // where that launch finds / leaves them; pack == nullptr: no such tail
+    const Stage1Result* s1 = nullptr;
+    const UnescapeResult* u = nullptr;
+    SingleDocPack* pack = nullptr;
+    bool optimistic = false;    // the chunk path ends in k_chunk_finish and nothing is queued behind it: a document it does not
+                                // take (pack->fallback != 0) is the caller's to run again with no_chunks
+    bool no_chunks = false;     // the single-wave sweep only
+};
+
 // device-side result of one batch walk; mirrors sjmi_walk_result in include/sjmi.h
 struct WalkResult {
     unsigned long long tape_words, host_documents, failed_documents;
     uint32_t flags, reserved;
 };
 static_assert(sizeof(WalkResult) == sizeof(sjmi_walk_result), "ABI struct mismatch");
+struct SingleDocPack {
+    Stage1Result s1;
+    UnescapeResult u;
+    WalkResult w;
+    unsigned long long to[2];
+    int32_t err;
+    uint32_t fallback;
+};
+static_assert(sizeof(SingleDocPack) <= 256, "d_single / h_single hold 256 bytes of results");
 
 // ablation switches for performance experiments only (results are NOT valid with any of them set)
 constexpr uint32_t DBG_NO_WRITE = 1, DBG_NO_LOOKBACK = 2;
@@ -121,7 +142,7 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
                        unsigned long long* d_tape, uint64_t tape_capacity, unsigned long long* d_tape_offsets,
                        int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream,
                        const Stage1Result* dev_count, const UnescapeResult* dev_strings, const uint32_t* d_soff,
-                       bool index_from_zero = false, bool results_zeroed = false);
+                       bool index_from_zero = false, bool results_zeroed = false, const SingleDocTail& tail = SingleDocTail());
 // coop_walk.hip: the cooperative walker (a wave per document); d_soff = offset of every string's record in d_sb, by ordinal
 hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_idx,
                             const unsigned long long* d_index_offsets, const uint32_t* d_doc_status, const uint32_t* d_soff,
@@ -129,7 +150,8 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
                             int max_depth, unsigned long long* d_scratch_tape, uint32_t* d_tape_lens, int32_t* d_doc_errors,
                             const Stage1Result* dev_count, const UnescapeResult* dev_strings, WalkResult* d_res,
                             hipStream_t stream, void* d_chunk_ws = nullptr, uint64_t count_bound = 0, void* d_deep_ws = nullptr,
-                            unsigned long long* d_single_tape_offsets = nullptr, uint64_t tape_capacity = 0, bool header_zeroed = false);
+                            unsigned long long* d_single_tape_offsets = nullptr, uint64_t tape_capacity = 0, bool header_zeroed = false,
+                            const SingleDocTail& tail = SingleDocTail());
 // nesting levels 64 .. 1023 of the wave-per-document walker live in global memory: bytes for a batch of n_docs documents
 size_t coop_deep_workspace_bytes(uint64_t n_docs);
 // workspace of the chunk-parallel path for one large document (coop_walk.hip)

@@ -128,7 +128,8 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
                        const uint8_t* d_sb, const unsigned long long* d_doc_str_ordinals, uint64_t string_base, int max_depth,
                        unsigned long long* d_tape, uint64_t tape_capacity, unsigned long long* d_tape_offsets,
                        int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream, const Stage1Result* dev_count,
-                       const UnescapeResult* dev_strings, const uint32_t* d_soff, bool index_from_zero, bool results_zeroed) {
+                       const UnescapeResult* dev_strings, const uint32_t* d_soff, bool index_from_zero, bool results_zeroed,
+                       const SingleDocTail& tail) {
     if (!d_soff) return hipErrorInvalidValue;  // (the record table of the string pass: strings.hip)
     uint8_t* ws = static_cast<uint8_t*>(d_ws);
     unsigned long long* scratch = reinterpret_cast<unsigned long long*>(ws);
@@ -148,7 +149,8 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
         e = coop_walk_launch(d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets, d_doc_status, d_soff, d_sb,
                              d_doc_str_ordinals, string_base, max_depth, scratch, lens, d_doc_errors, dev_count, dev_strings, d_res,
                              stream, n_docs == 1 ? ws + walk_chunks_offset(count, n_docs) : nullptr, count,
-                             ws + walk_deep_offset(count, n_docs), direct ? d_tape_offsets : nullptr, tape_capacity, results_zeroed);
+                             ws + walk_deep_offset(count, n_docs), direct ? d_tape_offsets : nullptr, tape_capacity, results_zeroed,
+                             direct ? tail : SingleDocTail());
         if (e != hipSuccess) return e;
         if (direct) return hipGetLastError();
         hipLaunchKernelGGL(k_tape_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, lens, d_doc_errors, n_docs, sums, d_res);
