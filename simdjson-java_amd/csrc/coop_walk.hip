@@ -179,6 +179,25 @@ __device__ int cw_primitive(const uint8_t* buf, const CW16& win, uint32_t idx, b
             *raw = sgn ? (~value + 1) : value;
             code = 0;
             slow_number = false;
+        } else if (is_num && nd >= 16u - sgn) {
+            // 16 .. 18 digits (ids, timestamps in nanoseconds: the window shows no terminator): the next 16 bytes of the document,
+            // once, for the lanes that need them -- the first 16 digits are the whole field as it stands, one or two more and the
+            // terminator come from the second window.  (19 digits may leave the long range: the scanner of sj_number.h decides.)
+            const CW16 w2 = *reinterpret_cast<const CW16*>(buf + idx + 16);
+            const uint32_t y3 = __builtin_amdgcn_alignbyte(w2.a, win.d, sgn), y4 = __builtin_amdgcn_alignbyte(w2.b, w2.a, sgn);
+            const uint32_t u3 = y3 ^ 0x30303030u, u4 = y4 ^ 0x30303030u;
+            const uint32_t rem = ffbl(nondigit(u4)) >> 3;  // digits 16, 17, ... in front of the first non-digit of the fifth dword
+            const bool all16 = (nondigit(t0) | nondigit(t1) | nondigit(t2) | nondigit(u3)) == 0u;
+            const bool term_ok = rem <= 2u && sjn_is_structural_or_ws((y4 >> (8u * rem)) & 0xFFu);
+            if (all16 && term_ok && (x0 & 0xFFu) != '0') {
+                const unsigned long long hi16 = (unsigned long long)eight(t0, t1) * 100000000ull + eight(t2, u3);
+                const uint32_t d16 = u4 & 0xFFu, d17 = (u4 >> 8) & 0xFFu;
+                const unsigned long long v = rem == 0u ? hi16 : rem == 1u ? hi16 * 10ull + d16 : hi16 * 100ull + (d16 * 10u + d17);
+                *type = 'l';
+                *raw = sgn ? (~v + 1) : v;
+                code = 0;
+                slow_number = false;
+            }
         } else if (is_atom) {
             *type = c;
             code = atom_ok ? 0 : (is_t ? SJMI_E_INVALID_TRUE : is_n ? SJMI_E_INVALID_NULL : SJMI_E_INVALID_FALSE);

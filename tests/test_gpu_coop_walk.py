@@ -216,3 +216,32 @@ def test_chunk_and_group_size_boundaries(ctx):
     for filler in (5000, 70000, 300000):
         for doc in ('["%s"]' % ("x" * filler), '{"k":"%s","n":[1,2,{"a":null}]}' % ("y" * filler), '"%s"' % ("z" * filler), " " * filler + "[1, 2]"):
             assert _single(ctx, doc.encode()) == "ok"
+
+
+def test_integer_literals_of_every_length(ctx):
+    """cw_primitive's branch-free integer paths: 1 .. 15 digits out of the 16-byte window, 16 .. 18 digits with the second
+    window, 19 and more through the scanner -- every length, both signs, every terminator, leading zeros, a bad byte behind
+    the digits, the long range's edges; inside arrays and objects so that the literal starts at every byte phase."""
+    rng = random.Random(977)
+    lits = []
+    for nd in range(1, 23):
+        for _ in range(6):
+            digits = str(rng.randrange(1, 10)) + "".join(str(rng.randrange(10)) for _ in range(nd - 1))
+            lits += [digits, "-" + digits]
+        lits += ["9" * nd, "-" + "9" * nd, "1" + "0" * (nd - 1), "0" + "1" * (nd - 1) if nd > 1 else "0", "-0" + "7" * (nd - 1)]
+    lits += ["9223372036854775807", "9223372036854775808", "-9223372036854775808", "-9223372036854775809", "999999999999999999",
+             "-999999999999999999", "1000000000000000000", "123456789012345678", "1234567890123456", "12345678901234567",
+             "-123456789012345", "-1234567890123456", "-12345678901234567", "-123456789012345678", "0", "-0", "-", "--1"]
+    docs = []
+    for lit in lits:
+        for term in (",", "]", " ]", "\n]", "\t,1]"):
+            docs.append(("[" + lit + term + ("" if "]" in term else "2]")).encode())
+        docs.append(('{"k":' + lit + "}").encode())
+        docs.append(('{"kk": ' + lit + ' ,"x":' + lit + "}").encode())
+        docs.append(("[" + lit + "x]").encode())        # a byte behind the digits that is neither separator nor digit
+        docs.append(("[" + lit + ".5]").encode())
+        docs.append(("[" + lit + "e2]").encode())
+    for d in docs[::7]:
+        assert _single(ctx, d) == "ok", d
+    tapes, strings, errors = gpu_walk(ctx, docs)
+    check_against_oracle(docs, tapes, strings, errors)  # (no hand-backs: host_ok is empty)
