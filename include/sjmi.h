@@ -225,9 +225,14 @@ int sjmi_stage1_batch(sjmi_ctx* ctx, const uint8_t* buf, uint64_t total_len, con
  * doc_status[k] = the SJMI_ST_* bits document k would get from sjmi_stage1 on its own; a document with a non-zero
  * status contributes NO indexes (index_offsets[k+1] == index_offsets[k], as the reference throws before its stage 2);
  * the others get exactly their own indexes (absolute byte offsets).  result.status = OR of the document statuses
- * (| SJMI_ST_CAPACITY), result.count = indexes written.  The plain batch above is ~3x faster but cannot attribute an
- * error to a document, and two documents with an unclosed string each cancel in its verdict.
- * Device form, asynchronous on `stream`; d_doc_status: n_docs uint32. */
+ * (| SJMI_ST_CAPACITY), result.count = indexes written.  The plain batch above cannot attribute an error to a document,
+ * and two documents with an unclosed string each cancel in its verdict.  This call tries it first all the same -- ONE
+ * plain launch over the packed buffer -- and accepts it ON THE DEVICE when that is provably what the per-document passes
+ * would give: every document ends in a control-character separator ('\n', '\r', '\t': an open string would turn it into
+ * an unescaped character), doc_offsets[0] == 0 and doc_offsets[n_docs] == total_len, and the global verdict is clean.
+ * The per-document passes are queued behind it and leave at once when it was accepted, so nothing comes back to the host.
+ * Device form, asynchronous on `stream`; d_doc_status: n_docs uint32; d_buf and d_indexes 16-byte aligned for the
+ * plain pass (else only the per-document passes run). */
 int sjmi_stage1_batch_isolated_device(sjmi_ctx* ctx, const void* d_buf, uint64_t total_len, const void* d_doc_offsets,
                                       uint64_t n_docs, void* d_indexes, uint64_t index_capacity, void* d_index_offsets,
                                       void* d_doc_status, void* d_result, void* stream);

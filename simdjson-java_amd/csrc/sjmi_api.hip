@@ -73,7 +73,10 @@ struct sjmi_ctx {
     void* d_ws_masks = nullptr;
     size_t ws_masks_bytes = 0;
     void* d_single = nullptr;                // sjmi_parse_document: delimiters, tape offsets, error and results of ONE document
-    uint32_t* d_batch_flags = nullptr;       // sjmi_parse_batch_device: the two words of the optimistic plain pass
+    uint32_t* d_batch_flags = nullptr;       // the two words of a batch's optimistic plain stage-1 pass ([1] != 0: accepted)
+    const void* accept_buf = nullptr;        // ... which batch they belong to (the string pass of the same batch reads the flag)
+    uint64_t accept_len = 0;
+    bool accept_valid = false;
     unsigned long long* d_tape = nullptr;    // ... and its tape, grown on demand
     size_t tape_bytes = 0;
     void* h_single = nullptr;                // pinned copy of the three result records
@@ -326,6 +329,7 @@ bool grow(sjmi_ctx* c, void** p, size_t* have, size_t need, const char* what) {
 // then makes its own).  Shards and the per-document passes of an isolated batch do not record any.
 void* parity_out(sjmi_ctx* c, const void* d_buf, uint64_t len) {
     c->par_valid = false;
+    c->accept_valid = false;  // (another stage-1 launch: a batch's acceptance flag no longer describes the parities)
     if (!grow(c, (void**)&c->d_blkpar, &c->blkpar_bytes, sjmi::strings_parity_words(len) * sizeof(unsigned long long), "hipMalloc(blkpar)"))
         return nullptr;
     c->par_buf = d_buf;
@@ -450,9 +454,12 @@ static int unescape_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, co
     }
     // a batch: over the batch itself if this context's last stage-1 launch was the plain pass over it, else (documents indexed
     // one by one) over the sanitized copy
-    const bool plain = c->par_valid && c->par_buf == d_buf && c->par_len == len;
-    return strings_batch_impl(c, d_buf, len, d_indexes, count, batch.d_doc_offsets, batch.d_index_offsets, batch.n_docs, plain, nullptr,
-                              d_string_buffer, string_capacity, batch.d_doc_str_offsets, d_result, st);
+    // (indexed by sjmi_stage1_batch_isolated*: whether the plain pass was accepted is a flag on the device)
+    const bool flagged = c->accept_valid && c->accept_buf == d_buf && c->accept_len == len;
+    const bool plain = !flagged && c->par_valid && c->par_buf == d_buf && c->par_len == len;
+    return strings_batch_impl(c, d_buf, len, d_indexes, count, batch.d_doc_offsets, batch.d_index_offsets, batch.n_docs, plain,
+                              flagged ? c->d_batch_flags + 1 : nullptr, d_string_buffer, string_capacity, batch.d_doc_str_offsets,
+                              d_result, st);
 }
 
 int sjmi_unescape_device(sjmi_ctx* c, const void* d_buf, uint64_t len, const void* d_indexes, uint64_t count,
@@ -883,11 +890,60 @@ int sjmi_stage1_batch(sjmi_ctx* c, const uint8_t* buf, uint64_t total_len, const
 static int stage1_batch_isolated_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets,
                                              uint64_t n_docs, void* d_indexes, uint64_t index_capacity, void* d_index_offsets,
                                              void* d_doc_status, void* d_result, void* stream, const uint32_t* d_skip);
+static int stage1_batch_isolated_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets,
+                                             uint64_t n_docs, void* d_indexes, uint64_t index_capacity, void* d_index_offsets,
+                                             void* d_doc_status, void* d_result, void* stream, const uint32_t* d_skip);
+// Stage 1 of a batch with per-document verdicts.  Optimistic: ONE plain k_stage1 launch over the packed batch, accepted on the
+// device when every document ends in a control-character separator, the documents cover the buffer exactly and the global
+// verdict is clean (batch.hip: then it is exactly what the per-document passes give); the per-document passes are queued behind
+// it and leave at once if it was accepted.  *d_skip_out = the device flag (!= 0: accepted) or nullptr (not tried); the string
+// pass of the same batch on this context reads it (c->accept_*).  (SJMI_BATCH_OPTIMISTIC=0 switches the plain pass off.)
+static int stage1_batch_optimistic(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets, uint64_t n_docs,
+                                   void* d_indexes, uint64_t index_capacity, void* d_index_offsets, void* d_doc_status,
+                                   void* d_result, void* stream, const uint32_t** d_skip_out) {
+    if (!c || !d_buf || !d_doc_offsets || !d_indexes || !d_index_offsets || !d_doc_status || !d_result) return SJMI_ERR_ARG;
+    if (total_len >= (1ull << 32)) return SJMI_ERR_ARG;
+    static const bool optimistic = !(getenv("SJMI_BATCH_OPTIMISTIC") && atoi(getenv("SJMI_BATCH_OPTIMISTIC")) == 0);
+    hipStream_t st0 = stream ? (hipStream_t)stream : c->stream;
+    const uint32_t* d_skip = nullptr;
+    c->accept_valid = false;
+    if (optimistic && n_docs && total_len && index_capacity >= 1 && !((uintptr_t)d_buf & 15) && !((uintptr_t)d_indexes & 15)) {
+        if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+        if (!c->d_batch_flags && fail(c, "hipMalloc(batch flags)", hipMalloc((void**)&c->d_batch_flags, 64))) return SJMI_ERR_HIP;
+        if (fail(c, "separator check", sjmi::batch_plain_check_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets,
+                                                                      n_docs, total_len, c->d_batch_flags, st0)))
+            return SJMI_ERR_HIP;
+        int rc0;
+        {
+            const AutoSafeOff plain_only(c);  // (a tripped liveness bound only rejects the plain pass: the per-document passes take over)
+            rc0 = stage1_device_impl(c, d_buf, total_len, d_indexes, index_capacity, d_result, stream, 0);
+        }
+        if (rc0 != SJMI_OK) return rc0;
+        if (fail(c, "plain accept", sjmi::batch_plain_accept_launch((const uint32_t*)d_indexes, (const sjmi::Stage1Result*)d_result,
+                                                                    (const unsigned long long*)d_doc_offsets, n_docs,
+                                                                    (unsigned long long*)d_index_offsets, (uint32_t*)d_doc_status,
+                                                                    c->d_batch_flags, st0)))
+            return SJMI_ERR_HIP;
+        d_skip = c->d_batch_flags + 1;
+    }
+    const int rc = stage1_batch_isolated_device_impl(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity,
+                                                     d_index_offsets, d_doc_status, d_result, stream, d_skip);
+    if (rc != SJMI_OK) return rc;
+    if (d_skip) {  // (set after stage1_device_impl's parity_out, which clears it)
+        c->accept_buf = d_buf;
+        c->accept_len = total_len;
+        c->accept_valid = true;
+    }
+    *d_skip_out = d_skip;
+    return SJMI_OK;
+}
+
 int sjmi_stage1_batch_isolated_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets,
                                       uint64_t n_docs, void* d_indexes, uint64_t index_capacity, void* d_index_offsets,
                                       void* d_doc_status, void* d_result, void* stream) {
-    return stage1_batch_isolated_device_impl(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets,
-                                             d_doc_status, d_result, stream, nullptr);
+    const uint32_t* d_skip = nullptr;
+    return stage1_batch_optimistic(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets, d_doc_status,
+                                   d_result, stream, &d_skip);
 }
 static int stage1_batch_isolated_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets,
                                              uint64_t n_docs, void* d_indexes, uint64_t index_capacity, void* d_index_offsets,
@@ -961,33 +1017,11 @@ int sjmi_parse_batch_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, 
         return SJMI_ERR_ARG;
     if (total_len >= (1ull << 32)) return SJMI_ERR_ARG;
     sjmi_batch_result* r = (sjmi_batch_result*)d_result;
-    hipStream_t st0 = stream ? (hipStream_t)stream : c->stream;
-    // Optimistic: one plain k_stage1 launch over the packed batch, accepted on the device when every document ends in a
-    // control-character separator and the global verdict is clean (batch.hip); the per-document passes are queued behind it
-    // and leave at once if it was.  (SJMI_BATCH_OPTIMISTIC=0 switches it off.)
-    static const bool optimistic = !(getenv("SJMI_BATCH_OPTIMISTIC") && atoi(getenv("SJMI_BATCH_OPTIMISTIC")) == 0);
+    // stage 1: ONE plain launch over the packed batch, accepted on the device when it is exact; the per-document passes are queued
+    // behind it and leave at once if it was (stage1_batch_optimistic)
     const uint32_t* d_skip = nullptr;
-    if (optimistic && n_docs && total_len && !((uintptr_t)d_buf & 15) && !((uintptr_t)d_indexes & 15)) {
-        if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
-        if (!c->d_batch_flags && fail(c, "hipMalloc(batch flags)", hipMalloc((void**)&c->d_batch_flags, 64))) return SJMI_ERR_HIP;
-        if (fail(c, "separator check", sjmi::batch_plain_check_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets,
-                                                                      n_docs, total_len, c->d_batch_flags, st0)))
-            return SJMI_ERR_HIP;
-        const bool keep_auto_safe = c->auto_safe;
-        c->auto_safe = false;  // (a tripped liveness bound only rejects the plain pass: the per-document passes take over)
-        const int rc0 = stage1_device_impl(c, d_buf, total_len, d_indexes, index_capacity, &r->stage1, stream, 0);
-        c->auto_safe = keep_auto_safe;
-        if (rc0 != SJMI_OK) return rc0;
-        if (fail(c, "plain accept", sjmi::batch_plain_accept_launch((const uint32_t*)d_indexes, (const sjmi::Stage1Result*)&r->stage1,
-                                                                    (const unsigned long long*)d_doc_offsets, n_docs,
-                                                                    (unsigned long long*)d_index_offsets, (uint32_t*)d_doc_status,
-                                                                    c->d_batch_flags, st0)))
-            return SJMI_ERR_HIP;
-        d_skip = c->d_batch_flags + 1;
-    }
-    // stage 1 (isolated: per-document verdicts), queued
-    int rc = stage1_batch_isolated_device_impl(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity,
-                                               d_index_offsets, d_doc_status, &r->stage1, stream, d_skip);
+    int rc = stage1_batch_optimistic(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets,
+                                     d_doc_status, &r->stage1, stream, &d_skip);
     if (rc != SJMI_OK) return rc;
     // string records and the walk: everything queued, nothing comes back to the host in between.  If the optimistic plain
     // pass was accepted the string pass runs over the batch itself, else over its sanitized copy -- chosen on the device
