@@ -14,10 +14,15 @@ from tests.conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_two_processes_share_the_gpu():
+@pytest.mark.parametrize("strings", [False, True])
+def test_two_processes_share_the_gpu(strings):
+    """strings: every launch is followed by the string pass -- a second persistent kernel with a scanner workgroup and bounded
+    spins but no SAFE mode (it holds no static assignment: every granule is taken by a running wave); its totals, flags and the
+    final buffer must be the oracle's in both processes."""
     worker = os.path.join(ROOT, "tools", "two_proc_worker.py")
     env = dict(os.environ)
-    procs = [subprocess.Popen([sys.executable, worker, "proc%d" % k, "400", "256"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+    args = ["200", "128", "strings"] if strings else ["400", "256"]
+    procs = [subprocess.Popen([sys.executable, worker, "proc%d" % k] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
              for k in range(2)]
     outs = []
     for p in procs:
