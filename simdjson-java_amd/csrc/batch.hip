@@ -69,13 +69,55 @@ __global__ void k_batch_plain_accept(const Stage1Result* __restrict__ res, uint3
 __global__ void __launch_bounds__(256)
 k_split_docs_accept(const uint32_t* __restrict__ idx, const Stage1Result* __restrict__ res, const unsigned long long* __restrict__ doc_offsets,
                     uint64_t n_docs, unsigned long long* __restrict__ index_offsets, uint32_t* __restrict__ doc_status,
-                    const uint32_t* __restrict__ flags) {
+                    const uint32_t* __restrict__ flags, Stage1Prefixes hint) {
     if (flags[1] == 0) return;
     const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (k > n_docs) return;
     const unsigned long long count = res->count;
     const unsigned long long target = doc_offsets[k];
     unsigned long long lo = 0, hi = count;
+    // the stage-1 scanner's per-granule prefixes bracket the answer: 12 steps inside one 16 KiB granule instead of 27 over all
+    // indexes (a structural at byte b lies in granule b / granule_bytes)
+    if (hint.pfx && hint.granule_bytes) {
+        const unsigned long long g = target / hint.granule_bytes;
+        if (g < hint.ngran) {
+            const unsigned long long above = hint.pfx[g], below = g ? hint.pfx[g - 1] : (2ull << 62);
+            if ((above >> 62) == 2 && (below >> 62) == 2) {
+                const unsigned long long a = below & 0xFFFFFFFFFFull, b = above & 0xFFFFFFFFFFull;
+                if (a <= b && b <= count) {
+                    lo = a;
+                    hi = b;
+                    // ... and inside the granule the structurals are spread evenly enough to guess: start at the interpolated
+                    // position and widen the bracket geometrically (the search is a chain of dependent cache misses: ~3 instead
+                    // of ~8 for the 200 lines a granule's indexes occupy)
+                    if (b - a > 32) {
+                        const unsigned long long gstart = g * hint.granule_bytes;
+                        unsigned long long p = a + (b - a) * (target - gstart) / hint.granule_bytes;
+                        if (p >= b) p = b - 1;
+                        if ((unsigned long long)idx[p] < target) {  // the answer is above p
+                            unsigned long long step = 16, q = p + 1;
+                            lo = q;
+                            while (q + step < b && (unsigned long long)idx[q + step] < target) {
+                                q += step + 1;
+                                lo = q;
+                                step *= 4;
+                            }
+                            if (q + step < b) hi = q + step;
+                        } else {                                     // at or below p
+                            unsigned long long step = 16, q = p;
+                            hi = q;
+                            while (q >= a + step + 1 && (unsigned long long)idx[q - step - 1] >= target) {
+                                q -= step + 1;
+                                hi = q;
+                                step *= 4;
+                            }
+                            if (q >= a + step + 1) lo = q - step;
+                        }
+                    }
+                }
+            }
+        }
+    }
     while (lo < hi) {
         const unsigned long long mid = (lo + hi) >> 1;
         if ((unsigned long long)idx[mid] < target) lo = mid + 1;
@@ -94,10 +136,10 @@ hipError_t batch_plain_check_launch(const uint8_t* d_buf, const unsigned long lo
 }
 hipError_t batch_plain_accept_launch(const uint32_t* d_idx, const Stage1Result* d_res, const unsigned long long* d_doc_offsets,
                                      uint64_t n_docs, unsigned long long* d_index_offsets, uint32_t* d_doc_status, uint32_t* d_flags,
-                                     hipStream_t stream) {
+                                     hipStream_t stream, const Stage1Prefixes& hint) {
     hipLaunchKernelGGL(k_batch_plain_accept, dim3(1), dim3(64), 0, stream, d_res, d_flags);
     hipLaunchKernelGGL(k_split_docs_accept, dim3((unsigned)((n_docs + 1 + 255) / 256)), dim3(256), 0, stream, d_idx, d_res, d_doc_offsets,
-                       n_docs, d_index_offsets, d_doc_status, (const uint32_t*)d_flags);
+                       n_docs, d_index_offsets, d_doc_status, (const uint32_t*)d_flags, hint);
     return hipGetLastError();
 }
 

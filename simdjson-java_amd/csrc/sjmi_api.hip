@@ -919,10 +919,14 @@ static int stage1_batch_optimistic(sjmi_ctx* c, const void* d_buf, uint64_t tota
             rc0 = stage1_device_impl(c, d_buf, total_len, d_indexes, index_capacity, d_result, stream, 0);
         }
         if (rc0 != SJMI_OK) return rc0;
+        // (a FAST launch leaves the scanner's per-granule prefixes in its half of the workspace: the split starts from them)
+        sjmi::Stage1Prefixes hint;
+        if (!(launch_flags(c) & (sjmi::FLAG_SAFE | sjmi::DBG_NO_LOOKBACK)) && c->ws_dev_last)
+            hint = sjmi::stage1_prefixes(c->ws_dev_last, total_len, c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(total_len));
         if (fail(c, "plain accept", sjmi::batch_plain_accept_launch((const uint32_t*)d_indexes, (const sjmi::Stage1Result*)d_result,
                                                                     (const unsigned long long*)d_doc_offsets, n_docs,
                                                                     (unsigned long long*)d_index_offsets, (uint32_t*)d_doc_status,
-                                                                    c->d_batch_flags, st0)))
+                                                                    c->d_batch_flags, st0, hint)))
             return SJMI_ERR_HIP;
         d_skip = c->d_batch_flags + 1;
     }

@@ -77,6 +77,12 @@ constexpr size_t WS_TICKET_OFFSET = 64;       // 8 u32 granule tickets, each alo
 constexpr size_t WS_TILE_STATE_OFFSET = 640;   // u64 aggregates[granules], then u64 prefixes[granules]
 
 size_t stage1_workspace_bytes(uint64_t len, int steps);
+struct Stage1Prefixes {
+    const unsigned long long* pfx = nullptr;
+    uint64_t ngran = 0;
+    uint32_t granule_bytes = 0;
+};
+Stage1Prefixes stage1_prefixes(const void* d_ws, uint64_t len, int steps);
 int stage1_pick_steps(uint64_t len);
 // optional work folded into the kernel (device-resident path): see zero_next_workspace / scanner_wave in stage1.hip
 struct Stage1Extras {
@@ -173,7 +179,7 @@ hipError_t batch_plain_check_launch(const uint8_t* d_buf, const unsigned long lo
                                     uint32_t* d_flags, hipStream_t stream);
 hipError_t batch_plain_accept_launch(const uint32_t* d_idx, const Stage1Result* d_res, const unsigned long long* d_doc_offsets,
                                      uint64_t n_docs, unsigned long long* d_index_offsets, uint32_t* d_doc_status, uint32_t* d_flags,
-                                     hipStream_t stream);
+                                     hipStream_t stream, const Stage1Prefixes& hint = Stage1Prefixes());
 // masks.hip: the reference's six per-block masks (6 x u64 per block, len / 64 + 1 blocks)
 size_t masks_workspace_bytes(uint64_t len);
 hipError_t masks_launch(const uint8_t* d_buf, uint64_t len, unsigned long long* d_masks, void* d_ws, hipStream_t stream);

@@ -947,6 +947,17 @@ static uint64_t granules_for(uint64_t len, int steps, bool no_tail = false) {
 size_t stage1_workspace_bytes(uint64_t len, int steps) {
     return WS_TILE_STATE_OFFSET + (2 + SJMI_TRACE_SLOTS) * (size_t)granules_for(len, steps) * sizeof(sj_u64);
 }
+// The scanner's inclusive prefixes of a finished FAST launch over (len, steps), still in its workspace until the launch after
+// next: entry g = [63:62] == 2, [39:0] structurals in granules 0..g (a granule = steps * 4 KiB of input).  For consumers that
+// look structurals up by byte position (batch.hip: the binary search of a document's first index starts inside its granule).
+Stage1Prefixes stage1_prefixes(const void* d_ws, uint64_t len, int steps) {
+    Stage1Prefixes v;
+    v.ngran = granules_for(len, steps);
+    v.granule_bytes = (uint32_t)steps * 4096u;
+    v.pfx = reinterpret_cast<const unsigned long long*>(static_cast<const uint8_t*>(d_ws) + WS_TILE_STATE_OFFSET) + v.ngran;
+    return v;
+}
+
 
 int stage1_pick_steps(uint64_t len) {
     // small documents: small granules so that more waves get work (tools/size_sweep.py: 0.6 MB 8.9 us with 4 KiB
