@@ -247,20 +247,23 @@ __device__ __forceinline__ int highest_bit_below(unsigned long long m, unsigned 
 //                    words, string bytes -- and its EXPORT: the containers it opens and leaves open (by relative level) and
 //                    the commas it adds to the innermost container it leaves untouched;
 //   k_group_summary / k_top_scan / k_group_replay: the scan of the summaries (applying one to a state is associative) that
-//                    gives every chunk its entry state, two levels, groups of ~sqrt(chunks) chunks;
+//                    gives every chunk its entry state, two levels, groups of ~sqrt(chunks / 4) chunks;
 //   k_coop_walk<true>(parallel, a wave per chunk): the walker proper, started from the chunk's entry state;
 //   k_chunk_finish   (one wave): the document's first error by position, the root words.
 // Relative levels live in the 64 lanes of the stack registers with a bias of 32; a chunk whose depth swings further, or a
 // document deeper than the stack, raises the fall-back flag and the single-wave sweep takes the document.
 // structurals per chunk and chunks per group are functions of the document's structural count n alone (every kernel
 // computes them from index_offsets): short chunks while there are fewer chunks than SIMDs to put them on (a step costs a
-// lone wave ~5 us, so a 128-structural chunk = 2 steps), longer ones after that; groups of ~sqrt(chunks)
+// lone wave ~5 us, so a 128-structural chunk = 2 steps), longer ones after that; groups of ~sqrt(chunks / 4)
 constexpr uint64_t CW_SMALL_N = 256u << 10;
 constexpr uint64_t CW_SINGLE_N = 1024;  // at most this many structurals: the single-wave sweep is quicker than the six launches
 __host__ __device__ inline uint32_t cw_chunk_of(uint64_t n) { return n <= CW_SMALL_N ? 128u : 512u; }
+#ifndef SJMI_CW_GROUP_BIAS
+#define SJMI_CW_GROUP_BIAS 4  // (groups of ~sqrt(chunks / 4): twitter.json 27 groups of 16 instead of 14 of 32 -- the two group kernels apply their summaries one after the other, the top scan its groups: 0.153 -> 0.147 ms)
+#endif
 __host__ __device__ inline uint32_t cw_group_of(uint64_t nchunks) {
     uint32_t g = 8;
-    while ((uint64_t)g * g < nchunks) g <<= 1;
+    while ((uint64_t)g * g * SJMI_CW_GROUP_BIAS < nchunks) g <<= 1;
     return g;
 }
 constexpr int CW_BIAS = 32;

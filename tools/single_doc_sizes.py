@@ -6,6 +6,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import simdjson_java_amd as S
+import simdjson_java_amd.binding as B
+if os.environ.get('SJMI_LIB'):
+    B._LIB = os.environ['SJMI_LIB']  # (A/B of library variants: tools/build_variant.sh)
 import ondemand_bench
 L = ondemand_bench.load_bench_lib()
 
