@@ -14,7 +14,7 @@
 //     like stage 1 (sj_block.h); which bytes are kept / dropped / patched is 64-bit boolean algebra in VGPRs.  The one
 //     global input it cannot derive locally -- is the block entered inside a string -- comes from stage 1, which
 //     records that bit for every block while it resolves its own parity chain (k_stage1's `blkpar` output);
-//   * one wave = one GRANULE of 64 blocks (4 KiB) at a time, taken by atomic ticket; the wave scans the lanes' byte
+//   * one wave = one GRANULE of 64 blocks (4 KiB) at a time, taken by atomic ticket (16 counters); the wave scans the lanes' byte
 //     and string counts (DPP), publishes the granule's AGGREGATE {bytes, strings} and goes on; a scanner workgroup
 //     turns aggregates into PREFIXes (the chain of stage 1, but a plain sum); the prefix of granule k is picked up
 //     while granule k+1 is being classified, so nobody waits for the chain;
@@ -22,7 +22,8 @@
 //     shifted to their byte position and OR-ed into a wave-private LDS tile (ds_or_b32: neighbouring lanes share
 //     dwords); headers are OR-ed in by the lane that holds the CLOSING quote (length = offset at the closing quote -
 //     offset at the opening quote - 4; the opening quote's offset travels to it through a DPP max-scan); escapes
-//     that change a byte's value are XOR-ed in afterwards; the tile leaves as aligned global_store_dwordx4;
+//     that change a byte's value are XOR-ed in afterwards; the tile leaves one iteration later as 16-byte stores to
+//     byte-granular addresses (gfx950 global memory runs in unaligned-access mode), its tail one byte per lane;
 //   * a string that is still open at the end of a granule gets its header from the granule that closes it: every
 //     granule publishes where its pending header sits (OPEN RECORD), the closing granule walks back to it and stores
 //     the four bytes itself; the opening granule leaves those four bytes out of its stores, so nothing is written twice.
