@@ -440,6 +440,13 @@ int sjmi_value_next(const sjmi_parser* p, const sjmi_value* container, const sjm
  * driver's staging copy (3-4x faster for the ~1 MB transfers of a single-document parse).  Purely a performance
  * hint: every entry point also works with pageable memory.  Unregister before freeing the memory. */
 int sjmi_host_register(sjmi_ctx* ctx, void* ptr, uint64_t bytes);
+/* Optional: a page-locked staging buffer for the INPUT of the single-document host entry points (sjmi_stage1,
+ * sjmi_stage1_unescape, sjmi_parse_document).  With one set (bytes >= the document's length), a document handed in from any
+ * other address is copied through it -- the reference's padIfNeeded copy (SimdJsonParser.java:42-48), which a caller needs
+ * anyway for its stage 2 -- and from 4 MiB on in chunks whose H2D copies run while the next chunk is being copied: the
+ * memcpy and the PCIe transfer of a 64 MiB document overlap instead of adding up.  After the call staging[0, len) holds the
+ * document.  pinned == NULL switches it off.  The buffer stays the caller's (register it with sjmi_host_register). */
+int sjmi_set_input_staging(sjmi_ctx* ctx, void* pinned, uint64_t bytes);
 int sjmi_host_unregister(sjmi_ctx* ctx, void* ptr);
 
 /* Run the on-device self-test of the bit-plane transposition; *mismatches == 0 on success. */

@@ -63,7 +63,7 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_unescape", "sjmi_unescape_device",
            "sjmi_parser_create", "sjmi_parser_destroy", "sjmi_parser_parse", "sjmi_parser_last_message",
            "sjmi_stage1_batch", "sjmi_stage1_batch_device", "sjmi_parser_parse_batch",
-           "sjmi_stage1_batch_isolated", "sjmi_stage1_batch_isolated_device", "sjmi_host_register",
+           "sjmi_stage1_batch_isolated", "sjmi_stage1_batch_isolated_device", "sjmi_host_register", "sjmi_set_input_staging",
            "sjmi_host_unregister", "sjmi_stage1_unescape", "sjmi_unescape_batch",
            "sjmi_unescape_batch_device", "sjmi_walk_batch_device", "sjmi_stage1_masks", "sjmi_stage1_masks_device",
            "sjmi_parser_root", "sjmi_parser_batch_root", "sjmi_value_type", "sjmi_value_as_long", "sjmi_value_as_double",

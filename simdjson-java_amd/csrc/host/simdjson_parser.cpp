@@ -199,6 +199,9 @@ SimdJsonParser::SimdJsonParser(int capacity, int maxDepth, int device)
     if (rc != SJMI_OK) throw std::runtime_error("SimdJsonParser: no usable MI355X device (sjmi_create rc=" + std::to_string(rc) + "); there is no CPU fallback");
     // parser-owned buffers that cross PCIe on every parse are page-locked (a hint: failures are ignored)
     pinned_[0] = sjmi_host_register(ctx_, paddedBuffer_.data(), paddedBuffer_.size()) == SJMI_OK ? paddedBuffer_.data() : nullptr;
+    // ... and the padded copy doubles as the engine's input staging: padIfNeeded happens inside the upload, in chunks that
+    // overlap their PCIe transfers for large documents (include/sjmi.h: sjmi_set_input_staging)
+    stagedInput_ = pinned_[0] && sjmi_set_input_staging(ctx_, paddedBuffer_.data(), (uint64_t)capacity) == SJMI_OK;
     pinned_[1] = sjmi_host_register(ctx_, indexes_.data(), indexes_.size() * sizeof(uint32_t)) == SJMI_OK ? (void*)indexes_.data() : nullptr;
     pinned_[2] = sjmi_host_register(ctx_, stringBuffer_.data(), stringBuffer_.size()) == SJMI_OK ? stringBuffer_.data() : nullptr;
     // (the tape: the download of the GPU walker's result, sjmi_parse_document)
@@ -248,8 +251,11 @@ void SimdJsonParser::stage1(const uint8_t* buffer, size_t len) {
 
 JsonValue SimdJsonParser::parse(const uint8_t* buffer, size_t len) {
     if (len > (size_t)capacity_) throw fail(E_CAPACITY);
-    // padIfNeeded (SimdJsonParser.java:42-48): the C++ caller's buffer has no known slack, so always copy
-    memcpy(paddedBuffer_.data(), buffer, len);
+    // padIfNeeded (SimdJsonParser.java:42-48): the C++ caller's buffer has no known slack, so always copy -- inside the engine's
+    // upload when the padded buffer is its staging buffer (the copy then overlaps the PCIe transfer), else here
+    const uint8_t* src = paddedBuffer_.data();
+    if (stagedInput_) src = buffer;
+    else memcpy(paddedBuffer_.data(), buffer, len);
     memset(paddedBuffer_.data() + len, 0, PADDING);
     // reset (:50-53)
     walker_.bitIndexes().reset();
@@ -261,7 +267,7 @@ JsonValue SimdJsonParser::parse(const uint8_t* buffer, size_t len) {
         int32_t err = 0;
         uint32_t status = 0;
         growStringBuffer(len + 4 * (len / 2 + 2) + 64);
-        const int rc = sjmi_parse_document(ctx_, paddedBuffer_.data(), len, maxDepth_, walker_.tape().raw(), walker_.tape().capacity(),
+        const int rc = sjmi_parse_document(ctx_, src, len, maxDepth_, walker_.tape().raw(), walker_.tape().capacity(),
                                            &words, stringBuffer_.data(), stringBuffer_.size(), &sbLen, &err, &status);
         if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_parse_document: ") + sjmi_last_error(ctx_));
         if (err == 0) {
@@ -270,7 +276,7 @@ JsonValue SimdJsonParser::parse(const uint8_t* buffer, size_t len) {
             return JsonValue(&walker_.tape(), 1, stringBuffer_.data());
         }
     }
-    stage1(paddedBuffer_.data(), len);
+    stage1(src, len);  // (after a declined all-device attempt the document is already in the padded buffer: src == it or re-staged)
     walker_.setStringBuffer(stringBuffer_.data());
     walker_.walkDocument(len);
     return JsonValue(&walker_.tape(), 1, stringBuffer_.data());  // TapeBuilder.createJsonValue :215-217

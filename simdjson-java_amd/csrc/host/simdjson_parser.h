@@ -273,6 +273,7 @@ private:
     std::unique_ptr<WorkerPool> pool_;  // created by the first parseBatch
     std::vector<uint32_t> docStatus_;
     void* pinned_[4] = {nullptr, nullptr, nullptr, nullptr};  // page-locked parser buffers (sjmi_host_register)
+    bool stagedInput_ = false;  // paddedBuffer_ is the engine's input staging (sjmi_set_input_staging)
     std::vector<int32_t> batchErrors_;
     std::unique_ptr<OnDemandJsonIterator> onDemand_;
     std::vector<uint32_t> skipUp_, skipMatch_;
