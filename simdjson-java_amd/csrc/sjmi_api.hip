@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <thread>
 #include <mutex>
 #include <new>
 #include <string>
@@ -268,10 +269,29 @@ static bool upload_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len) {
     if (!len) return true;
     if (c->staging && buf != c->staging && len <= c->staging_bytes) {
         const uint64_t chunk = len >= (4ull << 20) ? (2ull << 20) : len;
-        for (uint64_t off = 0; off < len; off += chunk) {
-            const uint64_t n = len - off < chunk ? len - off : chunk;
-            memcpy(c->staging + off, buf + off, n);
-            if (fail(c, "H2D", hipMemcpyAsync((uint8_t*)c->d_in + off, c->staging + off, n, hipMemcpyHostToDevice, c->stream))) return false;
+        // one thread copies ~25 GB/s, PCIe takes 57: from 16 MiB on a second thread copies (and queues) every other chunk (8 MiB: no gain, the thread costs what it saves)
+        std::atomic<bool> ok{true};
+        auto part = [&](uint64_t first, uint64_t stride, bool set_device) {
+            if (set_device && hipSetDevice(c->device) != hipSuccess) {
+                ok = false;
+                return;
+            }
+            for (uint64_t off = first * chunk; off < len; off += stride * chunk) {
+                const uint64_t n = len - off < chunk ? len - off : chunk;
+                memcpy(c->staging + off, buf + off, n);
+                if (hipMemcpyAsync((uint8_t*)c->d_in + off, c->staging + off, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) ok = false;
+            }
+        };
+        if (len >= (16ull << 20)) {
+            std::thread helper(part, (uint64_t)1, (uint64_t)2, true);
+            part(0, 2, false);
+            helper.join();
+        } else {
+            part(0, 1, false);
+        }
+        if (!ok) {
+            c->err = "H2D (staged upload) failed";
+            return false;
         }
         return true;
     }
