@@ -256,7 +256,7 @@ __device__ __forceinline__ int highest_bit_below(unsigned long long m, unsigned 
 // computes them from index_offsets): short chunks while there are fewer chunks than SIMDs to put them on (a step costs a
 // lone wave ~5 us, so a 128-structural chunk = 2 steps), longer ones after that; groups of ~sqrt(chunks / 4)
 constexpr uint64_t CW_SMALL_N = 256u << 10;
-constexpr uint64_t CW_SINGLE_N = 1024;  // at most this many structurals: the single-wave sweep is quicker than the six launches
+constexpr uint64_t CW_SINGLE_N = 512;   // at most this many structurals (8 steps of ~6 us): the single-wave sweep is quicker than the chunk path's launches
 __host__ __device__ inline uint32_t cw_chunk_of(uint64_t n) { return n <= CW_SMALL_N ? 128u : 512u; }
 #ifndef SJMI_CW_GROUP_BIAS
 #define SJMI_CW_GROUP_BIAS 4  // (groups of ~sqrt(chunks / 4): twitter.json 27 groups of 16 instead of 14 of 32 -- the two group kernels apply their summaries one after the other, the top scan its groups: 0.153 -> 0.147 ms)
@@ -1388,7 +1388,8 @@ static ChunkWs chunk_ws(void* ws, uint64_t count_bound, uint32_t* flags) {
 
 // d_chunk_ws != nullptr and one document of more than COOP_CHUNK_MIN structurals (by its bound): the chunk-parallel path,
 // with the single-wave sweep queued behind it for the (flagged) cases it does not take
-constexpr uint64_t COOP_CHUNK_MIN = 4096;
+constexpr uint64_t COOP_CHUNK_MIN = 1536;      // (a bound in BYTES + 1: documents carry 4 .. 12 bytes per structural)
+constexpr uint64_t COOP_OPTIMISTIC_MIN = 16384;  // below: the sweep for a document the chunk path declines is queued beforehand (no second round trip for a short document)
 constexpr uint64_t COOP_WALK_MAX_GRID = 8192;  // workgroups of the wave-per-document kernel (grid-stride over the documents)
 static size_t coop_slow_bytes() { return 64 + (size_t)CW_SLOW_CAP * 16; }
 // the list of undecided literals + the deep levels of every wave of that kernel (see k_coop_walk)
@@ -1420,7 +1421,7 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
     static const bool no_chunks = getenv("SJMI_COOP_CHUNKS") && atoi(getenv("SJMI_COOP_CHUNKS")) == 0;
     const bool chunked = d_chunk_ws && n_docs == 1 && count_bound > COOP_CHUNK_MIN && !no_chunks && !tail.no_chunks;
     SingleFinish fin = {slow, d_tape_lens, d_doc_errors, tape_capacity, d_single_tape_offsets, d_res, tail.s1, tail.u, tail.pack};
-    const bool optimistic = chunked && d_single_tape_offsets && tail.optimistic && tail.pack;
+    const bool optimistic = chunked && d_single_tape_offsets && tail.optimistic && tail.pack && count_bound > COOP_OPTIMISTIC_MIN;
     const uint32_t* only_if = nullptr;
     if (chunked) {
         cw = chunk_ws(d_chunk_ws, count_bound, reinterpret_cast<uint32_t*>(slow.count) + 8);  // (zeroed with the list's count above)

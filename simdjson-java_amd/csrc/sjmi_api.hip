@@ -319,12 +319,16 @@ int sjmi_stage1(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes
     if (!upload_document(c, buf, len)) return SJMI_ERR_HIP;
     const uint64_t dev_cap = c->capacity + 2 < index_capacity ? c->capacity + 2 : index_capacity;
     if (!c->d_res_tmp && fail(c, "hipMalloc(result)", hipMalloc((void**)&c->d_res_tmp, 64))) return SJMI_ERR_HIP;
+    const uint64_t spec_idx = len + 2 < dev_cap ? len + 2 : dev_cap;
+    const bool small = len <= (4u << 10);
     const AutoSafeOff own_retry(c);  // (the retry below is this call's own)
     for (int attempt = 0; attempt < 2; ++attempt) {
         // (the device entry point: double-buffered workspace, nothing but the kernel is queued once the context is warm)
         const int rc = stage1_device_impl(c, c->d_in, len, c->d_idx, dev_cap, c->d_res_tmp, c->stream, 0);
         if (rc != SJMI_OK) return rc;
+        // (a small document's indexes come back behind the same synchronisation, by their bound of one structural per byte)
         if (fail(c, "D2H(result)", hipMemcpyAsync(c->h_res, c->d_res_tmp, sizeof(sjmi_stage1_result), hipMemcpyDeviceToHost, c->stream)) ||
+            (small && fail(c, "D2H(indexes)", hipMemcpyAsync(indexes, c->d_idx, spec_idx * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream))) ||
             fail(c, "sync", hipStreamSynchronize(c->stream)))
             return SJMI_ERR_HIP;
         if (!(c->h_res->status & SJMI_ST_INTERNAL) || c->ticket_mode) break;
@@ -340,10 +344,11 @@ int sjmi_stage1(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes
         c->err = "index_capacity too small";
         return SJMI_ERR_CAPACITY;
     }
-    if (fail(c, "D2H(indexes)",
-             hipMemcpyAsync(indexes, c->d_idx, (c->h_res->count + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                            c->stream)) ||
-        fail(c, "sync", hipStreamSynchronize(c->stream)))
+    if (!(small && c->h_res->count + 1 <= spec_idx) &&
+        (fail(c, "D2H(indexes)",
+              hipMemcpyAsync(indexes, c->d_idx, (c->h_res->count + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                             c->stream)) ||
+         fail(c, "sync", hipStreamSynchronize(c->stream))))
         return SJMI_ERR_HIP;
     c->last_len = len;
     c->last_count = c->h_res->count;
@@ -646,6 +651,10 @@ int sjmi_stage1_unescape(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t
     if (!c->d_pack && fail(c, "hipMalloc(pack)", hipMalloc(&c->d_pack, 64))) return SJMI_ERR_HIP;
     if (!c->h_pack && fail(c, "hipHostMalloc(pack)", hipHostMalloc(&c->h_pack, 64))) return SJMI_ERR_HIP;
     if (!c->d_res_tmp && fail(c, "hipMalloc(result)", hipMalloc((void**)&c->d_res_tmp, 64))) return SJMI_ERR_HIP;
+    const uint64_t spec_idx = len + 2 < dev_cap ? len + 2 : dev_cap;
+    const uint64_t sb_bound = len + 4 * (len / 2 + 2);
+    const uint64_t spec_sb = string_buffer ? (sb_bound < string_capacity ? sb_bound : string_capacity) : 0;
+    const bool small = len <= (4u << 10);
     const AutoSafeOff own_retry(c);  // (the retry below is this call's own)
     for (int attempt = 0; attempt < 2; ++attempt) {
         const int s1rc = stage1_device_impl(c, c->d_in, len, c->d_idx, dev_cap, c->d_res_tmp, c->stream, 0);
@@ -656,9 +665,14 @@ int sjmi_stage1_unescape(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t
         sjmi::UnescapeResult* d_u = sjmi::strings_workspace_result(c->d_ws_strm);
         if (fail(c, "strings launch", sjmi::strings_launch(c->d_in, len, par, c->d_sb, c->sb_bytes, nullptr, 0, nullptr, c->d_ws_strm, d_u, c->stream)) ||
             fail(c, "error index", sjmi::strings_error_index_pack_launch(c->d_idx, (const sjmi::Stage1Result*)c->d_res_tmp, d_u, c->d_pack, c->stream)) ||
-            fail(c, "D2H(results)", hipMemcpyAsync(c->h_pack, c->d_pack, sizeof(Pack), hipMemcpyDeviceToHost, c->stream)) ||
-            fail(c, "sync", hipStreamSynchronize(c->stream)))
+            fail(c, "D2H(results)", hipMemcpyAsync(c->h_pack, c->d_pack, sizeof(Pack), hipMemcpyDeviceToHost, c->stream)))
             return SJMI_ERR_HIP;
+        // A SMALL document's outputs are downloaded speculatively, by their bounds (one structural per byte; 3 record bytes per
+        // 2 source bytes), behind the same synchronisation: the second host round trip costs more than the few KB it would save
+        if (small && (fail(c, "D2H(indexes)", hipMemcpyAsync(indexes, c->d_idx, spec_idx * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)) ||
+                      (spec_sb && fail(c, "D2H(sb)", hipMemcpyAsync(string_buffer, c->d_sb, spec_sb, hipMemcpyDeviceToHost, c->stream)))))
+            return SJMI_ERR_HIP;
+        if (fail(c, "sync", hipStreamSynchronize(c->stream))) return SJMI_ERR_HIP;
         const Pack* hp = static_cast<const Pack*>(c->h_pack);
         *c->h_res = hp->s1;
         r = hp->u;
@@ -701,6 +715,7 @@ int sjmi_stage1_unescape(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t
             return SJMI_ERR_CAPACITY;
         }
     }
+    if (small && c->h_res->count + 1 <= spec_idx && (!strings_ok || r.total_bytes <= spec_sb)) return SJMI_OK;  // (already here)
     if (fail(c, "D2H(indexes)",
              hipMemcpyAsync(indexes, c->d_idx, (c->h_res->count + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)) ||
         (strings_ok && r.total_bytes &&

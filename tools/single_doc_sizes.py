@@ -17,7 +17,7 @@ def arr(n):
     return b"[" + b",".join(b'{"id":%d,"name":"user %d","tags":["a","b"],"score":%d.5,"ok":true}' % (i, i, i % 97) for i in range(n)) + b"]"
 
 
-docs = [("1 KiB", arr(14)), ("14 KiB", arr(200)), ("136 KiB", arr(1900)),
+docs = [("1 KiB", arr(14)), ("4 KiB", arr(60)), ("14 KiB", arr(200)), ("136 KiB", arr(1900)),
         ("twitter.json", gzip.open(os.path.join(ROOT, "tests/golden/data/twitter.json.gz")).read()),
         ("1 MiB", arr(14200)), ("3.9 MiB", arr(55000)), ("16 MiB", arr(225000)), ("64 MiB", arr(900000))]
 out = {}
