@@ -222,3 +222,26 @@ def test_documents_around_the_stage2_placement_threshold(parser):
         _same(parser, "[" + body + "] 1")
         _same(parser, "[" + body.replace('"ok":true', '"ok":tru', 1) + "]")
         _same(parser, "[" + body[: len(body) // 2])
+
+
+@pytest.mark.parametrize("mode", [False, True])
+def test_large_documents_through_the_staged_upload(mode):
+    """sjmi_set_input_staging (the parser's padded buffer): a document of 4 MiB .. 16 MiB goes up in 2 MiB chunks whose PCIe
+    transfers overlap the copy of the next chunk, a larger one with a second copying thread -- the tape must be the oracle's,
+    also when the caller's buffer changes between calls (nothing may be read from it after the call returned)."""
+    import simdjson_java_amd as S
+    rng = random.Random(5)
+
+    def array(n):
+        return b"[" + b",".join(b'{"id":%d,"name":"user %d \\u00e9","tags":["a","b\\n"],"score":%d.5,"ok":true}' % (rng.randrange(10**12), i, i % 97)
+                                for i in range(n)) + b"]"
+    p = S.SimdJsonParser(capacity=24 * 1024 * 1024, gpu_walk=mode)
+    try:
+        for n in (60000, 70000, 230000):          # ~5.2 MiB, ~6 MiB (not a multiple of the chunk), ~20 MiB
+            doc = bytearray(array(n))
+            want = O.parse(bytes(doc))
+            got = p.parse(bytes(doc))
+            assert want.error == 0 and np.array_equal(got.tape, want.tape), n
+            assert got.strings == want.strings
+    finally:
+        p.close()
