@@ -10,6 +10,7 @@ int sjmi_create(sjmi_ctx** out, int, uint64_t) { if (out) *out = nullptr; return
 void sjmi_destroy(sjmi_ctx*) {}
 const char* sjmi_last_error(const sjmi_ctx*) { return "host simulation: no engine"; }
 int sjmi_host_register(sjmi_ctx*, void*, uint64_t) { return SJMI_ERR_NO_DEVICE; }
+int sjmi_set_input_staging(sjmi_ctx*, void*, uint64_t) { return SJMI_ERR_NO_DEVICE; }
 int sjmi_host_unregister(sjmi_ctx*, void*) { return SJMI_ERR_NO_DEVICE; }
 int sjmi_stage1_unescape(sjmi_ctx*, const uint8_t*, uint64_t, uint32_t*, uint64_t, uint64_t*, uint32_t*, uint8_t*, uint64_t,
                          uint64_t*, uint64_t*, uint32_t*) { return SJMI_ERR_NO_DEVICE; }
