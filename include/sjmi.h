@@ -349,7 +349,7 @@ const char* sjmi_parser_last_message(const sjmi_parser* p);
 /* Where stage 2 of sjmi_parser_parse runs: 0 = the host walker over the GPU-made indexes and string records, 1 = the
  * cooperative GPU walker (sjmi_parse_document): the tape comes from the device, and only a document that fails or is
  * handed back is walked again on the host (for the exact exception); < 0 (the default) = by size: the GPU walker for
- * documents of 256 KiB and more (twitter.json 0.178 vs 0.216 ms, 2.4 x faster at 1 MiB, 6 x from 16 MiB on), the host
+ * documents of 128 KiB and more (twitter.json 0.148 vs 0.188 ms, 2.4 x faster at 1 MiB, 6 x from 16 MiB on), the host
  * walker below.  Identical results. */
 int sjmi_parser_set_gpu_walk(sjmi_parser* p, int on);
 /* Batched parse (BASELINE.json configs[3]/[4]): the batch goes through the GPU (isolated stage 1 + string records)

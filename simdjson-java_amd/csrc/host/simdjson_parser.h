@@ -213,13 +213,13 @@ public:
     // parser-owned memory and is invalidated by the next parse(), exactly like the reference.
     JsonValue parse(const uint8_t* buffer, size_t len);
     // where stage 2 of parse() runs: 1 = on the GPU (the cooperative walker), 0 = the host walker, -1 (default) = by size --
-    // the GPU from GPU_WALK_AUTO_BYTES on, where it is the faster one (sjmi_parser_parse timed from C++, round 3: 0.104 vs
-    // 0.073 ms at 1 KiB, 0.157 vs 0.165 ms at 136 KiB, 0.178 vs 0.216 ms for twitter.json, 0.28 vs 0.68 ms at 1 MiB, 1.66 vs
-    // 9.9 ms at 16 MiB).  Round 2 switched at 1 MiB because a parse-and-select of twitter.json was then slower with the GPU-built
-    // tape (0.231 vs 0.214 ms: a tape the host built is still in its caches); with the streaming string pass the two are
-    // equal (0.2368 vs 0.2369 ms, tools/ondemand_bench.py), so the switch is where the call itself gets faster: the
-    // reference's own fixture is parsed with all three stages on the device by default.  Identical results either way.
-    static constexpr size_t GPU_WALK_AUTO_BYTES = 256u << 10;
+    // the GPU from GPU_WALK_AUTO_BYTES on, where the call is the faster one (sjmi_parser_parse timed from C++,
+    // tools/single_doc_sizes.py, end of round 3: 0.10 vs 0.05 ms at 1 KiB, 0.108 vs 0.072 ms at 14 KiB, 0.131-0.146 vs 0.148 ms
+    // at 136 KiB, 0.148 vs 0.188 ms for twitter.json, 0.25 vs 0.67 ms at 1 MiB, 1.43 vs 9.9 ms at 16 MiB, 5.05 vs 41 ms at 64 MiB).
+    // Round 2 switched at 1 MiB (a parse-and-select of twitter.json was then slower with the GPU-built tape: a tape the host
+    // built is still in its caches), round 3 at 256 KiB and then, with the latency work on the single-document path, at 128 KiB:
+    // the reference's own fixture is parsed with all three stages on the device by default.  Identical results either way.
+    static constexpr size_t GPU_WALK_AUTO_BYTES = 128u << 10;
     void setGpuWalk(int mode) { gpuWalk_ = mode < 0 ? -1 : (mode ? 1 : 0); }
 
     // Batched parse: documents packed NDJSON-style at doc_offsets[k] (n+1 entries).  One GPU pass for the batch (isolated

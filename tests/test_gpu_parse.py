@@ -212,10 +212,11 @@ def test_json_value_accessors_through_the_c_abi(parser, twitter):
 
 
 def test_documents_around_the_stage2_placement_threshold(parser):
-    """1 MiB is where the default placement of stage 2 changes (SimdJsonParser::GPU_WALK_AUTO_BYTES): documents just below
-    and above it and larger ones, valid and broken (a broken one is walked again on the host for the reference's exact message)."""
+    """128 KiB is where the default placement of stage 2 changes (SimdJsonParser::GPU_WALK_AUTO_BYTES; 1 MiB in round 2): documents
+    just below and above it and larger ones, valid and broken (a broken one is walked again on the host for the reference's exact
+    message)."""
     unit = '{"id":%d,"name":"user \\u00e9 %d","tags":["a","b"],"score":%d.5,"ok":true}'
-    for n in (1800, 13000, 15500, 40000):
+    for n in (1800, 2100, 13000, 15500, 40000):
         body = ",".join(unit % (i, i, i % 97) for i in range(n))
         _same(parser, "[" + body + "]")
         _same(parser, "[" + body + ",]")
