@@ -9,15 +9,18 @@
     the dominant kernel (k_stage1) and gives BOTH its cold time (the first K launches after the GPU sat idle) and its
     clock-settled time (`frac` is the settled one; `cold` holds the other).  `extra` carries the other configs of
     BASELINE.json measured in the same run, each with its own roofline block: configs[1] (twitter x1024), configs[2]
-    (4 GiB synthetic), the string-unescape path on twitter x1024, and configs[3] (1,000,000 ~1 KB documents: isolated
-    stage 1 -> string records -> GPU walk) in documents/s, kernel-only and including the H2D copy.
---gpus N > 1 (the driver's SCALE lines; launched with torch.distributed.run, one rank per GPU)
-    The batched path, as north_star states it: the 1,000,000-document configs[3] set is sharded by document
-    (sharding.partition_documents: contiguous, byte-balanced), every rank runs sjmi_parse_batch_device on its shard
-    (isolated stage 1 -> string records -> GPU walk, no host round trip), and RCCL is used ONLY for the all_gather of
-    the per-shard counts.  `value` = documents/s of the whole job, "scaling": "strong" (the total is fixed).  Rank 0
-    then runs the whole set alone in the same process: `single_gpu_same_run` is the N=1 figure this N is to be
-    compared with (the --gpus 1 line reports the same figure as extra.batch_1m_docs.value).
+    (4 GiB synthetic), the string-unescape path on twitter x1024, and configs[3] (1,000,000 UNIQUE ~1 KB documents, tools/docgen.c:
+    stage 1 with per-document verdicts -> string records -> GPU walk; a seeded sample of 10,000 checked against the oracle before
+    timing) in documents/s, kernel-only and including the H2D copy; their headline figures are repeated as flat scalars in `config`.
+--gpus N > 1 (the driver's SCALE lines; one rank per GPU under torch.distributed.run -- launched plainly as
+    `python bench.py --gpus N` it re-executes itself that way; fewer than N visible GPUs, or a process group whose size is
+    not N, is an ERROR (exit 3), never a silent single-GPU run)
+    The batched mode, sharded by document, RCCL ONLY as the all_gather of 4 x int64 per rank.  `metric` / `value` are the
+    N = 1 line's, weak-scaled: every rank scans its own 6801 twitter.json documents (4 GiB) per step, then the count
+    gather; value = aggregate GB/s, so value(N) / (N x value(1)) is the efficiency of the headline metric.  `batched` holds
+    configs[3] in documents/s both ways -- weak (`--docs` unique ~1 KB documents per rank) and strong (`--docs` in all,
+    contiguous byte-balanced ranges) -- each with documents_per_rank and the RCCL world size it saw, beside rank 0
+    running `--docs` documents alone in the same run (`single_gpu_same_run`).
 
 Prints ONE JSON line on rank 0.  cpu_baseline (N=1 only) = the AVX-512 restatement of the reference's two stage-1
 passes (oracle/sj_avx512.c) on 1 core and on all host cores; the reference itself is Java and needs a JVM, which is
@@ -277,18 +280,53 @@ def wall_steps(torch, fn, steps, dist=None):
     return el
 
 
-def make_batch_shard(torch, S, W, dev, ctx, lo, hi, docs_unit, lens, reps):
-    """documents [lo, hi) of the configs[3] set (pool x reps) as a BatchShard on `dev`"""
-    import numpy as np
+def make_batch_shard(torch, S, W, dev, ctx, lo, hi):
+    """documents [lo, hi) of the configs[3] set (1,000,000 UNIQUE documents, tools/docgen.c seed 20250825: document k is a
+    function of (seed, k), so a rank generates its own range only) as a BatchShard on `dev` -> (shard, local offsets)"""
     from simdjson_java_amd import sharding
-    offs = W.batch_offsets(lens, reps)
-    a, b = int(offs[lo]), int(offs[hi])
-    full, _ = W.repeat_on_device(docs_unit, reps, dev, pad=0)
-    shard_bytes = full[a:b].clone()
-    del full
-    local = (offs[lo:hi + 1] - offs[lo]).astype(np.uint64)
+    host = torch.empty(1300 * (hi - lo) + 64, dtype=torch.uint8).pin_memory()
+    data, offs = W.unique_docs(lo, hi - lo, out=host.numpy())
+    n = int(offs[-1])
+    shard_bytes = torch.empty(n, dtype=torch.uint8, device=dev)
+    shard_bytes.copy_(host[:n], non_blocking=True)
+    torch.cuda.synchronize()
+    del host
     # (this set: 5.4 B per structural, 0.84 string-buffer bytes and 0.13 tape words per input byte)
-    return sharding.BatchShard(ctx, shard_bytes, local, dev, index_ratio=4, string_ratio=1.0, tape_ratio=0.2)
+    return sharding.BatchShard(ctx, shard_bytes, offs, dev, index_ratio=4, string_ratio=1.0, tape_ratio=0.2), offs
+
+
+def check_batch_sample(torch, oracle, shard, offs, sample=10000, seed=20250825):
+    """per-document parity of a seeded sample of the batch against the oracle, outside every timed region: structural
+    indexes (document-relative), tape / string records as a tree (oracle.Parsed.to_python: type, int64, raw double bits,
+    UTF-8 bytes, order), the document's error code == 0"""
+    import random
+    import numpy as np
+    n_docs = shard.n_docs
+    ks = sorted(random.Random(seed).sample(range(n_docs), min(sample, n_docs)))
+    io = shard.index_offsets.cpu().numpy()
+    to = shard.tape_offsets.cpu().numpy()
+    err = shard.doc_errors.cpu().numpy()
+    c = shard.check()
+    sb = bytes(shard.sb[:c["string_bytes"]].cpu().numpy())
+    host_buf = shard.buf[:shard.n].cpu().numpy()
+    idx = shard.idx[:c["structurals"]].cpu().numpy().view(np.uint32)
+    tape = shard.tape[:int(to[-1])].cpu().numpy().view(np.uint64)
+    for k in ks:
+        a, b = int(offs[k]), int(offs[k + 1])
+        d = host_buf[a:b].tobytes()
+        w_idx, w_st = oracle.stage1(d)
+        assert w_st == 0 and int(err[k]) == 0, k
+        got = idx[int(io[k]):int(io[k + 1])].astype(np.int64) - a
+        assert np.array_equal(got, w_idx.astype(np.int64)), "document %d: indexes differ from the oracle's" % k
+        want = oracle.parse(d)
+        assert want.error == 0
+        assert oracle.Parsed(tape[int(to[k]):int(to[k + 1])], sb, 0, 0, 0).to_python() == want.to_python(), \
+            "document %d: tree differs from the oracle's" % k
+    return len(ks)
+
+
+BATCH_KERNELS = ("k_batch_sep_check + k_stage1 (one plain pass, accepted on the device) + k_strings + k_doc_prepare + tape-offset scan + "
+                 "k_coop_walk (the per-document passes and the sanitized-copy string pass are queued behind the plain pass and leave at once)")
 
 
 def batch_algorithmic_bytes(n, c):
@@ -500,6 +538,35 @@ def bench_single(args):
                       "users with default_profile", "value": legs["parse"]["one_core_ms_per_parse"], "unit": "ms per parse (one core)",
             "cpu_baseline": legs["parse"]}
     line["extra"] = extra
+    # the other configs' figures once more as flat scalars (a driver that keeps only the contract's keys keeps `config` and
+    # `roofline` but not `extra` or nested objects)
+    rf = line["roofline"]
+    rf["settled_frac"], rf["settled_avg_kernel_ms"] = rf["settled"]["frac"], rf["settled"]["avg_kernel_ms"]
+    rf["cold_frac"], rf["cold_avg_kernel_ms"] = rf["cold"]["frac"], rf["cold"]["avg_kernel_ms"]
+    flat = line["config"]
+
+    def put(key, sec, *path):
+        v = extra.get(sec)
+        for k in path:
+            v = v.get(k) if isinstance(v, dict) else None
+        if v is not None:
+            flat[key] = v
+
+    put("configs1_x1024_frac_settled", "stage1_twitter_x1024", "roofline", "frac")
+    put("configs1_x1024_frac_cold", "stage1_twitter_x1024", "roofline", "cold", "frac")
+    put("configs2_synthetic_4g_frac_settled", "stage1_synthetic_4g", "roofline", "frac")
+    put("unescape_x1024_ms", "unescape_twitter_x1024", "roofline", "avg_ms_per_call")
+    put("unescape_x1024_frac", "unescape_twitter_x1024", "roofline", "frac")
+    put("configs3_batch_docs_per_s", "batch_1m_docs", "value")
+    put("configs3_batch_ms", "batch_1m_docs", "ms_per_batch")
+    put("configs3_batch_frac", "batch_1m_docs", "roofline", "frac")
+    put("configs3_batch_documents", "batch_1m_docs", "documents")
+    put("configs3_batch_oracle_checked_documents", "batch_1m_docs", "oracle_checked_documents")
+    put("configs3_batch_docs_per_s_incl_h2d", "batch_1m_docs", "incl_h2d", "value")
+    put("parse_twitter_json_all_device_ms", "parse_single_document", "twitter_json", "gpu_walker", "ms")
+    put("parse_twitter_json_host_walker_ms", "parse_single_document", "twitter_json", "host_walker", "ms")
+    put("configs4_1024_trees_ms", "twitter_x1024_as_1024_trees", "value")
+    put("select_on_demand_ms", "parse_and_select_twitter_json", "value")
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(doc)
     print(json.dumps(line))
@@ -589,30 +656,31 @@ def trees_1024(S, doc, reps=1024, iters=3):
             "value": round(best, 3), "unit": "ms per batch", "docs_per_s": round(reps / best * 1e3, 1), "GB_per_s": round(host.size / best / 1e6, 3)}
 
 
-def batch_single_gpu(torch, S, W, dev, work, args, with_h2d=True):
-    docs, unit, lens = W.small_doc_pool(args.pool)
-    reps = max(1, args.docs // len(docs))
-    n_docs = len(docs) * reps
+def batch_single_gpu(torch, S, W, dev, work, args, with_h2d=True, n_docs=None, check=True):
+    from oracle import oracle  # (checker of the sample, outside the timed region)
+    n_docs = n_docs or args.docs
     ctx = S.Context(device=dev.index, capacity=1 << 20)
-    shard = make_batch_shard(torch, S, W, dev, ctx, 0, n_docs, unit, lens, reps)
+    shard, offs = make_batch_shard(torch, S, W, dev, ctx, 0, n_docs)
     st = work.cuda_stream
     for _ in range(3):
         shard.step(st)
     torch.cuda.synchronize()
     c = shard.check()
     assert c["failed_documents"] == 0 and c["host_documents"] == 0 and c["stage1_status"] == 0, c
+    checked = check_batch_sample(torch, oracle, shard, offs, args.sample) if check else 0
     el = wall_steps(torch, lambda: shard.step(st), args.batch_steps)
     ms = el / args.batch_steps * 1e3
     alg = batch_algorithmic_bytes(shard.n, c)
-    out = {"config": "configs[3] on one GPU: %d documents (%d unique ~1 KB documents x%d, %d B), device-resident: stage 1 (per-document "
-                     "verdicts) -> string records -> GPU walk (tapes), sjmi_parse_batch_device" % (n_docs, len(docs), reps, shard.n),
+    out = {"config": "configs[3] on one GPU: %d UNIQUE documents (tools/docgen.c, seed 20250825, lengths uniform in [768, 1280] B, %d B, "
+                     "%.1f structurals per document), device-resident: stage 1 (per-document verdicts) -> string records -> GPU walk "
+                     "(tapes), sjmi_parse_batch_device; %d seeded sample documents checked against the oracle before timing (indexes + tree)"
+                     % (n_docs, shard.n, c["structurals"] / n_docs, checked),
            "value": round(n_docs / (ms / 1e3), 1), "unit": "docs/s", "ms_per_batch": round(ms, 3), "counts": c,
+           "documents": n_docs, "oracle_checked_documents": checked,
            "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("batch_1m_docs"),
                         "traffic_source": pmc_source(),
-                        "kernel": "k_batch_sep_check + k_stage1 (one plain pass, accepted on the device) + k_split_docs_accept + k_strings + "
-                                  "k_doc_str_ordinals + k_coop_walk + k_tape_chunk_sums / _scan + k_tape_compact (the per-document passes "
-                                  "and the sanitized-copy string pass are queued behind the plain pass and leave at once)",
+                        "kernel": BATCH_KERNELS,
                         "algorithmic_bytes_per_launch": alg,
                         "algorithmic_bytes": "input read once + uint32 indexes + string records + tape words written once"}}
     if with_h2d:
@@ -635,87 +703,185 @@ def batch_single_gpu(torch, S, W, dev, work, args, with_h2d=True):
 # ---------------------------------------------------------------------------------------------------------------
 # N > 1: the sharded batch
 # ---------------------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def bench_sharded(args, world):
+    """N ranks, one per GPU, over RCCL (torch.distributed backend "nccl").  The path shards by DOCUMENT and the only
+    collective is the all_gather of 4 x int64 per rank (north_star).  ONE line, three measurements:
+      value            the headline metric of the N = 1 line, weak-scaled: every rank scans ITS shard of a batch of
+                       N x `reps` twitter.json documents (reps per rank = 4 GiB) -- stage 1 + the count gather per step;
+                       aggregate GB/s of JSON, so that value(N) / (N * value(1)) is the scaling efficiency of the metric;
+      batched.weak     configs[3], `--docs` UNIQUE ~1 KB documents PER RANK, sjmi_parse_batch_device + the count gather;
+      batched.strong   configs[3], `--docs` documents IN ALL, contiguous byte-balanced ranges (sharding.partition_documents)."""
     import numpy as np
     import torch
     import torch.distributed as dist
     import simdjson_java_amd as S
     from simdjson_java_amd import sharding
     import workloads as W
+    from oracle import oracle  # checker only
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # (test hook: SJMI_BENCH_BACKEND=gloo runs the ranks on whatever GPUs exist, e.g. two ranks on the one GPU of a test box)
+    # (test hooks: SJMI_BENCH_BACKEND=gloo + SJMI_BENCH_OVERSUBSCRIBE=1 run the ranks on whatever GPUs exist, e.g. two ranks on
+    #  the one GPU of a test box; without them a rank without a GPU of its own is an error, not a silent fallback)
     backend = os.environ.get("SJMI_BENCH_BACKEND", "nccl")
-    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    if ndev < world and os.environ.get("SJMI_BENCH_OVERSUBSCRIBE", "0") != "1":
+        print("bench.py: %d ranks but only %d GPU(s) visible -- refusing to run (one rank per GPU)" % (world, ndev), file=sys.stderr)
+        sys.exit(3)
+    dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
     if backend == "nccl":
         dist.init_process_group("nccl", device_id=dev)
     else:
         dist.init_process_group(backend)
+    if dist.get_world_size() != args.gpus:
+        print("bench.py: the process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus), file=sys.stderr)
+        sys.exit(3)
     work = torch.cuda.Stream(device=dev)
     work.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(work)
-
-    docs, unit, lens = W.small_doc_pool(args.pool)  # (seeded: every rank builds the same pool)
-    reps = max(1, args.docs // len(docs))
-    n_docs = len(docs) * reps
-    offs = W.batch_offsets(lens, reps)
-    lo, hi = sharding.partition_documents(offs, world)[rank]
-    ctx = S.Context(device=dev.index, capacity=1 << 20)
-    shard = make_batch_shard(torch, S, W, dev, ctx, lo, hi, unit, lens, reps)
     st = work.cuda_stream
+    oracle.build()
+
+    def gather_rows(row):  # the ONLY collective: [world, 4] int64, device tensors (gloo: through the host)
+        if backend == "nccl":
+            out = torch.empty(world * 4, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(out, row)
+            return out.view(world, 4)
+        outs = [torch.empty(4, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(outs, row.cpu())
+        return torch.stack(outs).to(dev)
+
+    # ---- (A) the headline metric, weak: stage 1 over this rank's `reps` twitter.json documents + the count gather ----
+    doc = W.load_twitter()
+    idx0, st0 = oracle.stage1(doc)
+    assert st0 == 0 and idx0.size == 55263
+    reps = args.reps
+    buf, n = W.repeat_on_device(doc, reps, dev)
+    s_total = idx0.size * reps
+    r1 = Stage1Runner(torch, S, dev, work, buf, n, s_total)
+    r1.launch()
+    torch.cuda.synchronize()
+    assert r1.status() == (s_total, 0)
+    ok, bad = W.closed_form_ok(r1.out, idx0, len(doc), reps)
+    assert ok, "rank %d: GPU indexes differ from the oracle's closed form (copies %d..)" % (rank, bad)
+    reps_t = torch.tensor([reps], dtype=torch.int64, device=dev)
+    zero_t = torch.zeros(1, dtype=torch.int64, device=dev)
     gathered = None
 
-    def step():
+    def step_a():
         nonlocal gathered
-        # kernels of the shard + the count gather (the only collective; issued in a group of one rank as well)
-        gathered = sharding.sharded_step(shard, st, always_gather=True)
+        r1.launch()
+        gathered = gather_rows(torch.cat([reps_t, r1.res[0:1], zero_t, r1.res[1:2] & 0xFF]))
 
-    for _ in range(max(args.warmup, 3)):
-        step()
-    torch.cuda.synchronize()
-    c = shard.check()
-    assert c["failed_documents"] == 0 and c["host_documents"] == 0 and c["stage1_status"] == 0, c
-    elapsed = wall_steps(torch, step, args.steps, dist)
-    g = gathered.cpu().numpy()
-    assert int(g[:, 0].sum()) == n_docs
-    # parity property at full size: the gathered totals must equal those of the whole set run on one GPU (below); the
-    # per-document parity of the same pool against the oracle is tests/test_gpu_fullscale.py
-    single = None
+    for _ in range(args.warmup + args.preheat):
+        step_a()
+    r1.ctx.set_profiling(True)
+    elapsed_a = wall_steps(torch, step_a, args.steps, dist)
+    kern_ms, launches = r1.ctx.kernel_time()
+    r1.ctx.set_profiling(False)
+    ga = gathered.cpu().numpy()
+    assert (ga[:, 1] == s_total).all() and (ga[:, 3] == 0).all() and int(ga[:, 0].sum()) == reps * world
+    kernel_ms = kern_ms / max(launches, 1)
+    r1.ctx.close()
+    del r1, buf
+    torch.cuda.empty_cache()
+
+    # ---- (B) configs[3]: the batched path, weak and strong ----
+    def run_batch(lo, hi, sample):
+        ctx = S.Context(device=dev.index, capacity=1 << 20)
+        shard, offs = make_batch_shard(torch, S, W, dev, ctx, lo, hi)
+        g = None
+
+        def step():
+            nonlocal g
+            if backend == "nccl":  # the shard's kernels, then the count gather, all in stream order (sharding.sharded_step)
+                g = sharding.sharded_step(shard, st, always_gather=True)
+            else:
+                shard.step(st)
+                g = gather_rows(shard.counts_tensor())
+
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        c = shard.check()
+        assert c["failed_documents"] == 0 and c["host_documents"] == 0 and c["stage1_status"] == 0, c
+        checked = check_batch_sample(torch, oracle, shard, offs, sample, seed=20250825 + rank)
+        el = wall_steps(torch, step, args.batch_steps, dist)
+        alone = None
+        if rank == 0:  # the same shard on rank 0 with the other GPUs idle (no collective partner needed: kernels only)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.batch_steps):
+                shard.step(st)
+            torch.cuda.synchronize()
+            alone = (time.perf_counter() - t0) / args.batch_steps * 1e3
+        dist.barrier()
+        gg = g.cpu().numpy()
+        ctx.close()
+        return el / args.batch_steps * 1e3, gg, c, checked, alone
+
+    d = args.docs
+    w_ms, w_g, w_c, w_chk, w_alone = run_batch(rank * d, (rank + 1) * d, args.sample // max(world, 1))
+    lens_all = W.unique_doc_lengths(0, d)
+    offs_all = np.concatenate([[0], np.cumsum(lens_all)]).astype(np.uint64)
+    lo, hi = sharding.partition_documents(offs_all, world)[rank]
+    s_ms, s_g, s_c, s_chk, s_alone = run_batch(lo, hi, args.sample // max(world, 1))
+    assert int(s_g[:, 0].sum()) == d and int(w_g[:, 0].sum()) == d * world
     if rank == 0:
-        res = batch_single_gpu(torch, S, W, dev, work, args, with_h2d=False)
-        single = {"value": res["value"], "unit": "docs/s", "ms_per_batch": res["ms_per_batch"], "counts": res["counts"]}
-        assert int(g[:, 1].sum()) == res["counts"]["structurals"] and int(g[:, 2].sum()) == res["counts"]["string_bytes"], \
-            "sharded totals differ from the single-GPU run of the same set"
-    dist.barrier()
-    if rank == 0:
-        ms = elapsed / args.steps * 1e3
-        value = n_docs * args.steps / elapsed
-        total_bytes = int(offs[-1])
-        line = {
-            "metric": "docs/s end-to-end (batched, sharded by document)", "value": round(value, 1), "unit": "docs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 3), "ms_per_step": round(ms, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
-            "data": "synthetic: %d ~1 KB JSON documents (%d unique x%d, tools/synth.py seed 20250825), %d B, resident in HBM, "
-                    "sharded over %d GPUs" % (n_docs, len(docs), reps, total_bytes, world),
-            "config": {"workload": "configs[3]: 1M small JSON documents batched across the GPUs: per rank isolated stage 1 -> string "
-                                   "records -> GPU walk on its contiguous byte-balanced shard (sjmi_parse_batch_device), then ONE RCCL "
-                                   "all_gather of 4 x int64 per rank (the count gather) per step",
-                       "documents": n_docs, "bytes": total_bytes, "documents_per_rank": [int(x) for x in g[:, 0]],
-                       "structurals_per_rank": [int(x) for x in g[:, 1]], "sharding": "by document, contiguous, byte-balanced",
-                       "collective": "all_gather_into_tensor of {docs, structurals, string bytes, failed docs} per rank"},
-            "backend": backend + (" (RCCL)" if backend == "nccl" else ""),
-            "single_gpu_same_run": single,
-            "speedup_vs_single_gpu_same_run": round(value / single["value"], 3) if single else None,
-            "roofline": {"bound": "hbm", "achieved": round(batch_algorithmic_bytes(total_bytes, {"structurals": int(g[:, 1].sum()),
-                         "string_bytes": int(g[:, 2].sum()), "tape_words": single["counts"]["tape_words"]}) / ms / 1e6, 2),
-                         "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": None, "traffic": None,
-                         "kernel": "batched path, all ranks", "note": "aggregate algorithmic bytes per second over all ranks vs N x 8 TB/s"},
+        ms = elapsed_a / args.steps * 1e3
+        value = world * n * args.steps / elapsed_a / 1e9
+        single_docs = d / (w_alone / 1e3)  # rank 0 alone on --docs documents = the one-GPU figure of this run
+        batched = {
+            "weak": {"value": round(d * world / (w_ms / 1e3), 1), "unit": "docs/s", "ms_per_step": round(w_ms, 4), "scaling": "weak",
+                     "documents": d * world, "documents_per_rank": [int(x) for x in w_g[:, 0]],
+                     "structurals_per_rank": [int(x) for x in w_g[:, 1]], "rccl_world_size": world,
+                     "efficiency_vs_rank0_alone": round(w_alone / w_ms, 4)},
+            "strong": {"value": round(d / (s_ms / 1e3), 1), "unit": "docs/s", "ms_per_step": round(s_ms, 4), "scaling": "strong",
+                       "documents": d, "documents_per_rank": [int(x) for x in s_g[:, 0]],
+                       "structurals_per_rank": [int(x) for x in s_g[:, 1]], "rccl_world_size": world,
+                       "rank0_alone_on_its_shard_ms": round(s_alone, 4),
+                       "speedup_vs_single_gpu_same_run": round(single_docs and (d / (s_ms / 1e3)) / single_docs, 3)},
+            "single_gpu_same_run": {"value": round(single_docs, 1), "unit": "docs/s", "ms_per_batch": round(w_alone, 4),
+                                    "documents": d, "note": "rank 0 on its weak shard with the other GPUs idle, kernels only"},
+            "oracle_checked_documents_per_rank": w_chk + s_chk,
+            "workload": "configs[3]: UNIQUE ~1 KB documents (tools/docgen.c seed 20250825, lengths uniform in [768, 1280] B), per rank "
+                        "sjmi_parse_batch_device on its contiguous range (stage 1 with per-document verdicts -> string records -> GPU "
+                        "walk), then ONE all_gather of 4 x int64 per rank per step",
         }
-        line["roofline"]["frac"] = round(line["roofline"]["achieved"] / (HBM_PEAK_GBS * world), 4)
+        line = {
+            "metric": "GB/s JSON scanned (stage-1)", "value": round(value, 2), "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic: twitter.json (631,515 B reference fixture) x%d documents per rank (%d B per rank), resident in HBM, "
+                    "sharded by document over %d GPUs" % (reps, n, world),
+            "config": {"workload": "batched mode, sharded by document: every rank runs stage 1 (UTF-8 validation + structural "
+                                   "indexing + uint32 compaction) over its own %d twitter.json documents, then ONE all_gather of "
+                                   "{docs, structurals, string bytes, status} per rank per step (the count gather, the only collective); "
+                                   "every rank's index array checked against the oracle's closed form before timing" % reps,
+                       "bytes_per_gpu": n, "structurals_per_gpu": s_total, "preheat_launches": args.preheat,
+                       "sharding": "by document, contiguous", "rccl_world_size": world, "backend": backend,
+                       "documents_per_rank": [int(x) for x in ga[:, 0]],
+                       "collective": "all_gather_into_tensor of 4 x int64 per rank",
+                       "batched_weak_docs_per_s": batched["weak"]["value"], "batched_strong_docs_per_s": batched["strong"]["value"],
+                       "batched_single_gpu_docs_per_s": batched["single_gpu_same_run"]["value"],
+                       "batched_documents": d},
+            "backend": backend + (" (RCCL)" if backend == "nccl" else ""),
+            "roofline": roofline(n + 4 * (s_total + 1), kernel_ms, n, "k_stage1 (rank 0)", launches,
+                                 timed_region="the K timed steps on rank 0 (HIP events on its launch stream)",
+                                 all_ranks_achieved=round(value, 2), all_ranks_peak=HBM_PEAK_GBS * world,
+                                 all_ranks_frac=round(value / (HBM_PEAK_GBS * world), 4)),
+            "batched": batched,
+        }
         print(json.dumps(line))
-    ctx.close()
+    dist.barrier()
     dist.destroy_process_group()
 
 
@@ -730,7 +896,7 @@ def main():
     ap.add_argument("--reps", type=int, default=6801, help="N=1: copies of twitter.json (6801 = 4 GiB north-star, 1024 = configs[1])")
     ap.add_argument("--tile-steps", type=int, default=0, help="force the chain granule = N x 4 KiB: 1, 2 or 4 (0 = auto)")
     ap.add_argument("--docs", type=int, default=1000000, help="documents of the configs[3] batch")
-    ap.add_argument("--pool", type=int, default=4000, help="unique documents of the configs[3] batch")
+    ap.add_argument("--pool", type=int, default=4000, help="unique documents of the bounded CPU-baseline sample of configs[3]")
     ap.add_argument("--batch-steps", type=int, default=10, help="N=1: timed steps of the configs[3] extra")
     ap.add_argument("--no-extras", action="store_true", help="N=1: only the primary workload")
     ap.add_argument("--sections", default="x1024,unescape,synth,batch,parse,select,trees",
@@ -741,23 +907,40 @@ def main():
     ap.add_argument("--sharded", action="store_true",
                     help="N=1: take the sharded branch anyway -- init_process_group('nccl'), the batch on one rank, the count gather as a "
                          "real RCCL all_gather_into_tensor in a group of one (prints the SCALE-style line instead of the BENCH line)")
+    ap.add_argument("--sample", type=int, default=10000, help="documents of the configs[3] batch checked against the oracle before timing")
     args = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        print("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus), file=sys.stderr)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            # launched plainly (`python bench.py --gpus N`): become the N ranks -- one process per GPU under torch.distributed.run
+            # -- instead of quietly measuring one GPU; fewer than N GPUs is an error
+            import torch
+            if torch.cuda.device_count() < args.gpus and os.environ.get("SJMI_BENCH_OVERSUBSCRIBE", "0") != "1":
+                print("bench.py: --gpus %d but only %d GPU(s) visible -- refusing to run" % (args.gpus, torch.cuda.device_count()),
+                      file=sys.stderr)
+                sys.exit(3)
+            env = dict(os.environ)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                   "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+            sys.exit(subprocess.call(cmd, env=env))
+        world = 1
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            print("bench.py: WORLD_SIZE (%d) != --gpus (%d) -- refusing to run" % (world, args.gpus), file=sys.stderr)
+            sys.exit(3)
     if world > 1:
         bench_sharded(args, world)
     elif args.sharded:
         # a process group of ONE rank over RCCL: what torch.distributed.run would have put into the environment
-        import socket
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("LOCAL_RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ["MASTER_PORT"] = str(_free_port())
         bench_sharded(args, 1)
     else:
         bench_single(args)

@@ -5,7 +5,6 @@
 #include "ondemand.h"
 #include "../sj_number.h"
 #include "../sj_bigdec.h"
-#include "../sj_bigdec.h"
 
 #include <stdio.h>
 #include <stdlib.h>

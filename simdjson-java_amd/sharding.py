@@ -119,12 +119,12 @@ def sharded_step(shard, stream=0, always_gather=False):
     collective even in a group of one rank (bench.py --sharded: the RCCL call path on a single GPU)."""
     import torch
     import torch.distributed as dist
-    shard.step(stream)
     if not stream and str(shard.device) != "cpu":
-        # stream handle 0 = "the engine context's own stream", which torch knows nothing about: the torch ops that read
-        # the result record below would not be ordered behind the kernels.  Callers that care about overlap pass the
-        # handle of the torch stream they are on (bench.py does).
-        torch.cuda.synchronize()
+        # stream handle 0 would mean "the engine context's own stream", which torch knows nothing about: the torch ops that
+        # read the result record below would not be ordered behind the kernels.  So the kernels go on the torch stream the
+        # caller is on -- plain stream order, no host synchronisation anywhere in the step.
+        stream = torch.cuda.current_stream(shard.device).cuda_stream
+    shard.step(stream)
     row = shard.counts_tensor()
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not always_gather):
         return row[None, :]

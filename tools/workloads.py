@@ -77,3 +77,58 @@ def small_doc_pool(unique=4000, same_schema=False):
 
 def batch_offsets(lens, reps):
     return np.concatenate([[0], np.cumsum(np.tile(lens, reps))]).astype(np.uint64)
+
+
+# ---- configs[3] as SURVEY.md 8(d) states it: 1,000,000 UNIQUE documents (tools/docgen.c) ----------------------------------
+_DOCGEN = None
+DOCGEN_SEED = 20250825
+
+
+def build_docgen(force=False):
+    """gcc -> tools/libdocgen.so (in-tree, travels to the GPU box; __graft_entry__.build() calls this)"""
+    import subprocess
+    src, lib = os.path.join(ROOT, "tools", "docgen.c"), os.path.join(ROOT, "tools", "libdocgen.so")
+    if force or not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", lib, src])
+    return lib
+
+
+def _docgen():
+    global _DOCGEN
+    if _DOCGEN is None:
+        import ctypes
+        L = ctypes.CDLL(build_docgen())
+        L.docgen_lengths.argtypes = [ctypes.c_uint64] * 3 + [ctypes.c_void_p]
+        L.docgen_lengths.restype = None
+        L.docgen_fill.argtypes = [ctypes.c_uint64] * 3 + [ctypes.c_void_p, ctypes.c_void_p]
+        L.docgen_fill.restype = None
+        _DOCGEN = L
+    return _DOCGEN
+
+
+def unique_doc_lengths(first, n, seed=DOCGEN_SEED, threads=None):
+    """lengths (incl. the '\\n' separator) of documents [first, first + n) of the set; a pure function of (seed, k)"""
+    from concurrent.futures import ThreadPoolExecutor
+    L = _docgen()
+    lens = np.zeros(n, dtype=np.uint64)
+    threads = threads or min(32, os.cpu_count() or 1)
+    step = max(1, (n + threads - 1) // threads)
+    with ThreadPoolExecutor(threads) as ex:  # (ctypes releases the GIL)
+        list(ex.map(lambda a: L.docgen_lengths(seed, first + a, min(step, n - a), lens[a:].ctypes.data), range(0, n, step)))
+    return lens
+
+
+def unique_docs(first, n, seed=DOCGEN_SEED, threads=None, out=None):
+    """documents [first, first + n) packed with one '\\n' behind each -> (uint8 array, u64 offsets[n + 1] from 0).
+    `out` (optional): a writable uint8 array to fill (e.g. the numpy view of a pinned torch tensor)."""
+    from concurrent.futures import ThreadPoolExecutor
+    L = _docgen()
+    lens = unique_doc_lengths(first, n, seed, threads)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    buf = out if out is not None else np.empty(int(offs[-1]), dtype=np.uint8)
+    assert buf.size >= int(offs[-1])
+    threads = threads or min(32, os.cpu_count() or 1)
+    step = max(1, (n + threads - 1) // threads)
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(lambda a: L.docgen_fill(seed, first + a, min(step, n - a), buf.ctypes.data, offs[a:].ctypes.data), range(0, n, step)))
+    return buf[:int(offs[-1])], offs
