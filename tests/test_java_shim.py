@@ -1,0 +1,94 @@
+"""The Java side of the boundary (no JVM in this image, so it is verified as far as text allows):
+* integration/simdjson-java.patch applies cleanly (`git apply --check`) to the three reference files it touches --
+  SimdJsonParser.java:55-58 (stage1), BitIndexes.java:5-12 (accessors), TapeBuilder.java:174-177 (visitString);
+  needs /root/reference, which only exists in the build container;
+* every downcall handle of java/org/simdjson/Sjmi.java names a function that include/sjmi.h declares AND libsjmi.so
+  exports, with a FunctionDescriptor that matches the C prototype argument for argument (pointer -> ADDRESS,
+  uint64_t / int64_t -> JAVA_LONG, int / uint32_t / int32_t -> JAVA_INT);
+* every handle INTEGRATION.md uses (Sjmi.XXX) exists in Sjmi.java."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from tests.conftest import ROOT
+
+REF = "/root/reference/src/main/java/org/simdjson"
+PATCH = os.path.join(ROOT, "integration", "simdjson-java.patch")
+SJMI_JAVA = os.path.join(ROOT, "java", "org", "simdjson", "Sjmi.java")
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference sources only exist in the build container")
+def test_patch_applies_to_the_reference_files(tmp_path):
+    dst = tmp_path / "src" / "main" / "java" / "org" / "simdjson"
+    dst.mkdir(parents=True)
+    for f in ("SimdJsonParser.java", "BitIndexes.java", "TapeBuilder.java"):
+        shutil.copy(os.path.join(REF, f), dst / f)
+    subprocess.check_call(["git", "init", "-q"], cwd=tmp_path)
+    out = subprocess.run(["git", "apply", "--check", "-p1", PATCH], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    subprocess.check_call(["git", "apply", "-p1", PATCH], cwd=tmp_path)
+    patched = (dst / "SimdJsonParser.java").read_text()
+    assert "Sjmi.STAGE1_UNESCAPE.invokeExact" in patched and "Utf8Validator.validate(buffer, length)" not in patched
+    assert "setWriteIdx" in (dst / "BitIndexes.java").read_text()
+    assert "StringErrors.of" in (dst / "TapeBuilder.java").read_text()
+    # the new files sit next to the patched ones
+    for f in ("Sjmi.java", "StringErrors.java"):
+        assert os.path.exists(os.path.join(ROOT, "java", "org", "simdjson", f))
+
+
+def _c_prototypes():
+    text = open(os.path.join(ROOT, "include", "sjmi.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|void|const char\*)\s+(sjmi_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
+        kinds = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    kinds.append("ADDRESS")
+                elif re.match(r"(const\s+)?(uint64_t|int64_t|size_t)\b", a):
+                    kinds.append("JAVA_LONG")
+                elif re.match(r"(const\s+)?(int|uint32_t|int32_t|unsigned)\b", a):
+                    kinds.append("JAVA_INT")
+                else:
+                    kinds.append("?" + a)
+        protos[name] = ({"int": "JAVA_INT", "void": None, "const char*": "ADDRESS"}[ret], kinds)
+    return protos
+
+
+def _java_handles():
+    src = open(SJMI_JAVA).read()
+    src = re.sub(r"//[^\n]*", "", src)
+    out = {}
+    for m in re.finditer(r"static final MethodHandle (\w+)\s*=\s*h\(\"(sjmi_\w+)\",\s*FunctionDescriptor\.(of|ofVoid)\(([^;]*?)\)\);", src, flags=re.S):
+        field, name, kind, args = m.group(1), m.group(2), m.group(3), [a.strip() for a in m.group(4).split(",") if a.strip()]
+        ret = None if kind == "ofVoid" else args.pop(0)
+        out[field] = (name, ret, args)
+    return out
+
+
+def test_every_handle_matches_its_c_prototype_and_is_exported():
+    import simdjson_java_amd as S
+    protos, handles = _c_prototypes(), _java_handles()
+    assert len(handles) >= 14
+    lib = S.lib()
+    for field, (name, ret, args) in handles.items():
+        assert name in protos, "%s binds %s, which include/sjmi.h does not declare" % (field, name)
+        want_ret, want_args = protos[name]
+        assert ret == want_ret, (field, ret, want_ret)
+        assert args == want_args, "%s: descriptor %s != C prototype %s" % (field, args, want_args)
+        assert hasattr(lib, name), name  # dlsym through ctypes
+
+
+def test_integration_md_only_uses_handles_that_exist():
+    handles = _java_handles()
+    used = set(re.findall(r"Sjmi\.([A-Z][A-Z0-9_]+)\b", open(os.path.join(ROOT, "INTEGRATION.md")).read()))
+    used |= set(re.findall(r"Sjmi\.([A-Z][A-Z0-9_]+)\b", open(PATCH).read()))
+    consts = {"ST_UTF8", "ST_UNCLOSED", "ST_UNESCAPED", "ST_CAPACITY", "ST_INTERNAL", "ST_HALO", "WALK_NEEDS_HOST"}
+    missing = sorted(u for u in used if u not in handles and u not in consts)
+    assert not missing, "INTEGRATION.md / the patch use Sjmi.%s, which java/org/simdjson/Sjmi.java does not define" % missing
