@@ -97,7 +97,11 @@ const char* sjmi_version(void);
 /* Replaces SimdJsonParser.stage1 (+ padIfNeeded) for HOST buffers: copies buf[0,len) to the
  * device (padding handled internally: bytes >= len are never read from `buf`), runs the fused
  * kernel, copies indexes[0..count] (sentinel included) and the verdict back.
- * indexes must hold index_capacity entries; needs index_capacity >= count+1. */
+ * indexes must hold index_capacity entries; needs index_capacity >= count+1.  Like BitIndexes.write's speculative
+ * stores (BitIndexes.java:14-41: "garbage may follow the valid prefix"), the call may write ANY entry of
+ * indexes[0, index_capacity) -- small documents are downloaded by their bound, not by their count -- so a caller
+ * must not keep other data inside that range; only indexes[0..count] are meaningful.  The same holds for
+ * string_buffer[0, string_capacity) of sjmi_stage1_unescape / sjmi_unescape (StringParser's over-copy, :33-34). */
 int sjmi_stage1(sjmi_ctx* ctx, const uint8_t* buf, uint64_t len, uint32_t* indexes, uint64_t index_capacity,
                 uint64_t* count, uint32_t* status);
 

@@ -429,6 +429,24 @@ void SimdJsonParser::parseBatch(const uint8_t* buffer, size_t totalLen, const ui
         }
     };
     std::thread feeders[2];
+    // The feeders wait for their sub-batches' bytes (copiedCv).  Whatever is thrown between here and the join below -- the
+    // pool, an allocation -- must not leave them waiting with joinable std::thread objects going out of scope (that is
+    // std::terminate): on the way out every sub-batch is marked copied, so the feeders run dry, and they are joined.
+    struct JoinFeeders {
+        std::thread* th;
+        std::vector<SubBatch>& subs;
+        std::mutex& m;
+        std::condition_variable& cv;
+        ~JoinFeeders() {
+            {
+                std::lock_guard<std::mutex> g(m);
+                for (SubBatch& sb : subs) sb.copied = true;
+            }
+            cv.notify_all();
+            for (int i = 0; i < 2; ++i)
+                if (th[i].joinable()) th[i].join();
+        }
+    } joinFeeders{feeders, subs, m, copiedCv};
     feeders[0] = std::thread(feed, ctx_, (size_t)0);
     if (J > 1) feeders[1] = std::thread(feed, ctx2_, (size_t)1);
     // padIfNeeded for the batch (SimdJsonParser.java:42-48), on the pool (one thread copies ~25 GB/s), sub-batch by sub-batch:

@@ -115,7 +115,7 @@ SJN_DEV inline unsigned long long sj_decide_double(ByteAt&& B, uint32_t p, unsig
         if (c == '-' || c == '+') c = B(++p);
         long long e = 0;
         while (c - '0' <= 9u) {
-            if (e < 100000000) e = e * 10 + (long long)(c - '0');
+            if (e < 100000000000000000LL) e = e * 10 + (long long)(c - '0');  // (the same 18-digit saturation as sj_scan_number: the two must agree on the decimal exponent)
             c = B(++p);
         }
         k += eneg ? -e : e;

@@ -9,6 +9,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <system_error>
 #include <utility>
 #include <vector>
 
@@ -282,13 +283,20 @@ static bool upload_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len) {
                 if (hipMemcpyAsync((uint8_t*)c->d_in + off, c->staging + off, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) ok = false;
             }
         };
-        if (len >= (16ull << 20)) {
-            std::thread helper(part, (uint64_t)1, (uint64_t)2, true);
-            part(0, 2, false);
-            helper.join();
-        } else {
-            part(0, 1, false);
+        bool split = len >= (16ull << 20);
+        if (split) {
+            std::thread helper;
+            try {  // (thread creation can fail -- EAGAIN: no exception may cross the C ABI into a JVM / ctypes caller)
+                helper = std::thread(part, (uint64_t)1, (uint64_t)2, true);
+            } catch (const std::system_error&) {
+                split = false;
+            }
+            if (split) {
+                part(0, 2, false);
+                helper.join();
+            }
         }
+        if (!split) part(0, 1, false);
         if (!ok) {
             c->err = "H2D (staged upload) failed";
             return false;
@@ -873,6 +881,8 @@ int sjmi_stage1_masks(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint64_t* m
     if (!grow(c, &c->d_masks, &c->masks_bytes, (size_t)nblocks * 48, "hipMalloc(masks)")) return SJMI_ERR_HIP;
     if (len && fail(c, "H2D", hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
     c->last_valid = false;  // (the context's document buffer now holds this document, without indexes)
+    c->par_valid = false;   // (... and without block parities: new bytes under the same pointer)
+    c->accept_valid = false;
     const int rc = sjmi_stage1_masks_device(c, c->d_in, len, c->d_masks, nblocks, c->stream);
     if (rc != SJMI_OK) return rc;
     if (fail(c, "D2H(masks)", hipMemcpyAsync(masks, c->d_masks, (size_t)nblocks * 48, hipMemcpyDeviceToHost, c->stream)) ||
@@ -1016,6 +1026,13 @@ static int stage1_batch_isolated_device_impl(sjmi_ctx* c, const void* d_buf, uin
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
     if (!grow(c, (void**)&c->d_doccnt, &c->doccnt_bytes, sjmi::batch_isolated_workspace_bytes(n_docs), "hipMalloc(doccnt)"))
         return SJMI_ERR_HIP;
+    if (!d_skip) {
+        // no plain pass in front of these per-document passes (switched off, misaligned buffers, an empty batch): block
+        // parities / an acceptance flag recorded for the same pointer and length by an EARLIER launch describe other bytes;
+        // the string pass of this batch must take the sanitized copy, not them
+        c->par_valid = false;
+        c->accept_valid = false;
+    }
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     if (fail(c, "isolated batch launch",
              sjmi::batch_isolated_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs,
