@@ -136,10 +136,114 @@ hipError_t batch_plain_check_launch(const uint8_t* d_buf, const unsigned long lo
 }
 hipError_t batch_plain_accept_launch(const uint32_t* d_idx, const Stage1Result* d_res, const unsigned long long* d_doc_offsets,
                                      uint64_t n_docs, unsigned long long* d_index_offsets, uint32_t* d_doc_status, uint32_t* d_flags,
-                                     hipStream_t stream, const Stage1Prefixes& hint) {
+                                     hipStream_t stream, const Stage1Prefixes& hint, bool split) {
     hipLaunchKernelGGL(k_batch_plain_accept, dim3(1), dim3(64), 0, stream, d_res, d_flags);
-    hipLaunchKernelGGL(k_split_docs_accept, dim3((unsigned)((n_docs + 1 + 255) / 256)), dim3(256), 0, stream, d_idx, d_res, d_doc_offsets,
+    if (split)
+        hipLaunchKernelGGL(k_split_docs_accept, dim3((unsigned)((n_docs + 1 + 255) / 256)), dim3(256), 0, stream, d_idx, d_res, d_doc_offsets,
                        n_docs, d_index_offsets, d_doc_status, (const uint32_t*)d_flags, hint);
+    return hipGetLastError();
+}
+
+// ---- one pass over the documents of an ACCEPTED plain batch (see DocPrepare in stage1.h) -------------------------------------
+// Thread k looks at BOUNDARY k = doc_offsets[k] (n_docs + 1 of them; a workgroup's last thread also at the one behind it):
+//   * the structurals of the boundary's 64-byte block that lie in front of it, read from the index array at the position
+//     k_stage1 recorded for the block (blkidx): how many (-> index_offsets[k], no search), how many tape words they make and
+//     how many of them open a string (-> the document's first string ordinal, on top of blk_ord of the string pass);
+//   * then document k = [boundary k, boundary k + 1): its predicted tape length = the per-block word counts of k_stage1
+//     (blkw, by the block's entry parity) over its blocks, corrected at both ends, + the two root words.
+// A batch is accepted only if every document passed stage 1, so every document begins outside a string.
+__device__ __forceinline__ uint32_t prep_words_of(uint32_t c) {  // tape words of a structural by its first byte
+    return (c == ',' || c == ':') ? 0u : ((c == '-' || c - '0' <= 9u) ? 2u : 1u);
+}
+__global__ void __launch_bounds__(PREP_DOCS)
+k_doc_prepare(DocPrepare a) {
+    if (a.flags[1] == 0) return;
+    __shared__ uint32_t s_io[PREP_DOCS + 1], s_pw[PREP_DOCS + 1];
+    __shared__ unsigned long long s_sum[PREP_DOCS / 64];
+    const uint64_t k0 = (uint64_t)blockIdx.x * PREP_DOCS, k = k0 + threadIdx.x;
+    const unsigned long long count = a.stage1->count, nstr = a.strings->reserved;
+    const bool strings_ok = !(a.strings->flags & 0xEu);
+    auto boundary = [&](uint64_t kb, uint32_t* io, uint32_t* pw, unsigned long long* ord) {
+        unsigned long long pos = a.doc_offsets[kb];
+        if (pos > a.total_len) pos = a.total_len;
+        // (the batch's end is a boundary like any other: the last document's structurals in the tail block are in front of it)
+        const unsigned long long b = pos >> 6;
+        unsigned long long j = a.blkidx[b];
+        uint32_t w = 0, q = 0;
+        for (int t = 0; t < 64 && j < count; ++t, ++j) {  // (a block has at most 64 structurals)
+            const uint32_t p = a.idx[j];
+            if ((unsigned long long)p >= pos) break;
+            const uint32_t c = a.buf[p];
+            w += prep_words_of(c);
+            q += c == '"';
+        }
+        *io = (uint32_t)j;
+        *pw = w;
+        unsigned long long o = strings_ok ? (unsigned long long)a.blk_ord[b] + q : nstr;
+        *ord = o > nstr ? nstr : o;
+        return pos;
+    };
+    uint32_t io = 0, pw = 0;
+    unsigned long long ord = 0, s = 0;
+    if (k <= a.n_docs) {
+        s = boundary(k, &io, &pw, &ord);
+        s_io[threadIdx.x] = io;
+        s_pw[threadIdx.x] = pw;
+        a.index_offsets[k] = io;
+        a.doc_ord[k] = ord;
+        if (a.doc_str_offsets) a.doc_str_offsets[k] = ord < nstr ? a.soff[ord] : a.strings->total_bytes;
+        if (threadIdx.x == PREP_DOCS - 1 && k < a.n_docs) {  // the boundary behind this workgroup's last document
+            uint32_t io2, pw2;
+            unsigned long long ord2;
+            (void)boundary(k + 1, &io2, &pw2, &ord2);
+            s_io[PREP_DOCS] = io2;
+            s_pw[PREP_DOCS] = pw2;
+        }
+    }
+    __syncthreads();
+    uint32_t len = 0;
+    if (k < a.n_docs) {
+        unsigned long long e = a.doc_offsets[k + 1];
+        if (e > a.total_len) e = a.total_len;
+        if (s > e) s = e;
+        // whole blocks [bs, be): block bs counted from its start (the part in front of the document comes off again below),
+        // the block that holds the end boundary only through the correction pw[k + 1]
+        const unsigned long long bs = s >> 6, be = e >> 6;
+        uint32_t sum = 0;
+        unsigned long long par = 0;
+        for (unsigned long long b = bs; b < be; ++b) {
+            if (b == bs || (b & 63) == 0) par = a.blkpar[b >> 6];
+            const uint32_t w2 = a.blkw[b];
+            sum += ((par >> (b & 63)) & 1ull) ? (w2 >> 8) : (w2 & 0xFFu);
+        }
+        const uint32_t to = s_io[threadIdx.x + 1];
+        len = sum - pw + s_pw[threadIdx.x + 1] + 2u;  // + the two root words (TapeBuilder.java:41-48)
+        a.lens[k] = len;
+        a.doc_status[k] = 0;
+        DocMeta m;
+        m.from = io;
+        m.to = to;
+        m.dso = (uint32_t)ord;
+        m.doc_start = (uint32_t)s;
+        m.doc_end = (uint32_t)e;
+        m.st = 0;
+        m.tape_lo = m.tape_hi = 0;  // (k_tape_offsets)
+        a.metas[k] = m;
+    }
+    // the workgroup's predicted words -> chunk_sums (the scan of k_tape_chunk_scan / k_tape_offsets, walk.hip)
+    unsigned long long v = len;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < PREP_DOCS / 64; ++w) t += s_sum[w];
+        a.chunk_sums[blockIdx.x] = t;
+    }
+}
+hipError_t batch_prepare_launch(const DocPrepare& a, hipStream_t stream) {
+    hipLaunchKernelGGL(k_doc_prepare, dim3((unsigned)((a.n_docs + 1 + PREP_DOCS - 1) / PREP_DOCS)), dim3(PREP_DOCS), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -376,6 +376,15 @@ k_single_finish(const uint8_t* __restrict__ buf, SingleFinish f) {
     cw_single_finish(buf, f, f.tape_lens[0], f.doc_errors[0], wa, wb);
 }
 
+// k_coop_walk<false> as the EXACT walker behind the token walker (see k_tok_walk): which documents, and where their tapes go
+struct ExactMode {
+    const uint32_t* list = nullptr;      // [0] = how many, ids from [16]; nullptr: every document
+    const DocMeta* metas = nullptr;      // != nullptr: document k's tape at metas[k].tape, room up to metas[k + 1].tape
+    unsigned long long* tape = nullptr;  // *sel != 0 (or sel == nullptr): the final tape; else tape_alt (the scratch tape)
+    unsigned long long* tape_alt = nullptr;
+    const uint32_t* sel = nullptr;
+};
+
 // One wave per document (grid-stride over the documents).  Documents are delimited by index_offsets (n_docs + 1 entries)
 // and doc_offsets; a single document is the batch of one.  Document k's tape is built in its slot of the scratch tape
 // (2 words per structural + 2, walk.hip packs the tapes back to back afterwards); soff[] = the string pass's record offsets
@@ -391,9 +400,14 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
             const unsigned long long* __restrict__ doc_str_offsets, unsigned long long string_base, int max_depth,
             unsigned long long* __restrict__ scratch_tape, uint32_t* __restrict__ tape_lens, int32_t* __restrict__ doc_errors, const Stage1Result* __restrict__ dev_count,
             const UnescapeResult* __restrict__ dev_strings, WalkResult* res, uint32_t abl, ChunkWs cw, const uint32_t* run_only_if,
-            unsigned long long* __restrict__ ovf, SlowList slow) {
+            unsigned long long* __restrict__ ovf, SlowList slow, ExactMode ex) {
     if (run_only_if && *run_only_if == 0) return;   // (the single-wave sweep behind a chunked launch: only on fall-back)
     if (CHUNKED && *cw.fallback != 0) return;
+    // LIST MODE (the exact walker behind k_tok_walk): the documents are those the token walker listed; a document's tape goes
+    // where its DocMeta says -- the final tape when *ex.sel != 0 (then this kernel also counts the failures), else the scratch tape
+    const uint32_t* const list = CHUNKED ? nullptr : ex.list;
+    const bool final_mode = !CHUNKED && ex.metas && ex.sel && *ex.sel != 0;  // (the tapes were laid out before the walk)
+    if (!CHUNKED && ex.metas) scratch_tape = (!ex.sel || *ex.sel != 0) ? ex.tape : ex.tape_alt;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // the per-wave stack of open containers lives in two VGPRs: LANE L holds level L (tape position of the opening word,
@@ -466,6 +480,8 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
     Meta m = {0, 0, 0, 0, 0, 0}, m_next = m;
     Head hd = {0, 0, 0, 0};
     uint32_t n_items = (uint32_t)n_docs;
+    if (list) n_items = list[0] < n_items ? list[0] : n_items;
+    auto doc_id = [&](uint32_t kk) -> uint32_t { return list ? list[16 + kk] : kk; };
     uint32_t chunk = 0;
     if (CHUNKED) {  // the work items are the chunks of document 0
         m = load_meta(0);
@@ -476,20 +492,20 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
             hd = load_head(m, a, b);
         }
     } else if (k < n_items) {
-        m = load_meta(k);
+        m = load_meta(doc_id(k));
         hd = load_head(m, m.from, m.to);
     }
     bool more = false;
     for (; k < n_items; k = more ? k + nwaves : n_items) {
         more = n_items - k > nwaves;  // (k + nwaves < n_items, without a sum that could wrap)
-        if (!CHUNKED && more) m_next = load_meta(k + nwaves);
+        if (!CHUNKED && more) m_next = load_meta(doc_id(k + nwaves));
         int code = 0;
         uint32_t tlen = 0, err_at = 0xFFFFFFFFu;
         const uint32_t st = m.st;
         const uint32_t from = m.from, to = m.to;
         const uint32_t wfrom = CHUNKED ? from + k * chunk : from;
         const uint32_t wto = CHUNKED ? (to - wfrom > chunk ? wfrom + chunk : to) : to;
-        const uint32_t kdoc = CHUNKED ? 0u : k;
+        const uint32_t kdoc = CHUNKED ? 0u : doc_id(k);
         // SimdJsonParser.stage1 order: Utf8Validator.validate (:165-167), then StructuralIndexer.index (:297-302)
         if (upstream_failed) code = SJMI_E_CAPACITY;
         else if (st & SJMI_ST_UTF8) code = SJMI_E_UTF8;
@@ -500,8 +516,14 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
         if (code == 0) {
             const uint32_t doc_start = m.doc_start, doc_end = m.doc_end;
             const uint32_t n = to - from;
-            unsigned long long* const T = scratch_tape + 2ull * from + 2ull * kdoc;  // this document's slot (word 0 = root)
-            const uint32_t room = 2u * n + 2u;                              // a structural makes at most two words
+            // this document's slot (word 0 = root): two words per structural + 2 of the scratch tape, or what its DocMeta says
+            unsigned long long t_off = 2ull * from + 2ull * kdoc, t_room = 2ull * n + 2ull;
+            if (!CHUNKED && ex.metas) {
+                t_off = ((unsigned long long)ex.metas[kdoc].tape_hi << 32) | ex.metas[kdoc].tape_lo;
+                t_room = (((unsigned long long)ex.metas[kdoc + 1].tape_hi << 32) | ex.metas[kdoc + 1].tape_lo) - t_off;
+            }
+            unsigned long long* const T = scratch_tape + t_off;
+            const uint32_t room = t_room > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t_room;
             // running state (wave-uniform)
             uint32_t H0 = 0;                 // open containers in front of the step
             uint32_t T0 = 1;                 // tape position of the step's first word (0 = the root word)
@@ -813,17 +835,352 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
             continue;
         }
         if (lane == 0) {
-            tape_lens[k] = tlen;
-            doc_errors[k] = code;
+            if (tape_lens) tape_lens[kdoc] = tlen;
+            doc_errors[kdoc] = code;
         }
         n_host += code == SJMI_WALK_NEEDS_HOST;
         n_bad += code > 0;
         m = m_next;
         if (more) hd = load_head(m, m.from, m.to);
     }
-    (void)res;
-    (void)n_host;
-    (void)n_bad;  // (host / failed documents are counted by the packing kernels from doc_errors)
+    // (host / failed documents: counted by the packing kernels from doc_errors -- except when the tapes were laid out before
+    //  the walk, where nothing runs behind this kernel and only the documents of its list can have failed)
+    if (final_mode && lane == 0) {
+        if (n_host) atomicAdd(&res->host_documents, n_host);
+        if (n_bad) atomicAdd(&res->failed_documents, n_bad);
+    }
+}
+
+// ---- the BATCH walker: tokens, not structurals ---------------------------------------------------------------------------
+// k_coop_walk above gives every structural a lane, and nearly half of a document's structurals are ',' and ':' -- they make no
+// tape word, yet they occupy lanes of every scan, ballot and store of a step.  k_tok_walk walks TOKENS: the structurals are
+// ingested 64 at a time (class from the first byte of the 16-byte window, as above), the separators are folded into a two-bit
+// "what stands in front of me" field of the token behind them, and the tokens -- position, class, that field, window -- are
+// compacted into a per-wave ring in LDS; a TOKEN STEP then runs the scans of the cooperative walker over 64 tokens = ~116
+// structurals of a typical record.  Grammar in token form (JsonIterator.java:68-193, the same predicates, re-keyed):
+//     first child of '['          no separator, a value            first child of '{'     no separator, a string (key)
+//     behind a key                ':' and a value                  behind a value         ',' + value (array) / ',' + key (object)
+//                                                                                          or no separator + the container's own close
+//     two separators in a row, a separator in front of the root or behind the last token: never valid.
+// The kernel is OPTIMISTIC: it builds the tape of a document that is well formed, and hands every other document -- any failing
+// predicate, a stage-1 status, a root that is not a container, a malformed escape, a literal for k_slow_doubles, nesting beyond
+// the 64 levels of the register stack -- to k_coop_walk (list mode), which walks it again and produces the reference's exact
+// error code (or its tape).  A well-formed batch never gets there.
+struct TokArgs {
+    const uint8_t* buf;
+    const uint32_t* idx;
+    const DocMeta* metas;
+    uint32_t n_docs;
+    int max_depth;
+    const uint32_t* soff;
+    const uint8_t* sb;
+    unsigned long long string_base;
+    unsigned long long* tape;       // *sel != 0 (or sel == nullptr): the tapes' final place; else tape_alt (the scratch tape)
+    unsigned long long* tape_alt;
+    const uint32_t* sel;
+    int32_t* doc_errors;
+    uint32_t* tape_lens;            // scratch mode only (walk.hip packs by them); may be nullptr
+    uint32_t* list;                 // [0] = number of documents for the exact walker, their ids from [16]
+    const Stage1Result* dev_count;
+    const UnescapeResult* dev_strings;
+};
+struct __attribute__((aligned(16))) TokRing {
+    uint4 win[128];
+    uint32_t p[128];
+    uint32_t info[128];  // class | pre << 3 (0 none, 1 ',', 2 ':') | two separators in front << 5
+};
+constexpr int32_t CW_NEEDS_EXACT = -100;  // (internal, overwritten by the exact walker)
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
+k_tok_walk(TokArgs a) {
+    __shared__ TokRing rings[4];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    TokRing& ring = rings[wv];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t nwaves = gridDim.x * 4u;
+    unsigned long long* const tape = (a.sel && *a.sel == 0) ? a.tape_alt : a.tape;
+    const bool upstream_failed = (a.dev_count && (a.dev_count->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL))) ||
+                                 (a.dev_strings && (a.dev_strings->flags & 0xFu));
+    const bool string_errors = a.dev_strings && a.dev_strings->first_error_inv != 0;
+    uint32_t st_tpos = 0, st_cnt = 0;  // the stack of open containers: LANE L = level L (tape position of the opening word, commas so far)
+    auto load_pos = [&](uint32_t from, uint32_t to, uint32_t c, uint32_t dflt) -> uint32_t {
+        const uint32_t i = from + c * 64u + (uint32_t)lane;
+        return i < to ? a.idx[i] : dflt;
+    };
+    uint32_t k = blockIdx.x * 4u + (uint32_t)wv;
+    DocMeta m = {}, m_next = {};
+    unsigned long long t_end = 0, t_end_next = 0;
+    uint32_t p0 = 0, p1 = 0;  // positions of the document's first two chunks of structurals (requested a document ahead)
+    if (k < a.n_docs) {
+        m = a.metas[k];
+        t_end = ((unsigned long long)a.metas[k + 1].tape_hi << 32) | a.metas[k + 1].tape_lo;
+        p0 = load_pos(m.from, m.to, 0, m.doc_start);
+        p1 = load_pos(m.from, m.to, 1, m.doc_start);
+    }
+    for (; k < a.n_docs; k += nwaves) {
+        const bool more = a.n_docs - k > nwaves;
+        if (more) {
+            m_next = a.metas[k + nwaves];
+            t_end_next = ((unsigned long long)a.metas[k + nwaves + 1].tape_hi << 32) | a.metas[k + nwaves + 1].tape_lo;
+        }
+        const uint32_t from = m.from, to = m.to, n = to - from;
+        const unsigned long long t_off = ((unsigned long long)m.tape_hi << 32) | m.tape_lo;
+        unsigned long long* const T = tape + t_off;
+        const unsigned long long room64 = t_end - t_off;
+        const uint32_t room = room64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)room64;
+        bool ok = !upstream_failed && m.st == 0 && n != 0 && n <= 0x7FFFFF00u && to <= 0xFFFFFF00u;
+        uint32_t tlen = 0;
+        if (ok) {
+            const uint32_t doc_start = m.doc_start, doc_end = m.doc_end;
+            const uint32_t nchunks = (n + 63u) / 64u;
+            // ---- running state (wave-uniform) ----
+            uint32_t H0 = 0, T0 = 1, S0 = m.dso;
+            unsigned long long arr_mask = 0;
+            uint32_t prev_cls = K_COMMA;
+            bool prev_empty_open = false, prev_is_key = false, root_closed = false, at_start = true;
+            uint32_t pq_tpos = 0, pq_off = 0;
+            bool pq_live = false;
+            // ingest state
+            uint32_t c = 0, head = 0, tail = 0;
+            uint32_t sep1 = 0, sep2 = 0, colon1 = 0;
+            uint32_t p_cur = p0, p_nxt = p1;
+            CW16 win_cur = *reinterpret_cast<const CW16*>(a.buf + p_cur);
+            while (ok) {
+                // ---- ingest chunks of 64 structurals until a token step has its 64 tokens and one to look ahead at ----
+                while (c < nchunks && tail - head < 65u) {
+                    const uint32_t base = from + c * 64u;
+                    const uint32_t nvl = to - base < 64u ? to - base : 64u;
+                    const bool valid = (uint32_t)lane < nvl;
+                    const uint32_t p = p_cur;
+                    const CW16 w = win_cur;
+                    p_cur = p_nxt;
+                    if (c + 1 < nchunks) win_cur = *reinterpret_cast<const CW16*>(a.buf + p_cur);
+                    p_nxt = c + 2 < nchunks ? load_pos(from, to, c + 2, doc_start) : doc_start;
+                    const uint32_t cls = valid ? class_of(w.a & 0xFFu) : K_QUOTE;
+                    const bool sep = valid && (cls == K_COMMA || cls == K_COLON);
+                    const unsigned long long S = __ballot(sep), CO = __ballot(valid && cls == K_COLON);
+                    const unsigned long long S1 = (S << 1) | sep1, S2 = (S << 2) | ((unsigned long long)sep1 << 1) | sep2;
+                    const unsigned long long C1 = (CO << 1) | colon1;
+                    const uint32_t pre_sep = (uint32_t)(S1 >> lane) & 1u, pre_colon = (uint32_t)(C1 >> lane) & 1u;
+                    const uint32_t two = pre_sep & ((uint32_t)(S2 >> lane) & 1u);
+                    const uint32_t info = cls | ((pre_sep ? (pre_colon ? 2u : 1u) : 0u) << 3) | (two << 5);
+                    const bool tok = valid && !sep;
+                    const unsigned long long TM = __ballot(tok);
+                    const uint32_t slot = (tail + (uint32_t)__popcll(TM & lt_mask)) & 127u;
+                    if (tok) {
+                        ring.p[slot] = p;
+                        ring.info[slot] = info;
+                        ring.win[slot] = make_uint4(w.a, w.b, w.c, w.d);
+                    }
+                    tail += (uint32_t)__popcll(TM);
+                    // carries into the next chunk: are the last / the last but one structural separators, is the last a ':'
+                    const uint32_t lb = nvl - 1u;
+                    const uint32_t s_last = (uint32_t)(S >> lb) & 1u;
+                    sep2 = lb ? (uint32_t)(S >> (lb - 1u)) & 1u : sep1;
+                    sep1 = s_last;
+                    colon1 = (uint32_t)(CO >> lb) & 1u;
+                    ++c;
+                    if (c == nchunks && s_last) ok = false;  // a separator behind the last token
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t avail = tail - head;
+                if (avail == 0u || !ok) break;
+                const uint32_t nv = avail < 64u ? avail : 64u;
+                // ---- one token step ----
+                const bool valid = (uint32_t)lane < nv;
+                const uint32_t e = (head + (uint32_t)lane) & 127u;
+                const uint32_t p = ring.p[e], info = valid ? ring.info[e] : (uint32_t)K_COMMA;
+                const uint4 wq = ring.win[e];
+                const CW16 win = {wq.x, wq.y, wq.z, wq.w};
+                const bool has_next = (uint32_t)lane + 1u < avail;
+                const uint32_t ninfo = has_next ? ring.info[(e + 1u) & 127u] : (uint32_t)K_COMMA;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (root_closed) {  // something follows the root value (JsonIterator.java:196-198)
+                    ok = false;
+                    break;
+                }
+                const uint32_t ch = win.a & 0xFFu;
+                const uint32_t cls = info & 7u, pre = (info >> 3) & 3u;
+                const uint32_t cls_next = ninfo & 7u, pre_next = (ninfo >> 3) & 3u;
+                const bool is_open = valid && cls <= K_OPEN_O, is_close = valid && (cls == K_CLOSE_A || cls == K_CLOSE_O);
+                uint32_t cls_prev = (uint32_t)__shfl_up((int)cls, 1);
+                if (lane == 0) cls_prev = prev_cls;
+                const bool first = at_start && lane == 0;
+                // (1) empty containers: an opening bracket directly followed by its closing bracket is ONE value (TapeBuilder.java:205-208)
+                const bool empty_open = is_open && has_next && cls_next == cls + 2u && pre_next == 0u;
+                int eo_prev = __shfl_up((int)empty_open, 1);
+                if (lane == 0) eo_prev = prev_empty_open;
+                const bool empty_close = is_close && eo_prev && !first;
+                // (2) depth and (3) tape position in front of every token: one ladder, three fields
+                const uint32_t up = is_open ? 1u : 0u, down = is_close ? 1u : 0u;
+                const bool is_num = valid && cls == K_PRIM && (ch == '-' || ch - '0' <= 9u);
+                const uint32_t words = !valid ? 0u : (is_num ? 2u : 1u);
+                const uint32_t scan3 = cw_incl_scan(up | (down << 8) | (words << 16));
+                const uint32_t iu = scan3 & 0xFFu, id = (scan3 >> 8) & 0xFFu, iw = scan3 >> 16;
+                const int h = (int)H0 + (int)(iu - up) - (int)(id - down);
+                const uint32_t tpos = T0 + iw - words;
+                const bool is_str = valid && cls == K_QUOTE;
+                const unsigned long long qm = __ballot(is_str);
+                const uint32_t sord = S0 + (uint32_t)__popcll(qm & lt_mask);
+                const uint32_t rec_off = is_str ? a.soff[sord] : 0u;  // (used one step later)
+                // (4) the container of every token: one trip per depth level present in the step
+                const int plevel = h - 1;
+                int hmin = cw_wave_minmax<false>(valid ? plevel : 0x7FFF), hmax = cw_wave_minmax<true>(valid ? (is_open ? h : plevel) : -0x7FFF);
+                if (hmin < 0) hmin = 0;
+                if (hmax >= CW_LEVELS) hmax = CW_LEVELS - 1;  // (deeper: handed to the exact walker below)
+                const int key = valid ? (is_open ? h : plevel) : -1;
+                const bool comma_in_front = valid && pre == 1u;
+                const uint32_t st_tpos0 = st_tpos, st_cnt0 = st_cnt;
+                const unsigned long long arr_mask0 = arr_mask;
+                int par_lane = -1;
+                uint32_t kc = 0;
+                for (int L = hmin; L <= hmax; ++L) {
+                    const unsigned long long O = __ballot(is_open && h == L);             // opens of level L
+                    const unsigned long long C = __ballot(comma_in_front && plevel == L); // elements of level L that follow a comma
+                    const unsigned long long Z = __ballot(is_close && plevel == L);       // closes of level-L containers
+                    if (plevel == L) par_lane = highest_bit_below(O, lt_mask);
+                    if (key == L) kc = (uint32_t)__popcll(C & lt_mask);
+                    // the stack entry of level L behind the step (wave-uniform, branch-free): the LAST open of the level stays open
+                    // unless a close of the level follows it; without an open (and without a close) the old container collects the commas
+                    const bool has_o = O != 0;
+                    const int al = has_o ? 63 - __builtin_clzll(O) : 0;
+                    const unsigned long long above = has_o ? (al == 63 ? 0ull : ~((2ull << al) - 1ull)) : ~0ull;
+                    const bool still = has_o && !(Z & above);
+                    const bool addc = !has_o && !Z && C != 0;
+                    const uint32_t nc = (uint32_t)__popcll(C & above);
+                    const uint32_t sk_cnt = (uint32_t)__builtin_amdgcn_readlane((int)st_cnt, L);
+                    const uint32_t tp = (uint32_t)__builtin_amdgcn_readlane((int)tpos, al);
+                    const uint32_t kd = (uint32_t)__builtin_amdgcn_readlane((int)cls, al);
+                    const uint32_t newcnt = still ? nc : sk_cnt + nc;
+                    st_cnt = (lane == L && (still || addc)) ? newcnt : st_cnt;
+                    st_tpos = (lane == L && still) ? tp : st_tpos;
+                    const unsigned long long bit = 1ull << L;
+                    arr_mask = still ? (kd == K_OPEN_A ? (arr_mask | bit) : (arr_mask & ~bit)) : arr_mask;
+                }
+                const bool par_in_wave = par_lane >= 0;
+                const int pl = par_in_wave ? par_lane : (plevel < 0 ? 0 : plevel);
+                // the parent's values: from its lane of this step, or from the stack as it stood in front of the step (lane = level).
+                // (a shuffle reads the SOURCE lane's operand, and a lane may be asked as a parent of this step by one reader and as a
+                //  stack level by another: four shuffles, every reader uses one pair)
+                const uint32_t s_tpos = (uint32_t)__shfl((int)tpos, pl);
+                const uint32_t s_pack = (uint32_t)__shfl((int)(kc | (cls == K_OPEN_A ? 0x100u : 0u)), pl);
+                const uint32_t b_tpos = (uint32_t)__shfl((int)st_tpos0, pl);
+                const uint32_t b_cnt = (uint32_t)__shfl((int)st_cnt0, pl);
+                const bool sk_arr = plevel >= 0 && ((arr_mask0 >> (plevel & 63)) & 1ull) != 0;
+                const bool par_is_array_ = par_in_wave ? (s_pack & 0x100u) != 0 : sk_arr;
+                const uint32_t par_tpos = par_in_wave ? s_tpos : b_tpos;
+                const uint32_t par_cnt = par_in_wave ? kc - (s_pack & 0xFFu) : b_cnt + kc;
+                // (5) the token grammar
+                const bool prev_open_ne = cls_prev <= K_OPEN_O && !eo_prev && !first;
+                const bool par_is_array = prev_open_ne ? cls_prev == K_OPEN_A : par_is_array_;
+                const bool key_pos = prev_open_ne ? cls_prev == K_OPEN_O : (pre == 1u && !par_is_array);
+                // is_key needs "my predecessor is not a key" only for the comma case, where the predecessor ended a value or it is an error anyway
+                const bool is_key = valid && !first && !empty_close && cls == K_QUOTE && key_pos;
+                int ik_prev = __shfl_up((int)is_key, 1);
+                if (lane == 0) ik_prev = prev_is_key;
+                bool good = true;
+                if (valid) {
+                    if (info & 32u) good = false;                                   // two separators in a row
+                    else if (first) good = is_open && pre == 0u;                      // (a root that is not a container: the exact walker)
+                    else if (empty_close) good = true;
+                    else if (prev_open_ne) good = pre == 0u && (cls_prev == K_OPEN_A ? !is_close : cls == K_QUOTE);   // :68-77
+                    else if (ik_prev) good = pre == 2u && !is_close;                  // :84-86
+                    else if (pre == 1u) good = par_is_array ? !is_close : cls == K_QUOTE;                             // :121-123
+                    else if (pre == 0u) good = cls == (par_is_array ? (uint32_t)K_CLOSE_A : (uint32_t)K_CLOSE_O) && plevel >= 0;  // :131,:189
+                    else good = false;
+                    if (is_open && !empty_open && (h + 1 >= a.max_depth || h + 1 >= CW_LEVELS)) good = false;        // :69-70 / deeper than the stack
+                }
+                uint32_t ptype = 0;
+                unsigned long long praw = 0;
+                if (valid && good) {
+                    if (cls == K_QUOTE) {
+                        if (string_errors) {  // a string the reference's StringParser would have thrown on: record header FF FF FF <code>
+                            const uint8_t* hh = a.sb + rec_off;
+                            if (hh[0] == 0xFF && hh[1] == 0xFF && hh[2] == 0xFF) good = false;
+                        }
+                    } else if (cls == K_PRIM) {
+                        good = cw_primitive(a.buf, win, p, false, doc_end, &ptype, &praw) == 0;
+                    }
+                }
+                // (6) where the root value ends
+                const bool closes_root = is_close && h == 1;
+                const unsigned long long rc = __ballot(closes_root);
+                const int rc_lane = rc ? __builtin_ctzll(rc) : 64;
+                if (valid && lane > rc_lane) good = false;  // trailing content
+                if (__ballot(!good)) {
+                    ok = false;
+                    break;
+                }
+                if (rc) root_closed = true;
+                // (7) the tape words of this step
+                if (pq_live && pq_tpos < room) T[pq_tpos] = tape_word('"', a.string_base + pq_off);  // the previous step's strings
+                pq_live = valid && cls == K_QUOTE;
+                pq_tpos = tpos;
+                pq_off = rec_off;
+                if (valid) {
+                    if (cls == K_QUOTE) {
+                    } else if (cls == K_PRIM) {
+                        if (tpos < room) T[tpos] = tape_word(ptype, 0);
+                        if (is_num && tpos + 1 < room) T[tpos + 1] = praw;
+                    } else if (empty_open) {
+                        if (tpos < room) T[tpos] = tape_word(ch, tpos + 2);          // TapeBuilder.java:205-208
+                    } else if (empty_close) {
+                        if (tpos < room) T[tpos] = tape_word(ch, tpos);              // (= position of the opening word + 1)
+                    } else if (is_close) {
+                        uint32_t cnt = par_cnt + 1u;
+                        if (cnt > 0xFFFFFFu) cnt = 0xFFFFFFu;
+                        if (tpos < room) T[tpos] = tape_word(ch, par_tpos);                                                   // :197-203
+                        if (par_tpos < room) T[par_tpos] = tape_word(ch - 2, (unsigned long long)(tpos + 1) | ((unsigned long long)cnt << 32));
+                    }
+                }
+                // (8) carries
+                const uint32_t tot3 = cw_last(scan3);
+                H0 = (uint32_t)((int)H0 + (int)(tot3 & 0xFFu) - (int)((tot3 >> 8) & 0xFFu));
+                T0 += tot3 >> 16;
+                S0 += (uint32_t)__popcll(qm);
+                const int lastv = (int)nv - 1;
+                prev_cls = (uint32_t)__builtin_amdgcn_readlane((int)cls, lastv);
+                prev_empty_open = __builtin_amdgcn_readlane((int)empty_open, lastv) != 0;
+                prev_is_key = __builtin_amdgcn_readlane((int)is_key, lastv) != 0;
+                at_start = false;
+                head += nv;
+            }
+            if (pq_live && pq_tpos < room) T[pq_tpos] = tape_word('"', a.string_base + pq_off);  // the last step's strings
+            if (ok && !root_closed) ok = false;  // the root container is never closed (JsonIterator.java:39-41,:51-53)
+            if (ok) {
+                tlen = T0 + 1;  // + the closing root word
+                if (tlen <= room) {
+                    if (lane == 0) {
+                        T[T0] = tape_word('r', 0);      // visitDocumentEnd, TapeBuilder.java:45-48
+                        T[0] = tape_word('r', tlen);
+                    }
+                } else {
+                    ok = false;  // (no room: the exact walker reports it)
+                    tlen = 0;
+                }
+            }
+        }
+        if (lane == 0) {
+            if (ok) {
+                a.doc_errors[k] = 0;
+                if (a.tape_lens) a.tape_lens[k] = tlen;
+            } else {
+                a.doc_errors[k] = CW_NEEDS_EXACT;
+                if (a.tape_lens) a.tape_lens[k] = 0;
+                const uint32_t slot = atomicAdd(&a.list[0], 1u);
+                a.list[16 + slot] = k;
+            }
+        }
+        m = m_next;
+        t_end = t_end_next;
+        if (more) {
+            p0 = load_pos(m.from, m.to, 0, m.doc_start);
+            p1 = load_pos(m.from, m.to, 1, m.doc_start);
+        }
+    }
 }
 
 // ---- the chunk passes around k_coop_walk<true> --------------------------------------------------------------------------
@@ -1437,7 +1794,7 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
         hipLaunchKernelGGL((k_coop_walk<true>), dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets,
                            d_doc_status, d_soff, d_sb, d_doc_str_offsets, (unsigned long long)string_base, max_depth,
                            d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res, abl, cw, (const uint32_t*)nullptr,
-                           (unsigned long long*)nullptr, slow);
+                           (unsigned long long*)nullptr, slow, ExactMode());
         hipLaunchKernelGGL(k_chunk_finish, dim3(1), dim3(64), 0, stream, d_buf, d_idx, d_index_offsets, d_doc_status, d_scratch_tape,
                            d_tape_lens, d_doc_errors, dev_count, dev_strings, cw, fin, optimistic ? 1u : 0u);
         if (optimistic) return hipGetLastError();  // (three launches fewer on the single-document latency path)
@@ -1448,11 +1805,59 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
     hipLaunchKernelGGL((k_coop_walk<false>), dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets,
                        d_doc_status, d_soff, d_sb, d_doc_str_offsets, (unsigned long long)string_base, max_depth,
                        d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res, abl, cw, only_if,
-                       static_cast<unsigned long long*>(d_deep_ws), slow);
+                       static_cast<unsigned long long*>(d_deep_ws), slow, ExactMode());
     if (d_single_tape_offsets)
         hipLaunchKernelGGL(k_single_finish, dim3(1), dim3(64), 0, stream, d_buf, fin);
     else
         hipLaunchKernelGGL(k_slow_doubles, dim3(256), dim3(64), 0, stream, d_buf, slow);  // (nothing listed: 256 waves that leave at once)
+    return hipGetLastError();
+}
+
+// A batch: the token walker over every document, then the exact walker over the documents it listed (none of a well-formed
+// batch: its workgroups read the list's count and leave), then the literals the exact walker could not decide.
+hipError_t tok_walk_launch(const TokLaunch& t, hipStream_t stream) {
+    if (!t.n_docs) return hipSuccess;
+    SlowList slow;
+    slow.count = static_cast<unsigned long long*>(t.d_deep_ws);
+    slow.rec = slow.count + 8;
+    slow.cap = CW_SLOW_CAP;
+    unsigned long long* const deep = reinterpret_cast<unsigned long long*>(static_cast<uint8_t*>(t.d_deep_ws) + coop_slow_bytes());
+    hipError_t e0 = hipMemsetAsync(slow.count, 0, 64, stream);
+    if (e0 != hipSuccess) return e0;
+    TokArgs a;
+    a.buf = t.d_buf;
+    a.idx = t.d_idx;
+    a.metas = t.d_metas;
+    a.n_docs = (uint32_t)t.n_docs;
+    a.max_depth = t.max_depth;
+    a.soff = t.d_soff;
+    a.sb = t.d_sb;
+    a.string_base = t.string_base;
+    a.tape = t.d_tape;
+    a.tape_alt = t.d_scratch;
+    a.sel = t.d_sel;
+    a.doc_errors = t.d_doc_errors;
+    a.tape_lens = t.d_tape_lens;
+    a.list = t.d_list;
+    a.dev_count = t.dev_count;
+    a.dev_strings = t.dev_strings;
+    const uint64_t want = (t.n_docs + 3) / 4;  // four documents (waves) per workgroup and trip
+    static const unsigned tok_grid_max = getenv("SJMI_TOK_GRID") ? (unsigned)atoi(getenv("SJMI_TOK_GRID")) : (unsigned)COOP_WALK_MAX_GRID;
+    const unsigned grid = (unsigned)(want < tok_grid_max ? want : tok_grid_max);
+    hipLaunchKernelGGL(k_tok_walk, dim3(grid), dim3(256), 0, stream, a);
+    ExactMode ex;
+    ex.list = t.d_list;
+    ex.metas = t.d_metas;
+    ex.tape = t.d_tape;
+    ex.tape_alt = t.d_scratch;
+    ex.sel = t.d_sel;
+    const uint32_t abl = (uint32_t)(getenv("SJMI_COOP_ABLATE") ? atoi(getenv("SJMI_COOP_ABLATE")) : 0);
+    const unsigned xgrid = (unsigned)(want < 1024 ? want : 1024);
+    hipLaunchKernelGGL((k_coop_walk<false>), dim3(xgrid), dim3(256), 0, stream, t.d_buf, t.d_doc_offsets, t.n_docs, t.d_idx,
+                       t.d_index_offsets, t.d_doc_status, t.d_soff, t.d_sb, t.d_doc_str_ordinals, (unsigned long long)t.string_base,
+                       t.max_depth, t.d_scratch, t.d_tape_lens, t.d_doc_errors, t.dev_count, t.dev_strings, t.d_res, abl, ChunkWs{},
+                       (const uint32_t*)nullptr, deep, slow, ex);
+    hipLaunchKernelGGL(k_slow_doubles, dim3(256), dim3(64), 0, stream, t.d_buf, slow);  // (nothing listed: 256 waves that leave at once)
     return hipGetLastError();
 }
 

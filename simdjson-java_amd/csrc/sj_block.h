@@ -44,6 +44,7 @@ struct SjBlockMasks {
     uint32_t ue0;    // unescaped control char inside a string, if parity 0   (:231,:252)
     uint32_t ue1;    // ... if incoming parity is 1
     uint32_t utf8;   // block contains a UTF-8 error                          (Utf8Validator.java:109-110,165)
+    uint32_t words;  // (want_words) tape words the block's structurals make, entered outside a string | inside << 8: see sj_block
 };
 
 // The reference's own per-block locals that the kernels never materialise (they work with pot / sm0): filled in on
@@ -79,8 +80,12 @@ SJ_HD void sj_mask_tail(sj_u64 p[8], uint32_t valid) {
 
 // do_utf8 = false skips the UTF-8 algebra; only legal when the caller knows the block is pure ASCII and uc is
 // all zero (the kernel decides per wave with a ballot), in which case the result is identical.
+// want_words: also count the TAPE WORDS the block's structurals make (Tape.java:33-43, TapeBuilder.java:41-48,191-208: a
+// bracket, a string or an atom one word, a number two, ',' and ':' none) for both entry parities (<= 128 each).  Exact for a
+// well-formed document -- there a primitive that begins with '-' or a digit IS a number -- which is all the batch pipeline uses
+// it for (it lays the tapes out before the documents are walked; a malformed document's slot is merely unused).
 SJ_HD SjBlockMasks sj_block(const sj_u64 p[8], uint32_t e_in, uint32_t p_in, SjUtf8Carry uc, bool do_utf8 = true,
-                            SjBlockDetail* det = nullptr) {
+                            SjBlockDetail* det = nullptr, bool want_words = false) {
     const sj_u64 p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4], p5 = p[5], p6 = p[6], p7 = p[7];
     const sj_u64 a = ~p7 & ~p6;  // 0x00..0x3F
     const sj_u64 b = ~p7 & p6;   // 0x40..0x7F
@@ -154,6 +159,21 @@ SJ_HD SjBlockMasks sj_block(const sj_u64 p[8], uint32_t e_in, uint32_t p_in, SjU
         det->ws = ws;
     }
     SjBlockMasks r;
+    r.words = 0;
+    if (want_words) {
+        const sj_u64 a5 = a & p5;                                                    // 0x20..0x3F
+        const sj_u64 comma_colon = a5 & ((~p4 & n_1100) | (p4 & n_1010));            // 0x2C, 0x3A (not the op table's 0x0C, 0x1A)
+        const sj_u64 number = a5 & ((p4 & (~p3 | (n10 & ~p1))) | (~p4 & n_1101));    // 0x30..0x39, 0x2D
+        const sj_u64 sm0_ = in0 ^ quote, s0 = pot & ~sm0_, s1 = pot & sm0_;
+        auto pc = [](sj_u64 m) -> uint32_t {
+#if defined(__HIP_DEVICE_COMPILE__)
+            return (uint32_t)__popcll(m);
+#else
+            return (uint32_t)__builtin_popcountll(m);
+#endif
+        };
+        r.words = (pc(s0 & ~comma_colon) + pc(s0 & number)) | ((pc(s1 & ~comma_colon) + pc(s1 & number)) << 8);
+    }
     r.pot = pot;
     r.sm0 = in0 ^ quote;
     r.qpar = (uint32_t)(in0 >> 63);

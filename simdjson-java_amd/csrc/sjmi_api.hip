@@ -77,6 +77,11 @@ struct sjmi_ctx {
     void* d_ws_masks = nullptr;
     size_t ws_masks_bytes = 0;
     void* d_single = nullptr;                // sjmi_parse_document: delimiters, tape offsets, error and results of ONE document
+    uint32_t* d_blkidx = nullptr;            // fused batch pipeline: k_stage1's per-block side outputs (stage1.h Stage1Extras)
+    size_t blkidx_bytes = 0;
+    uint16_t* d_blkw = nullptr;
+    size_t blkw_bytes = 0;
+    bool batch_side = false;                 // ... wanted from the next stage1_device_impl call
     uint32_t* d_batch_flags = nullptr;       // the two words of a batch's optimistic plain stage-1 pass ([1] != 0: accepted)
     const void* accept_buf = nullptr;        // ... which batch they belong to (the string pass of the same batch reads the flag)
     uint64_t accept_len = 0;
@@ -218,6 +223,8 @@ void sjmi_destroy(sjmi_ctx* c) {
     if (c->d_ws_walk) (void)hipFree(c->d_ws_walk);
     if (c->d_single) (void)hipFree(c->d_single);
     if (c->d_batch_flags) (void)hipFree(c->d_batch_flags);
+    if (c->d_blkidx) (void)hipFree(c->d_blkidx);
+    if (c->d_blkw) (void)hipFree(c->d_blkw);
     if (c->d_tape) (void)hipFree(c->d_tape);
     if (c->h_single) (void)hipHostFree(c->h_single);
     if (c->d_masks) (void)hipFree(c->d_masks);
@@ -442,7 +449,7 @@ static int strings_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, voi
 static int strings_batch_impl(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_indexes, uint64_t count_bound,
                               const void* d_doc_offsets, const void* d_index_offsets, uint64_t n_docs, bool plain,
                               const uint32_t* d_accept, void* d_string_buffer, uint64_t string_capacity, void* d_doc_str_offsets,
-                              void* d_result, hipStream_t st) {
+                              void* d_result, hipStream_t st, bool ordinals_by_prepare = false) {
     const uint64_t soff_cap = count_bound + 64;
     if (!grow(c, (void**)&c->d_soff, &c->soff_bytes, soff_cap * sizeof(uint32_t), "hipMalloc(soff)") ||
         !grow(c, (void**)&c->d_blk_ord, &c->blk_ord_bytes, (total_len / 64 + 2) * sizeof(uint32_t), "hipMalloc(blk_ord)") ||
@@ -491,7 +498,7 @@ static int strings_batch_impl(sjmi_ctx* c, const void* d_buf, uint64_t total_len
         fail(c, "doc ordinals",
              sjmi::strings_doc_ordinals_launch(buf0, par0, alt, total_len, (const unsigned long long*)d_doc_offsets, n_docs, c->d_blk_ord,
                                                c->d_soff, (const sjmi::UnescapeResult*)d_result, c->d_doc_ord,
-                                               (unsigned long long*)d_doc_str_offsets, st)))
+                                               (unsigned long long*)d_doc_str_offsets, st, ordinals_by_prepare ? d_accept : nullptr)))
         return SJMI_ERR_HIP;
     if (!c->d_ures_walk && fail(c, "hipMalloc(ures_walk)", hipMalloc((void**)&c->d_ures_walk, sizeof(sjmi_unescape_result)))) return SJMI_ERR_HIP;
     if (fail(c, "D2D(ures)", hipMemcpyAsync(c->d_ures_walk, d_result, sizeof(sjmi_unescape_result), hipMemcpyDeviceToDevice, st))) return SJMI_ERR_HIP;
@@ -817,6 +824,14 @@ static int stage1_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, void
     ex.result_out = fast ? d_result : nullptr;
     ex.blkpar = shard_flags ? nullptr : parity_out(c, d_buf, len);
     if (shard_flags) c->par_valid = false;
+    if (c->batch_side && !shard_flags) {  // (the fused batch pipeline's plain pass: per-block index positions and tape words)
+        const size_t entries = sjmi::stage1_block_entries(len);
+        if (!grow(c, (void**)&c->d_blkidx, &c->blkidx_bytes, entries * sizeof(uint32_t), "hipMalloc(blkidx)") ||
+            !grow(c, (void**)&c->d_blkw, &c->blkw_bytes, entries * sizeof(uint16_t), "hipMalloc(blkw)"))
+            return SJMI_ERR_HIP;
+        ex.blkidx = c->d_blkidx;
+        ex.blkw = c->d_blkw;
+    }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->profiling) {
         if (c->events_used == c->events.size()) {
@@ -967,9 +982,11 @@ static int stage1_batch_isolated_device_impl(sjmi_ctx* c, const void* d_buf, uin
 // verdict is clean (batch.hip: then it is exactly what the per-document passes give); the per-document passes are queued behind
 // it and leave at once if it was accepted.  *d_skip_out = the device flag (!= 0: accepted) or nullptr (not tried); the string
 // pass of the same batch on this context reads it (c->accept_*).  (SJMI_BATCH_OPTIMISTIC=0 switches the plain pass off.)
+// for_pipeline (sjmi_parse_batch_device): the plain launch also leaves the per-block side outputs batch.hip k_doc_prepare reads
+// (queued behind the string pass: it replaces the split and takes over the string ordinals), so no split is queued here.
 static int stage1_batch_optimistic(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets, uint64_t n_docs,
                                    void* d_indexes, uint64_t index_capacity, void* d_index_offsets, void* d_doc_status,
-                                   void* d_result, void* stream, const uint32_t** d_skip_out) {
+                                   void* d_result, void* stream, const uint32_t** d_skip_out, bool for_pipeline = false) {
     if (!c || !d_buf || !d_doc_offsets || !d_indexes || !d_index_offsets || !d_doc_status || !d_result) return SJMI_ERR_ARG;
     if (total_len >= (1ull << 32)) return SJMI_ERR_ARG;
     static const bool optimistic = !(getenv("SJMI_BATCH_OPTIMISTIC") && atoi(getenv("SJMI_BATCH_OPTIMISTIC")) == 0);
@@ -985,7 +1002,9 @@ static int stage1_batch_optimistic(sjmi_ctx* c, const void* d_buf, uint64_t tota
         int rc0;
         {
             const AutoSafeOff plain_only(c);  // (a tripped liveness bound only rejects the plain pass: the per-document passes take over)
+            c->batch_side = for_pipeline;
             rc0 = stage1_device_impl(c, d_buf, total_len, d_indexes, index_capacity, d_result, stream, 0);
+            c->batch_side = false;
         }
         if (rc0 != SJMI_OK) return rc0;
         // (a FAST launch leaves the scanner's per-granule prefixes in its half of the workspace: the split starts from them)
@@ -995,7 +1014,7 @@ static int stage1_batch_optimistic(sjmi_ctx* c, const void* d_buf, uint64_t tota
         if (fail(c, "plain accept", sjmi::batch_plain_accept_launch((const uint32_t*)d_indexes, (const sjmi::Stage1Result*)d_result,
                                                                     (const unsigned long long*)d_doc_offsets, n_docs,
                                                                     (unsigned long long*)d_index_offsets, (uint32_t*)d_doc_status,
-                                                                    c->d_batch_flags, st0, hint)))
+                                                                    c->d_batch_flags, st0, hint, !for_pipeline)))
             return SJMI_ERR_HIP;
         d_skip = c->d_batch_flags + 1;
     }
@@ -1101,7 +1120,7 @@ int sjmi_parse_batch_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, 
     // behind it and leave at once if it was (stage1_batch_optimistic)
     const uint32_t* d_skip = nullptr;
     int rc = stage1_batch_optimistic(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets,
-                                     d_doc_status, &r->stage1, stream, &d_skip);
+                                     d_doc_status, &r->stage1, stream, &d_skip, true);
     if (rc != SJMI_OK) return rc;
     // string records and the walk: everything queued, nothing comes back to the host in between.  If the optimistic plain
     // pass was accepted the string pass runs over the batch itself, else over its sanitized copy -- chosen on the device
@@ -1109,15 +1128,43 @@ int sjmi_parse_batch_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, 
     if (!grow(c, &c->d_ws_walk, &c->ws_walk_bytes, sjmi::walk_workspace_bytes(bound, n_docs), "hipMalloc(ws_walk)")) return SJMI_ERR_HIP;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     rc = strings_batch_impl(c, d_buf, total_len, d_indexes, bound, d_doc_offsets, d_index_offsets, n_docs, false, d_skip, d_string_buffer,
-                            string_capacity, d_doc_string_offsets, &r->strings, st);
+                            string_capacity, d_doc_string_offsets, &r->strings, st, d_skip != nullptr);
     if (rc != SJMI_OK) return rc;
+    if (d_skip) {
+        // the accepted plain pass: ONE pass over the documents gives every document its index range, first string, predicted tape
+        // length and walker record (batch.hip k_doc_prepare; leaves at once when the plain pass was rejected)
+        const sjmi::WalkPrepared wp = sjmi::walk_prepared(c->d_ws_walk, bound, n_docs);
+        sjmi::DocPrepare pa;
+        pa.buf = (const uint8_t*)d_buf;
+        pa.idx = (const uint32_t*)d_indexes;
+        pa.doc_offsets = (const unsigned long long*)d_doc_offsets;
+        pa.n_docs = n_docs;
+        pa.total_len = total_len;
+        pa.blkidx = c->d_blkidx;
+        pa.blkw = c->d_blkw;
+        pa.blkpar = c->d_blkpar;
+        pa.blk_ord = c->d_blk_ord;
+        pa.soff = c->d_soff;
+        pa.strings = (const sjmi::UnescapeResult*)&r->strings;
+        pa.stage1 = (const sjmi::Stage1Result*)&r->stage1;
+        pa.flags = c->d_batch_flags;
+        pa.index_offsets = (unsigned long long*)d_index_offsets;
+        pa.doc_status = (uint32_t*)d_doc_status;
+        pa.doc_ord = c->d_doc_ord;
+        pa.doc_str_offsets = (unsigned long long*)d_doc_string_offsets;
+        pa.lens = wp.lens;
+        pa.chunk_sums = wp.chunk_sums;
+        pa.metas = wp.metas;
+        if (fail(c, "prepare launch", sjmi::batch_prepare_launch(pa, st))) return SJMI_ERR_HIP;
+    }
     if (fail(c, "walk launch",
              sjmi::walk_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs, (const uint32_t*)d_indexes,
                                bound, (const unsigned long long*)d_index_offsets, (const uint32_t*)d_doc_status,
                                (const uint8_t*)d_string_buffer, c->d_doc_ord, 0, max_depth,
                                (unsigned long long*)d_tape, tape_capacity, (unsigned long long*)d_tape_offsets,
                                (int32_t*)d_doc_errors, c->d_ws_walk, (sjmi::WalkResult*)&r->walk, st,
-                               (const sjmi::Stage1Result*)&r->stage1, (const sjmi::UnescapeResult*)&r->strings, c->d_soff)))
+                               (const sjmi::Stage1Result*)&r->stage1, (const sjmi::UnescapeResult*)&r->strings, c->d_soff, false, false,
+                               sjmi::SingleDocTail(), d_skip)))
         return SJMI_ERR_HIP;
     return SJMI_OK;
 }

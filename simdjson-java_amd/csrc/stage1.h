@@ -84,6 +84,7 @@ struct Stage1Prefixes {
 };
 Stage1Prefixes stage1_prefixes(const void* d_ws, uint64_t len, int steps);
 int stage1_pick_steps(uint64_t len);
+size_t stage1_block_entries(uint64_t len);
 // optional work folded into the kernel (device-resident path): see zero_next_workspace / scanner_wave in stage1.hip
 struct Stage1Extras {
     bool workspace_is_zero = false;  // skip the workspace memset (a previous launch zeroed this workspace)
@@ -91,6 +92,8 @@ struct Stage1Extras {
     size_t zero_bytes = 0;           //   ... this many bytes of it (multiple of 16)
     void* result_out = nullptr;      // device sjmi_stage1_result written by the scanner (FAST mode only)
     const uint32_t* skip = nullptr;  // device flag: != 0 -> the launch does nothing (fused batch pipeline)
+    void* blkidx = nullptr;          // batch side outputs (both or neither): u32 per 64-byte block = index position of the block's
+    void* blkw = nullptr;            //   first structural; u16 per block = its tape words for entry parity 0 | 1 << 8; stage1_block_entries(len) each
     void* blkpar = nullptr;          // side output for strings.hip: u64 per 4 KiB of input, bit l = block l is entered inside a
                                      // string (StructuralIndexer.java:233-234's prevInString, per block); len / 4096 + 4 words
 };
@@ -121,7 +124,7 @@ hipError_t strings_sanitize_launch(const uint8_t* d_buf, uint64_t total_len, con
 hipError_t strings_doc_ordinals_launch(const uint8_t* d_buf, const unsigned long long* d_blkpar, const StringsAlt& alt, uint64_t len,
                                        const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_blk_ord,
                                        const uint32_t* d_soff, const UnescapeResult* d_res, unsigned long long* d_doc_ord,
-                                       unsigned long long* d_doc_str_offsets, hipStream_t stream);
+                                       unsigned long long* d_doc_str_offsets, hipStream_t stream, const uint32_t* d_skip = nullptr);
 size_t strings_parse_pack_bytes();
 hipError_t strings_error_index_pack_launch(const uint32_t* d_idx, const Stage1Result* dev_count, const UnescapeResult* d_res, void* d_pack,
                                            hipStream_t stream);
@@ -139,6 +142,43 @@ struct UnescapeBatch {
 hipError_t split_docs_launch(const uint32_t* d_idx, const Stage1Result* d_res, const unsigned long long* d_doc_offsets,
                              uint64_t n_docs, unsigned long long* d_index_offsets, hipStream_t stream);
 size_t batch_isolated_workspace_bytes(uint64_t n_docs);
+// What the batch walker (coop_walk.hip k_tok_walk) reads per document, one 32-byte record instead of six arrays: n_docs + 1
+// records, the last one carrying only `tape` (a document's room on the tape = the next record's `tape` - its own).
+struct DocMeta {
+    uint32_t from, to;            // its structurals: indexes[from, to)
+    uint32_t dso;                 // ordinal of its first string in the string pass's record table
+    uint32_t doc_start, doc_end;  // its bytes
+    uint32_t st;                  // its stage-1 status (SJMI_ST_*)
+    uint32_t tape_lo, tape_hi;    // where its tape goes (word offset)
+};
+static_assert(sizeof(DocMeta) == 32, "one s_load_dwordx8");
+// The accepted plain pass of the fused batch pipeline, everything a document needs from it in ONE pass over the documents
+// (batch.hip k_doc_prepare; replaces the binary search of k_split_docs_accept and k_doc_str_ordinals): index_offsets, doc_status
+// = 0, the ordinal / record offset of its first string, its PREDICTED tape length (exact for a well-formed document) and the
+// DocMeta record without `tape`; chunk_sums[j] = predicted words of documents [256 j, 256 j + 256).
+struct DocPrepare {
+    const uint8_t* buf;
+    const uint32_t* idx;
+    const unsigned long long* doc_offsets;
+    uint64_t n_docs, total_len;
+    const uint32_t* blkidx;
+    const uint16_t* blkw;
+    const unsigned long long* blkpar;
+    const uint32_t* blk_ord;
+    const uint32_t* soff;
+    const UnescapeResult* strings;
+    const Stage1Result* stage1;
+    const uint32_t* flags;  // [1] != 0: the plain pass was accepted
+    unsigned long long* index_offsets;
+    uint32_t* doc_status;
+    unsigned long long* doc_ord;
+    unsigned long long* doc_str_offsets;
+    uint32_t* lens;
+    unsigned long long* chunk_sums;
+    DocMeta* metas;
+};
+constexpr int PREP_DOCS = 256;  // documents per workgroup of k_doc_prepare = per chunk of the tape-offset scan
+hipError_t batch_prepare_launch(const DocPrepare& a, hipStream_t stream);
 // walk.hip: stage 2 of every document of a batch (the cooperative walker + packing of the tapes); d_doc_str_ordinals[k] =
 // ordinal of document k's first string in the record table d_soff of the string pass (strings.hip)
 size_t walk_workspace_bytes(uint64_t count, uint64_t n_docs);
@@ -148,7 +188,44 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
                        unsigned long long* d_tape, uint64_t tape_capacity, unsigned long long* d_tape_offsets,
                        int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream,
                        const Stage1Result* dev_count, const UnescapeResult* dev_strings, const uint32_t* d_soff,
-                       bool index_from_zero = false, bool results_zeroed = false, const SingleDocTail& tail = SingleDocTail());
+                       bool index_from_zero = false, bool results_zeroed = false, const SingleDocTail& tail = SingleDocTail(),
+                       const uint32_t* d_prepared = nullptr);
+// d_prepared (the fused batch pipeline): device flag, != 0 = batch.hip k_doc_prepare ran (the accepted plain pass) and left
+// every document's DocMeta / predicted tape length in the walk workspace (walk_prepared): the tapes are laid out before the
+// walk and written at their final addresses -- there a document that fails keeps its (unused) slot: tape_offsets[k + 1] -
+// tape_offsets[k] is its PREDICTED length, the words are unspecified, doc_errors[k] says so.
+struct WalkPrepared {
+    DocMeta* metas;
+    uint32_t* lens;
+    unsigned long long* chunk_sums;
+};
+WalkPrepared walk_prepared(void* d_ws, uint64_t count, uint64_t n_docs);
+// coop_walk.hip: the batch walkers -- k_tok_walk over tokens, then k_coop_walk (list mode) for the documents it declined
+struct TokLaunch {
+    const uint8_t* d_buf;
+    const uint32_t* d_idx;
+    const DocMeta* d_metas;
+    uint64_t n_docs;
+    const unsigned long long* d_doc_offsets;
+    const unsigned long long* d_index_offsets;
+    const uint32_t* d_doc_status;
+    const unsigned long long* d_doc_str_ordinals;
+    const uint32_t* d_soff;
+    const uint8_t* d_sb;
+    uint64_t string_base;
+    int max_depth;
+    unsigned long long* d_tape;     // *d_sel != 0 (or d_sel == nullptr): where the DocMeta offsets point
+    unsigned long long* d_scratch;  // otherwise
+    const uint32_t* d_sel;
+    uint32_t* d_tape_lens;
+    int32_t* d_doc_errors;
+    uint32_t* d_list;
+    const Stage1Result* dev_count;
+    const UnescapeResult* dev_strings;
+    WalkResult* d_res;
+    void* d_deep_ws;
+};
+hipError_t tok_walk_launch(const TokLaunch& t, hipStream_t stream);
 // coop_walk.hip: the cooperative walker (a wave per document); d_soff = offset of every string's record in d_sb, by ordinal
 hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_idx,
                             const unsigned long long* d_index_offsets, const uint32_t* d_doc_status, const uint32_t* d_soff,
@@ -179,7 +256,7 @@ hipError_t batch_plain_check_launch(const uint8_t* d_buf, const unsigned long lo
                                     uint32_t* d_flags, hipStream_t stream);
 hipError_t batch_plain_accept_launch(const uint32_t* d_idx, const Stage1Result* d_res, const unsigned long long* d_doc_offsets,
                                      uint64_t n_docs, unsigned long long* d_index_offsets, uint32_t* d_doc_status, uint32_t* d_flags,
-                                     hipStream_t stream, const Stage1Prefixes& hint = Stage1Prefixes());
+                                     hipStream_t stream, const Stage1Prefixes& hint = Stage1Prefixes(), bool split = true);
 // masks.hip: the reference's six per-block masks (6 x u64 per block, len / 64 + 1 blocks)
 size_t masks_workspace_bytes(uint64_t len);
 hipError_t masks_launch(const uint8_t* d_buf, uint64_t len, unsigned long long* d_masks, void* d_ws, hipStream_t stream);

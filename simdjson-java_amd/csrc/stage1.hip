@@ -548,11 +548,15 @@ union WaveShared {
     static_assert(sizeof(Parked<S>) <= LDSW, "LDS slice too small");
 };
 
-template <int S, int LDSW, bool SAFE>
+// BATCH: two more side outputs for the fused batch pipeline (batch.hip k_doc_prepare), per 64-byte block: blkidx = position in
+// the index array of the block's first structural (what a document's index_offsets entry is read from instead of a binary
+// search), blkw = the tape words its structurals make for both entry parities (sj_block_tape_words).
+template <int S, int LDSW, bool SAFE, bool BATCH>
 __global__ void __launch_bounds__(256)
 k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out, sj_u64 out_cap,
          sj_u64* gstate, uint32_t* ticket, Stage1Result* res, uint32_t ngran, uint32_t dbg, uint4* zero_ptr,
-         uint32_t zero_chunks, Stage1Result* result_out, sj_u64* __restrict__ blkpar, const uint32_t* __restrict__ skip) {
+         uint32_t zero_chunks, Stage1Result* result_out, sj_u64* __restrict__ blkpar, const uint32_t* __restrict__ skip,
+         uint32_t* __restrict__ blkidx, uint16_t* __restrict__ blkw) {
     constexpr int E = S, CAP = LDSW / 4;
     if (skip && *skip) return;  // (fused batch pipeline: this pass is not needed; uniform for the whole launch)
     static_assert(S <= 4, "meta packs 14-bit offsets: at most 4 steps per granule");
@@ -685,10 +689,11 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
                     sj_mask_tail(p, rem < 64 ? (uint32_t)rem : 64u);
                     // the UTF-8 algebra is skipped when no lane of the wave has a non-ASCII byte or a pending carry
                     const bool need_utf8 = __ballot((p[7] != 0) | ((uc.c1 | uc.c2 | uc.c3 | uc.sec) != 0)) != 0;
-                    const SjBlockMasks bm = sj_block(p, e_in, p_in, uc, need_utf8);
+                    const SjBlockMasks bm = sj_block(p, e_in, p_in, uc, need_utf8, nullptr, BATCH);
                     pot[s] = bm.pot;
                     sm[s] = bm.sm0;
                     fl[s] = bm.qpar | (bm.ue0 << 1) | (bm.ue1 << 2) | (bm.utf8 << 3);
+                    if (BATCH) blkw[blk] = (uint16_t)bm.words;
                 }
                 slow |= unresolved ? (1u << s) : 0u;
             }
@@ -714,10 +719,11 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
                     sj_transpose_butterfly(w, p);
                     const sj_u64 rem = len - start;
                     sj_mask_tail(p, rem < 64 ? (uint32_t)rem : 64u);
-                    const SjBlockMasks bm = sj_block(p, e_in, p_in, sj_utf8_carry(halo));
+                    const SjBlockMasks bm = sj_block(p, e_in, p_in, sj_utf8_carry(halo), true, nullptr, BATCH);
                     pot[s] = bm.pot;
                     sm[s] = bm.sm0;
                     fl[s] = bm.qpar | (bm.ue0 << 1) | (bm.ue1 << 2) | (bm.utf8 << 3);
+                    if (BATCH && blk < nblocks) blkw[blk] = (uint16_t)bm.words;
                 }
             }
             // in-string parity, structurals and their offsets, all RELATIVE TO THE GRANULE being entered outside a
@@ -832,6 +838,7 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
                     mk[e] = pe ? (pt ^ mm) : mm;
                     const uint32_t o0 = mt & 0x3FFFu, op = (mt >> 14) & 0x3FFFu;
                     pos[e] = (pe ? op - o0 : o0) - gbase;
+                    if (BATCH) blkidx[(pblk0 + (sj_u64)s * 64) + lane] = (uint32_t)(cnt_in + gbase) + pos[e];  // (array padded to whole granules)
                     if ((mt >> (28 + pe)) & 1u) err |= SJMI_ST_UNESCAPED;  // :252,:300-302
                     if (blkpar) {  // (wave-uniform) StructuralIndexer.java:233-234's prevInString, for every block
                         const sj_u64 pm = __ballot(((mt >> 30) ^ pe) & 1u);
@@ -966,7 +973,7 @@ int stage1_pick_steps(uint64_t len) {
 }
 
 // workgroups of k_stage1<...> that are resident at the same time on the current device (fast mode's grid)
-template <int S, int LDSW, bool SAFE>
+template <int S, int LDSW, bool SAFE, bool BATCH>
 static hipError_t resident_workgroups(unsigned* out) {
     static std::atomic<unsigned> cached[16];  // (contexts on several host threads may get here together)
     int dev = 0;
@@ -974,7 +981,7 @@ static hipError_t resident_workgroups(unsigned* out) {
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 16 || !cached[dev]) {
         int per_cu = 0, cus = 0;
-        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stage1<S, LDSW, SAFE>, 256, 0)) != hipSuccess) return e;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stage1<S, LDSW, SAFE, BATCH>, 256, 0)) != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
         const unsigned n = (unsigned)(per_cu > 0 ? per_cu : 1) * (unsigned)(cus > 0 ? cus : 1);
         if (dev < 0 || dev >= 16) {
@@ -987,12 +994,12 @@ static hipError_t resident_workgroups(unsigned* out) {
     return hipSuccess;
 }
 
-template <int S, int LDSW, bool SAFE>
+template <int S, int LDSW, bool SAFE, bool BATCH>
 static hipError_t launch_mode(const uint8_t* d_buf, uint64_t len, uint32_t* d_out, uint64_t out_cap, sj_u64* gs,
                                  uint32_t* ticket, Stage1Result* res, uint64_t ngran, hipStream_t stream,
                                  hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg, const Stage1Extras& ex) {
     unsigned resident = 0;
-    hipError_t e = resident_workgroups<S, LDSW, SAFE>(&resident);
+    hipError_t e = resident_workgroups<S, LDSW, SAFE, BATCH>(&resident);
     if (e != hipSuccess) return e;
     const uint64_t want = (ngran + 3) / 4 + (SAFE ? 0 : 1);  // 4 worker waves each + the scanner workgroup
     if (dbg & DBG_SMALL_GRID) resident = SAFE ? 8 : 9;  // test hook: far fewer granules in flight than a scanner window
@@ -1001,14 +1008,16 @@ static hipError_t launch_mode(const uint8_t* d_buf, uint64_t len, uint32_t* d_ou
     const uint32_t zc = (uint32_t)(ex.zero_bytes / 16);
     Stage1Result* ro = static_cast<Stage1Result*>(ex.result_out);
     sj_u64* bp = static_cast<sj_u64*>(ex.blkpar);
+    uint32_t* bi = static_cast<uint32_t*>(ex.blkidx);
+    uint16_t* bw = static_cast<uint16_t*>(ex.blkw);
     if (ev_start && ev_stop) {
         // the events are attached to the dispatch itself (its start / end timestamps), not recorded around it:
         // hipEventRecord pairs added 10-25 us of queue latency to a 200 us kernel
-        hipExtLaunchKernelGGL((k_stage1<S, LDSW, SAFE>), grid, block, 0, stream, ev_start, ev_stop, 0, d_buf, (sj_u64)len,
-                              d_out, (sj_u64)out_cap, gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro, bp, ex.skip);
+        hipExtLaunchKernelGGL((k_stage1<S, LDSW, SAFE, BATCH>), grid, block, 0, stream, ev_start, ev_stop, 0, d_buf, (sj_u64)len,
+                              d_out, (sj_u64)out_cap, gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro, bp, ex.skip, bi, bw);
     } else {
-        hipLaunchKernelGGL((k_stage1<S, LDSW, SAFE>), grid, block, 0, stream, d_buf, (sj_u64)len, d_out, (sj_u64)out_cap,
-                           gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro, bp, ex.skip);
+        hipLaunchKernelGGL((k_stage1<S, LDSW, SAFE, BATCH>), grid, block, 0, stream, d_buf, (sj_u64)len, d_out, (sj_u64)out_cap,
+                           gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro, bp, ex.skip, bi, bw);
     }
     return hipGetLastError();
 }
@@ -1017,10 +1026,16 @@ template <int S, int LDSW>
 static hipError_t launch_variant(const uint8_t* d_buf, uint64_t len, uint32_t* d_out, uint64_t out_cap, sj_u64* gs,
                                  uint32_t* ticket, Stage1Result* res, uint64_t ngran, hipStream_t stream,
                                  hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg, const Stage1Extras& ex) {
-    return (dbg & FLAG_SAFE)
-               ? launch_mode<S, LDSW, true>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg, ex)
-               : launch_mode<S, LDSW, false>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg, ex);
+    const bool batch = ex.blkidx && ex.blkw;  // (both or neither)
+    if (dbg & FLAG_SAFE)
+        return batch ? launch_mode<S, LDSW, true, true>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg, ex)
+                     : launch_mode<S, LDSW, true, false>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg, ex);
+    return batch ? launch_mode<S, LDSW, false, true>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg, ex)
+                 : launch_mode<S, LDSW, false, false>(d_buf, len, d_out, out_cap, gs, ticket, res, ngran, stream, ev_start, ev_stop, dbg, ex);
 }
+
+// entries of the per-block side outputs of a BATCH launch over len bytes (whole granules: the kernel stores unguarded)
+size_t stage1_block_entries(uint64_t len) { return (size_t)((len / 64 + 1 + 255) / 256 + 1) * 256; }
 
 hipError_t stage1_launch(const uint8_t* d_buf, uint64_t len, uint32_t* d_out, uint64_t out_cap, void* d_ws,
                          int steps, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t dbg, const Stage1Extras& ex) {

@@ -942,7 +942,8 @@ k_doc_str_ordinals(const uint8_t* __restrict__ buf0, const uint8_t* __restrict__
                    const sj_u64* __restrict__ par1, const uint32_t* __restrict__ sel, uint64_t len,
                    const unsigned long long* __restrict__ doc_offsets, uint64_t n_docs, const uint32_t* __restrict__ blk_ord,
                    const uint32_t* __restrict__ soff, const UnescapeResult* __restrict__ res, unsigned long long* __restrict__ doc_ord,
-                   unsigned long long* __restrict__ doc_str_offsets) {
+                   unsigned long long* __restrict__ doc_str_offsets, const uint32_t* __restrict__ skip) {
+    if (skip && *skip) return;  // (the fused pipeline's accepted plain pass: batch.hip k_doc_prepare computes these)
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k > n_docs) return;
     const bool alt = sel && *sel == 0;
@@ -989,10 +990,10 @@ k_doc_str_ordinals(const uint8_t* __restrict__ buf0, const uint8_t* __restrict__
 hipError_t strings_doc_ordinals_launch(const uint8_t* d_buf, const unsigned long long* d_blkpar, const StringsAlt& alt, uint64_t len,
                                        const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_blk_ord,
                                        const uint32_t* d_soff, const UnescapeResult* d_res, unsigned long long* d_doc_ord,
-                                       unsigned long long* d_doc_str_offsets, hipStream_t stream) {
+                                       unsigned long long* d_doc_str_offsets, hipStream_t stream, const uint32_t* d_skip) {
     hipLaunchKernelGGL(k_doc_str_ordinals, dim3((unsigned)((n_docs + 1 + 255) / 256)), dim3(256), 0, stream, d_buf, alt.d_buf,
                        reinterpret_cast<const sj_u64*>(d_blkpar), reinterpret_cast<const sj_u64*>(alt.d_blkpar), alt.d_sel, len, d_doc_offsets,
-                       n_docs, d_blk_ord, d_soff, d_res, d_doc_ord, d_doc_str_offsets);
+                       n_docs, d_blk_ord, d_soff, d_res, d_doc_ord, d_doc_str_offsets, d_skip);
     return hipGetLastError();
 }
 

@@ -45,7 +45,8 @@ __device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long
 
 __global__ void __launch_bounds__(1024)
 k_tape_chunk_sums(const uint32_t* __restrict__ tape_lens, const int32_t* __restrict__ doc_errors, uint64_t n_docs,
-                  unsigned long long* __restrict__ chunk_sums, WalkResult* res) {
+                  unsigned long long* __restrict__ chunk_sums, WalkResult* res, const uint32_t* __restrict__ skip) {
+    if (skip && *skip) return;  // (the tapes were laid out before the walk: nothing to pack)
     __shared__ unsigned long long s_wave[16];
     const uint64_t k = (uint64_t)blockIdx.x * PACK_DOCS + threadIdx.x;
     unsigned long long total;
@@ -61,7 +62,8 @@ k_tape_chunk_sums(const uint32_t* __restrict__ tape_lens, const int32_t* __restr
 
 __global__ void __launch_bounds__(1024)
 k_tape_chunk_scan(unsigned long long* __restrict__ chunk_sums, uint64_t nchunks, uint64_t n_docs, uint64_t tape_capacity,
-                  unsigned long long* __restrict__ tape_offsets, WalkResult* res) {
+                  unsigned long long* __restrict__ tape_offsets, WalkResult* res, const uint32_t* __restrict__ gate, uint32_t gate_want) {
+    if (gate && (*gate != 0) != (gate_want != 0)) return;
     __shared__ unsigned long long s_wave[16];
     unsigned long long carry = 0;
     for (uint64_t b = 0; b < nchunks; b += 1024) {
@@ -86,7 +88,8 @@ __global__ void __launch_bounds__(1024)
 k_tape_compact(const unsigned long long* __restrict__ scratch_tape, const uint32_t* __restrict__ tape_lens,
                const unsigned long long* __restrict__ index_offsets, uint64_t n_docs,
                const unsigned long long* __restrict__ chunk_base, unsigned long long* __restrict__ tape, uint64_t tape_capacity,
-               unsigned long long* __restrict__ tape_offsets) {
+               unsigned long long* __restrict__ tape_offsets, const uint32_t* __restrict__ skip) {
+    if (skip && *skip) return;
     __shared__ unsigned long long s_wave[16];
     __shared__ unsigned long long s_off[PACK_DOCS];
     const uint64_t k0 = (uint64_t)blockIdx.x * PACK_DOCS, k = k0 + threadIdx.x;
@@ -107,6 +110,56 @@ k_tape_compact(const unsigned long long* __restrict__ scratch_tape, const uint32
     }
 }
 
+// ---- tapes laid out BEFORE the walk (the accepted plain pass of the fused pipeline: batch.hip k_doc_prepare left every document's
+// predicted length and the sums per PREP_DOCS documents; k_tape_chunk_scan turns those into chunk bases) ----------------------
+__global__ void __launch_bounds__(PREP_DOCS)
+k_tape_offsets(const uint32_t* __restrict__ lens, const unsigned long long* __restrict__ chunk_base, uint64_t n_docs,
+               uint64_t tape_capacity, unsigned long long* __restrict__ tape_offsets, DocMeta* __restrict__ metas,
+               uint32_t* __restrict__ list, const uint32_t* __restrict__ gate) {
+    if (gate && *gate == 0) return;
+    __shared__ unsigned long long s_wave[16];
+    const uint64_t k = (uint64_t)blockIdx.x * PREP_DOCS + threadIdx.x;
+    unsigned long long total;
+    unsigned long long off = chunk_base[blockIdx.x] + block_excl_scan(k < n_docs ? lens[k] : 0u, s_wave, &total);
+    if (k <= n_docs) {
+        if (k == n_docs) off = tape_offsets[n_docs];  // (the total: k_tape_chunk_scan)
+        tape_offsets[k] = off;
+        // a tape that does not fit is reported (WalkResult.flags) and never overrun: offsets beyond the capacity collapse onto
+        // it, so the documents there have no room and the walkers write nothing
+        const unsigned long long o = off > tape_capacity ? tape_capacity : off;
+        metas[k].tape_lo = (uint32_t)o;
+        metas[k].tape_hi = (uint32_t)(o >> 32);
+    }
+    if (k == 0) list[0] = 0;
+}
+// the same records from the arrays of the three separate calls; the tapes go to the scratch tape (two words per structural + 2
+// per document: document k's slot begins at 2 * index_offsets[k] + 2 k) and are packed afterwards
+__global__ void __launch_bounds__(256)
+k_doc_meta(const unsigned long long* __restrict__ doc_offsets, const unsigned long long* __restrict__ index_offsets,
+           const uint32_t* __restrict__ doc_status, const unsigned long long* __restrict__ doc_str_ordinals, uint64_t n_docs,
+           DocMeta* __restrict__ metas, uint32_t* __restrict__ list, const uint32_t* __restrict__ skip) {
+    if (skip && *skip) return;
+    const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k == 0) list[0] = 0;
+    if (k > n_docs) return;
+    DocMeta m = {};
+    const unsigned long long from = index_offsets[k];
+    const unsigned long long slot = scratch_slot(from, k);
+    m.tape_lo = (uint32_t)slot;
+    m.tape_hi = (uint32_t)(slot >> 32);
+    if (k < n_docs) {
+        m.from = (uint32_t)from;
+        m.to = (uint32_t)index_offsets[k + 1];
+        m.dso = (uint32_t)doc_str_ordinals[k];
+        m.doc_start = (uint32_t)doc_offsets[k];
+        m.doc_end = (uint32_t)doc_offsets[k + 1];
+        m.st = doc_status ? doc_status[k] : 0u;
+        // (a structural range the 32-bit fields cannot hold: the exact walker hands such a document back)
+        if (from > 0xFFFFFF00ull || index_offsets[k + 1] > 0xFFFFFF00ull) m.st |= SJMI_ST_INTERNAL;
+    }
+    metas[k] = m;
+}
+
 // workspace: scratch tape (2 count + 2 n words) | tape lengths [n] | chunk sums
 static size_t walk_lens_offset(uint64_t count, uint64_t n_docs) { return ((2 * count + 2 * n_docs + 8) * sizeof(unsigned long long) + 63) / 64 * 64; }
 static size_t walk_sums_offset(uint64_t count, uint64_t n_docs) { return walk_lens_offset(count, n_docs) + (n_docs * sizeof(uint32_t) + 63) / 64 * 64 + 64; }
@@ -116,9 +169,22 @@ static size_t walk_chunks_offset(uint64_t count, uint64_t n_docs) {
 static size_t walk_deep_offset(uint64_t count, uint64_t n_docs) {
     return (walk_chunks_offset(count, n_docs) + (n_docs == 1 ? coop_chunk_workspace_bytes(count) : 0) + 255) / 256 * 256;
 }
+// ... | DocMeta [n + 1] | the exact walker's list [16 + n] | predicted lengths [n] | their sums per PREP_DOCS documents
+static size_t walk_metas_offset(uint64_t count, uint64_t n_docs) { return (walk_deep_offset(count, n_docs) + coop_deep_workspace_bytes(n_docs) + 255) / 256 * 256; }
+static size_t walk_list_offset(uint64_t count, uint64_t n_docs) { return walk_metas_offset(count, n_docs) + (n_docs + 2) * sizeof(DocMeta); }
+static size_t walk_plens_offset(uint64_t count, uint64_t n_docs) { return (walk_list_offset(count, n_docs) + (n_docs + 32) * sizeof(uint32_t) + 63) / 64 * 64; }
+static size_t walk_psums_offset(uint64_t count, uint64_t n_docs) { return (walk_plens_offset(count, n_docs) + (n_docs + 16) * sizeof(uint32_t) + 63) / 64 * 64; }
 size_t walk_workspace_bytes(uint64_t count, uint64_t n_docs) {
     // (+ the chunk states of the chunk-parallel path for one large document, + the deep nesting levels of every wave)
-    return walk_deep_offset(count, n_docs) + coop_deep_workspace_bytes(n_docs);
+    return walk_psums_offset(count, n_docs) + ((n_docs + 1) / PREP_DOCS + 4) * sizeof(unsigned long long) + 64;
+}
+WalkPrepared walk_prepared(void* d_ws, uint64_t count, uint64_t n_docs) {
+    uint8_t* ws = static_cast<uint8_t*>(d_ws);
+    WalkPrepared w;
+    w.metas = reinterpret_cast<DocMeta*>(ws + walk_metas_offset(count, n_docs));
+    w.lens = reinterpret_cast<uint32_t*>(ws + walk_plens_offset(count, n_docs));
+    w.chunk_sums = reinterpret_cast<unsigned long long*>(ws + walk_psums_offset(count, n_docs));
+    return w;
 }
 
 void* walk_slow_header(void* d_ws, uint64_t count, uint64_t n_docs) { return static_cast<uint8_t*>(d_ws) + walk_deep_offset(count, n_docs); }
@@ -129,7 +195,7 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
                        unsigned long long* d_tape, uint64_t tape_capacity, unsigned long long* d_tape_offsets,
                        int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream, const Stage1Result* dev_count,
                        const UnescapeResult* dev_strings, const uint32_t* d_soff, bool index_from_zero, bool results_zeroed,
-                       const SingleDocTail& tail) {
+                       const SingleDocTail& tail, const uint32_t* d_prepared) {
     if (!d_soff) return hipErrorInvalidValue;  // (the record table of the string pass: strings.hip)
     uint8_t* ws = static_cast<uint8_t*>(d_ws);
     unsigned long long* scratch = reinterpret_cast<unsigned long long*>(ws);
@@ -142,7 +208,52 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
     hipError_t e = results_zeroed ? hipSuccess : hipMemsetAsync(d_res, 0, sizeof(WalkResult), stream);
     if (e != hipSuccess) return e;
     const uint64_t nchunks = (n_docs + PACK_DOCS - 1) / PACK_DOCS;
-    if (n_docs) {
+    static const bool tokens_off = getenv("SJMI_TOKEN_WALK") && atoi(getenv("SJMI_TOKEN_WALK")) == 0;
+    const uint32_t* packed_skip = nullptr;  // device flag != 0: the tapes were laid out before the walk, nothing is packed behind it
+    if (n_docs > 1 && !tokens_off) {
+        // ---- a batch: the token walker (coop_walk.hip k_tok_walk) with the exact walker behind it for what it declines ----
+        const WalkPrepared wp = walk_prepared(d_ws, count, n_docs);
+        uint32_t* list = reinterpret_cast<uint32_t*>(ws + walk_list_offset(count, n_docs));
+        if (d_prepared) {
+            // the fused pipeline's accepted plain pass (*d_prepared != 0): batch.hip k_doc_prepare left the predicted lengths, so
+            // the tapes are laid out NOW and the walkers store at the final addresses
+            const uint64_t pchunks = (n_docs + PREP_DOCS - 1) / PREP_DOCS;
+            hipLaunchKernelGGL(k_tape_chunk_scan, dim3(1), dim3(1024), 0, stream, wp.chunk_sums, pchunks, n_docs, tape_capacity,
+                               d_tape_offsets, d_res, d_prepared, 1u);
+            hipLaunchKernelGGL(k_tape_offsets, dim3((unsigned)((n_docs + 1 + PREP_DOCS - 1) / PREP_DOCS)), dim3(PREP_DOCS), 0, stream,
+                               (const uint32_t*)wp.lens, (const unsigned long long*)wp.chunk_sums, n_docs, tape_capacity, d_tape_offsets,
+                               wp.metas, list, d_prepared);
+            packed_skip = d_prepared;
+        }
+        hipLaunchKernelGGL(k_doc_meta, dim3((unsigned)((n_docs + 1 + 255) / 256)), dim3(256), 0, stream, d_doc_offsets, d_index_offsets,
+                           d_doc_status, d_doc_str_ordinals, n_docs, wp.metas, list, packed_skip);
+        TokLaunch t;
+        t.d_buf = d_buf;
+        t.d_idx = d_idx;
+        t.d_metas = wp.metas;
+        t.n_docs = n_docs;
+        t.d_doc_offsets = d_doc_offsets;
+        t.d_index_offsets = d_index_offsets;
+        t.d_doc_status = d_doc_status;
+        t.d_doc_str_ordinals = d_doc_str_ordinals;
+        t.d_soff = d_soff;
+        t.d_sb = d_sb;
+        t.string_base = string_base;
+        t.max_depth = max_depth;
+        t.d_tape = d_prepared ? d_tape : scratch;
+        t.d_scratch = scratch;
+        t.d_sel = d_prepared;
+        t.d_tape_lens = lens;
+        t.d_doc_errors = d_doc_errors;
+        t.d_list = list;
+        t.dev_count = dev_count;
+        t.dev_strings = dev_strings;
+        t.d_res = d_res;
+        t.d_deep_ws = ws + walk_deep_offset(count, n_docs);
+        e = tok_walk_launch(t, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_tape_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, lens, d_doc_errors, n_docs, sums, d_res, packed_skip);
+    } else if (n_docs) {
         // the cooperative walker (coop_walk.hip): a wave per document; STRING payloads from the string pass's record table
         // (direct = one document written in place: the walker's last launch also decides the listed literals and writes the
         //  tape offsets and counters -- three small launches fewer on the single-document latency path)
@@ -153,12 +264,14 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
                              direct ? tail : SingleDocTail());
         if (e != hipSuccess) return e;
         if (direct) return hipGetLastError();
-        hipLaunchKernelGGL(k_tape_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, lens, d_doc_errors, n_docs, sums, d_res);
+        hipLaunchKernelGGL(k_tape_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, lens, d_doc_errors, n_docs, sums, d_res,
+                           (const uint32_t*)nullptr);
     }
-    hipLaunchKernelGGL(k_tape_chunk_scan, dim3(1), dim3(1024), 0, stream, sums, nchunks, n_docs, tape_capacity, d_tape_offsets, d_res);
+    hipLaunchKernelGGL(k_tape_chunk_scan, dim3(1), dim3(1024), 0, stream, sums, nchunks, n_docs, tape_capacity, d_tape_offsets, d_res,
+                       packed_skip, 0u);
     if (n_docs && !direct)
         hipLaunchKernelGGL(k_tape_compact, dim3((unsigned)nchunks), dim3(1024), 0, stream, scratch, lens, d_index_offsets, n_docs,
-                           sums, d_tape, tape_capacity, d_tape_offsets);
+                           sums, d_tape, tape_capacity, d_tape_offsets, packed_skip);
     return hipGetLastError();
 }
 

@@ -45,6 +45,9 @@ def test_fused_pipeline_equals_the_three_calls_and_the_oracle():
         for k, d in enumerate(docs):
             got = tape[int(to[k]):int(to[k + 1])]
             if errors[k] != 0:
+                # (a failing document has no tape.  Its slot is empty when the tapes are packed behind the walk -- this batch, with
+                #  documents that fail stage 1 -- and holds unspecified words of its PREDICTED length when the accepted plain pass laid
+                #  the tapes out before the walk: test_optimistic_plain_pass_and_its_rejections)
                 assert got.size == 0
                 n_bad += 1
                 continue
@@ -137,8 +140,7 @@ def test_optimistic_plain_pass_and_its_rejections(separator, monkeypatch):
                 got = tape[int(to[k]):int(to[k + 1])]
                 assert int(err[k]) == want.error, (name, k, d[:40], int(err[k]), want.error)
                 if want.error:
-                    n_bad += 1
-                    assert got.size == 0
+                    n_bad += 1  # (no tape; the slot's size says nothing: see include/sjmi.h, sjmi_parse_batch_device)
                 else:
                     assert O.Parsed(got, strings, 0, 0, 0).to_python() == want.to_python(), (name, k)
             assert c["failed_documents"] == n_bad, name
