@@ -890,13 +890,57 @@ struct __attribute__((aligned(16))) TokRing {
     uint32_t info[128];  // class | pre << 3 (0 none, 1 ',', 2 ':') | two separators in front << 5
 };
 constexpr int32_t CW_NEEDS_EXACT = -100;  // (internal, overwritten by the exact walker)
+// Primitives are parsed DENSELY: a token step only queues its atoms and numbers (window, position, where the words go, which
+// document), and whenever 64 are waiting they are parsed with every lane at work -- a quarter of a record's tokens are
+// primitives, so parsing them inside the step ran the ~170 instructions of cw_primitive on 16 live lanes.  The queue lives
+// across documents; a literal that turns out malformed (or needs k_slow_doubles) sends ITS document to the exact walker,
+// whatever the token walker thought of it.
+struct __attribute__((aligned(16))) PrimQueue {
+    uint4 win[128];
+    unsigned long long dst[128];
+    uint32_t p[128];
+    uint32_t doc[128];
+};
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
 k_tok_walk(TokArgs a) {
     __shared__ TokRing rings[4];
+    __shared__ PrimQueue queues[4];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     TokRing& ring = rings[wv];
+    PrimQueue& pq = queues[wv];
+    uint32_t qhead = 0, qtail = 0;
+    // a document for the exact walker: listed once, whoever finds out first (doc_errors[] starts at 0: k_doc_prepare / k_doc_meta)
+    auto send_to_exact = [&](uint32_t doc) {
+        if (atomicExch(&a.doc_errors[doc], CW_NEEDS_EXACT) != CW_NEEDS_EXACT) {
+            const uint32_t slot = atomicAdd(&a.list[0], 1u);
+            a.list[16 + slot] = doc;
+        }
+    };
+    auto flush_primitives = [&](uint32_t nq) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool live = (uint32_t)lane < nq;
+        const uint32_t e = (qhead + (uint32_t)lane) & 127u;
+        const uint4 wq = pq.win[e];
+        const CW16 win = {wq.x, wq.y, wq.z, wq.w};
+        unsigned long long* const dst = reinterpret_cast<unsigned long long*>(pq.dst[e]);
+        const uint32_t p = pq.p[e], doc = pq.doc[e];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (live) {
+            uint32_t ptype = 0;
+            unsigned long long praw = 0;
+            if (cw_primitive(a.buf, win, p, false, 0u, &ptype, &praw) == 0) {
+                dst[0] = tape_word(ptype, 0);
+                if (ptype == 'l' || ptype == 'd') dst[1] = praw;
+            } else {
+                send_to_exact(doc);
+            }
+        }
+        qhead += nq;
+    };
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t nwaves = gridDim.x * 4u;
     unsigned long long* const tape = (a.sel && *a.sel == 0) ? a.tape_alt : a.tape;
@@ -932,7 +976,7 @@ k_tok_walk(TokArgs a) {
         bool ok = !upstream_failed && m.st == 0 && n != 0 && n <= 0x7FFFFF00u && to <= 0xFFFFFF00u;
         uint32_t tlen = 0;
         if (ok) {
-            const uint32_t doc_start = m.doc_start, doc_end = m.doc_end;
+            const uint32_t doc_start = m.doc_start;
             const uint32_t nchunks = (n + 63u) / 64u;
             // ---- running state (wave-uniform) ----
             uint32_t H0 = 0, T0 = 1, S0 = m.dso;
@@ -1093,18 +1137,12 @@ k_tok_walk(TokArgs a) {
                     else good = false;
                     if (is_open && !empty_open && (h + 1 >= a.max_depth || h + 1 >= CW_LEVELS)) good = false;        // :69-70 / deeper than the stack
                 }
-                uint32_t ptype = 0;
-                unsigned long long praw = 0;
-                if (valid && good) {
-                    if (cls == K_QUOTE) {
-                        if (string_errors) {  // a string the reference's StringParser would have thrown on: record header FF FF FF <code>
-                            const uint8_t* hh = a.sb + rec_off;
-                            if (hh[0] == 0xFF && hh[1] == 0xFF && hh[2] == 0xFF) good = false;
-                        }
-                    } else if (cls == K_PRIM) {
-                        good = cw_primitive(a.buf, win, p, false, doc_end, &ptype, &praw) == 0;
-                    }
+                if (valid && good && cls == K_QUOTE && string_errors) {
+                    // a string the reference's StringParser would have thrown on: record header FF FF FF <code>
+                    const uint8_t* hh = a.sb + rec_off;
+                    if (hh[0] == 0xFF && hh[1] == 0xFF && hh[2] == 0xFF) good = false;
                 }
+                if (valid && cls == K_PRIM && tpos + words > room) good = false;  // (no room for its words: the exact walker reports it)
                 // (6) where the root value ends
                 const bool closes_root = is_close && h == 1;
                 const unsigned long long rc = __ballot(closes_root);
@@ -1120,11 +1158,22 @@ k_tok_walk(TokArgs a) {
                 pq_live = valid && cls == K_QUOTE;
                 pq_tpos = tpos;
                 pq_off = rec_off;
+                {   // atoms and numbers: queued, parsed 64 at a time (flush_primitives)
+                    const bool is_prim = valid && cls == K_PRIM;
+                    const unsigned long long PM = __ballot(is_prim);
+                    if (PM) {
+                        const uint32_t qs = (qtail + (uint32_t)__popcll(PM & lt_mask)) & 127u;
+                        if (is_prim) {
+                            pq.win[qs] = wq;
+                            pq.dst[qs] = reinterpret_cast<unsigned long long>(T + tpos);
+                            pq.p[qs] = p;
+                            pq.doc[qs] = k;
+                        }
+                        qtail += (uint32_t)__popcll(PM);
+                    }
+                }
                 if (valid) {
-                    if (cls == K_QUOTE) {
-                    } else if (cls == K_PRIM) {
-                        if (tpos < room) T[tpos] = tape_word(ptype, 0);
-                        if (is_num && tpos + 1 < room) T[tpos + 1] = praw;
+                    if (cls == K_QUOTE || cls == K_PRIM) {
                     } else if (empty_open) {
                         if (tpos < room) T[tpos] = tape_word(ch, tpos + 2);          // TapeBuilder.java:205-208
                     } else if (empty_close) {
@@ -1147,6 +1196,7 @@ k_tok_walk(TokArgs a) {
                 prev_is_key = __builtin_amdgcn_readlane((int)is_key, lastv) != 0;
                 at_start = false;
                 head += nv;
+                if (qtail - qhead >= 64u) flush_primitives(64u);
             }
             if (pq_live && pq_tpos < room) T[pq_tpos] = tape_word('"', a.string_base + pq_off);  // the last step's strings
             if (ok && !root_closed) ok = false;  // the root container is never closed (JsonIterator.java:39-41,:51-53)
@@ -1164,15 +1214,8 @@ k_tok_walk(TokArgs a) {
             }
         }
         if (lane == 0) {
-            if (ok) {
-                a.doc_errors[k] = 0;
-                if (a.tape_lens) a.tape_lens[k] = tlen;
-            } else {
-                a.doc_errors[k] = CW_NEEDS_EXACT;
-                if (a.tape_lens) a.tape_lens[k] = 0;
-                const uint32_t slot = atomicAdd(&a.list[0], 1u);
-                a.list[16 + slot] = k;
-            }
+            if (a.tape_lens) a.tape_lens[k] = ok ? tlen : 0u;
+            if (!ok) send_to_exact(k);
         }
         m = m_next;
         t_end = t_end_next;
@@ -1181,6 +1224,7 @@ k_tok_walk(TokArgs a) {
             p1 = load_pos(m.from, m.to, 1, m.doc_start);
         }
     }
+    if (qtail != qhead) flush_primitives(qtail - qhead);  // (fewer than 64 by construction)
 }
 
 // ---- the chunk passes around k_coop_walk<true> --------------------------------------------------------------------------

@@ -115,12 +115,13 @@ k_tape_compact(const unsigned long long* __restrict__ scratch_tape, const uint32
 __global__ void __launch_bounds__(PREP_DOCS)
 k_tape_offsets(const uint32_t* __restrict__ lens, const unsigned long long* __restrict__ chunk_base, uint64_t n_docs,
                uint64_t tape_capacity, unsigned long long* __restrict__ tape_offsets, DocMeta* __restrict__ metas,
-               uint32_t* __restrict__ list, const uint32_t* __restrict__ gate) {
+               uint32_t* __restrict__ list, const uint32_t* __restrict__ gate, int32_t* __restrict__ doc_errors) {
     if (gate && *gate == 0) return;
     __shared__ unsigned long long s_wave[16];
     const uint64_t k = (uint64_t)blockIdx.x * PREP_DOCS + threadIdx.x;
     unsigned long long total;
     unsigned long long off = chunk_base[blockIdx.x] + block_excl_scan(k < n_docs ? lens[k] : 0u, s_wave, &total);
+    if (k < n_docs) doc_errors[k] = 0;  // (the token walker only writes to it when it declines a document)
     if (k <= n_docs) {
         if (k == n_docs) off = tape_offsets[n_docs];  // (the total: k_tape_chunk_scan)
         tape_offsets[k] = off;
@@ -137,11 +138,12 @@ k_tape_offsets(const uint32_t* __restrict__ lens, const unsigned long long* __re
 __global__ void __launch_bounds__(256)
 k_doc_meta(const unsigned long long* __restrict__ doc_offsets, const unsigned long long* __restrict__ index_offsets,
            const uint32_t* __restrict__ doc_status, const unsigned long long* __restrict__ doc_str_ordinals, uint64_t n_docs,
-           DocMeta* __restrict__ metas, uint32_t* __restrict__ list, const uint32_t* __restrict__ skip) {
+           DocMeta* __restrict__ metas, uint32_t* __restrict__ list, const uint32_t* __restrict__ skip, int32_t* __restrict__ doc_errors) {
     if (skip && *skip) return;
     const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (k == 0) list[0] = 0;
     if (k > n_docs) return;
+    if (k < n_docs) doc_errors[k] = 0;  // (the token walker only writes to it when it declines a document)
     DocMeta m = {};
     const unsigned long long from = index_offsets[k];
     const unsigned long long slot = scratch_slot(from, k);
@@ -222,11 +224,11 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
                                d_tape_offsets, d_res, d_prepared, 1u);
             hipLaunchKernelGGL(k_tape_offsets, dim3((unsigned)((n_docs + 1 + PREP_DOCS - 1) / PREP_DOCS)), dim3(PREP_DOCS), 0, stream,
                                (const uint32_t*)wp.lens, (const unsigned long long*)wp.chunk_sums, n_docs, tape_capacity, d_tape_offsets,
-                               wp.metas, list, d_prepared);
+                               wp.metas, list, d_prepared, d_doc_errors);
             packed_skip = d_prepared;
         }
         hipLaunchKernelGGL(k_doc_meta, dim3((unsigned)((n_docs + 1 + 255) / 256)), dim3(256), 0, stream, d_doc_offsets, d_index_offsets,
-                           d_doc_status, d_doc_str_ordinals, n_docs, wp.metas, list, packed_skip);
+                           d_doc_status, d_doc_str_ordinals, n_docs, wp.metas, list, packed_skip, d_doc_errors);
         TokLaunch t;
         t.d_buf = d_buf;
         t.d_idx = d_idx;
