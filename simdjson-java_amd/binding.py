@@ -110,7 +110,8 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
-        L = C.CDLL(_LIB)
+        # (SJMI_LIB: an experiment build of the same sources, tools/build_variant.sh -- A/B measurements only)
+        L = C.CDLL(os.environ.get("SJMI_LIB") or _LIB)
         L.sjmi_create.restype = C.c_int
         L.sjmi_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_uint64]
         L.sjmi_destroy.restype = None

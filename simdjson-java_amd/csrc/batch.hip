@@ -170,12 +170,30 @@ k_doc_prepare(DocPrepare a) {
         const unsigned long long b = pos >> 6;
         unsigned long long j = a.blkidx[b];
         uint32_t w = 0, q = 0;
-        for (int t = 0; t < 64 && j < count; ++t, ++j) {  // (a block has at most 64 structurals)
-            const uint32_t p = a.idx[j];
-            if ((unsigned long long)p >= pos) break;
-            const uint32_t c = a.buf[p];
-            w += prep_words_of(c);
-            q += c == '"';
+        // the block's first 16 structurals and their first bytes in TWO round trips (all loads of a stage are independent); a
+        // boundary has ~6 structurals of its block in front of it, so the one-by-one loop behind this is rarely entered
+        uint32_t e[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) e[t] = j + t < count ? a.idx[j + t] : 0xFFFFFFFFu;
+        uint32_t c16[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) c16[t] = (unsigned long long)e[t] < pos ? (uint32_t)a.buf[e[t]] : 0x2Cu;  // (',' = no word, no quote)
+        uint32_t nb = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            nb += (unsigned long long)e[t] < pos ? 1u : 0u;
+            w += prep_words_of(c16[t]);
+            q += c16[t] == '"';
+        }
+        j += nb;
+        if (nb == 16u) {
+            for (int t = 16; t < 64 && j < count; ++t, ++j) {  // (a block has at most 64 structurals)
+                const uint32_t p = a.idx[j];
+                if ((unsigned long long)p >= pos) break;
+                const uint32_t c = a.buf[p];
+                w += prep_words_of(c);
+                q += c == '"';
+            }
         }
         *io = (uint32_t)j;
         *pw = w;
@@ -210,11 +228,24 @@ k_doc_prepare(DocPrepare a) {
         // the block that holds the end boundary only through the correction pw[k + 1]
         const unsigned long long bs = s >> 6, be = e >> 6;
         uint32_t sum = 0;
-        unsigned long long par = 0;
-        for (unsigned long long b = bs; b < be; ++b) {
-            if (b == bs || (b & 63) == 0) par = a.blkpar[b >> 6];
-            const uint32_t w2 = a.blkw[b];
-            sum += ((par >> (b & 63)) & 1ull) ? (w2 >> 8) : (w2 & 0xFFu);
+        {
+            // eight blocks per trip: their word counts in one 16-byte load (the arrays are padded), their entry parities from
+            // the one or two 64-block words the trip touches
+            struct __attribute__((packed, aligned(2))) W8 { uint32_t a, b, c, d; };
+            for (unsigned long long b0 = bs; b0 < be; b0 += 8) {
+                const W8 v = *reinterpret_cast<const W8*>(a.blkw + b0);
+                const unsigned long long p0 = a.blkpar[b0 >> 6], p1 = a.blkpar[(b0 + 7) >> 6];
+                const uint32_t sh = (uint32_t)(b0 & 63);
+                const uint32_t pb = (uint32_t)((p0 >> sh) | (sh > 56 ? p1 << (64 - sh) : 0ull)) & 0xFFu;  // bit t: block b0 + t enters inside a string
+                const uint32_t ww[4] = {v.a, v.b, v.c, v.d};
+                const uint32_t left = be - b0 < 8 ? (uint32_t)(be - b0) : 8u;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const uint32_t w2 = (ww[t >> 1] >> (16 * (t & 1))) & 0xFFFFu;
+                    const uint32_t wv = ((pb >> t) & 1u) ? (w2 >> 8) : (w2 & 0xFFu);
+                    sum += (uint32_t)t < left ? wv : 0u;
+                }
+            }
         }
         const uint32_t to = s_io[threadIdx.x + 1];
         len = sum - pw + s_pw[threadIdx.x + 1] + 2u;  // + the two root words (TapeBuilder.java:41-48)

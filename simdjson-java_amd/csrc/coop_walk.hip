@@ -866,6 +866,9 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
 // predicate, a stage-1 status, a root that is not a container, a malformed escape, a literal for k_slow_doubles, nesting beyond
 // the 64 levels of the register stack -- to k_coop_walk (list mode), which walks it again and produces the reference's exact
 // error code (or its tape).  A well-formed batch never gets there.
+// (a ballot of a CONDITION: HIP's __ballot(int) compares its argument with zero in the VALU even when the condition already is
+//  a lane mask in SGPRs -- v_cndmask + v_cmp per ballot; the builtin lets the compiler keep the mask)
+__device__ __forceinline__ unsigned long long cw_ballot(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 struct TokArgs {
     const uint8_t* buf;
     const uint32_t* idx;
@@ -902,7 +905,10 @@ struct __attribute__((aligned(16))) PrimQueue {
     uint32_t doc[128];
 };
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
+#ifndef SJMI_TOK_WAVES
+#define SJMI_TOK_WAVES 5
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SJMI_TOK_WAVES, SJMI_TOK_WAVES)))
 k_tok_walk(TokArgs a) {
     __shared__ TokRing rings[4];
     __shared__ PrimQueue queues[4];
@@ -1003,14 +1009,14 @@ k_tok_walk(TokArgs a) {
                     p_nxt = c + 2 < nchunks ? load_pos(from, to, c + 2, doc_start) : doc_start;
                     const uint32_t cls = valid ? class_of(w.a & 0xFFu) : K_QUOTE;
                     const bool sep = valid && (cls == K_COMMA || cls == K_COLON);
-                    const unsigned long long S = __ballot(sep), CO = __ballot(valid && cls == K_COLON);
+                    const unsigned long long S = cw_ballot(sep), CO = cw_ballot(valid && cls == K_COLON);
                     const unsigned long long S1 = (S << 1) | sep1, S2 = (S << 2) | ((unsigned long long)sep1 << 1) | sep2;
                     const unsigned long long C1 = (CO << 1) | colon1;
                     const uint32_t pre_sep = (uint32_t)(S1 >> lane) & 1u, pre_colon = (uint32_t)(C1 >> lane) & 1u;
                     const uint32_t two = pre_sep & ((uint32_t)(S2 >> lane) & 1u);
                     const uint32_t info = cls | ((pre_sep ? (pre_colon ? 2u : 1u) : 0u) << 3) | (two << 5);
                     const bool tok = valid && !sep;
-                    const unsigned long long TM = __ballot(tok);
+                    const unsigned long long TM = cw_ballot(tok);
                     const uint32_t slot = (tail + (uint32_t)__popcll(TM & lt_mask)) & 127u;
                     if (tok) {
                         ring.p[slot] = p;
@@ -1067,7 +1073,7 @@ k_tok_walk(TokArgs a) {
                 const int h = (int)H0 + (int)(iu - up) - (int)(id - down);
                 const uint32_t tpos = T0 + iw - words;
                 const bool is_str = valid && cls == K_QUOTE;
-                const unsigned long long qm = __ballot(is_str);
+                const unsigned long long qm = cw_ballot(is_str);
                 const uint32_t sord = S0 + (uint32_t)__popcll(qm & lt_mask);
                 const uint32_t rec_off = is_str ? a.soff[sord] : 0u;  // (used one step later)
                 // (4) the container of every token: one trip per depth level present in the step
@@ -1082,9 +1088,9 @@ k_tok_walk(TokArgs a) {
                 int par_lane = -1;
                 uint32_t kc = 0;
                 for (int L = hmin; L <= hmax; ++L) {
-                    const unsigned long long O = __ballot(is_open && h == L);             // opens of level L
-                    const unsigned long long C = __ballot(comma_in_front && plevel == L); // elements of level L that follow a comma
-                    const unsigned long long Z = __ballot(is_close && plevel == L);       // closes of level-L containers
+                    const unsigned long long O = cw_ballot(is_open && h == L);             // opens of level L
+                    const unsigned long long C = cw_ballot(comma_in_front && plevel == L); // elements of level L that follow a comma
+                    const unsigned long long Z = cw_ballot(is_close && plevel == L);       // closes of level-L containers
                     if (plevel == L) par_lane = highest_bit_below(O, lt_mask);
                     if (key == L) kc = (uint32_t)__popcll(C & lt_mask);
                     // the stack entry of level L behind the step (wave-uniform, branch-free): the LAST open of the level stays open
@@ -1145,10 +1151,10 @@ k_tok_walk(TokArgs a) {
                 if (valid && cls == K_PRIM && tpos + words > room) good = false;  // (no room for its words: the exact walker reports it)
                 // (6) where the root value ends
                 const bool closes_root = is_close && h == 1;
-                const unsigned long long rc = __ballot(closes_root);
+                const unsigned long long rc = cw_ballot(closes_root);
                 const int rc_lane = rc ? __builtin_ctzll(rc) : 64;
                 if (valid && lane > rc_lane) good = false;  // trailing content
-                if (__ballot(!good)) {
+                if (cw_ballot(!good)) {
                     ok = false;
                     break;
                 }
@@ -1160,7 +1166,7 @@ k_tok_walk(TokArgs a) {
                 pq_off = rec_off;
                 {   // atoms and numbers: queued, parsed 64 at a time (flush_primitives)
                     const bool is_prim = valid && cls == K_PRIM;
-                    const unsigned long long PM = __ballot(is_prim);
+                    const unsigned long long PM = cw_ballot(is_prim);
                     if (PM) {
                         const uint32_t qs = (qtail + (uint32_t)__popcll(PM & lt_mask)) & 127u;
                         if (is_prim) {

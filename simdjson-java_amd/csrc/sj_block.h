@@ -161,9 +161,12 @@ SJ_HD SjBlockMasks sj_block(const sj_u64 p[8], uint32_t e_in, uint32_t p_in, SjU
     SjBlockMasks r;
     r.words = 0;
     if (want_words) {
-        const sj_u64 a5 = a & p5;                                                    // 0x20..0x3F
-        const sj_u64 comma_colon = a5 & ((~p4 & n_1100) | (p4 & n_1010));            // 0x2C, 0x3A (not the op table's 0x0C, 0x1A)
-        const sj_u64 number = a5 & ((p4 & (~p3 | (n10 & ~p1))) | (~p4 & n_1101));    // 0x30..0x39, 0x2D
+        // (from the planes themselves, which are live to the end of the UTF-8 algebra anyway: re-using the nibble decodes of
+        //  the top would keep five more masks alive across it -- the FAST S = 4 kernel then needs 132 VGPRs instead of 128)
+        const sj_u64 a5 = ~p7 & ~p6 & p5;                                            // 0x20..0x3F
+        const sj_u64 hi3 = p3 & p2, x1100 = hi3 & ~p1;                               // low nibble 110x
+        const sj_u64 comma_colon = a5 & ((~p4 & x1100 & ~p0) | (p4 & p3 & ~p2 & p1 & ~p0));   // 0x2C, 0x3A (not the op table's 0x0C, 0x1A)
+        const sj_u64 number = a5 & ((p4 & (~p3 | (~p2 & ~p1))) | (~p4 & x1100 & p0));          // 0x30..0x39, 0x2D
         const sj_u64 sm0_ = in0 ^ quote, s0 = pot & ~sm0_, s1 = pot & sm0_;
         auto pc = [](sj_u64 m) -> uint32_t {
 #if defined(__HIP_DEVICE_COMPILE__)

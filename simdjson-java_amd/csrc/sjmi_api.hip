@@ -1003,7 +1003,12 @@ static int stage1_batch_optimistic(sjmi_ctx* c, const void* d_buf, uint64_t tota
         {
             const AutoSafeOff plain_only(c);  // (a tripped liveness bound only rejects the plain pass: the per-document passes take over)
             c->batch_side = for_pipeline;
+            // (experiments: SJMI_BATCH_STEPS = granule of the pipeline's plain pass in units of 4 KiB)
+            static const int batch_steps = getenv("SJMI_BATCH_STEPS") ? atoi(getenv("SJMI_BATCH_STEPS")) : 0;
+            const int keep_steps = c->forced_steps;
+            if (for_pipeline && (batch_steps == 1 || batch_steps == 2 || batch_steps == 4)) c->forced_steps = batch_steps;
             rc0 = stage1_device_impl(c, d_buf, total_len, d_indexes, index_capacity, d_result, stream, 0);
+            c->forced_steps = keep_steps;
             c->batch_side = false;
         }
         if (rc0 != SJMI_OK) return rc0;

@@ -552,11 +552,11 @@ union WaveShared {
 // the index array of the block's first structural (what a document's index_offsets entry is read from instead of a binary
 // search), blkw = the tape words its structurals make for both entry parities (sj_block_tape_words).
 template <int S, int LDSW, bool SAFE, bool BATCH>
-__global__ void __launch_bounds__(256)
-k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out, sj_u64 out_cap,
-         sj_u64* gstate, uint32_t* ticket, Stage1Result* res, uint32_t ngran, uint32_t dbg, uint4* zero_ptr,
-         uint32_t zero_chunks, Stage1Result* result_out, sj_u64* __restrict__ blkpar, const uint32_t* __restrict__ skip,
-         uint32_t* __restrict__ blkidx, uint16_t* __restrict__ blkw) {
+__device__ __forceinline__ void
+stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out, sj_u64 out_cap,
+            sj_u64* gstate, uint32_t* ticket, Stage1Result* res, uint32_t ngran, uint32_t dbg, uint4* zero_ptr,
+            uint32_t zero_chunks, Stage1Result* result_out, sj_u64* __restrict__ blkpar, const uint32_t* __restrict__ skip,
+            uint32_t* __restrict__ blkidx, uint16_t* __restrict__ blkw) {
     constexpr int E = S, CAP = LDSW / 4;
     if (skip && *skip) return;  // (fused batch pipeline: this pass is not needed; uniform for the whole launch)
     static_assert(S <= 4, "meta packs 14-bit offsets: at most 4 steps per granule");
@@ -942,6 +942,44 @@ k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out
     zero_next_workspace(zero_ptr, zero_chunks, worker, nworkers, lane);
 }
 
+// The kernels proper.  The BATCH flavour is pinned to the occupancy of the plain one (four waves per SIMD = 128 VGPRs): its two
+// side outputs cost the register allocator 4 VGPRs at S = 4, and 132 would mean three waves (the plain pass of a 1M-document
+// batch: 0.51 ms instead of 0.43); spilling them is the cheaper way out.
+template <int S, int LDSW, bool SAFE, bool BATCH>
+struct Stage1Kernel;
+template <int S, int LDSW, bool SAFE>
+__global__ void __launch_bounds__(256)
+k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out, sj_u64 out_cap,
+         sj_u64* gstate, uint32_t* ticket, Stage1Result* res, uint32_t ngran, uint32_t dbg, uint4* zero_ptr,
+         uint32_t zero_chunks, Stage1Result* result_out, sj_u64* __restrict__ blkpar, const uint32_t* __restrict__ skip,
+         uint32_t* __restrict__ blkidx, uint16_t* __restrict__ blkw) {
+    stage1_body<S, LDSW, SAFE, false>(buf, len, out, out_cap, gstate, ticket, res, ngran, dbg, zero_ptr, zero_chunks, result_out, blkpar,
+                                      skip, blkidx, blkw);
+}
+#ifndef SJMI_S1_BATCH_WAVES
+#define SJMI_S1_BATCH_WAVES 4
+#endif
+template <int S, int LDSW, bool SAFE>
+__global__ void __launch_bounds__(256)
+#if SJMI_S1_BATCH_WAVES
+__attribute__((amdgpu_waves_per_eu(SJMI_S1_BATCH_WAVES, SJMI_S1_BATCH_WAVES)))
+#endif
+k_stage1_batch(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out, sj_u64 out_cap,
+               sj_u64* gstate, uint32_t* ticket, Stage1Result* res, uint32_t ngran, uint32_t dbg, uint4* zero_ptr,
+               uint32_t zero_chunks, Stage1Result* result_out, sj_u64* __restrict__ blkpar, const uint32_t* __restrict__ skip,
+               uint32_t* __restrict__ blkidx, uint16_t* __restrict__ blkw) {
+    stage1_body<S, LDSW, SAFE, true>(buf, len, out, out_cap, gstate, ticket, res, ngran, dbg, zero_ptr, zero_chunks, result_out, blkpar,
+                                     skip, blkidx, blkw);
+}
+template <int S, int LDSW, bool SAFE>
+struct Stage1Kernel<S, LDSW, SAFE, false> {
+    static constexpr auto fn = k_stage1<S, LDSW, SAFE>;
+};
+template <int S, int LDSW, bool SAFE>
+struct Stage1Kernel<S, LDSW, SAFE, true> {
+    static constexpr auto fn = k_stage1_batch<S, LDSW, SAFE>;
+};
+
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
@@ -981,7 +1019,7 @@ static hipError_t resident_workgroups(unsigned* out) {
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 16 || !cached[dev]) {
         int per_cu = 0, cus = 0;
-        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stage1<S, LDSW, SAFE, BATCH>, 256, 0)) != hipSuccess) return e;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, Stage1Kernel<S, LDSW, SAFE, BATCH>::fn, 256, 0)) != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
         const unsigned n = (unsigned)(per_cu > 0 ? per_cu : 1) * (unsigned)(cus > 0 ? cus : 1);
         if (dev < 0 || dev >= 16) {
@@ -1013,10 +1051,10 @@ static hipError_t launch_mode(const uint8_t* d_buf, uint64_t len, uint32_t* d_ou
     if (ev_start && ev_stop) {
         // the events are attached to the dispatch itself (its start / end timestamps), not recorded around it:
         // hipEventRecord pairs added 10-25 us of queue latency to a 200 us kernel
-        hipExtLaunchKernelGGL((k_stage1<S, LDSW, SAFE, BATCH>), grid, block, 0, stream, ev_start, ev_stop, 0, d_buf, (sj_u64)len,
+        hipExtLaunchKernelGGL((Stage1Kernel<S, LDSW, SAFE, BATCH>::fn), grid, block, 0, stream, ev_start, ev_stop, 0, d_buf, (sj_u64)len,
                               d_out, (sj_u64)out_cap, gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro, bp, ex.skip, bi, bw);
     } else {
-        hipLaunchKernelGGL((k_stage1<S, LDSW, SAFE, BATCH>), grid, block, 0, stream, d_buf, (sj_u64)len, d_out, (sj_u64)out_cap,
+        hipLaunchKernelGGL((Stage1Kernel<S, LDSW, SAFE, BATCH>::fn), grid, block, 0, stream, d_buf, (sj_u64)len, d_out, (sj_u64)out_cap,
                            gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro, bp, ex.skip, bi, bw);
     }
     return hipGetLastError();
