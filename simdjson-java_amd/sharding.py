@@ -119,12 +119,24 @@ def sharded_step(shard, stream=0, always_gather=False):
     collective even in a group of one rank (bench.py --sharded: the RCCL call path on a single GPU)."""
     import torch
     import torch.distributed as dist
+    side = None
     if not stream and str(shard.device) != "cpu":
-        # stream handle 0 would mean "the engine context's own stream", which torch knows nothing about: the torch ops that
-        # read the result record below would not be ordered behind the kernels.  So the kernels go on the torch stream the
-        # caller is on -- plain stream order, no host synchronisation anywhere in the step.
-        stream = torch.cuda.current_stream(shard.device).cuda_stream
+        # stream handle 0 means "the engine context's own stream" to the C ABI -- and it is also the handle of torch's legacy
+        # default stream, so it cannot name that one.  The torch ops that read the result record below must be ordered behind
+        # the kernels: the kernels go on a side stream of the shard's, fenced against the caller's current stream on both
+        # sides with events (wait_stream) -- stream order only, no host synchronisation anywhere in the step.
+        cur = torch.cuda.current_stream(shard.device)
+        if cur.cuda_stream:
+            stream = cur.cuda_stream
+        else:
+            side = getattr(shard, "_side_stream", None)
+            if side is None:
+                side = shard._side_stream = torch.cuda.Stream(device=shard.device)
+            side.wait_stream(cur)
+            stream = side.cuda_stream
     shard.step(stream)
+    if side is not None:
+        torch.cuda.current_stream(shard.device).wait_stream(side)
     row = shard.counts_tensor()
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not always_gather):
         return row[None, :]
