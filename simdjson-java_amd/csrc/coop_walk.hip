@@ -887,26 +887,22 @@ struct TokArgs {
     const Stage1Result* dev_count;
     const UnescapeResult* dev_strings;
 };
-struct __attribute__((aligned(16))) TokRing {
-    uint4 win[128];
-    uint32_t p[128];
-    uint32_t info[128];  // class | pre << 3 (0 none, 1 ',', 2 ':') | two separators in front << 5
+struct __attribute__((aligned(8))) TokRing {
+    uint2 e[128];  // .x = position, .y = class | pre << 3 (0 none, 1 ',', 2 ':') | two separators in front << 5 | first byte << 8
 };
 constexpr int32_t CW_NEEDS_EXACT = -100;  // (internal, overwritten by the exact walker)
 // Primitives are parsed DENSELY: a token step only queues its atoms and numbers (window, position, where the words go, which
 // document), and whenever 64 are waiting they are parsed with every lane at work -- a quarter of a record's tokens are
-// primitives, so parsing them inside the step ran the ~170 instructions of cw_primitive on 16 live lanes.  The queue lives
+// primitives, so parsing them inside the step ran the ~170 instructions of cw_primitive on 16 live lanes (and made every
+// structural carry a 16-byte window through the ring: now the ingest loads ONE byte per structural).  The queue lives
 // across documents; a literal that turns out malformed (or needs k_slow_doubles) sends ITS document to the exact walker,
 // whatever the token walker thought of it.
 struct __attribute__((aligned(16))) PrimQueue {
-    uint4 win[128];
-    unsigned long long dst[128];
-    uint32_t p[128];
-    uint32_t doc[128];
+    uint4 e[128];  // .x = position (its 16-byte window is loaded when the queue is flushed: 64 dense loads), .y = document, .zw = where the words go
 };
 
 #ifndef SJMI_TOK_WAVES
-#define SJMI_TOK_WAVES 5
+#define SJMI_TOK_WAVES 6
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SJMI_TOK_WAVES, SJMI_TOK_WAVES)))
 k_tok_walk(TokArgs a) {
@@ -929,12 +925,12 @@ k_tok_walk(TokArgs a) {
         __builtin_amdgcn_wave_barrier();
         const bool live = (uint32_t)lane < nq;
         const uint32_t e = (qhead + (uint32_t)lane) & 127u;
-        const uint4 wq = pq.win[e];
-        const CW16 win = {wq.x, wq.y, wq.z, wq.w};
-        unsigned long long* const dst = reinterpret_cast<unsigned long long*>(pq.dst[e]);
-        const uint32_t p = pq.p[e], doc = pq.doc[e];
+        const uint4 q = pq.e[e];
+        const uint32_t p = live ? q.x : 0u, doc = q.y;
+        unsigned long long* const dst = reinterpret_cast<unsigned long long*>(((unsigned long long)q.w << 32) | q.z);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        const CW16 win = *reinterpret_cast<const CW16*>(a.buf + p);
         if (live) {
             uint32_t ptype = 0;
             unsigned long long praw = 0;
@@ -994,35 +990,34 @@ k_tok_walk(TokArgs a) {
             // ingest state
             uint32_t c = 0, head = 0, tail = 0;
             uint32_t sep1 = 0, sep2 = 0, colon1 = 0;
+            // positions are requested two chunks ahead of their use, first bytes one chunk ahead
             uint32_t p_cur = p0, p_nxt = p1;
-            CW16 win_cur = *reinterpret_cast<const CW16*>(a.buf + p_cur);
+            uint32_t b_cur = a.buf[p_cur], b_nxt = nchunks > 1u ? (uint32_t)a.buf[p_nxt] : 0u;
+            uint32_t p_nn = nchunks > 2u ? load_pos(from, to, 2, doc_start) : doc_start;
             while (ok) {
                 // ---- ingest chunks of 64 structurals until a token step has its 64 tokens and one to look ahead at ----
                 while (c < nchunks && tail - head < 65u) {
                     const uint32_t base = from + c * 64u;
                     const uint32_t nvl = to - base < 64u ? to - base : 64u;
                     const bool valid = (uint32_t)lane < nvl;
-                    const uint32_t p = p_cur;
-                    const CW16 w = win_cur;
+                    const uint32_t p = p_cur, b0 = b_cur;
                     p_cur = p_nxt;
-                    if (c + 1 < nchunks) win_cur = *reinterpret_cast<const CW16*>(a.buf + p_cur);
-                    p_nxt = c + 2 < nchunks ? load_pos(from, to, c + 2, doc_start) : doc_start;
-                    const uint32_t cls = valid ? class_of(w.a & 0xFFu) : K_QUOTE;
+                    b_cur = b_nxt;
+                    p_nxt = p_nn;
+                    if (c + 2 < nchunks) b_nxt = a.buf[p_nxt];
+                    p_nn = c + 3 < nchunks ? load_pos(from, to, c + 3, doc_start) : doc_start;
+                    const uint32_t cls = valid ? class_of(b0) : K_QUOTE;
                     const bool sep = valid && (cls == K_COMMA || cls == K_COLON);
                     const unsigned long long S = cw_ballot(sep), CO = cw_ballot(valid && cls == K_COLON);
                     const unsigned long long S1 = (S << 1) | sep1, S2 = (S << 2) | ((unsigned long long)sep1 << 1) | sep2;
                     const unsigned long long C1 = (CO << 1) | colon1;
                     const uint32_t pre_sep = (uint32_t)(S1 >> lane) & 1u, pre_colon = (uint32_t)(C1 >> lane) & 1u;
                     const uint32_t two = pre_sep & ((uint32_t)(S2 >> lane) & 1u);
-                    const uint32_t info = cls | ((pre_sep ? (pre_colon ? 2u : 1u) : 0u) << 3) | (two << 5);
+                    const uint32_t info = cls | ((pre_sep ? (pre_colon ? 2u : 1u) : 0u) << 3) | (two << 5) | (b0 << 8);
                     const bool tok = valid && !sep;
                     const unsigned long long TM = cw_ballot(tok);
                     const uint32_t slot = (tail + (uint32_t)__popcll(TM & lt_mask)) & 127u;
-                    if (tok) {
-                        ring.p[slot] = p;
-                        ring.info[slot] = info;
-                        ring.win[slot] = make_uint4(w.a, w.b, w.c, w.d);
-                    }
+                    if (tok) ring.e[slot] = make_uint2(p, info);
                     tail += (uint32_t)__popcll(TM);
                     // carries into the next chunk: are the last / the last but one structural separators, is the last a ':'
                     const uint32_t lb = nvl - 1u;
@@ -1041,18 +1036,17 @@ k_tok_walk(TokArgs a) {
                 // ---- one token step ----
                 const bool valid = (uint32_t)lane < nv;
                 const uint32_t e = (head + (uint32_t)lane) & 127u;
-                const uint32_t p = ring.p[e], info = valid ? ring.info[e] : (uint32_t)K_COMMA;
-                const uint4 wq = ring.win[e];
-                const CW16 win = {wq.x, wq.y, wq.z, wq.w};
+                const uint2 re = ring.e[e];
+                const uint32_t p = re.x, info = valid ? re.y : (uint32_t)K_COMMA;
                 const bool has_next = (uint32_t)lane + 1u < avail;
-                const uint32_t ninfo = has_next ? ring.info[(e + 1u) & 127u] : (uint32_t)K_COMMA;
+                const uint32_t ninfo = has_next ? ring.e[(e + 1u) & 127u].y : (uint32_t)K_COMMA;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if (root_closed) {  // something follows the root value (JsonIterator.java:196-198)
                     ok = false;
                     break;
                 }
-                const uint32_t ch = win.a & 0xFFu;
+                const uint32_t ch = (info >> 8) & 0xFFu;
                 const uint32_t cls = info & 7u, pre = (info >> 3) & 3u;
                 const uint32_t cls_next = ninfo & 7u, pre_next = (ninfo >> 3) & 3u;
                 const bool is_open = valid && cls <= K_OPEN_O, is_close = valid && (cls == K_CLOSE_A || cls == K_CLOSE_O);
@@ -1170,10 +1164,8 @@ k_tok_walk(TokArgs a) {
                     if (PM) {
                         const uint32_t qs = (qtail + (uint32_t)__popcll(PM & lt_mask)) & 127u;
                         if (is_prim) {
-                            pq.win[qs] = wq;
-                            pq.dst[qs] = reinterpret_cast<unsigned long long>(T + tpos);
-                            pq.p[qs] = p;
-                            pq.doc[qs] = k;
+                            const unsigned long long d = reinterpret_cast<unsigned long long>(T + tpos);
+                            pq.e[qs] = make_uint4(p, k, (uint32_t)d, (uint32_t)(d >> 32));
                         }
                         qtail += (uint32_t)__popcll(PM);
                     }

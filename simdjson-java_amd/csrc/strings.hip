@@ -430,7 +430,12 @@ k_strings(const StrArgs a0) {
             const uint32_t euc_hi_prev = (uint32_t)__shfl_up((int)(uint32_t)(euc >> 32), 1);
             const bool halo_bs = blk > 0 && active && (swar_has_backslash(hq.y) | swar_has_backslash(hq.z) | swar_has_backslash(hq.w));
             const bool trig = euc != 0 || (lane > 0 ? (euc_hi_prev >> 22) != 0 : halo_bs);
+#ifdef SJMI_STR_NO_U  /* experiment: how fast is the pass without the \u look-back in its register budget */
+            const bool do_u = false;
+            (void)trig;
+#else
             const bool do_u = __ballot(trig) != 0;
+#endif
             SjStrHalo halo;
             halo.e_in = 0;
             if (do_u) {
