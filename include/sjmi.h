@@ -300,7 +300,14 @@ int sjmi_walk_batch_device(sjmi_ctx* ctx, const void* d_buf, const void* d_doc_o
  * a control-character separator ('\n', '\r', '\t'), the documents cover the buffer exactly (doc_offsets[0] == 0 and
  * doc_offsets[n_docs] == total_len: bytes outside the documents would feed state into them) and the global verdict is
  * clean -- then it is exactly what the per-document passes give; otherwise those run (queued behind it, they leave at once
- * when it was accepted). */
+ * when it was accepted).
+ * Tapes: when the plain pass was accepted the tapes are laid out BEFORE the documents are walked (a document's tape length
+ * is a function of its structurals' first bytes: TapeBuilder.java:41-48,191-208, Tape.java:33-43) and written at their final
+ * addresses.  A document that then fails stage 2 (doc_errors[k] != 0) keeps its slot: tape_offsets[k + 1] - tape_offsets[k] is
+ * its PREDICTED length and the words there are unspecified; walk.tape_words counts the slots.  Every well-formed document's
+ * tape is where and what it always was, and a batch without failing documents is packed exactly as before.  (When the plain
+ * pass was rejected -- some document fails stage 1, a separator is missing -- the tapes are packed behind the walk and a
+ * failing document's range is empty, as with sjmi_walk_batch_device.) */
 typedef struct sjmi_batch_result {
     sjmi_stage1_result stage1;
     sjmi_unescape_result strings;
