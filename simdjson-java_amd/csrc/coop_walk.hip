@@ -383,6 +383,7 @@ struct ExactMode {
     unsigned long long* tape = nullptr;  // *sel != 0 (or sel == nullptr): the final tape; else tape_alt (the scratch tape)
     unsigned long long* tape_alt = nullptr;
     const uint32_t* sel = nullptr;
+    unsigned long long cap = 0;          // != 0 (one document written in place into the CALLER's tape): words of room there
 };
 
 // One wave per document (grid-stride over the documents).  Documents are delimited by index_offsets (n_docs + 1 entries)
@@ -522,6 +523,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                 t_off = ((unsigned long long)ex.metas[kdoc].tape_hi << 32) | ex.metas[kdoc].tape_lo;
                 t_room = (((unsigned long long)ex.metas[kdoc + 1].tape_hi << 32) | ex.metas[kdoc + 1].tape_lo) - t_off;
             }
+            if (ex.cap && t_room > ex.cap) t_room = ex.cap;  // (a tape that does not fit is reported, never overrun)
             unsigned long long* const T = scratch_tape + t_off;
             const uint32_t room = t_room > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t_room;
             // running state (wave-uniform)
@@ -821,8 +823,8 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
                         T[0] = tape_word('r', tlen);
                     }
                 }
-                if (tlen > room) {  // (cannot happen: two words per structural + 2)
-                    tlen = 0;
+                if (tlen > room && !ex.cap) {  // (cannot happen: two words per structural + 2; with ex.cap: the caller's tape is too small,
+                    tlen = 0;                  //  reported through the length itself)
                     code = SJMI_E_INTERNAL;
                 }
             }
@@ -1531,7 +1533,7 @@ k_chunk_finish(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ idx
             unsigned long long* const T = scratch_tape + 2 * from;
             const uint32_t T0 = cw.fin[1];
             tlen = T0 + 1;
-            if (lane == 0) {
+            if (lane == 0 && tlen <= fin.tape_capacity) {
                 T[T0] = tape_word('r', 0);      // visitDocumentEnd, TapeBuilder.java:45-48
                 T[0] = tape_word('r', tlen);
             }
@@ -1822,6 +1824,8 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
     SingleFinish fin = {slow, d_tape_lens, d_doc_errors, tape_capacity, d_single_tape_offsets, d_res, tail.s1, tail.u, tail.pack};
     const bool optimistic = chunked && d_single_tape_offsets && tail.optimistic && tail.pack && count_bound > COOP_OPTIMISTIC_MIN;
     const uint32_t* only_if = nullptr;
+    ExactMode in_place;
+    in_place.cap = tail.in_place_cap;
     if (chunked) {
         cw = chunk_ws(d_chunk_ws, count_bound, reinterpret_cast<uint32_t*>(slow.count) + 8);  // (zeroed with the list's count above)
         const uint64_t nchunks = chunk_bound(count_bound);
@@ -1836,7 +1840,7 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
         hipLaunchKernelGGL((k_coop_walk<true>), dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets,
                            d_doc_status, d_soff, d_sb, d_doc_str_offsets, (unsigned long long)string_base, max_depth,
                            d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res, abl, cw, (const uint32_t*)nullptr,
-                           (unsigned long long*)nullptr, slow, ExactMode());
+                           (unsigned long long*)nullptr, slow, in_place);
         hipLaunchKernelGGL(k_chunk_finish, dim3(1), dim3(64), 0, stream, d_buf, d_idx, d_index_offsets, d_doc_status, d_scratch_tape,
                            d_tape_lens, d_doc_errors, dev_count, dev_strings, cw, fin, optimistic ? 1u : 0u);
         if (optimistic) return hipGetLastError();  // (three launches fewer on the single-document latency path)
@@ -1847,7 +1851,7 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
     hipLaunchKernelGGL((k_coop_walk<false>), dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_idx, d_index_offsets,
                        d_doc_status, d_soff, d_sb, d_doc_str_offsets, (unsigned long long)string_base, max_depth,
                        d_scratch_tape, d_tape_lens, d_doc_errors, dev_count, dev_strings, d_res, abl, cw, only_if,
-                       static_cast<unsigned long long*>(d_deep_ws), slow, ExactMode());
+                       static_cast<unsigned long long*>(d_deep_ws), slow, in_place);
     if (d_single_tape_offsets)
         hipLaunchKernelGGL(k_single_finish, dim3(1), dim3(64), 0, stream, d_buf, fin);
     else

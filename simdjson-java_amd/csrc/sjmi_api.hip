@@ -77,6 +77,13 @@ struct sjmi_ctx {
     void* d_ws_masks = nullptr;
     size_t ws_masks_bytes = 0;
     void* d_single = nullptr;                // sjmi_parse_document: delimiters, tape offsets, error and results of ONE document
+    void* s1_zero2 = nullptr;                // one-shot extras of the next stage1_device_impl call (sjmi_parse_document):
+    size_t s1_zero2_bytes = 0;               //   a second region its workers zero, the single-document setup its scanner writes
+    sjmi::Stage1Single s1_single;
+    bool s1_single_done = false;             // ... the last launch was FAST and did write it
+    const void* zc_host = nullptr;           // sjmi_parse_document: the caller's tape if it is device-visible (registered / pinned)
+    unsigned long long* zc_dev = nullptr;    // ... as the device sees it
+    void* h_single_dev = nullptr;            // h_single as the device sees it
     uint32_t* d_blkidx = nullptr;            // fused batch pipeline: k_stage1's per-block side outputs (stage1.h Stage1Extras)
     size_t blkidx_bytes = 0;
     uint16_t* d_blkw = nullptr;
@@ -424,7 +431,7 @@ const unsigned long long* parity_for(sjmi_ctx* c, const void* d_buf, uint64_t le
 // d_result == nullptr: the record inside the pass's workspace (zeroed with it: no memset of its own), returned in *used
 static int strings_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_string_buffer, uint64_t string_capacity,
                                uint32_t* d_soff, uint64_t soff_cap, uint32_t* d_blk_ord, void* d_result, hipStream_t st,
-                               sjmi::UnescapeResult** used = nullptr) {
+                               sjmi::UnescapeResult** used = nullptr, bool ws_is_zero = false) {
     const unsigned long long* par = parity_for(c, d_buf, len, st);
     if (!par) return SJMI_ERR_HIP;
     if (!grow(c, &c->d_ws_strm, &c->ws_strm_bytes, sjmi::strings_workspace_bytes(len), "hipMalloc(ws_strm)")) return SJMI_ERR_HIP;
@@ -434,7 +441,7 @@ static int strings_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, voi
     if ((!own && fail(c, "memset(result)", hipMemsetAsync(d_result, 0, sizeof(sjmi_unescape_result), st))) ||
         fail(c, "strings launch",
              sjmi::strings_launch((const uint8_t*)d_buf, len, par, (uint8_t*)d_string_buffer, string_capacity, d_soff, soff_cap,
-                                  d_blk_ord, c->d_ws_strm, (sjmi::UnescapeResult*)d_result, st)))
+                                  d_blk_ord, c->d_ws_strm, (sjmi::UnescapeResult*)d_result, st, nullptr, nullptr, sjmi::StringsAlt(), ws_is_zero)))
         return SJMI_ERR_HIP;
     return SJMI_OK;
 }
@@ -824,6 +831,10 @@ static int stage1_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, void
     ex.result_out = fast ? d_result : nullptr;
     ex.blkpar = shard_flags ? nullptr : parity_out(c, d_buf, len);
     if (shard_flags) c->par_valid = false;
+    ex.zero2 = c->s1_zero2;
+    ex.zero2_bytes = c->s1_zero2_bytes;
+    if (fast) ex.single = c->s1_single;
+    c->s1_single_done = fast && c->s1_single.index_offsets != nullptr;
     if (c->batch_side && !shard_flags) {  // (the fused batch pipeline's plain pass: per-block index positions and tape words)
         const size_t entries = sjmi::stage1_block_entries(len);
         if (!grow(c, (void**)&c->d_blkidx, &c->blkidx_bytes, entries * sizeof(uint32_t), "hipMalloc(blkidx)") ||
@@ -1213,6 +1224,24 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
     sjmi::WalkResult* d_wres = (sjmi::WalkResult*)(d64 + 13);
     sjmi::Stage1Result* d_res1 = (sjmi::Stage1Result*)(d64 + 20);
     SingleDocResults* h = (SingleDocResults*)c->h_single;
+    // ZERO-COPY OUTPUTS: a tape that lives in page-locked, device-visible host memory (sjmi_host_register / hipHostMalloc: what
+    // SimdJsonParser does with its buffers) is written by the walkers directly, over PCIe, and the packed result records land in
+    // the context's pinned page the same way -- no download of either, ONE host synchronisation instead of two (twitter.json:
+    // 0.147 -> ~0.12 ms).  A pageable tape takes the staged path below.
+    static const bool zero_copy_off = getenv("SJMI_ZERO_COPY") && atoi(getenv("SJMI_ZERO_COPY")) == 0;
+    if (c->zc_host != tape) {
+        c->zc_host = tape;
+        c->zc_dev = nullptr;
+        void* dp = nullptr;
+        if (!zero_copy_off && tape_capacity >= 16 && hipHostGetDevicePointer(&dp, tape, 0) == hipSuccess && dp) c->zc_dev = (unsigned long long*)dp;
+        else (void)hipGetLastError();  // (not device-visible: not an error)
+    }
+    if (!c->h_single_dev) {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, c->h_single, 0) == hipSuccess && dp) c->h_single_dev = dp;
+        else (void)hipGetLastError();
+    }
+    const bool zero_copy = c->zc_dev != nullptr && c->h_single_dev != nullptr;
     const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(len);
     if (!upload_document(c, buf, len)) return SJMI_ERR_HIP;
     c->soff_idx = nullptr;
@@ -1226,24 +1255,44 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
     // list header zeroed by the setup kernel.
     (void)steps;
     const AutoSafeOff own_retry(c);  // (the retry below is this call's own)
+    // (the string pass's workspace is zeroed by the stage-1 workers on their way out, and the delimiters / zeroed records the walk
+    //  needs are written by the stage-1 scanner together with the result record: a memset and a launch less in the chain)
+    const size_t strm_bytes = (sjmi::strings_workspace_bytes(len) + 15) & ~(size_t)15;
+    if (!grow(c, &c->d_ws_strm, &c->ws_strm_bytes, strm_bytes, "hipMalloc(ws_strm)")) return SJMI_ERR_HIP;
     for (int attempt = 0; attempt < 2; ++attempt) {
         strings_in_flight = false;
+        c->s1_zero2 = c->d_ws_strm;
+        c->s1_zero2_bytes = strm_bytes;
+        c->s1_single.doc_offsets = d_doc;
+        c->s1_single.index_offsets = d_io;
+        c->s1_single.doc_status = d_st;
+        c->s1_single.doc_str_offsets = d_dso;
+        c->s1_single.walk_result = reinterpret_cast<uint32_t*>(d_wres);
+        c->s1_single.slow_header = static_cast<uint32_t*>(sjmi::walk_slow_header(c->d_ws_walk, bound, 1));
         const int s1rc = stage1_device_impl(c, c->d_in, len, c->d_idx, c->capacity + 2, d_res1, c->stream, 0);
+        c->s1_zero2 = nullptr;
+        c->s1_zero2_bytes = 0;
+        c->s1_single = sjmi::Stage1Single();
+        const bool setup_done = c->s1_single_done;
+        c->s1_single_done = false;
         if (s1rc != SJMI_OK) return s1rc;
-        const int src = strings_device_impl(c, c->d_in, len, c->d_sb, c->sb_bytes, c->d_soff, (size_t)len / 2 + 2, nullptr, nullptr, c->stream, &d_ures);
+        const int src = strings_device_impl(c, c->d_in, len, c->d_sb, c->sb_bytes, c->d_soff, (size_t)len / 2 + 2, nullptr, nullptr, c->stream, &d_ures, true);
         if (src != SJMI_OK) return src;
         sjmi::SingleDocTail tail;
         tail.s1 = d_res1;
         tail.u = d_ures;
-        tail.pack = (sjmi::SingleDocPack*)((uint8_t*)c->d_single + 256);
+        tail.pack = zero_copy ? (sjmi::SingleDocPack*)c->h_single_dev : (sjmi::SingleDocPack*)((uint8_t*)c->d_single + 256);
+        tail.in_place_cap = zero_copy ? tape_capacity : 0;
+        unsigned long long* const walk_tape = zero_copy ? c->zc_dev : c->d_tape;
+        const uint64_t walk_cap = zero_copy ? tape_capacity : 2 * bound + 8;
         tail.optimistic = true;  // (a large document's chunk path ends in k_chunk_finish: a document it declines comes back flagged)
         if ((early_strings && fail(c, "event", hipEventRecord(c->strings_ready, c->stream))) ||
-            fail(c, "setup", sjmi::single_doc_setup_launch(d_res1, len, d_doc, d_io, d_st, d_dso, c->stream, d_wres,
-                                                           sjmi::walk_slow_header(c->d_ws_walk, bound, 1))) ||
+            (!setup_done && fail(c, "setup", sjmi::single_doc_setup_launch(d_res1, len, d_doc, d_io, d_st, d_dso, c->stream, d_wres,
+                                                                           sjmi::walk_slow_header(c->d_ws_walk, bound, 1)))) ||
             fail(c, "walk launch",
-                 sjmi::walk_launch(c->d_in, d_doc, 1, c->d_idx, bound, d_io, d_st, c->d_sb, d_dso, 0, max_depth, c->d_tape,
-                                   2 * bound + 8, d_to, d_err, c->d_ws_walk, d_wres, c->stream, d_res1, d_ures, c->d_soff, true, true, tail)) ||
-            fail(c, "D2H", hipMemcpyAsync(h, tail.pack, sizeof *h, hipMemcpyDeviceToHost, c->stream)))
+                 sjmi::walk_launch(c->d_in, d_doc, 1, c->d_idx, bound, d_io, d_st, c->d_sb, d_dso, 0, max_depth, walk_tape,
+                                   walk_cap, d_to, d_err, c->d_ws_walk, d_wres, c->stream, d_res1, d_ures, c->d_soff, true, true, tail)) ||
+            (!zero_copy && fail(c, "D2H", hipMemcpyAsync(h, tail.pack, sizeof *h, hipMemcpyDeviceToHost, c->stream))))
             return SJMI_ERR_HIP;
         // (everything of the main stream is queued: now the early look at the string records)
         if (early_strings) {
@@ -1266,9 +1315,9 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
             if (fail(c, "setup", sjmi::single_doc_setup_launch(d_res1, len, d_doc, d_io, d_st, d_dso, c->stream, d_wres,
                                                                sjmi::walk_slow_header(c->d_ws_walk, bound, 1))) ||
                 fail(c, "walk launch",
-                     sjmi::walk_launch(c->d_in, d_doc, 1, c->d_idx, bound, d_io, d_st, c->d_sb, d_dso, 0, max_depth, c->d_tape,
-                                       2 * bound + 8, d_to, d_err, c->d_ws_walk, d_wres, c->stream, d_res1, d_ures, c->d_soff, true, true, tail)) ||
-                fail(c, "D2H", hipMemcpyAsync(h, tail.pack, sizeof *h, hipMemcpyDeviceToHost, c->stream)) ||
+                     sjmi::walk_launch(c->d_in, d_doc, 1, c->d_idx, bound, d_io, d_st, c->d_sb, d_dso, 0, max_depth, walk_tape,
+                                       walk_cap, d_to, d_err, c->d_ws_walk, d_wres, c->stream, d_res1, d_ures, c->d_soff, true, true, tail)) ||
+                (!zero_copy && fail(c, "D2H", hipMemcpyAsync(h, tail.pack, sizeof *h, hipMemcpyDeviceToHost, c->stream))) ||
                 fail(c, "sync", hipStreamSynchronize(c->stream)))
                 return SJMI_ERR_HIP;
         }
@@ -1293,10 +1342,10 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
         c->err = "tape or string capacity too small";
         return SJMI_ERR_CAPACITY;
     }
-    if (fail(c, "D2H(tape)", hipMemcpyAsync(tape, c->d_tape + h->to[0], words * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream)) ||
-        (h->u.total_bytes && !strings_in_flight &&
-         fail(c, "D2H(sb)", hipMemcpyAsync(string_buffer, c->d_sb, h->u.total_bytes, hipMemcpyDeviceToHost, c->stream))) ||
-        fail(c, "sync", hipStreamSynchronize(c->stream)))
+    const bool copy_strings = h->u.total_bytes && !strings_in_flight;
+    if ((!zero_copy && fail(c, "D2H(tape)", hipMemcpyAsync(tape, c->d_tape + h->to[0], words * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream))) ||
+        (copy_strings && fail(c, "D2H(sb)", hipMemcpyAsync(string_buffer, c->d_sb, h->u.total_bytes, hipMemcpyDeviceToHost, c->stream))) ||
+        ((!zero_copy || copy_strings) && fail(c, "sync", hipStreamSynchronize(c->stream))))
         return SJMI_ERR_HIP;
     *tape_len = words;
     *strings_len = h->u.total_bytes;

@@ -35,6 +35,8 @@ struct SingleDocTail {          // where that launch finds / leaves them; pack =
     bool optimistic = false;    // the chunk path ends in k_chunk_finish and nothing is queued behind it: a document it does not
                                 // take (pack->fallback != 0) is the caller's to run again with no_chunks
     bool no_chunks = false;     // the single-wave sweep only
+    uint64_t in_place_cap = 0;  // != 0: d_tape is the CALLER's tape (mapped host memory) with this many words: the walkers write
+                                // it in place whatever the structural count's bound says, clamped to it
 };
 
 // device-side result of one batch walk; mirrors sjmi_walk_result in include/sjmi.h
@@ -85,6 +87,16 @@ struct Stage1Prefixes {
 Stage1Prefixes stage1_prefixes(const void* d_ws, uint64_t len, int steps);
 int stage1_pick_steps(uint64_t len);
 size_t stage1_block_entries(uint64_t len);
+// sjmi_parse_document: the delimiters of ONE document for the batch kernels behind stage 1 (doc / index / string offsets, status)
+// and the two small records the walk wants zeroed -- written by the stage-1 scanner together with the result record
+struct Stage1Single {
+    unsigned long long* doc_offsets = nullptr;
+    unsigned long long* index_offsets = nullptr;  // nullptr: nothing to do
+    uint32_t* doc_status = nullptr;
+    unsigned long long* doc_str_offsets = nullptr;
+    uint32_t* walk_result = nullptr;   // sizeof(WalkResult) bytes
+    uint32_t* slow_header = nullptr;   // 64 bytes
+};
 // optional work folded into the kernel (device-resident path): see zero_next_workspace / scanner_wave in stage1.hip
 struct Stage1Extras {
     bool workspace_is_zero = false;  // skip the workspace memset (a previous launch zeroed this workspace)
@@ -92,6 +104,9 @@ struct Stage1Extras {
     size_t zero_bytes = 0;           //   ... this many bytes of it (multiple of 16)
     void* result_out = nullptr;      // device sjmi_stage1_result written by the scanner (FAST mode only)
     const uint32_t* skip = nullptr;  // device flag: != 0 -> the launch does nothing (fused batch pipeline)
+    void* zero2 = nullptr;           // a second region zeroed by the workers on their way out (16-byte aligned, multiple of 16 bytes):
+    size_t zero2_bytes = 0;          //   the string pass's workspace on the single-document latency path (one memset less)
+    Stage1Single single;             // ... and what k_single_doc_setup would write, done by the scanner (FAST mode; one launch less)
     void* blkidx = nullptr;          // batch side outputs (both or neither): u32 per 64-byte block = index position of the block's
     void* blkw = nullptr;            //   first structural; u16 per block = its tape words for entry parity 0 | 1 << 8; stage1_block_entries(len) each
     void* blkpar = nullptr;          // side output for strings.hip: u64 per 4 KiB of input, bit l = block l is entered inside a
@@ -114,7 +129,7 @@ struct StringsAlt {
 hipError_t strings_launch(const uint8_t* d_buf, uint64_t len, const unsigned long long* d_blkpar, uint8_t* d_sb, uint64_t sb_cap,
                           uint32_t* d_soff, uint64_t soff_cap, uint32_t* d_blk_ord, void* d_ws, UnescapeResult* d_res,
                           hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
-                          const StringsAlt& alt = StringsAlt());
+                          const StringsAlt& alt = StringsAlt(), bool workspace_is_zero = false);
 // batches whose documents were indexed one by one: the copy the string pass runs on (failed documents blanked); d_skip != null
 // and *d_skip != 0: nothing to do (the optimistic plain pass was accepted)
 hipError_t strings_sanitize_launch(const uint8_t* d_buf, uint64_t total_len, const unsigned long long* d_doc_offsets,

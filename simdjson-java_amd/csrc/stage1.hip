@@ -316,9 +316,23 @@ __device__ __forceinline__ void scanner_publish(const sj_u64 v[SCAN_K], sj_u64* 
     }
 }
 
+// (one lane, behind the result record: see Stage1Single)
+__device__ __forceinline__ void single_doc_setup(const Stage1Single& ss, sj_u64 len, sj_u64 count, uint32_t status) {
+    if (!ss.index_offsets) return;
+    ss.doc_offsets[0] = 0;
+    ss.doc_offsets[1] = len;
+    ss.index_offsets[0] = 0;
+    ss.index_offsets[1] = (status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL)) ? 0ull : count;
+    ss.doc_status[0] = status & 0xFFu;
+    ss.doc_str_offsets[0] = 0;
+    ss.doc_str_offsets[1] = 0;
+    for (int i = 0; i < (int)(sizeof(WalkResult) / 4); ++i) ss.walk_result[i] = 0;
+    for (int i = 0; i < 16; ++i) ss.slow_header[i] = 0;
+}
+
 __device__ __forceinline__ void scanner_wave(ScanHandoff* hand, int wave, const sj_u64* agg, sj_u64* pfx, uint32_t n,
                                              int lane, uint32_t* out, sj_u64 out_cap, Stage1Result* res,
-                                             Stage1Result* result_out) {
+                                             Stage1Result* result_out, const Stage1Single& ss, sj_u64 len) {
     __builtin_amdgcn_s_setprio(3);  // everybody waits for these four waves
     constexpr uint32_t WIN = 64 * SCAN_K;
     const sj_u64 lt_mask = (1ull << lane) - 1ull;
@@ -405,6 +419,7 @@ __device__ __forceinline__ void scanner_wave(ScanHandoff* hand, int wave, const 
                             result_out->count = 0;
                             result_out->status = SJMI_ST_INTERNAL;
                             result_out->reserved = 0;
+                            single_doc_setup(ss, len, 0, SJMI_ST_INTERNAL);
                         }
                     }
                     return;
@@ -434,9 +449,11 @@ __device__ __forceinline__ void scanner_wave(ScanHandoff* hand, int wave, const 
             else e |= SJMI_ST_CAPACITY;      // (== some granule did not fit: they are written in order)
             if (e) __hip_atomic_fetch_or(&res->status, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (result_out) {  // device-resident path: the caller's record, without a copy queued behind the kernel
+                const uint32_t st_all = e | __hip_atomic_load(&res->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 result_out->count = C2;
-                result_out->status = e | __hip_atomic_load(&res->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                result_out->status = st_all;
                 result_out->reserved = 0;
+                single_doc_setup(ss, len, C2, st_all);
             }
         }
     }
@@ -556,7 +573,7 @@ __device__ __forceinline__ void
 stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out, sj_u64 out_cap,
             sj_u64* gstate, uint32_t* ticket, Stage1Result* res, uint32_t ngran, uint32_t dbg, uint4* zero_ptr,
             uint32_t zero_chunks, Stage1Result* result_out, sj_u64* __restrict__ blkpar, const uint32_t* __restrict__ skip,
-            uint32_t* __restrict__ blkidx, uint16_t* __restrict__ blkw) {
+            uint32_t* __restrict__ blkidx, uint16_t* __restrict__ blkw, uint4* zero2_ptr, uint32_t zero2_chunks, const Stage1Single& ss) {
     constexpr int E = S, CAP = LDSW / 4;
     if (skip && *skip) return;  // (fused batch pipeline: this pass is not needed; uniform for the whole launch)
     static_assert(S <= 4, "meta packs 14-bit offsets: at most 4 steps per granule");
@@ -582,7 +599,7 @@ stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ 
             hand.C = 0;
         }
         __syncthreads();
-        if (!(dbg & DBG_NO_LOOKBACK)) scanner_wave(&hand, wave, agg, pfx, ngran, lane, out, out_cap, res, result_out);
+        if (!(dbg & DBG_NO_LOOKBACK)) scanner_wave(&hand, wave, agg, pfx, ngran, lane, out, out_cap, res, result_out, ss, len);
         return;
     }
     const uint32_t nworkers = (gridDim.x - (safe ? 0u : 1u)) * 4u;
@@ -940,6 +957,7 @@ stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ 
     if (lane == 0 && err && !(dbg & DBG_NO_LOOKBACK))  // (with fake prefixes every granule would report errors)
         __hip_atomic_fetch_or(&res->status, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     zero_next_workspace(zero_ptr, zero_chunks, worker, nworkers, lane);
+    zero_next_workspace(zero2_ptr, zero2_chunks, worker, nworkers, lane);
 }
 
 // The kernels proper.  The BATCH flavour is pinned to the occupancy of the plain one (four waves per SIMD = 128 VGPRs): its two
@@ -952,9 +970,9 @@ __global__ void __launch_bounds__(256)
 k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out, sj_u64 out_cap,
          sj_u64* gstate, uint32_t* ticket, Stage1Result* res, uint32_t ngran, uint32_t dbg, uint4* zero_ptr,
          uint32_t zero_chunks, Stage1Result* result_out, sj_u64* __restrict__ blkpar, const uint32_t* __restrict__ skip,
-         uint32_t* __restrict__ blkidx, uint16_t* __restrict__ blkw) {
+         uint32_t* __restrict__ blkidx, uint16_t* __restrict__ blkw, uint4* zero2_ptr, uint32_t zero2_chunks, Stage1Single ss) {
     stage1_body<S, LDSW, SAFE, false>(buf, len, out, out_cap, gstate, ticket, res, ngran, dbg, zero_ptr, zero_chunks, result_out, blkpar,
-                                      skip, blkidx, blkw);
+                                      skip, blkidx, blkw, zero2_ptr, zero2_chunks, ss);
 }
 #ifndef SJMI_S1_BATCH_WAVES
 #define SJMI_S1_BATCH_WAVES 4
@@ -967,9 +985,9 @@ __attribute__((amdgpu_waves_per_eu(SJMI_S1_BATCH_WAVES, SJMI_S1_BATCH_WAVES)))
 k_stage1_batch(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out, sj_u64 out_cap,
                sj_u64* gstate, uint32_t* ticket, Stage1Result* res, uint32_t ngran, uint32_t dbg, uint4* zero_ptr,
                uint32_t zero_chunks, Stage1Result* result_out, sj_u64* __restrict__ blkpar, const uint32_t* __restrict__ skip,
-               uint32_t* __restrict__ blkidx, uint16_t* __restrict__ blkw) {
+               uint32_t* __restrict__ blkidx, uint16_t* __restrict__ blkw, uint4* zero2_ptr, uint32_t zero2_chunks, Stage1Single ss) {
     stage1_body<S, LDSW, SAFE, true>(buf, len, out, out_cap, gstate, ticket, res, ngran, dbg, zero_ptr, zero_chunks, result_out, blkpar,
-                                     skip, blkidx, blkw);
+                                     skip, blkidx, blkw, zero2_ptr, zero2_chunks, ss);
 }
 template <int S, int LDSW, bool SAFE>
 struct Stage1Kernel<S, LDSW, SAFE, false> {
@@ -1048,14 +1066,16 @@ static hipError_t launch_mode(const uint8_t* d_buf, uint64_t len, uint32_t* d_ou
     sj_u64* bp = static_cast<sj_u64*>(ex.blkpar);
     uint32_t* bi = static_cast<uint32_t*>(ex.blkidx);
     uint16_t* bw = static_cast<uint16_t*>(ex.blkw);
+    uint4* z2 = static_cast<uint4*>(ex.zero2);
+    const uint32_t z2c = (uint32_t)(ex.zero2_bytes / 16);
     if (ev_start && ev_stop) {
         // the events are attached to the dispatch itself (its start / end timestamps), not recorded around it:
         // hipEventRecord pairs added 10-25 us of queue latency to a 200 us kernel
         hipExtLaunchKernelGGL((Stage1Kernel<S, LDSW, SAFE, BATCH>::fn), grid, block, 0, stream, ev_start, ev_stop, 0, d_buf, (sj_u64)len,
-                              d_out, (sj_u64)out_cap, gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro, bp, ex.skip, bi, bw);
+                              d_out, (sj_u64)out_cap, gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro, bp, ex.skip, bi, bw, z2, z2c, ex.single);
     } else {
         hipLaunchKernelGGL((Stage1Kernel<S, LDSW, SAFE, BATCH>::fn), grid, block, 0, stream, d_buf, (sj_u64)len, d_out, (sj_u64)out_cap,
-                           gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro, bp, ex.skip, bi, bw);
+                           gs, ticket, res, (uint32_t)ngran, dbg, zp, zc, ro, bp, ex.skip, bi, bw, z2, z2c, ex.single);
     }
     return hipGetLastError();
 }

@@ -860,9 +860,9 @@ static hipError_t str_resident(unsigned* out) {
 // string literal of buf[0, len) go to d_sb; optional: d_soff (offset of record k), d_blk_ord (see StrArgs)
 hipError_t strings_launch(const uint8_t* d_buf, uint64_t len, const unsigned long long* d_blkpar, uint8_t* d_sb, uint64_t sb_cap,
                           uint32_t* d_soff, uint64_t soff_cap, uint32_t* d_blk_ord, void* d_ws, UnescapeResult* d_res,
-                          hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, const StringsAlt& alt) {
+                          hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, const StringsAlt& alt, bool workspace_is_zero) {
     const uint64_t ngran = str_granules(len);
-    hipError_t e = hipMemsetAsync(d_ws, 0, strings_workspace_bytes(len), stream);
+    hipError_t e = workspace_is_zero ? hipSuccess : hipMemsetAsync(d_ws, 0, strings_workspace_bytes(len), stream);
     if (e != hipSuccess) return e;
     uint8_t* ws = static_cast<uint8_t*>(d_ws);
     StrArgs a;

@@ -203,7 +203,7 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
     unsigned long long* scratch = reinterpret_cast<unsigned long long*>(ws);
     // one document whose index range starts at 0 (only sjmi_parse_document knows that: the walker's slot for document 0 is
     // T = tape + 2 * index_offsets[0]) and room for two words per structural: the walker writes the tape in place
-    const bool direct = index_from_zero && n_docs == 1 && tape_capacity >= 2 * count + 2;
+    const bool direct = index_from_zero && n_docs == 1 && (tape_capacity >= 2 * count + 2 || tail.in_place_cap != 0);
     if (direct) scratch = d_tape;
     uint32_t* lens = reinterpret_cast<uint32_t*>(ws + walk_lens_offset(count, n_docs));
     unsigned long long* sums = reinterpret_cast<unsigned long long*>(ws + walk_sums_offset(count, n_docs));
