@@ -748,6 +748,12 @@ def bench_sharded(args, world):
     work.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(work)
     st = work.cuda_stream
+    # (anything that might still have to be compiled -- the checker, the document generator; all of it normally travels prebuilt --
+    #  is built by rank 0 alone, the others wait: N ranks compiling the same .so at once would corrupt it)
+    if rank == 0:
+        oracle.build()
+        W.build_docgen()
+    dist.barrier()
     oracle.build()
 
     def gather_rows(row):  # the ONLY collective: [world, 4] int64, device tensors (gloo: through the host)

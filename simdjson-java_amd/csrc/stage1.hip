@@ -622,7 +622,7 @@ stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ 
     // identical and the chain's back-pressure keeps them together (measured: 6 or 8 classes are equally fast, 4
     // are ticket-bound, 32 drift apart: +2 %).  Only the FIRST granule of every wave is static (= its worker index,
     // the counters start behind those): taking it by ticket as well would make a launch whose workgroups are not all
-    // resident degrade gracefully instead of timing out into SAFE mode, but costs 6 % (A/B: tools/abtest.sh).
+    // resident degrade gracefully instead of timing out into SAFE mode, but costs 6 % (A/B: tools/archive/abtest.sh).
     // SAFE: one counter, every granule by ticket, taken when needed (any running wave can take any granule).
     const uint32_t NC = safe ? 1u : (nworkers < TICKET_CLASSES ? nworkers : TICKET_CLASSES);
     const uint32_t cls = worker % NC;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Turn a tools/prof.sh output directory (gpurun_out/prof_<tag>) into the tracked summaries under profiles/<round>/:
+"""Turn a tools/archive/prof.sh output directory (gpurun_out/prof_<tag>) into the tracked summaries under profiles/<round>/:
 kernel_stats.csv (rocprofv3 --kernel-trace --stats), kernel_durations.json (per-launch durations of k_stage1 from the
 kernel trace, so the steady state can be told from the clock ramp), pmc_summary.json (per-launch counter averages)."""
 import collections, csv, glob, json, os, shutil, sys
