@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "sj_block.h"
+#include "sj_strings.h"
 #include "stage1.h"
 
 namespace sjmi {
@@ -183,17 +184,23 @@ k_doc_prepare(DocPrepare a) {
         for (int t = 0; t < 16; ++t) {
             nb += (unsigned long long)e[t] < pos ? 1u : 0u;
             w += prep_words_of(c16[t]);
-            q += c16[t] == '"';
         }
         j += nb;
         if (nb == 16u) {
             for (int t = 16; t < 64 && j < count; ++t, ++j) {  // (a block has at most 64 structurals)
                 const uint32_t p = a.idx[j];
                 if ((unsigned long long)p >= pos) break;
-                const uint32_t c = a.buf[p];
-                w += prep_words_of(c);
-                q += c == '"';
+                w += prep_words_of(a.buf[p]);
             }
+        }
+        // the strings opened in the block in front of the boundary: counted on the BYTES (the '"' structurals would miss a quote
+        // directly behind a primitive -- 1"abc" -- which opens a string for the string pass all the same: a malformed document,
+        // but the documents behind it in the same block need their ordinals right)
+        if (pos & 63) {
+            const unsigned long long start = b << 6;
+            const uint32_t in_str = (uint32_t)(a.blkpar[b >> 6] >> (b & 63)) & 1u;
+            const uint32_t e_in = b ? sj_backslash_run_parity(a.buf, 0, start) : 0u;
+            q = sj_str_opens_before(a.buf, start, (uint32_t)(pos & 63), in_str, e_in);
         }
         *io = (uint32_t)j;
         *pw = w;

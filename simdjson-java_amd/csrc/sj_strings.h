@@ -95,6 +95,32 @@ SJ_HD T sj_escaped_mask(T bsraw, uint32_t e_in) {
     return (EVEN ^ (T)(seq_even << 1)) & follows;
 }
 
+// The strings OPENED in the first `upto` bytes (< 64) of the 64-byte block at buf + start, given whether the block is entered
+// inside a string and whether its first byte is escaped: quotes and backslashes of the block as 64-bit masks (a SWAR compare
+// per dword, a multiply gathers the four flag bits), then StructuralIndexer.java:211-234 on them.  NOT the '"' structurals of the
+// index array: a quote directly behind a primitive (1"abc") opens a string for the string pass without being a structural.
+SJ_HD uint32_t sj_str_opens_before(const uint8_t* buf, sj_u64 start, uint32_t upto, uint32_t in_str, uint32_t e_in) {
+    sj_u64 qm = 0, bm = 0;
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t w = reinterpret_cast<const uint32_t*>(buf + start)[i];
+        const uint32_t zq = w ^ 0x22222222u, zb = w ^ 0x5C5C5C5Cu;
+        const uint32_t fq = ~(((zq & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | zq) & 0x80808080u;  // 0x80 where the byte matches
+        const uint32_t fb = ~(((zb & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | zb) & 0x80808080u;
+        const sj_u64 nq = (((fq >> 7) * 0x00204081u) >> 21) & 0xFu, nb = (((fb >> 7) * 0x00204081u) >> 21) & 0xFu;
+        qm |= nq << (4 * i);
+        bm |= nb << (4 * i);
+    }
+    const sj_u64 quote = qm & ~sj_escaped_mask<sj_u64>(bm, e_in);
+    const sj_u64 in0 = sj_prefix_xor(quote);
+    const sj_u64 opens = quote & (in_str ? ~in0 : in0);
+    const sj_u64 below = upto >= 64u ? ~0ull : ((1ull << upto) - 1ull);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popcll(opens & below);
+#else
+    return (uint32_t)__builtin_popcountll(opens & below);
+#endif
+}
+
 struct SjStrBlock {
     sj_u64 K;            // kept bytes (content that is copied, slots of \u sequences included)
     sj_u64 O, CL;        // opening / closing quotes

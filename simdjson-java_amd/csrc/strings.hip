@@ -962,30 +962,10 @@ k_doc_str_ordinals(const uint8_t* __restrict__ buf0, const uint8_t* __restrict__
         const unsigned long long b = pos >> 6, start = b * 64;
         ord = blk_ord[b];
         if (pos > start) {
-            // the strings opened in [start, pos): quotes and backslashes of the block as 64-bit masks (SWAR compare per dword, a
-            // multiply gathers the four flag bits), then StructuralIndexer.java:211-234 on them
+            // the strings opened in [start, pos) (sj_strings.h: counted on the bytes, from the block's entry state)
             const uint32_t in_str = (uint32_t)(par[b >> 6] >> (b & 63)) & 1u;
             const uint32_t e_in = b ? sj_backslash_run_parity(buf, 0, start) : 0u;
-            sj_u64 qm = 0, bm = 0;
-            const uint4* src = reinterpret_cast<const uint4*>(buf + start);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint4 v = src[q];
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const uint32_t zq = w[t] ^ 0x22222222u, zb = w[t] ^ 0x5C5C5C5Cu;
-                    const uint32_t fq = ~(((zq & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | zq) & 0x80808080u;  // 0x80 where the byte matches
-                    const uint32_t fb = ~(((zb & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | zb) & 0x80808080u;
-                    const sj_u64 nq = (((fq >> 7) * 0x00204081u) >> 21) & 0xFu, nb = (((fb >> 7) * 0x00204081u) >> 21) & 0xFu;
-                    qm |= nq << (16 * q + 4 * t);
-                    bm |= nb << (16 * q + 4 * t);
-                }
-            }
-            const sj_u64 quote = qm & ~sj_escaped_mask<sj_u64>(bm, e_in);
-            const sj_u64 in0 = sj_prefix_xor(quote);
-            const sj_u64 opens = quote & (in_str ? ~in0 : in0);
-            ord += (unsigned long long)__popcll(opens & ((1ull << (pos - start)) - 1ull));
+            ord += (unsigned long long)sj_str_opens_before(buf, start, (uint32_t)(pos - start), in_str, e_in);
         }
         if (ord > nstr) ord = nstr;
     }

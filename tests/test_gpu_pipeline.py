@@ -146,3 +146,35 @@ def test_optimistic_plain_pass_and_its_rejections(separator, monkeypatch):
             assert c["failed_documents"] == n_bad, name
     finally:
         ctx.close()
+
+
+def test_accepted_batch_with_strings_that_are_not_structurals():
+    """A quote directly behind a primitive (1"abc", true"x") opens a string for the string pass without being a structural
+    (StructuralIndexer.java:243-248: a scalar start needs a non-scalar in front of it).  Such a document passes stage 1 and fails
+    stage 2 -- but the documents BEHIND it in the same 64-byte block take their first string ordinal from a count of the strings
+    opened in front of them, and that count must see the quote (found by tools/soak_pipeline.py, round 4: the accepted plain
+    pass counted '"' structurals).  Every document against the oracle, through the fused call."""
+    import simdjson_java_amd as S
+    rng = random.Random(5)
+    good = _small_docs(rng, 400)
+    odd = [b'1"abc"', b'true"x"', b'[1"a","b"]', b'{"k":2"v"}', b'null"n""m"', b'-0"z"']
+    docs = []
+    for i in range(1200):
+        docs.append(odd[i % len(odd)] if i % 3 == 0 else (good[i % len(good)] if i % 3 == 1 else [b'"s%d"' % i, b'["a","b%d"]' % i, b'{"q":"r"}'][i % 9 // 3]))
+    ctx = S.Context(0, 1 << 20)
+    try:
+        buf = b"".join(d + b"\n" for d in docs)
+        offs = np.concatenate([[0], np.cumsum([len(d) + 1 for d in docs])]).astype(np.uint64)
+        c, tape, to, err, strings, io, idx = _run_shard(ctx, buf, offs, len(docs))
+        assert c["stage1_status"] == 0  # (every document passes stage 1: the plain pass is accepted)
+        n_bad = 0
+        for k, d in enumerate(docs):
+            want = O.parse(d + b"\n")
+            assert int(err[k]) == want.error, (k, d, int(err[k]), want.error)
+            if want.error:
+                n_bad += 1
+            else:
+                assert O.Parsed(tape[int(to[k]):int(to[k + 1])], strings, 0, 0, 0).to_python() == want.to_python(), (k, d)
+        assert n_bad >= 400 and c["failed_documents"] == n_bad
+    finally:
+        ctx.close()
