@@ -178,3 +178,30 @@ def test_accepted_batch_with_strings_that_are_not_structurals():
         assert n_bad >= 400 and c["failed_documents"] == n_bad
     finally:
         ctx.close()
+
+
+def test_accepted_batch_with_a_large_and_a_deep_document(twitter):
+    """Documents the token walker's per-document assumptions do not cover, inside an ACCEPTED batch (all pass stage 1, newline
+    separators): one large document (twitter.json: 864 chunks of structurals through the ring), nesting beyond the 64 levels of
+    the register stack (handed to the exact walker), nesting beyond max_depth, a document of one token -- every document against
+    the oracle, tapes at their final addresses."""
+    import simdjson_java_amd as S
+    rng = random.Random(11)
+    small = _small_docs(rng, 300)
+    deep70 = b"[" * 70 + b"1" + b"]" * 70
+    deep1100 = b"[" * 1100 + b"]" * 1100
+    docs = small[:100] + [twitter.rstrip(b"\n")] + small[100:200] + [deep70, b"7", b'"root string"', deep1100, b"[]", b"{}"] + small[200:]
+    ctx = S.Context(0, 4 << 20)
+    try:
+        buf = b"".join(d + b"\n" for d in docs)
+        offs = np.concatenate([[0], np.cumsum([len(d) + 1 for d in docs])]).astype(np.uint64)
+        c, tape, to, err, strings, io, idx = _run_shard(ctx, buf, offs, len(docs))
+        assert c["stage1_status"] == 0
+        for k, d in enumerate(docs):
+            want = O.parse(d + b"\n")
+            assert int(err[k]) == want.error, (k, d[:40], int(err[k]), want.error)
+            if want.error == 0:
+                assert O.Parsed(tape[int(to[k]):int(to[k + 1])], strings, 0, 0, 0).to_python() == want.to_python(), (k, d[:40])
+        assert c["failed_documents"] == 1 and c["host_documents"] == 0  # (the 1,100-level document: maxDepth 1024)
+    finally:
+        ctx.close()
