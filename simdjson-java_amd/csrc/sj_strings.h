@@ -101,8 +101,17 @@ SJ_HD T sj_escaped_mask(T bsraw, uint32_t e_in) {
 // index array: a quote directly behind a primitive (1"abc") opens a string for the string pass without being a structural.
 SJ_HD uint32_t sj_str_opens_before(const uint8_t* buf, sj_u64 start, uint32_t upto, uint32_t in_str, uint32_t e_in) {
     sj_u64 qm = 0, bm = 0;
+    uint32_t w16[16];  // (the block is 16-byte aligned: four 16-byte loads on the device)
+    for (int v = 0; v < 4; ++v) {
+        struct alignas(16) Q4 { uint32_t a, b, c, d; };
+        const Q4 q4 = reinterpret_cast<const Q4*>(buf + start)[v];
+        w16[4 * v] = q4.a;
+        w16[4 * v + 1] = q4.b;
+        w16[4 * v + 2] = q4.c;
+        w16[4 * v + 3] = q4.d;
+    }
     for (int i = 0; i < 16; ++i) {
-        const uint32_t w = reinterpret_cast<const uint32_t*>(buf + start)[i];
+        const uint32_t w = w16[i];
         const uint32_t zq = w ^ 0x22222222u, zb = w ^ 0x5C5C5C5Cu;
         const uint32_t fq = ~(((zq & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | zq) & 0x80808080u;  // 0x80 where the byte matches
         const uint32_t fb = ~(((zb & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | zb) & 0x80808080u;
