@@ -892,6 +892,10 @@ struct TokArgs {
 struct __attribute__((aligned(8))) TokRing {
     uint2 e[128];  // .x = position, .y = class | pre << 3 (0 none, 1 ',', 2 ':') | two separators in front << 5 | first byte << 8
 };
+struct __attribute__((aligned(8))) TokStack {
+    uint2 stk[64];      // the open containers of the wave's document by level: .x = tape position of the opening word, .y = commas so far | is-array << 31
+    uint32_t cnt[64];   // per token of the current step: an opening bracket's commas so far | closed-in-this-step << 30
+};
 constexpr int32_t CW_NEEDS_EXACT = -100;  // (internal, overwritten by the exact walker)
 // Primitives are parsed DENSELY: a token step only queues its atoms and numbers (window, position, where the words go, which
 // document), and whenever 64 are waiting they are parsed with every lane at work -- a quarter of a record's tokens are
@@ -910,10 +914,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SJMI_T
 k_tok_walk(TokArgs a) {
     __shared__ TokRing rings[4];
     __shared__ PrimQueue queues[4];
+    __shared__ TokStack stacks[4];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     TokRing& ring = rings[wv];
     PrimQueue& pq = queues[wv];
+    TokStack& st = stacks[wv];
     uint32_t qhead = 0, qtail = 0;
     // a document for the exact walker: listed once, whoever finds out first (doc_errors[] starts at 0: k_doc_prepare / k_doc_meta)
     auto send_to_exact = [&](uint32_t doc) {
@@ -951,7 +957,6 @@ k_tok_walk(TokArgs a) {
     const bool upstream_failed = (a.dev_count && (a.dev_count->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL))) ||
                                  (a.dev_strings && (a.dev_strings->flags & 0xFu));
     const bool string_errors = a.dev_strings && a.dev_strings->first_error_inv != 0;
-    uint32_t st_tpos = 0, st_cnt = 0;  // the stack of open containers: LANE L = level L (tape position of the opening word, commas so far)
     auto load_pos = [&](uint32_t from, uint32_t to, uint32_t c, uint32_t dflt) -> uint32_t {
         const uint32_t i = from + c * 64u + (uint32_t)lane;
         return i < to ? a.idx[i] : dflt;
@@ -977,14 +982,14 @@ k_tok_walk(TokArgs a) {
         unsigned long long* const T = tape + t_off;
         const unsigned long long room64 = t_end - t_off;
         const uint32_t room = room64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)room64;
-        bool ok = !upstream_failed && m.st == 0 && n != 0 && n <= 0x7FFFFF00u && to <= 0xFFFFFF00u;
+        // (more than 2^30 structurals: the comma counters keep two flag bits -- such a document goes to the exact walker)
+        bool ok = !upstream_failed && m.st == 0 && n != 0 && n < (1u << 30) && to <= 0xFFFFFF00u;
         uint32_t tlen = 0;
         if (ok) {
             const uint32_t doc_start = m.doc_start;
             const uint32_t nchunks = (n + 63u) / 64u;
             // ---- running state (wave-uniform) ----
             uint32_t H0 = 0, T0 = 1, S0 = m.dso;
-            unsigned long long arr_mask = 0;
             uint32_t prev_cls = K_COMMA;
             bool prev_empty_open = false, prev_is_key = false, root_closed = false, at_start = true;
             uint32_t pq_tpos = 0, pq_off = 0;
@@ -1072,53 +1077,46 @@ k_tok_walk(TokArgs a) {
                 const unsigned long long qm = cw_ballot(is_str);
                 const uint32_t sord = S0 + (uint32_t)__popcll(qm & lt_mask);
                 const uint32_t rec_off = is_str ? a.soff[sord] : 0u;  // (used one step later)
-                // (4) the container of every token: one trip per depth level present in the step
+                // (4) the container of every token.  One trip per depth level present in the step finds the opening bracket of
+                // a token's container among the step's own 64 tokens (the last open of that level in front of it); a container
+                // opened in an earlier step sits on the wave's STACK IN LDS, entry = level: {tape position of its opening word,
+                // commas so far | is-array << 31}.  Comma counts are LDS atomics -- every token that follows a ',' adds one to its
+                // container's counter (the opener's slot of this step, or the stack entry), every closing bracket marks its
+                // opener's slot closed -- so the level loop carries no per-level scalar bookkeeping at all, and what the next
+                // steps need is three LDS operations: the openers that were not closed push themselves.
                 const int plevel = h - 1;
                 int hmin = cw_wave_minmax<false>(valid ? plevel : 0x7FFF), hmax = cw_wave_minmax<true>(valid ? (is_open ? h : plevel) : -0x7FFF);
                 if (hmin < 0) hmin = 0;
                 if (hmax >= CW_LEVELS) hmax = CW_LEVELS - 1;  // (deeper: handed to the exact walker below)
-                const int key = valid ? (is_open ? h : plevel) : -1;
                 const bool comma_in_front = valid && pre == 1u;
-                const uint32_t st_tpos0 = st_tpos, st_cnt0 = st_cnt;
-                const unsigned long long arr_mask0 = arr_mask;
                 int par_lane = -1;
-                uint32_t kc = 0;
                 for (int L = hmin; L <= hmax; ++L) {
-                    const unsigned long long O = cw_ballot(is_open && h == L);             // opens of level L
-                    const unsigned long long C = cw_ballot(comma_in_front && plevel == L); // elements of level L that follow a comma
-                    const unsigned long long Z = cw_ballot(is_close && plevel == L);       // closes of level-L containers
+                    const unsigned long long O = cw_ballot(is_open && h == L);  // opens of level L
                     if (plevel == L) par_lane = highest_bit_below(O, lt_mask);
-                    if (key == L) kc = (uint32_t)__popcll(C & lt_mask);
-                    // the stack entry of level L behind the step (wave-uniform, branch-free): the LAST open of the level stays open
-                    // unless a close of the level follows it; without an open (and without a close) the old container collects the commas
-                    const bool has_o = O != 0;
-                    const int al = has_o ? 63 - __builtin_clzll(O) : 0;
-                    const unsigned long long above = has_o ? (al == 63 ? 0ull : ~((2ull << al) - 1ull)) : ~0ull;
-                    const bool still = has_o && !(Z & above);
-                    const bool addc = !has_o && !Z && C != 0;
-                    const uint32_t nc = (uint32_t)__popcll(C & above);
-                    const uint32_t sk_cnt = (uint32_t)__builtin_amdgcn_readlane((int)st_cnt, L);
-                    const uint32_t tp = (uint32_t)__builtin_amdgcn_readlane((int)tpos, al);
-                    const uint32_t kd = (uint32_t)__builtin_amdgcn_readlane((int)cls, al);
-                    const uint32_t newcnt = still ? nc : sk_cnt + nc;
-                    st_cnt = (lane == L && (still || addc)) ? newcnt : st_cnt;
-                    st_tpos = (lane == L && still) ? tp : st_tpos;
-                    const unsigned long long bit = 1ull << L;
-                    arr_mask = still ? (kd == K_OPEN_A ? (arr_mask | bit) : (arr_mask & ~bit)) : arr_mask;
                 }
-                const bool par_in_wave = par_lane >= 0;
-                const int pl = par_in_wave ? par_lane : (plevel < 0 ? 0 : plevel);
-                // the parent's values: from its lane of this step, or from the stack as it stood in front of the step (lane = level).
-                // (a shuffle reads the SOURCE lane's operand, and a lane may be asked as a parent of this step by one reader and as a
-                //  stack level by another: four shuffles, every reader uses one pair)
+                const bool par_in_wave = par_lane >= 0, has_par = valid && plevel >= 0;
+                const uint32_t lvl = (uint32_t)plevel & 63u;
+                st.cnt[lane] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                uint32_t* const my_counter = par_in_wave ? &st.cnt[par_lane] : &st.stk[lvl].y;
+                if (has_par && comma_in_front) atomicAdd(my_counter, 1u);
+                if (is_close && !empty_close && par_in_wave) atomicOr(&st.cnt[par_lane], 0x40000000u);  // (its opener does not stay open)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint2 se = st.stk[lvl];          // the stack entry of my level (as the earlier steps left it + this step's commas)
+                const uint32_t pcnt = *my_counter;     // my container's commas (all of them lie in front of its closing bracket)
+                const uint32_t own = st.cnt[lane];     // an opening bracket's own slot
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (is_open && !empty_open && !(own & 0x40000000u) && h < CW_LEVELS)
+                    st.stk[h & 63] = make_uint2(tpos, (own & 0x3FFFFFFFu) | (cls == K_OPEN_A ? 0x80000000u : 0u));
+                const int pl = par_in_wave ? par_lane : 0;
                 const uint32_t s_tpos = (uint32_t)__shfl((int)tpos, pl);
-                const uint32_t s_pack = (uint32_t)__shfl((int)(kc | (cls == K_OPEN_A ? 0x100u : 0u)), pl);
-                const uint32_t b_tpos = (uint32_t)__shfl((int)st_tpos0, pl);
-                const uint32_t b_cnt = (uint32_t)__shfl((int)st_cnt0, pl);
-                const bool sk_arr = plevel >= 0 && ((arr_mask0 >> (plevel & 63)) & 1ull) != 0;
-                const bool par_is_array_ = par_in_wave ? (s_pack & 0x100u) != 0 : sk_arr;
-                const uint32_t par_tpos = par_in_wave ? s_tpos : b_tpos;
-                const uint32_t par_cnt = par_in_wave ? kc - (s_pack & 0xFFu) : b_cnt + kc;
+                const uint32_t s_arr = (uint32_t)__shfl((int)(cls == K_OPEN_A ? 1u : 0u), pl);
+                const bool par_is_array_ = par_in_wave ? s_arr != 0 : (plevel >= 0 && (se.y >> 31) != 0);
+                const uint32_t par_tpos = par_in_wave ? s_tpos : se.x;
+                const uint32_t par_cnt = pcnt & 0x3FFFFFFFu;
                 // (5) the token grammar
                 const bool prev_open_ne = cls_prev <= K_OPEN_O && !eo_prev && !first;
                 const bool par_is_array = prev_open_ne ? cls_prev == K_OPEN_A : par_is_array_;
