@@ -908,7 +908,7 @@ struct __attribute__((aligned(16))) PrimQueue {
 };
 
 #ifndef SJMI_TOK_WAVES
-#define SJMI_TOK_WAVES 6
+#define SJMI_TOK_WAVES 7
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SJMI_TOK_WAVES, SJMI_TOK_WAVES)))
 k_tok_walk(TokArgs a) {
@@ -1170,18 +1170,15 @@ k_tok_walk(TokArgs a) {
                         qtail += (uint32_t)__popcll(PM);
                     }
                 }
-                if (valid) {
-                    if (cls == K_QUOTE || cls == K_PRIM) {
-                    } else if (empty_open) {
-                        if (tpos < room) T[tpos] = tape_word(ch, tpos + 2);          // TapeBuilder.java:205-208
-                    } else if (empty_close) {
-                        if (tpos < room) T[tpos] = tape_word(ch, tpos);              // (= position of the opening word + 1)
-                    } else if (is_close) {
-                        uint32_t cnt = par_cnt + 1u;
-                        if (cnt > 0xFFFFFFu) cnt = 0xFFFFFFu;
-                        if (tpos < room) T[tpos] = tape_word(ch, par_tpos);                                                   // :197-203
-                        if (par_tpos < room) T[par_tpos] = tape_word(ch - 2, (unsigned long long)(tpos + 1) | ((unsigned long long)cnt << 32));
-                    }
+                {   // brackets: an empty pair is two self-contained words (TapeBuilder.java:205-208); a closing bracket writes its own
+                    // word and its container's opening word (:197-203: element count = commas + 1, saturated)
+                    const bool w1 = valid && (empty_open || is_close) && tpos < room;
+                    const uint32_t pay1 = empty_open ? tpos + 2u : (empty_close ? tpos : par_tpos);
+                    if (w1) T[tpos] = tape_word(ch, pay1);
+                    const bool w2 = is_close && !empty_close && par_tpos < room;
+                    uint32_t cnt = par_cnt + 1u;
+                    if (cnt > 0xFFFFFFu) cnt = 0xFFFFFFu;
+                    if (w2) T[par_tpos] = tape_word(ch - 2, (unsigned long long)(tpos + 1) | ((unsigned long long)cnt << 32));
                 }
                 // (8) carries
                 const uint32_t tot3 = cw_last(scan3);
