@@ -205,3 +205,69 @@ def test_accepted_batch_with_a_large_and_a_deep_document(twitter):
         assert c["failed_documents"] == 1 and c["host_documents"] == 0  # (the 1,100-level document: maxDepth 1024)
     finally:
         ctx.close()
+
+
+def test_accepted_batch_delimiters_equal_the_per_document_passes():
+    """k_doc_prepare (accepted plain pass) reads a document's index range, first string and tape slot off stage 1's per-block
+    side outputs instead of searching / packing.  Layouts that stress it: documents that begin exactly on a block boundary, many
+    documents inside one block, dense structurals (more than 16 in front of a boundary inside its block), long documents, strings
+    across boundaries.  index_offsets, doc_string_offsets and (all documents valid) tape_offsets must be those of the three
+    separate calls (per-document passes + packing behind the walk)."""
+    import torch
+    import simdjson_java_amd as S
+    from simdjson_java_amd import sharding
+    rng = random.Random(77)
+    docs = []
+    for i in range(3000):
+        r = rng.random()
+        if r < 0.25:
+            docs.append(rng.choice([b"1", b"[]", b"{}", b'""', b"[1]", b'"a"', b"null", b"-0", b'{"a":1}']))
+        elif r < 0.40:
+            n = rng.randrange(1, 80)
+            docs.append(b"[" + b",".join(b"1" for _ in range(n)) + b"]")                 # a structural every byte
+        elif r < 0.50:
+            docs.append(b'["' + b"x" * rng.randrange(0, 200) + b'","' + b"\\\\" * rng.randrange(0, 40) + b'"]')
+        elif r < 0.55:
+            d = b'{"k":[' + b",".join(b'{"a":"b","c":[1,2.5,true,null]}' for _ in range(rng.randrange(50, 300))) + b"]}"
+            docs.append(d)
+        else:
+            docs.extend(_small_docs(rng, 1))
+        if r > 0.97:  # pad so that the NEXT document begins on a 64-byte boundary
+            tot = sum(len(d) + 1 for d in docs)
+            pad = (-tot - 3) % 64
+            docs.append(b"[" + b" " * pad + b"]")
+    ctx = S.Context(0, 1 << 20)
+    try:
+        buf, offs = _pack(docs)
+        shard = sharding.BatchShard(ctx, buf, offs, torch.device("cuda", 0))
+        shard.step(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        c = shard.check()
+        assert c["stage1_status"] == 0 and c["failed_documents"] == 0, c
+        got_io = shard.index_offsets.cpu().numpy()
+        got_dso = shard.doc_string_offsets.cpu().numpy()
+        got_to = shard.tape_offsets.cpu().numpy()
+        got_tape = shard.tape.cpu().numpy().view(np.uint64)[:int(got_to[-1])]
+        # the three separate calls on the same context (isolated stage 1 is exact whatever the plain pass does)
+        import tests.test_gpu_walk as TW
+        tapes, strings, errors = TW.gpu_walk(ctx, docs)
+        assert not errors.any()
+        want_to = np.concatenate([[0], np.cumsum([t.size for t in tapes])])
+        assert np.array_equal(got_to, want_to)
+        assert np.array_equal(got_tape, np.concatenate(tapes))
+        assert bytes(shard.sb[:c["string_bytes"]].cpu().numpy()) == strings
+        # index / string offsets: recomputed from the oracle
+        want_io, want_dso, si, so = [0], [], 0, 0
+        for d in docs:
+            idx, st = O.stage1(d + b"\n")
+            assert st == 0
+            want_dso.append(so)
+            p = O.parse(d + b"\n")
+            so += len(p.strings)
+            si += idx.size
+            want_io.append(si)
+        want_dso.append(so)
+        assert np.array_equal(got_io, np.asarray(want_io))
+        assert np.array_equal(got_dso, np.asarray(want_dso))
+    finally:
+        ctx.close()
