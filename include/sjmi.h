@@ -449,7 +449,15 @@ int sjmi_value_next(const sjmi_parser* p, const sjmi_value* container, const sjm
 /* Optional: page-lock caller-owned host memory that is passed to the host-buffer entry points again and again
  * (SimdJsonParser's padded input, index array and string buffer): H2D / D2H copies of pinned memory skip the
  * driver's staging copy (3-4x faster for the ~1 MB transfers of a single-document parse).  Purely a performance
- * hint: every entry point also works with pageable memory.  Unregister before freeing the memory. */
+ * hint: every entry point also works with pageable memory.  Unregister before freeing the memory.
+ * ZERO-COPY OUTPUTS: when the output arrays of sjmi_stage1 (indexes), sjmi_stage1_unescape (indexes AND string_buffer) or
+ * sjmi_parse_document (tape) are page-locked, device-visible and 16-byte aligned, the kernels write them directly over PCIe:
+ * no download, one host synchronisation per call.  The results are the same bytes; as on the staged path, array elements
+ * behind the returned counts (up to the capacities) may be overwritten.  A context remembers the device view of such a
+ * buffer; sjmi_host_register / sjmi_host_unregister (on any context) make every context forget them, so memory that was
+ * page-locked by other means (hipHostMalloc / hipHostRegister of the caller's own) must stay page-locked as long as it is
+ * passed to a context, or be followed by one sjmi_host_unregister call (its failure for a foreign pointer is harmless).
+ * SJMI_ZERO_COPY=0 in the environment switches the zero-copy paths off. */
 int sjmi_host_register(sjmi_ctx* ctx, void* ptr, uint64_t bytes);
 /* Optional: a page-locked staging buffer for the INPUT of the single-document host entry points (sjmi_stage1,
  * sjmi_stage1_unescape, sjmi_parse_document).  With one set (bytes >= the document's length), a document handed in from any

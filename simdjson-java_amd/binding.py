@@ -264,12 +264,14 @@ class Context:
     def set_tile_steps(self, steps):
         self._check(lib().sjmi_set_tile_steps(self._h, steps), "sjmi_set_tile_steps")
 
-    def stage1(self, data, length=None, index_capacity=None):
-        """Host-buffer path (SimdJsonParser.stage1 + padIfNeeded): -> (indexes incl. sentinel stripped, status)."""
+    def stage1(self, data, length=None, index_capacity=None, idx=None):
+        """Host-buffer path (SimdJsonParser.stage1 + padIfNeeded): -> (indexes incl. sentinel stripped, status).
+        idx: the caller's own np.uint32 index array (e.g. page-locked: the zero-copy path)."""
         a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, np.uint8)
         n = a.size if length is None else length
-        cap = (n + 2) if index_capacity is None else index_capacity
-        idx = np.empty(max(cap, 1), dtype=np.uint32)
+        cap = ((n + 2) if index_capacity is None else index_capacity) if idx is None else idx.size
+        if idx is None:
+            idx = np.empty(max(cap, 1), dtype=np.uint32)
         cnt = C.c_uint64(0)
         st = C.c_uint32(0)
         ptr = a.ctypes.data if a.size else None

@@ -77,6 +77,13 @@ struct sjmi_ctx {
     void* d_ws_masks = nullptr;
     size_t ws_masks_bytes = 0;
     void* d_single = nullptr;                // sjmi_parse_document: delimiters, tape offsets, error and results of ONE document
+    struct HostView { const void* host = nullptr; void* dev = nullptr; };
+    uint64_t pin_epoch = 0;                  // g_pin_epoch when the views below were taken (a (un)register anywhere drops them)
+    HostView views[6];                       // device views of caller buffers that are page-locked and device-visible (zero-copy outputs)
+    int view_next = 0;
+    const uint32_t* idx_last = nullptr;      // where the last host-form stage-1 call left its indexes (c->d_idx, or the caller's array)
+    void* h_res_dev = nullptr;               // h_res / h_pack as the device sees them
+    void* h_pack_dev = nullptr;
     void* s1_zero2 = nullptr;                // one-shot extras of the next stage1_device_impl call (sjmi_parse_document):
     size_t s1_zero2_bytes = 0;               //   a second region its workers zero, the single-document setup its scanner writes
     sjmi::Stage1Single s1_single;
@@ -326,6 +333,36 @@ struct AutoSafeOff {
     explicit AutoSafeOff(sjmi_ctx* ctx) : c(ctx), keep(ctx->auto_safe) { ctx->auto_safe = false; }
     ~AutoSafeOff() { c->auto_safe = keep; }
 };
+// The device's view of a caller buffer that is page-locked and device-visible (sjmi_host_register / hipHostMalloc), or nullptr
+// (pageable memory: the staged path).  The kernels then write their outputs straight into it over PCIe -- no download, and no
+// second host synchronisation whose only purpose was to learn how much to download.  Cached per pointer (a handful of buffers
+// per parser).  SJMI_ZERO_COPY=0 switches every zero-copy path off.
+static std::atomic<uint64_t> g_pin_epoch{1};  // bumped by sjmi_host_register / sjmi_host_unregister: cached views are stale
+static void drop_stale_views(sjmi_ctx* c) {
+    const uint64_t e = g_pin_epoch.load(std::memory_order_acquire);
+    if (c->pin_epoch == e) return;
+    c->pin_epoch = e;
+    for (auto& v : c->views) v = {};
+    c->zc_host = nullptr;
+    c->zc_dev = nullptr;
+}
+static void* device_view(sjmi_ctx* c, const void* host) {
+    static const bool off = getenv("SJMI_ZERO_COPY") && atoi(getenv("SJMI_ZERO_COPY")) == 0;
+    if (off || !host) return nullptr;
+    drop_stale_views(c);
+    for (const auto& v : c->views)
+        if (v.host == host) return v.dev;
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, const_cast<void*>(host), 0) != hipSuccess) {
+        (void)hipGetLastError();  // (not device-visible: not an error)
+        dp = nullptr;
+    }
+    c->views[c->view_next].host = host;
+    c->views[c->view_next].dev = dp;
+    c->view_next = (c->view_next + 1) % 6;
+    return dp;
+}
+
 static int stage1_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, void* d_indexes, uint64_t index_capacity,
                               void* d_result, void* stream, uint32_t shard_flags);
 int sjmi_stage1(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes, uint64_t index_capacity,
@@ -344,6 +381,36 @@ int sjmi_stage1(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes
     const uint64_t spec_idx = len + 2 < dev_cap ? len + 2 : dev_cap;
     const bool small = len <= (4u << 10);
     const AutoSafeOff own_retry(c);  // (the retry below is this call's own)
+    // zero-copy: the caller's index array is device-visible -> the kernel writes indexes[0..count] there, the scanner the record
+    // into the pinned result page: one synchronisation, no download
+    uint32_t* const zc_idx = ((uintptr_t)indexes & 15) ? nullptr : (uint32_t*)device_view(c, indexes);
+    if (!c->h_res_dev) c->h_res_dev = device_view(c, c->h_res);
+    if (zc_idx && c->h_res_dev) {
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const int rc = stage1_device_impl(c, c->d_in, len, zc_idx, dev_cap, c->h_res_dev, c->stream, 0);
+            if (rc != SJMI_OK) return rc;
+            if (fail(c, "sync", hipStreamSynchronize(c->stream))) return SJMI_ERR_HIP;
+            if (!(c->h_res->status & SJMI_ST_INTERNAL) || c->ticket_mode) break;
+            c->ticket_mode = true;
+        }
+        *status = c->h_res->status & 0xFFu;
+        *count = c->h_res->count;
+        if (c->h_res->status & SJMI_ST_INTERNAL) {
+            c->err = "look-back timeout";
+            return SJMI_ERR_INTERNAL;
+        }
+        if (c->h_res->status & SJMI_ST_CAPACITY) {
+            c->err = "index_capacity too small";
+            return SJMI_ERR_CAPACITY;
+        }
+        c->idx_last = zc_idx;
+        c->last_len = len;
+        c->last_count = c->h_res->count;
+        c->last_valid = true;
+        c->last_batch = false;
+        return SJMI_OK;
+    }
+    c->idx_last = c->d_idx;
     for (int attempt = 0; attempt < 2; ++attempt) {
         // (the device entry point: double-buffered workspace, nothing but the kernel is queued once the context is warm)
         const int rc = stage1_device_impl(c, c->d_in, len, c->d_idx, dev_cap, c->d_res_tmp, c->stream, 0);
@@ -570,7 +637,8 @@ static int unescape_host(sjmi_ctx* c, uint8_t* string_buffer, uint64_t string_ca
         batch.n_docs = n_docs;
         batch.d_doc_str_offsets = doc_string_offsets ? c->d_docstr : nullptr;
     }
-    const int rc = unescape_device_impl(c, c->d_in, c->last_len, c->d_idx, c->last_count, c->d_sb, c->sb_bytes, c->d_ures,
+    const uint32_t* const idx_dev = c->idx_last ? c->idx_last : c->d_idx;
+    const int rc = unescape_device_impl(c, c->d_in, c->last_len, idx_dev, c->last_count, c->d_sb, c->sb_bytes, c->d_ures,
                                         c->stream, batch);
     if (rc != SJMI_OK) return rc;
     sjmi_unescape_result r;
@@ -579,7 +647,7 @@ static int unescape_host(sjmi_ctx* c, uint8_t* string_buffer, uint64_t string_ca
     if (streamed) {
         if (!c->d_err_index && fail(c, "hipMalloc(err_index)", hipMalloc((void**)&c->d_err_index, sizeof(unsigned long long))))
             return SJMI_ERR_HIP;
-        if (fail(c, "error index", sjmi::strings_error_index_launch(c->d_idx, c->last_count, nullptr, (const sjmi::UnescapeResult*)c->d_ures,
+        if (fail(c, "error index", sjmi::strings_error_index_launch(idx_dev, c->last_count, nullptr, (const sjmi::UnescapeResult*)c->d_ures,
                                                                     c->d_err_index, c->stream)) ||
             fail(c, "D2H(err_index)", hipMemcpyAsync(&err_index, c->d_err_index, sizeof err_index, hipMemcpyDeviceToHost, c->stream)))
             return SJMI_ERR_HIP;
@@ -678,21 +746,33 @@ int sjmi_stage1_unescape(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t
     const uint64_t spec_sb = string_buffer ? (sb_bound < string_capacity ? sb_bound : string_capacity) : 0;
     const bool small = len <= (4u << 10);
     const AutoSafeOff own_retry(c);  // (the retry below is this call's own)
+    // ZERO-COPY (both output arrays device-visible: a parser with page-locked buffers): stage 1 writes the indexes, the string
+    // pass the records and the last small kernel the packed result records straight into the caller's / the context's pinned
+    // memory -- no download, ONE host synchronisation (twitter.json: two copies of 221 + 440 KB and a round trip less)
+    uint32_t* const zc_idx = ((uintptr_t)indexes & 15) ? nullptr : (uint32_t*)device_view(c, indexes);
+    uint8_t* const zc_sb = zc_idx && !((uintptr_t)string_buffer & 15) ? (uint8_t*)device_view(c, string_buffer) : nullptr;
+    if (!c->h_pack_dev) c->h_pack_dev = device_view(c, c->h_pack);
+    const bool zero_copy = zc_idx && zc_sb && c->h_pack_dev;
+    uint32_t* const idx_out = zero_copy ? zc_idx : c->d_idx;
+    c->idx_last = idx_out;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        const int s1rc = stage1_device_impl(c, c->d_in, len, c->d_idx, dev_cap, c->d_res_tmp, c->stream, 0);
+        const int s1rc = stage1_device_impl(c, c->d_in, len, idx_out, dev_cap, c->d_res_tmp, c->stream, 0);
         if (s1rc != SJMI_OK) return s1rc;
         if (!grow(c, &c->d_ws_strm, &c->ws_strm_bytes, sjmi::strings_workspace_bytes(len), "hipMalloc(ws_strm)")) return SJMI_ERR_HIP;
         const unsigned long long* par = parity_for(c, c->d_in, len, c->stream);
         if (!par) return SJMI_ERR_HIP;
         sjmi::UnescapeResult* d_u = sjmi::strings_workspace_result(c->d_ws_strm);
-        if (fail(c, "strings launch", sjmi::strings_launch(c->d_in, len, par, c->d_sb, c->sb_bytes, nullptr, 0, nullptr, c->d_ws_strm, d_u, c->stream)) ||
-            fail(c, "error index", sjmi::strings_error_index_pack_launch(c->d_idx, (const sjmi::Stage1Result*)c->d_res_tmp, d_u, c->d_pack, c->stream)) ||
-            fail(c, "D2H(results)", hipMemcpyAsync(c->h_pack, c->d_pack, sizeof(Pack), hipMemcpyDeviceToHost, c->stream)))
+        if (fail(c, "strings launch", sjmi::strings_launch(c->d_in, len, par, zero_copy ? zc_sb : c->d_sb, zero_copy ? string_capacity : c->sb_bytes,
+                                                           nullptr, 0, nullptr, c->d_ws_strm, d_u, c->stream)) ||
+            fail(c, "error index", sjmi::strings_error_index_pack_launch(idx_out, (const sjmi::Stage1Result*)c->d_res_tmp, d_u,
+                                                                         zero_copy ? c->h_pack_dev : c->d_pack, c->stream)) ||
+            (!zero_copy && fail(c, "D2H(results)", hipMemcpyAsync(c->h_pack, c->d_pack, sizeof(Pack), hipMemcpyDeviceToHost, c->stream))))
             return SJMI_ERR_HIP;
         // A SMALL document's outputs are downloaded speculatively, by their bounds (one structural per byte; 3 record bytes per
         // 2 source bytes), behind the same synchronisation: the second host round trip costs more than the few KB it would save
-        if (small && (fail(c, "D2H(indexes)", hipMemcpyAsync(indexes, c->d_idx, spec_idx * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)) ||
-                      (spec_sb && fail(c, "D2H(sb)", hipMemcpyAsync(string_buffer, c->d_sb, spec_sb, hipMemcpyDeviceToHost, c->stream)))))
+        if (!zero_copy && small &&
+            (fail(c, "D2H(indexes)", hipMemcpyAsync(indexes, c->d_idx, spec_idx * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)) ||
+             (spec_sb && fail(c, "D2H(sb)", hipMemcpyAsync(string_buffer, c->d_sb, spec_sb, hipMemcpyDeviceToHost, c->stream)))))
             return SJMI_ERR_HIP;
         if (fail(c, "sync", hipStreamSynchronize(c->stream))) return SJMI_ERR_HIP;
         const Pack* hp = static_cast<const Pack*>(c->h_pack);
@@ -737,6 +817,7 @@ int sjmi_stage1_unescape(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t
             return SJMI_ERR_CAPACITY;
         }
     }
+    if (zero_copy) return SJMI_OK;  // (indexes and records are in the caller's arrays already)
     if (small && c->h_res->count + 1 <= spec_idx && (!strings_ok || r.total_bytes <= spec_sb)) return SJMI_OK;  // (already here)
     if (fail(c, "D2H(indexes)",
              hipMemcpyAsync(indexes, c->d_idx, (c->h_res->count + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)) ||
@@ -1229,6 +1310,7 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
     // the context's pinned page the same way -- no download of either, ONE host synchronisation instead of two (twitter.json:
     // 0.147 -> ~0.12 ms).  A pageable tape takes the staged path below.
     static const bool zero_copy_off = getenv("SJMI_ZERO_COPY") && atoi(getenv("SJMI_ZERO_COPY")) == 0;
+    drop_stale_views(c);
     if (c->zc_host != tape) {
         c->zc_host = tape;
         c->zc_dev = nullptr;
@@ -1383,7 +1465,7 @@ int sjmi_match_brackets(sjmi_ctx* c, uint32_t* up, uint32_t* match, uint64_t cap
     if (fail(c, "H2D", hipMemcpyAsync(d_io, io, sizeof io, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
     // (a large document: chunk-parallel, with the chunk states in the walk workspace)
     if (!grow(c, &c->d_ws_walk, &c->ws_walk_bytes, sjmi::coop_chunk_workspace_bytes(count), "hipMalloc(ws_walk)")) return SJMI_ERR_HIP;
-    if (fail(c, "match launch", sjmi::coop_match_launch(c->d_in, 1, c->d_idx, d_io, (uint32_t*)c->d_sb, (uint32_t*)c->d_tape, c->stream,
+    if (fail(c, "match launch", sjmi::coop_match_launch(c->d_in, 1, c->idx_last ? c->idx_last : c->d_idx, d_io, (uint32_t*)c->d_sb, (uint32_t*)c->d_tape, c->stream,
                                                         c->d_ws_walk, count)))
         return SJMI_ERR_HIP;
     if (count && (fail(c, "D2H(up)", hipMemcpyAsync(up, c->d_sb, count * 4, hipMemcpyDeviceToHost, c->stream)) ||
@@ -1396,12 +1478,14 @@ int sjmi_match_brackets(sjmi_ctx* c, uint32_t* up, uint32_t* match, uint64_t cap
 int sjmi_host_register(sjmi_ctx* c, void* ptr, uint64_t bytes) {
     if (!c || !ptr || !bytes) return SJMI_ERR_ARG;
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    g_pin_epoch.fetch_add(1, std::memory_order_acq_rel);
     if (fail(c, "hipHostRegister", hipHostRegister(ptr, bytes, hipHostRegisterDefault))) return SJMI_ERR_HIP;
     return SJMI_OK;
 }
 
 int sjmi_host_unregister(sjmi_ctx* c, void* ptr) {
     if (!c || !ptr) return SJMI_ERR_ARG;
+    g_pin_epoch.fetch_add(1, std::memory_order_acq_rel);  // (every context forgets its zero-copy views, whatever the outcome)
     if (fail(c, "hipHostUnregister", hipHostUnregister(ptr))) return SJMI_ERR_HIP;
     return SJMI_OK;
 }
