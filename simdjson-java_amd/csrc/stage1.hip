@@ -33,6 +33,7 @@
 #include <atomic>
 
 #include "sj_block.h"
+#include "sj_block32.h"
 #include "stage1.h"
 
 namespace sjmi {
@@ -505,6 +506,9 @@ struct StepData {
 
 // Branch-free on purpose (a block index past the end is clamped and its data ignored by the caller):
 // a conditional load makes hipcc drain the whole load queue (s_waitcnt vmcnt(0)) at the join.
+// (Measured and dropped, round 4: 32-bit offsets, i.e. loads in the "scalar base + 32-bit vector offset" form.  They save a dozen
+// slow-class VALU instructions of 64-bit address arithmetic per step -- and the kernel is 3 % SLOWER, 0.1907 against 0.1850 ms for
+// twitter x1024, tools/ab_stage1.sh.)
 __device__ __forceinline__ void load_step(StepData& d, const uint8_t* __restrict__ buf, sj_u64 blk, sj_u64 nblocks, bool left_halo = false) {
     const sj_u64 b = blk < nblocks ? blk : nblocks - 1;
     const uint4* src = reinterpret_cast<const uint4*>(buf + b * 64);
@@ -607,7 +611,7 @@ stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ 
     WaveShared<S, LDSW>& ws = sh[wave];
     // the reference always processes one tail block (:255-294); a shard that is not the document's last one ends on a block
     // boundary and has none (its successor validates what straddles the boundary from its own left halo)
-    const sj_u64 nblocks = len / 64 + ((dbg & FLAG_NO_TAIL) ? 0 : 1);
+    const uint32_t nblocks = (uint32_t)(len / 64) + ((dbg & FLAG_NO_TAIL) ? 0u : 1u);  // (len < 4 GiB)
     const uint32_t halo_blocks = dbg >> 16;       // shard: readable 64-byte blocks in front of buf (0 = a whole document)
     const bool left_halo = halo_blocks != 0;
     const uint32_t entry_par = (dbg & FLAG_ENTRY_PARITY) ? 1u : 0u;
@@ -647,7 +651,7 @@ stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ 
     uint32_t prev = NO_TILE, prev_par = 0, prev_c0 = 0, prev_c1 = 0;  // the parked granule and its aggregate
     uint32_t err = 0;
     StepData d;  // the step being loaded / classified (single buffer: re-used as soon as it has been transposed)
-    load_step(d, buf, (sj_u64)cur * (64 * S) + lane, nblocks, left_halo);
+    load_step(d, buf, cur * (64u * S) + (uint32_t)lane, nblocks, left_halo);
 
     for (;;) {
         const bool have = cur < ngran;  // wave-uniform
@@ -664,7 +668,7 @@ stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ 
             // wave last in a persistent kernel: classifications of 25 us instead of 9 in the timeline)
             __builtin_amdgcn_s_setprio(2);
             SJMI_TSTAMP(cur, 0);
-            const sj_u64 blk0 = (sj_u64)cur * (64 * S);
+            const uint32_t blk0 = cur * (64u * S);  // (block numbers are 32-bit: load_step)
             sj_u64 sm[S];
             uint32_t fl[S];     // bit0 quote parity, bit1 ue0, bit2 ue1, bit3 utf8 error
             uint32_t slow = 0;  // steps whose carries the halo could not resolve (long backslash run)
@@ -674,14 +678,14 @@ stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ 
                 // software pipeline with ONE buffer: step s was loaded during the algebra of step s-1 (step 0 before
                 // the previous granule's expansion); as soon as it is transposed into planes, its registers take the
                 // loads of step s+1.  (Ping-pong buffers cost 18 more VGPRs = one wave per SIMD at S = 4.)
-                const sj_u64 blk = blk0 + (sj_u64)s * 64 + lane;
+                const uint32_t blk = blk0 + (uint32_t)s * 64u + (uint32_t)lane;
                 const uint32_t w[16] = {d.q0.x, d.q0.y, d.q0.z, d.q0.w, d.q1.x, d.q1.y, d.q1.z, d.q1.w,
                                         d.q2.x, d.q2.y, d.q2.z, d.q2.w, d.q3.x, d.q3.y, d.q3.z, d.q3.w};
                 const sj_u64 halo = d.halo;
-                sj_u64 p[8];
-                sj_transpose_butterfly(w, p);
+                uint32_t plo[8], phi[8];  // the block's eight bit planes, bytes 0..31 / 32..63 (sj_block32.h)
+                sj_transpose32(w, plo, phi);
                 asm volatile("" ::: "memory");
-                if (s + 1 < S) load_step(d, buf, blk0 + (sj_u64)(s + 1) * 64 + lane, nblocks, left_halo);
+                if (s + 1 < S) load_step(d, buf, blk0 + (uint32_t)(s + 1) * 64u + (uint32_t)lane, nblocks, left_halo);
                 if (s == S - 1 && !safe) {
                     // requested one step ahead of their use: late enough that granules are started in ticket order
                     // (a ticket held through a whole slow iteration delays every granule behind it), early enough to
@@ -695,21 +699,25 @@ stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ 
                 fl[s] = 0;
                 bool unresolved = false;
                 if (blk < nblocks) {
-                    const sj_u64 start = blk * 64;
+                    const bool has_halo = blk > 0 || left_halo;
                     uint32_t e_in = 0, p_in = 0;
-                    SjUtf8Carry uc = {0, 0, 0, 0};
-                    if (blk > 0 || left_halo) {
-                        uc = sj_utf8_carry(halo);
-                        unresolved = !sj_carry_from_halo(halo, &e_in, &p_in);
+                    if (has_halo) unresolved = !sj_carry_from_halo(halo, &e_in, &p_in);
+                    // (wave-uniform: only the wave-step that holds the document's last block masks a tail)
+                    if (blk0 + (uint32_t)s * 64u + 63u >= nblocks - 1u) {
+                        const sj_u64 rem = len - (sj_u64)blk * 64;
+                        sj_mask_tail32(plo, phi, rem < 64 ? (uint32_t)rem : 64u);
                     }
-                    const sj_u64 rem = len - start;
-                    sj_mask_tail(p, rem < 64 ? (uint32_t)rem : 64u);
-                    // the UTF-8 algebra is skipped when no lane of the wave has a non-ASCII byte or a pending carry
-                    const bool need_utf8 = __ballot((p[7] != 0) | ((uc.c1 | uc.c2 | uc.c3 | uc.sec) != 0)) != 0;
-                    const SjBlockMasks bm = sj_block(p, e_in, p_in, uc, need_utf8, nullptr, BATCH);
-                    pot[s] = bm.pot;
-                    sm[s] = bm.sm0;
-                    fl[s] = bm.qpar | (bm.ue0 << 1) | (bm.ue1 << 2) | (bm.utf8 << 3);
+                    // the UTF-8 algebra AND the carries into it are skipped when no lane of the wave has a non-ASCII byte in its
+                    // block or in the four bytes before it (a pending carry needs a byte >= 0xC0 there)
+                    const uint32_t halo_hi = has_halo ? (uint32_t)(halo >> 32) & 0x80808080u : 0u;
+                    const bool need_utf8 = __ballot((plo[7] | phi[7] | halo_hi) != 0) != 0;
+                    SjUtf8Carry uc = {0, 0, 0, 0};
+                    if (need_utf8 && has_halo) uc = sj_utf8_carry(halo);
+                    const SjBlockMasks32 bm = sj_block32(plo, phi, e_in, p_in, uc, need_utf8, BATCH);
+                    pot[s] = ((sj_u64)bm.pot.hi << 32) | bm.pot.lo;
+                    sm[s] = ((sj_u64)bm.sm0.hi << 32) | bm.sm0.lo;
+                    // (min: 0 / 1 from zero / nonzero in one instruction)
+                    fl[s] = bm.qpar | (min(bm.ue0, 1u) << 1) | (min(bm.ue1, 1u) << 2) | (min(bm.utf8, 1u) << 3);
                     if (BATCH) blkw[blk] = (uint16_t)bm.words;
                 }
                 slow |= unresolved ? (1u << s) : 0u;
@@ -790,7 +798,7 @@ stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ 
             }
         }
         // first step of the next granule: in flight during the expansion below (clamped, so harmless without one)
-        load_step(d, buf, (sj_u64)nxt * (64 * S) + lane, nblocks, left_halo);
+        load_step(d, buf, nxt * (64u * S) + (uint32_t)lane, nblocks, left_halo);  // (NO_TILE wraps: any block will do)
 
         // =================== E: resolve granule `prev`'s prefix, expand and store its indexes ===================
         if (prev != NO_TILE) {
