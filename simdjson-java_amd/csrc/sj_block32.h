@@ -1,16 +1,25 @@
-// sj_block32.h -- the per-block stage-1 algebra of sj_block.h written for the FAST VALU class of gfx950.
+// sj_block32.h -- the per-block stage-1 algebra of sj_block.h written for the FEWEST VALU instructions on gfx950.
 //
-// tools/microbench/valu_rates.hip / valu_mix.hip (profiles/r4/valu_rates.json): a CDNA4 SIMD retires a wave64 v_and / v_or /
-// v_xor / v_not / v_add_u32 / v_sub_u32 / v_mov_b32 / shift-by-constant / v_bitop3_b32 (VGPR or literal operands) every ~2.1
-// cycles when two or more waves issue them, but needs ~4.3 cycles for everything else -- v_perm_b32, v_bfi_b32, v_or3_b32,
-// v_and_or_b32, v_lshl_or_b32, v_alignbit_b32, v_bfe_u32, every 64-bit shift / add, DPP, v_cmp, v_bcnt, v_readlane, LDS and
-// memory instructions -- and one such instruction among sixteen fast ones already costs the fast ones half their advantage.
-// sj_block.h mixes the two classes (32 v_perm per block, 64-bit shifts and adds, compares).  This file computes the same
-// masks from the same 64 bytes with fast-class instructions only:
-//   * the transposition is five butterfly stages (16, 8, 4, 2, 1) of {shift, shift, v_bitop3, v_bitop3} per register pair;
-//   * every 64-bit mask is a {lo, hi} pair of 32-bit registers, shifts and the one addition are spelt out in 32-bit operations;
-//   * three-input boolean functions are explicit v_bitop3_b32 (the instruction selector would otherwise pick v_or3 / v_bfi /
-//     v_and_or, which are slow-class), and shifted values pass through an empty asm so that no funnel shift is formed.
+// k_stage1 is bound by VALU issue (one wave64 instruction per ~4.2 cycles per SIMD in its instruction mix), so what counts is
+// the NUMBER of instructions.  Against sj_block.h (which hipcc lowers 64-bit operation by 64-bit operation):
+//   * every 64-bit mask is a {lo, hi} pair of 32-bit registers, and every three-input boolean function is ONE explicit
+//     v_bitop3_b32 (the instruction selector forms them only where two-input operations happen to line up);
+//   * the transposition is two byte stages of v_perm_b32 (as before) and three bit stages of {shift, shift, v_bitop3, v_bitop3}
+//     per register pair -- 4 instead of 5-6 instructions: 128 per block instead of 152;
+//   * shifts across the halves are v_alignbit_b32 / v_lshl_or_b32, the one addition and the prefix XOR stay 64-bit
+//     (v_add_co / v_addc, v_lshlrev_b64 + two v_xor per stage), the second-byte checks of UTF-8 shift the two CONDITION planes
+//     right instead of four lead masks left.
+// What was measured on the way (tools/microbench/valu_rates.hip, valu_mix.hip, profiles/r4/valu_*.jsonl; tools/ab_stage1.sh):
+// gfx950 has a FAST class of VALU instructions -- v_and / v_or / v_xor / v_not / v_add_u32 / v_sub_u32 / v_mov_b32 / shifts by a
+// constant / v_bitop3_b32, with VGPR or literal operands -- that a SIMD retires every ~2.1 cycles when two or more waves issue
+// them, against ~4.3 for everything else (v_perm, v_bfi, v_or3, v_and_or, v_lshl_or, v_alignbit, v_bfe, 64-bit shifts and
+// adds, DPP, v_cmp, v_bcnt, v_readlane, any SGPR operand; LDS and memory instructions count too).  But one slow instruction
+// among sixteen fast ones already costs the fast ones half their advantage (2.1 -> 3.0 cycles; 1 in 8: 3.6), for EVERY wave on
+// the SIMD.  A first version of this file used fast-class instructions only (five butterfly stages, 32-bit shifts spelt out,
+// masks in vector registers: 85 % of the classification fast-class): +3 % -- and replacing its fast sequences by FEWER slow
+// instructions (this version) gained another 8 %.  Synchronising the phases of the sixteen waves of a CU (1024-thread
+// workgroups, barriers between classification and expansion) so that fast code meets fast code: -7 % to -13 %.  The fast
+// class is out of reach for a kernel that also loads, scans and scatters; the count is what pays.
 // Results are bit-identical to sj_block (tests/host_sim/block32.cpp fuzzes one against the other; the kernels' parity tests
 // cover the device code).  Reference lines as in sj_block.h.
 #pragma once
@@ -32,13 +41,6 @@ SJ_HD uint32_t sj_bop(uint32_t a, uint32_t b, uint32_t c) {
     return r;
 #endif
 }
-// keeps the instruction selector from fusing a shift with its consumer into a slow-class instruction (no code)
-SJ_HD uint32_t sj_opq(uint32_t x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm("" : "+v"(x));
-#endif
-    return x;
-}
 enum : uint32_t {
     SJ_TT_MUX_C = 0xE4,      // c ? a : b
     SJ_TT_OR3 = 0xFE,        // a | b | c
@@ -55,23 +57,13 @@ enum : uint32_t {
     SJ_TT_AB_OR_C = 0xEA,    // (a & b) | c
     SJ_TT_ANB_OR_C = 0xBA,   // (a & ~b) | c
     SJ_TT_A_N_BC = 0x70,     // a & ~(b & c)
-    SJ_TT_CARRY = 0xD4,      // carry out of a + b given the sum c: (a & b) | ((a | b) & ~c)
     SJ_TT_ANC_OR_BC = 0xD8,  // (a & ~c) | (b & c)
     SJ_TT_XOR_AND = 0x28,    // (a ^ b) & c
 };
 
-// a constant in a VECTOR register: v_bitop3_b32 takes no literal, and with the mask in a scalar register it is a slow-class
-// instruction (tools/microbench: 4.3 instead of 2.1 cycles) -- half of every butterfly.  One v_mov_b32 per stage instead
-// (volatile: not hoisted out of the kernel's loop, where five more live registers would cost a wave per SIMD).
-SJ_HD uint32_t sj_vconst(uint32_t c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("v_mov_b32 %0, %1" : "=v"(c) : "i"(c));
-#endif
-    return c;
-}
-
 // one butterfly stage between two registers: afterwards x holds the elements whose position bit (of weight S) was clear, y
-// those whose bit was set, and the position bit tells which register an element came from.  m = positions with the bit clear.
+// those whose bit was set, and the position bit tells which register an element came from.  m = positions with the bit clear
+// (a scalar register: v_bitop3_b32 takes no literal).
 template <int S>
 SJ_HD void sj_butterfly(uint32_t& x, uint32_t& y, uint32_t m) {
     const uint32_t xs = x >> S, ys = y << S;
@@ -79,33 +71,18 @@ SJ_HD void sj_butterfly(uint32_t& x, uint32_t& y, uint32_t m) {
     y = sj_bop<SJ_TT_MUX_C>(xs, y, m);
     x = nx;
 }
-
-// one 32-byte half: w8 = its 8 dwords -> x[k] = its 32 bits of plane k (bit j = bit k of byte j).  85 fast-class instructions.
-// Element (byte j = j4 j3 j2 j1 j0, bit k = k2 k1 k0) starts in register (j4 j3 j2) at position (j1 j0 | k2 k1 k0); the five
-// stages exchange register-index bits with position bits until the position is (j4 j3 j2 j1 j0) and the register (k1 k0 k2).
+// one 32-byte half: w8 = its 8 dwords -> x[k] = its 32 bits of plane k (bit j = bit k of byte j).  16 v_perm_b32 gather byte
+// 8c + r of the half into byte c of register r (sj_transpose4x4_bytes), three butterfly stages exchange the register index with
+// the bit index inside the bytes: 64 instructions.
 SJ_HD void sj_transpose_half32(const uint32_t w8[8], uint32_t x[8]) {
-    uint32_t r[8];
-    for (int i = 0; i < 8; ++i) r[i] = w8[i];
-    uint32_t m = sj_vconst(0x0000FFFFu);
-    for (int i = 0; i < 4; ++i) sj_butterfly<16>(r[i], r[i + 4], m);                           // register bit 2: j4 <-> j1
-    m = sj_vconst(0x00FF00FFu);
-    for (int i = 0; i < 8; i += 4) {                                                           // register bit 1: j3 <-> j0
-        sj_butterfly<8>(r[i], r[i + 2], m);
-        sj_butterfly<8>(r[i + 1], r[i + 3], m);
+    sj_transpose4x4_bytes(w8[0], w8[2], w8[4], w8[6], x);
+    sj_transpose4x4_bytes(w8[1], w8[3], w8[5], w8[7], x + 4);
+    for (int r = 0; r < 4; ++r) sj_butterfly<4>(x[r], x[r + 4], 0x0F0F0F0Fu);
+    for (int r = 0; r < 8; r += 4) {
+        sj_butterfly<2>(x[r], x[r + 2], 0x33333333u);
+        sj_butterfly<2>(x[r + 1], x[r + 3], 0x33333333u);
     }
-    // registers are now (j1 j0 j2), positions (j4 j3 | k2 k1 k0)
-    m = sj_vconst(0x33333333u);
-    for (int i = 0; i < 4; ++i) sj_butterfly<2>(r[i], r[i + 4], m);                            // j1 <-> k1
-    m = sj_vconst(0x55555555u);
-    for (int i = 0; i < 8; i += 4) {                                                           // j0 <-> k0
-        sj_butterfly<1>(r[i], r[i + 2], m);
-        sj_butterfly<1>(r[i + 1], r[i + 3], m);
-    }
-    m = sj_vconst(0x0F0F0F0Fu);
-    for (int i = 0; i < 8; i += 2) sj_butterfly<4>(r[i], r[i + 1], m);                         // j2 <-> k2
-    // plane k lies in register (k1 k0 k2)
-    x[0] = r[0]; x[1] = r[2]; x[2] = r[4]; x[3] = r[6];
-    x[4] = r[1]; x[5] = r[3]; x[6] = r[5]; x[7] = r[7];
+    for (int r = 0; r < 8; r += 2) sj_butterfly<1>(x[r], x[r + 1], 0x55555555u);
 }
 
 SJ_HD void sj_transpose32(const uint32_t w[16], uint32_t lo[8], uint32_t hi[8]) {
@@ -113,36 +90,44 @@ SJ_HD void sj_transpose32(const uint32_t w[16], uint32_t lo[8], uint32_t hi[8]) 
     sj_transpose_half32(w + 8, hi);
 }
 
+// ({hi, lo} >> n)[31:0], 0 < n < 32: v_alignbit_b32
+SJ_HD uint32_t sj_funnel(uint32_t hi, uint32_t lo, uint32_t n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, n);
+#else
+    return (uint32_t)(((((sj_u64)hi) << 32) | lo) >> n);
+#endif
+}
 // (x << 1) | cin, cin = 0 / 1
 SJ_HD SjPair sj_shl1(SjPair x, uint32_t cin) {
     SjPair r;
-    r.lo = sj_opq(x.lo << 1) | cin;
-    r.hi = sj_opq(x.hi << 1) | sj_opq(x.lo >> 31);
+    r.lo = (x.lo << 1) | cin;
+    r.hi = sj_funnel(x.hi, x.lo, 31);
     return r;
 }
 // (x << 1) | y
 SJ_HD SjPair sj_shl1_or(SjPair x, SjPair y) {
     SjPair r;
-    r.lo = sj_opq(x.lo << 1) | y.lo;
-    r.hi = sj_bop<SJ_TT_OR3>(sj_opq(x.hi << 1), sj_opq(x.lo >> 31), y.hi);
+    r.lo = (x.lo << 1) | y.lo;
+    r.hi = sj_funnel(x.hi, x.lo, 31) | y.hi;
     return r;
 }
 SJ_HD SjPair sj_shr1(SjPair x) {
     SjPair r;
-    r.lo = sj_opq(x.lo >> 1) | sj_opq(x.hi << 31);
+    r.lo = sj_funnel(x.hi, x.lo, 1);
     r.hi = x.hi >> 1;
     return r;
 }
-// prefix XOR over the 64 bits (StructuralIndexer.java:311-319): inside each half, then the low half's parity into the high one
+// prefix XOR over the 64 bits (StructuralIndexer.java:311-319)
 SJ_HD SjPair sj_prefix_xor32(SjPair m) {
-    uint32_t a = m.lo, b = m.hi;
-    a ^= sj_opq(a << 1);  b ^= sj_opq(b << 1);
-    a ^= sj_opq(a << 2);  b ^= sj_opq(b << 2);
-    a ^= sj_opq(a << 4);  b ^= sj_opq(b << 4);
-    a ^= sj_opq(a << 8);  b ^= sj_opq(b << 8);
-    a ^= sj_opq(a << 16); b ^= sj_opq(b << 16);
-    b ^= (uint32_t)((int32_t)a >> 31);
-    SjPair r = {a, b};
+    sj_u64 v = ((sj_u64)m.hi << 32) | m.lo;
+    v ^= v << 1;
+    v ^= v << 2;
+    v ^= v << 4;
+    v ^= v << 8;
+    v ^= v << 16;
+    v ^= v << 32;
+    SjPair r = {(uint32_t)v, (uint32_t)(v >> 32)};
     return r;
 }
 
@@ -199,7 +184,7 @@ SJ_HD SjHalfClasses sj_classes32(const uint32_t p[8]) {
 }
 
 
-// sj_block with {lo, hi} planes.  sectab: see sj_utf8_carry32.
+// sj_block with {lo, hi} planes
 SJ_HD SjBlockMasks32 sj_block32(const uint32_t lo[8], const uint32_t hi[8], uint32_t e_in, uint32_t p_in, SjUtf8Carry uc,
                                 bool do_utf8 = true, bool want_words = false) {
     const SjHalfClasses cl = sj_classes32(lo), ch = sj_classes32(hi);
@@ -208,10 +193,8 @@ SJ_HD SjBlockMasks32 sj_block32(const uint32_t lo[8], const uint32_t hi[8], uint
     const SjPair fe = sj_shl1(bs, e_in);  // follows_escape
     const uint32_t ODD = 0xAAAAAAAAu, EVEN = 0x55555555u;
     const SjPair os = {(bs.lo & ODD) & ~fe.lo, (bs.hi & ODD) & ~fe.hi};  // odd_starts
-    SjPair se;                                                           // seq_even = odd_starts + bs
-    se.lo = os.lo + bs.lo;
-    const uint32_t carry = sj_bop<SJ_TT_CARRY>(os.lo, bs.lo, se.lo) >> 31;
-    se.hi = os.hi + bs.hi + carry;
+    const sj_u64 sum = (((sj_u64)os.hi << 32) | os.lo) + (((sj_u64)bs.hi << 32) | bs.lo);  // seq_even = odd_starts + bs
+    const SjPair se = {(uint32_t)sum, (uint32_t)(sum >> 32)};
     const SjPair se1 = sj_shl1(se, 0);
     const SjPair escaped = {(EVEN ^ se1.lo) & fe.lo, (EVEN ^ se1.hi) & fe.hi};
     // ---- strings (:232-234) ----
