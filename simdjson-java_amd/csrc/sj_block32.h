@@ -74,15 +74,21 @@ SJ_HD void sj_butterfly(uint32_t& x, uint32_t& y, uint32_t m) {
 // one 32-byte half: w8 = its 8 dwords -> x[k] = its 32 bits of plane k (bit j = bit k of byte j).  16 v_perm_b32 gather byte
 // 8c + r of the half into byte c of register r (sj_transpose4x4_bytes), three butterfly stages exchange the register index with
 // the bit index inside the bytes: 64 instructions.
-SJ_HD void sj_transpose_half32(const uint32_t w8[8], uint32_t x[8]) {
+SJ_HD void sj_transpose_half32_bytes(const uint32_t w8[8], uint32_t x[8]) {
     sj_transpose4x4_bytes(w8[0], w8[2], w8[4], w8[6], x);
     sj_transpose4x4_bytes(w8[1], w8[3], w8[5], w8[7], x + 4);
+}
+SJ_HD void sj_transpose_half32_bits(uint32_t x[8]) {
     for (int r = 0; r < 4; ++r) sj_butterfly<4>(x[r], x[r + 4], 0x0F0F0F0Fu);
     for (int r = 0; r < 8; r += 4) {
         sj_butterfly<2>(x[r], x[r + 2], 0x33333333u);
         sj_butterfly<2>(x[r + 1], x[r + 3], 0x33333333u);
     }
     for (int r = 0; r < 8; r += 2) sj_butterfly<1>(x[r], x[r + 1], 0x55555555u);
+}
+SJ_HD void sj_transpose_half32(const uint32_t w8[8], uint32_t x[8]) {
+    sj_transpose_half32_bytes(w8, x);
+    sj_transpose_half32_bits(x);
 }
 
 SJ_HD void sj_transpose32(const uint32_t w[16], uint32_t lo[8], uint32_t hi[8]) {
@@ -184,9 +190,42 @@ SJ_HD SjHalfClasses sj_classes32(const uint32_t p[8]) {
 }
 
 
+// The UTF-8 carries as the kernel wants them: the three "must be a continuation" bits merged (sj_block ORs them anyway), and of the
+// lead in byte -1 only whether it is one of the FOUR whose second byte has a restricted range -- 0xE0, 0xED, 0xF0, 0xF4: in
+// twitter.json 13 bytes of 631,515, so that whole wave-steps go without the second-byte checks (sj_block32's `any`).
+struct SjUtf8Lazy {
+    uint32_t c123;     // c1 | c2 | c3 of SjUtf8Carry
+    uint32_t special;  // byte -1 if it is 0xE0 / 0xED / 0xF0 / 0xF4, else 0
+};
+SJ_HD uint32_t sj_utf8_special_lead(uint32_t c) {  // c = a byte value: is it one of the four?
+    const uint32_t M = (1u << 0x00) | (1u << 0x0D) | (1u << 0x10) | (1u << 0x14);  // by c - 0xE0
+    return (uint32_t)(c >= 0xE0u) & ((M >> (c & 31u)) & 1u);
+}
+SJ_HD SjUtf8Lazy sj_utf8_carry_lazy(sj_u64 halo) {
+    const uint32_t hh = (uint32_t)(halo >> 32);  // bytes -4..-1; only bit 7 of each byte is meaningful below
+    const uint32_t geC0 = hh & (hh << 1);        // byte >= 0xC0: a 2/3/4-byte lead
+    const uint32_t geE0 = geC0 & (hh << 2);      // byte >= 0xE0: a 3/4-byte lead
+    const uint32_t geF0 = geE0 & (hh << 3);      // byte >= 0xF0: a 4-byte lead
+    SjUtf8Lazy c;
+    // byte 0 continues a lead in byte -1, a 3/4-byte lead in byte -2 or a 4-byte lead in byte -3; byte 1 a 3/4-byte lead in byte -1
+    // or a 4-byte lead in byte -2; byte 2 a 4-byte lead in byte -1
+    c.c123 = ((geC0 >> 31) | ((geE0 >> 23) & 1u) | ((geF0 >> 15) & 1u)) | (((geE0 >> 30) | (geF0 >> 22)) & 2u) | ((geF0 >> 29) & 4u);
+    const uint32_t h1 = hh >> 24;
+    c.special = sj_utf8_special_lead(h1) ? h1 : 0u;
+    return c;
+}
+SJ_HD SjUtf8Lazy sj_utf8_lazy_of(SjUtf8Carry uc) {  // (tests, the slow path: from the full form)
+    SjUtf8Lazy c;
+    c.c123 = uc.c1 | uc.c2 | uc.c3;
+    c.special = (uc.sec & 1u) ? 0xE0u : (uc.sec & 2u) ? 0xEDu : (uc.sec & 4u) ? 0xF0u : (uc.sec & 8u) ? 0xF4u : 0u;
+    return c;
+}
+
 // sj_block with {lo, hi} planes
-SJ_HD SjBlockMasks32 sj_block32(const uint32_t lo[8], const uint32_t hi[8], uint32_t e_in, uint32_t p_in, SjUtf8Carry uc,
-                                bool do_utf8 = true, bool want_words = false) {
+// any(x): is x nonzero in ANY block the caller processes together (a ballot over the wave in the kernels; x != 0 for one block)
+template <class ANY>
+SJ_HD SjBlockMasks32 sj_block32(const uint32_t lo[8], const uint32_t hi[8], uint32_t e_in, uint32_t p_in, SjUtf8Lazy uc,
+                                bool do_utf8, bool want_words, ANY&& any) {
     const SjHalfClasses cl = sj_classes32(lo), ch = sj_classes32(hi);
     // ---- escapes (:211-229) ----
     SjPair bs = {cl.bs & ~e_in, ch.bs};
@@ -239,9 +278,14 @@ SJ_HD SjBlockMasks32 sj_block32(const uint32_t lo[8], const uint32_t hi[8], uint
         // expected continuations: E = (L4 << 3) | (L34 << 2) | (L234 << 1) | carries = (((L4 << 1 | L34) << 1) | L234) << 1 | carries
         const SjPair l4 = {L4[0], L4[1]}, l34 = {L34[0], L34[1]}, l234 = {L234[0], L234[1]};
         const SjPair E = sj_shl1(sj_shl1_or(sj_shl1_or(l4, l34), l234), 0);
-        const uint32_t c123 = sj_bop<SJ_TT_OR3>(uc.c1, uc.c2, uc.c3);
-        e[0] = sj_bop<SJ_TT_A_OR_BXC>(e[0], cont[0], E.lo | c123);  // TOO_SHORT / TOO_LONG / TWO_CONTINUATIONS
+        e[0] = sj_bop<SJ_TT_A_OR_BXC>(e[0], cont[0], E.lo | uc.c123);  // TOO_SHORT / TOO_LONG / TWO_CONTINUATIONS
         e[1] = sj_bop<SJ_TT_A_OR_BXC>(e[1], cont[1], E.hi);
+        err = e[0] | e[1];
+        // the leads whose second byte has a restricted range: 0xE0 (L3, low nibble 0000), 0xED (L3, 1101), 0xF0 (L4, 0000),
+        // 0xF4 (L4, x100) -- in this block or in front of it?  Mostly not (see SjUtf8Lazy): a wave-uniform skip
+        const uint32_t sp0 = sj_bop<SJ_TT_A_AND_BORC>(L3[0], cl.n_0000, cl.n_1101) | sj_bop<SJ_TT_A_AND_BORC>(L4[0], cl.n_0000, l4a[0]);
+        const uint32_t sp1 = sj_bop<SJ_TT_A_AND_BORC>(L3[1], ch.n_0000, ch.n_1101) | sj_bop<SJ_TT_A_AND_BORC>(L4[1], ch.n_0000, l4a[1]);
+        if (any(sj_bop<SJ_TT_OR3>(sp0, sp1, uc.special))) {
         const SjPair p5 = {lo[5], hi[5]}, p4 = {lo[4], hi[4]};
         const SjPair q5 = sj_shr1(p5), q4 = sj_shr1(p4);
         const uint32_t Q5[2] = {q5.lo, q5.hi}, Q4[2] = {q4.lo, q4.hi};
@@ -258,9 +302,10 @@ SJ_HD SjBlockMasks32 sj_block32(const uint32_t lo[8], const uint32_t hi[8], uint
         }
         // ... and the lead in byte -1 against this block's byte 0
         const uint32_t b5 = lo[5] & 1u, b4 = lo[4] & 1u;
-        const uint32_t s = uc.sec;
-        const uint32_t first = ((s & 1u) & ~b5) | (((s >> 1) & 1u) & b5) | (((s >> 2) & 1u) & ~b5 & ~b4) | (((s >> 3) & 1u) & (b5 | b4));
+        const uint32_t k0 = uc.special == 0xE0u, k1 = uc.special == 0xEDu, k2 = uc.special == 0xF0u, k3 = uc.special == 0xF4u;
+        const uint32_t first = (k0 & ~b5) | (k1 & b5) | (k2 & ~b5 & ~b4) | (k3 & (b5 | b4));
         err = e[0] | e[1] | first;
+        }
     }
     r.utf8 = err;
     r.words = 0;
@@ -286,4 +331,10 @@ SJ_HD SjBlockMasks32 sj_block32(const uint32_t lo[8], const uint32_t hi[8], uint
         r.words = w0 | (w1 << 8);
     }
     return r;
+}
+
+// ... one block on its own, carries in the full form (tests, the slow path of the kernels)
+SJ_HD SjBlockMasks32 sj_block32(const uint32_t lo[8], const uint32_t hi[8], uint32_t e_in, uint32_t p_in, SjUtf8Carry uc,
+                                bool do_utf8 = true, bool want_words = false) {
+    return sj_block32(lo, hi, e_in, p_in, sj_utf8_lazy_of(uc), do_utf8, want_words, [](uint32_t x) { return x != 0; });
 }

@@ -711,9 +711,9 @@ stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ 
                     // block or in the four bytes before it (a pending carry needs a byte >= 0xC0 there)
                     const uint32_t halo_hi = has_halo ? (uint32_t)(halo >> 32) & 0x80808080u : 0u;
                     const bool need_utf8 = __ballot((plo[7] | phi[7] | halo_hi) != 0) != 0;
-                    SjUtf8Carry uc = {0, 0, 0, 0};
-                    if (need_utf8 && has_halo) uc = sj_utf8_carry(halo);
-                    const SjBlockMasks32 bm = sj_block32(plo, phi, e_in, p_in, uc, need_utf8, BATCH);
+                    SjUtf8Lazy uc = {0, 0};
+                    if (need_utf8 && has_halo) uc = sj_utf8_carry_lazy(halo);
+                    const SjBlockMasks32 bm = sj_block32(plo, phi, e_in, p_in, uc, need_utf8, BATCH, [](uint32_t x) { return __ballot(x != 0) != 0; });
                     pot[s] = ((sj_u64)bm.pot.hi << 32) | bm.pot.lo;
                     sm[s] = ((sj_u64)bm.sm0.hi << 32) | bm.sm0.lo;
                     // (min: 0 / 1 from zero / nonzero in one instruction)

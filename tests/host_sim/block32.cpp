@@ -55,6 +55,8 @@ extern "C" int block32_fuzz(uint64_t seed, uint64_t rounds, uint64_t* fails_at) 
                 memcpy(&halo, hb, 8);
             }
             uc = sj_utf8_carry(halo);
+            const SjUtf8Lazy a = sj_utf8_carry_lazy(halo), b = sj_utf8_lazy_of(uc);
+            if (a.c123 != b.c123 || a.special != b.special) { *fails_at = it; return 12; }
         }
         const bool words = (rnd() & 1) != 0;
         const SjBlockMasks a = sj_block(p, e_in, p_in, uc, true, nullptr, words);
