@@ -876,23 +876,25 @@ stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ 
                 if (fits && !(dbg & DBG_NO_WRITE)) {
                     const uint32_t WT = gend - gbase;
                     uint32_t* dst0 = out + cnt_in + gbase;
-                    if (WT + 3 <= (uint32_t)CAP) {
-                        // common case: everything fits in one round, so the per-bit loops need no window test.  Entries
-                        // are staged at the same position modulo 4 as their final index, so that whole 16-byte quads of
-                        // the LDS slice go out as global_store_dwordx4 (the index array is 16-byte aligned); only the
-                        // two boundary quads of the run need element-wise stores.
-                        const uint32_t g0 = (uint32_t)((cnt_in + gbase) & 3ull);
+                    // One round of the fast form: steps [e0, e1) of the group, whose rcount indexes begin rbase entries into the
+                    // group, fit the staging slots, so the per-bit loops need no window test.  Entries are staged at the same
+                    // position modulo 4 as their final index, so that whole 16-byte quads of the LDS slice go out as
+                    // global_store_dwordx4 (the index array is 16-byte aligned); only the two boundary quads of the run need
+                    // element-wise stores.
+                    auto fast_round = [&](int e0, int e1, uint32_t rbase, uint32_t rcount) {
+                        const uint32_t g0 = (uint32_t)((cnt_in + gbase + rbase) & 3ull);
 #pragma unroll
                         for (int e = 0; e < E; ++e) {
+                            if (e < e0 || e >= e1) continue;  // (wave-uniform; e itself stays a constant: mk / pos are registers)
                             const uint32_t bstart = (uint32_t)((pblk0 + (sj_u64)(g * E + e) * 64 + lane) * 64);
-                            uint32_t* q = stage + g0 + pos[e];
+                            uint32_t* q = stage + g0 + (pos[e] - rbase);
                             for (uint32_t lo = (uint32_t)mk[e]; lo; lo &= lo - 1) *q++ = bstart | (uint32_t)__builtin_ctz(lo);
                             for (uint32_t hi = (uint32_t)(mk[e] >> 32); hi; hi &= hi - 1)
                                 *q++ = bstart | 32u | (uint32_t)__builtin_ctz(hi);
                         }
                         wave_lds_fence();
-                        const uint32_t span = g0 + WT;
-                        uint32_t* gbp = dst0 - g0;  // 16-byte aligned
+                        const uint32_t span = g0 + rcount;
+                        uint32_t* gbp = dst0 + rbase - g0;  // 16-byte aligned
                         for (uint32_t qi = lane; qi * 4 < span; qi += 64) {
                             const uint4 v = reinterpret_cast<const uint4*>(stage)[qi];
                             const uint32_t lo = qi * 4;
@@ -906,6 +908,15 @@ stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ 
                             }
                         }
                         wave_lds_fence();
+                    };
+                    // (a structural every ~5 bytes -- the documents of configs[3] -- makes 3,000 per 16 KiB granule: more than
+                    //  the 2,304 slots, but each half of the granule fits)
+                    const uint32_t split = E >= 2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)pos[E / 2]) : 0u;
+                    if (WT + 3 <= (uint32_t)CAP) {
+                        fast_round(0, E, 0, WT);
+                    } else if (E >= 2 && split + 3 <= (uint32_t)CAP && WT - split + 3 <= (uint32_t)CAP) {
+                        fast_round(0, E / 2, 0, split);
+                        fast_round(E / 2, E, split, WT - split);
                     } else {
                         for (uint32_t base = 0; base < WT; base += CAP) {
                             const uint32_t lim = base + CAP;

@@ -263,3 +263,19 @@ def test_device_path_twitter_x64(ctx, twitter):
     got = out[:idx0.size * reps].to(torch.int64) & 0xFFFFFFFF
     assert torch.equal(got, want)
     assert int(out[idx0.size * reps].item()) == 0
+
+
+@pytest.mark.parametrize("unit,what", [(b'"abcdef",', "two fast rounds of two steps (1 structural per 4.5 bytes: 3,640 per 16 KiB granule)"),
+                                       (b'12345,', "the windowed path (1 per 3 bytes: neither half of a granule fits the 2,304 staging slots)"),
+                                       (b'"abcdefghijklmnopqr",', "one round (1 per 10.5 bytes)"),
+                                       (b'"abcdef",' * 700 + b'12345,' * 900 + b'"abcdefghijklmnopqr",' * 300, "all three forms, changing inside granules")])
+def test_index_emission_rounds_by_structural_density(ctx, unit, what):
+    """k_stage1's expansion stages a 16 KiB granule's indexes in 2,304 LDS slots per wave: one round when they fit, two rounds of
+    two steps when each half fits, windows otherwise (stage1.hip, fast_round): every form against the oracle, S = 4."""
+    ctx.set_tile_steps(4)
+    try:
+        for total in (3 * 16384 + 100, 41 * 16384 + 5000):
+            d = b"[" + unit * (total // len(unit)) + b"0]"
+            _check(ctx, d)
+    finally:
+        ctx.set_tile_steps(0)
