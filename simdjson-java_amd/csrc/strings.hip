@@ -381,6 +381,7 @@ k_strings(const StrArgs a0) {
         uint32_t w[16];
         SjStrBlock m;
         uint32_t base = 0, oexcl = 0, tot_out = 0, tot_open = 0, prevD = 0, xerr = 0;
+        uint32_t entered_in = 0;  // the lane's block begins inside a string
         uint32_t pend_rel = STR_NONE, fclose_rel = STR_NONE, fclose_err = 0;
         bool any_err = false;
         sj_u64 blk = 0;
@@ -453,6 +454,7 @@ k_strings(const StrArgs a0) {
                 }
             }
             m = sj_str_block(p, s, pin, any_esc || do_u, do_u, &halo);
+            entered_in = pin;
             const uint32_t nout = sj_str_out_bytes(m), nopen = (uint32_t)__popcll(m.O);
             const uint32_t packed = str_incl_scan(nout | (nopen << 16));
             const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)packed, 63);
@@ -690,44 +692,42 @@ k_strings(const StrArgs a0) {
             //      a variable are slow) ----
             if (SJMI_STR_ABL & 1) {
             } else if (!any_err) {
-                const uint32_t CLlo = (uint32_t)m.CL, CLhi = (uint32_t)(m.CL >> 32);
-                const uint32_t nKlo = (uint32_t)__popc(Klo);
-                for (uint32_t cl = CLlo; cl; cl &= cl - 1) {
-                    const uint32_t c = (uint32_t)__builtin_ctz(cl);
-                    const uint32_t ltc = (1u << c) - 1u, olt = Olo & ltc;
-                    uint32_t Do, n;
-                    if (olt) {
-                        const uint32_t lto = (1u << (31u - (uint32_t)__builtin_clz(olt))) - 1u;
-                        Do = B + (uint32_t)__popc(Klo & lto) + 4u * (uint32_t)__popc(olt) - 4u;
-                        n = (uint32_t)__popc(Klo & ltc & ~lto);
-                    } else if (prevD) {
-                        Do = prevD - 1u;
-                        n = B + (uint32_t)__popc(Klo & ltc) - Do - 4u;
-                    } else {
-                        continue;  // opened in an earlier granule: the flush writes that header
-                    }
-                    tile_or(tile, Do, __builtin_bswap32(n));
+                // The records of a block lie back to back -- [be32 length][bytes][be32 length][bytes] ...: nothing is kept between
+                // a closing quote and the next opening one -- so the header of the NEXT string begins where the output offset of a
+                // closing quote ends, and that offset is one v_bcnt (popcount + addend) once the header slots in front of it are
+                // counted by the trip number: quotes alternate, so the k-th closing quote of the block has k openings in front of
+                // it, one more if the block is entered outside a string.  (Round 3 located every header from scratch: two more
+                // popcounts, a v_ffbh and the arithmetic around them per closing quote -- 34 instead of 19 instructions a trip, and
+                // the trips are the busiest lane's.)
+                uint32_t CLlo = (uint32_t)m.CL, CLhi = (uint32_t)(m.CL >> 32);
+                // where the content of the string that is open (or opens first) begins = its header + 4
+                uint32_t from = (entered_in ? prevD - 1u : B) + 4u;
+                uint32_t slots = entered_in ? B : B + 4u;  // B + 4 x openings in front of the closing quote at hand
+                if (entered_in && !prevD) {
+                    // opened in an earlier granule (the flush writes that header): pass over the block's first closing quote
+                    const uint32_t inlo = CLlo != 0;
+                    const uint32_t c = (uint32_t)__builtin_ctz(inlo ? CLlo : (CLhi ? CLhi : 1u));
+                    const uint32_t ltc = (1u << c) - 1u;
+                    const uint32_t end = inlo ? slots + (uint32_t)__popc(Klo & ltc) : slots + (uint32_t)__popc(Klo) + (uint32_t)__popc(Khi & ltc);
+                    if (inlo) CLlo &= CLlo - 1;
+                    else CLhi &= CLhi - 1;
+                    from = end + 4u;
+                    slots += 4u;
                 }
+                for (uint32_t cl = CLlo; cl; cl &= cl - 1) {
+                    const uint32_t ltc = (1u << (uint32_t)__builtin_ctz(cl)) - 1u;
+                    const uint32_t end = (uint32_t)__popc(Klo & ltc) + slots;
+                    tile_or(tile, from - 4u, __builtin_bswap32(end - from));
+                    from = end + 4u;
+                    slots += 4u;
+                }
+                slots += (uint32_t)__popc(Klo);
                 for (uint32_t cl = CLhi; cl; cl &= cl - 1) {
-                    const uint32_t c = (uint32_t)__builtin_ctz(cl);
-                    const uint32_t ltc = (1u << c) - 1u, olt = Ohi & ltc;
-                    uint32_t Do, n;
-                    if (olt) {
-                        const uint32_t lto = (1u << (31u - (uint32_t)__builtin_clz(olt))) - 1u;
-                        Do = Bhi + (uint32_t)__popc(Khi & lto) + 4u * (uint32_t)__popc(olt) - 4u;
-                        n = (uint32_t)__popc(Khi & ltc & ~lto);
-                    } else if (Olo) {
-                        const uint32_t lto = (1u << (31u - (uint32_t)__builtin_clz(Olo))) - 1u;
-                        const uint32_t kb = (uint32_t)__popc(Klo & lto);
-                        Do = B + kb + 4u * (uint32_t)__popc(Olo) - 4u;
-                        n = nKlo - kb + (uint32_t)__popc(Khi & ltc);
-                    } else if (prevD) {
-                        Do = prevD - 1u;
-                        n = Bhi + (uint32_t)__popc(Khi & ltc) - Do - 4u;
-                    } else {
-                        continue;
-                    }
-                    tile_or(tile, Do, __builtin_bswap32(n));
+                    const uint32_t ltc = (1u << (uint32_t)__builtin_ctz(cl)) - 1u;
+                    const uint32_t end = (uint32_t)__popc(Khi & ltc) + slots;
+                    tile_or(tile, from - 4u, __builtin_bswap32(end - from));
+                    from = end + 4u;
+                    slots += 4u;
                 }
             } else {  // (rare: some string of the wave's 4 KiB has a malformed escape)
                 for (sj_u64 cl = m.CL; cl; cl &= cl - 1) {
