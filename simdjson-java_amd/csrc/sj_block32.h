@@ -44,7 +44,6 @@ SJ_HD uint32_t sj_bop(uint32_t a, uint32_t b, uint32_t c) {
 enum : uint32_t {
     SJ_TT_MUX_C = 0xE4,      // c ? a : b
     SJ_TT_OR3 = 0xFE,        // a | b | c
-    SJ_TT_XOR3 = 0x96,       // a ^ b ^ c
     SJ_TT_A_NB_NC = 0x10,    // a & ~b & ~c
     SJ_TT_A_B_NC = 0x40,     // a & b & ~c
     SJ_TT_A_NB_C = 0x20,     // a & ~b & c
@@ -58,7 +57,6 @@ enum : uint32_t {
     SJ_TT_ANB_OR_C = 0xBA,   // (a & ~b) | c
     SJ_TT_A_N_BC = 0x70,     // a & ~(b & c)
     SJ_TT_ANC_OR_BC = 0xD8,  // (a & ~c) | (b & c)
-    SJ_TT_XOR_AND = 0x28,    // (a ^ b) & c
 };
 
 // one butterfly stage between two registers: afterwards x holds the elements whose position bit (of weight S) was clear, y
