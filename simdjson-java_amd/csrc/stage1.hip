@@ -9,8 +9,10 @@
 //   * one lane  = one 64-byte block (the reference's loop step), loaded as 4 x dwordx4; the loads of a step are
 //     requested as soon as the previous step has been transposed out of the registers they land in;
 //   * the block is transposed to 8 bit planes (v_perm_b32 byte transposes + one 8x8 bit-matrix butterfly across
-//     8 registers per 32-byte half, sj_block.h; an earlier v_and + v_msad_u8 form is kept for the self-test) and
-//     all classification / escape / string / UTF-8 logic is 64-bit boolean algebra in VGPRs;
+//     8 registers per 32-byte half; an earlier v_and + v_msad_u8 form is kept for the self-test) and all
+//     classification / escape / string / UTF-8 logic is boolean algebra on the planes in VGPRs: sj_block.h states it
+//     on 64-bit masks, sj_block32.h -- what the streaming loop runs since round 4 -- on 32-bit halves with one explicit
+//     v_bitop3_b32 per three-input function (a sixth fewer instructions; bit-identical, fuzzed against each other);
 //   * the three serial carries of the reference loop (prevEscaped, prevScalar, previous 4 UTF-8
 //     bytes) are LOCAL: each lane re-derives them from the 8 bytes before its block;
 //   * the two truly global carries -- in-string parity (XOR scan) and the output offset (+ scan of
@@ -23,9 +25,11 @@
 //     (structurals(p) = p ? pot & sm : pot & ~sm), so each granule publishes counts for BOTH parities
 //     and the chain composes functions {0,1} -> (parity, count);
 //   * indexes are expanded into a wave-private LDS slice and leave the CU as aligned 16-byte stores.
-// Measured cost model on gfx950 (tools/ubench/valu_rate.hip): VOP2 integer ops issue in 2 cycles per
-// wave, every VOP3 op (v_msad_u8, v_or3, v_lshl_or, v_bfi, v_bcnt, 64-bit shifts) in 4; ~650 VALU instructions
-// per 4 KiB wave-step (SQ_INSTS_VALU, profiles/r1).
+// Measured cost model on gfx950 (tools/microbench/valu_rates.hip, valu_mix.hip; profiles/r4/valu_*.jsonl): plain 32-bit
+// logic / add / mov / shift-by-constant / v_bitop3_b32 retire in ~2.1 cycles per wave ONLY in streams of their own kind; one
+// other instruction among sixteen (v_perm, v_bfi, v_or3, v_lshl_or, v_bcnt, v_cmp, DPP, 64-bit shifts, LDS, loads) already
+// makes it 3.0, and this kernel's mix runs at ~4.2 -- so the instruction COUNT is what is tuned: 539 VALU instructions per
+// 4 KiB wave-step on twitter.json (SQ_INSTS_VALU, tools/pmc_stage1.sh; 653 with sj_block.h in the loop).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
