@@ -104,7 +104,7 @@ struct StrArgs {
     uint32_t* blk_ord;     // optional: ordinal of the first string opened at or behind every block's first byte
     sj_u64* gstate;        // aggregates[ngran] | prefixes[ngran] | open records[ngran]
     uint32_t* ticket;      // STR_TICKET_CLASSES counters, 64 bytes apart
-    uint32_t* wsflags;     // [0] status bits (SJMI_ST_INTERNAL), [1] the scanner's CU
+    uint32_t* wsflags;     // [0] status bits (SJMI_ST_INTERNAL), [1] the scanner's CU, [2] the role ticket
     UnescapeResult* res;
     uint32_t ngran;
     uint32_t flags;
@@ -332,7 +332,15 @@ k_strings(const StrArgs a0) {
     sj_u64* const orec = a.gstate + 2 * (sj_u64)ngran;
     const uint32_t my_cu = (((uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 8) & 0xFFu) |
                            (((uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) << 8) | 0x80000000u;
-    if (blockIdx.x == 0) {
+    // Roles by ARRIVAL, not by workgroup number: the first workgroup that gets a CU is the scanner, so the scanner is resident
+    // whenever a worker is.  (Workgroups are not placed in order when another process's persistent kernel holds part of the GPU:
+    // with the scanner = workgroup 0, two processes alternating stage 1 and this pass left workers polling for a scanner that was
+    // still waiting for a slot -- one tripped spin bound, flags 4, in about one of ten runs of tests/test_gpu_two_process.py.)
+    __shared__ uint32_t s_role;
+    if (threadIdx.x == 0) s_role = __hip_atomic_fetch_add(&a.wsflags[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t role = s_role;
+    if (role == 0) {
         if (threadIdx.x == 0) {
             __hip_atomic_store(&a.wsflags[1], my_cu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             hand.seq = 0;
@@ -346,7 +354,7 @@ k_strings(const StrArgs a0) {
     if (threadIdx.x < 16) s_lut[threadIdx.x] = sj_str_pack_selector(threadIdx.x);
     __syncthreads();
     const uint32_t nworkers = (gridDim.x - 1u) * 4u;
-    const uint32_t worker = (blockIdx.x - 1u) * 4u + (uint32_t)wave;
+    const uint32_t worker = (role - 1u) * 4u + (uint32_t)wave;
     uint32_t* const tile = sh[wave].tile;
     const sj_u64 nblocks = a.len / 64 + 1;
     const sj_u64 lt_lane = (1ull << lane) - 1ull;
@@ -829,7 +837,7 @@ k_strings(const StrArgs a0) {
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr size_t STR_WS_FLAGS_OFFSET = 0;     // u32 status, u32 scanner CU
+constexpr size_t STR_WS_FLAGS_OFFSET = 0;     // u32 status, u32 scanner CU, u32 role ticket (workgroups in their order of arrival)
 constexpr size_t STR_WS_RESULT_OFFSET = 32;   // a result record zeroed with the workspace (strings_workspace_result)
 constexpr size_t STR_WS_TICKET_OFFSET = 64;   // the ticket counters, 64 bytes apart
 constexpr size_t STR_WS_STATE_OFFSET = 64 + 32 * 64;  // (room for 32 ticket counters)
