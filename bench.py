@@ -44,6 +44,25 @@ PROFILE_DIR = os.path.join(ROOT, "profiles", "r4")
 # ---------------------------------------------------------------------------------------------------------------
 # CPU baseline
 # ---------------------------------------------------------------------------------------------------------------
+JAVA_HARNESS = os.path.join(ROOT, "java", "bench", "org", "simdjson", "RefStage1Bench.java")
+REFERENCE_SRC_CANDIDATES = (os.environ.get("SJMI_REFERENCE_SRC", ""), "/root/reference/src/main/java")
+JAVA_MIN_MAJOR = int(os.environ.get("SJMI_JAVA_MIN", "24"))  # the reference's README.md:76 asks for JDK 24
+
+
+def java_major(exe):
+    """major version of a `java` / `javac` executable, or None"""
+    import re
+    try:
+        out = subprocess.run([exe, "-version"], capture_output=True, text=True, timeout=20)
+    except Exception:  # noqa: BLE001
+        return None
+    m = re.search(r'(?:version "|javac )(\d+)(?:\.(\d+))?', (out.stderr or "") + (out.stdout or ""))
+    if not m:
+        return None
+    major = int(m.group(1))
+    return int(m.group(2) or 0) if major == 1 else major  # ("1.8.0" -> 8)
+
+
 def probe_java():
     """Is a JDK that could run the reference (JDK >= 24 with jdk.incubator.vector) on this box?  (The reference's sources
     are not on the GPU box in any case: /root/reference exists only in the build container.)"""
@@ -55,6 +74,53 @@ def probe_java():
         return "java present: " + (out.stderr or out.stdout).splitlines()[0]
     except Exception as e:  # noqa: BLE001
         return "java probe failed: %r" % (e,)
+
+
+def reference_jvm_commands(ref_src, out_dir, doc_path, threads, seconds, slice_bytes=32 << 20, species="512"):
+    """-> (javac command, java command) that build the reference's main sources + java/bench/org/simdjson/RefStage1Bench.java
+    into out_dir and run the harness (plain javac, no Gradle, no JMH; src/main has no external dependency)"""
+    sources = sorted(os.path.join(d, f) for d, _, fs in os.walk(ref_src) for f in fs if f.endswith(".java"))
+    javac = [shutil.which("javac") or "javac", "--add-modules", "jdk.incubator.vector", "-nowarn", "-d", out_dir] + sources + [JAVA_HARNESS]
+    java = [shutil.which("java") or "java", "--add-modules", "jdk.incubator.vector", "-Dorg.simdjson.species=%s" % species,
+            "-cp", out_dir, "org.simdjson.RefStage1Bench", doc_path, str(int(threads)), "%.1f" % seconds, str(int(slice_bytes))]
+    return javac, java
+
+
+def reference_jvm_baseline(doc, seconds=5.0):
+    """The REFERENCE ITSELF on this box's host cores -- Utf8Validator.validate + StructuralIndexer.index (= SimdJsonParser.stage1,
+    SimdJsonParser.java:55-58) and SimdJsonParser.parse, 1 thread and all cores -- when a JDK >= 24 (java + javac) and the
+    reference's sources are here.  -> (dict or None, reason).  Never raises: the port stays the baseline when it cannot run."""
+    import tempfile
+    java, javac = shutil.which("java"), shutil.which("javac")
+    if not java or not javac:
+        return None, "no JDK on PATH (java: %s, javac: %s)" % (java or "absent", javac or "absent")
+    major = java_major(java)
+    if major is None or major < JAVA_MIN_MAJOR:
+        return None, "JDK %s < %d" % (major, JAVA_MIN_MAJOR)
+    ref = next((d for d in REFERENCE_SRC_CANDIDATES if d and os.path.isdir(os.path.join(d, "org", "simdjson"))), None)
+    if not ref:
+        return None, "JDK %d present, but the reference's sources are not on this box (SJMI_REFERENCE_SRC)" % major
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with tempfile.TemporaryDirectory(prefix="sjmi_ref_") as tmp:
+            doc_path = os.path.join(tmp, "doc.json")
+            with open(doc_path, "wb") as f:
+                f.write(doc)
+            out_dir = os.path.join(tmp, "classes")
+            os.makedirs(out_dir)
+            c_javac, c_java = reference_jvm_commands(ref, out_dir, doc_path, cores, seconds)
+            b = subprocess.run(c_javac, capture_output=True, text=True, timeout=300)
+            if b.returncode != 0:
+                return None, "javac failed: " + (b.stderr or b.stdout)[-300:]
+            r = subprocess.run(c_java, capture_output=True, text=True, timeout=120 + 6 * seconds)
+            if r.returncode != 0:
+                return None, "java failed: " + (r.stderr or r.stdout)[-300:]
+            res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            res["cores"] = cores
+            res["command"] = " ".join(c_java[:5]) + " ... RefStage1Bench"
+            return res, "ok"
+    except Exception as e:  # noqa: BLE001
+        return None, "reference harness failed: %r" % (e,)
 
 
 def cpu_baseline(doc, seconds=8.0):
@@ -108,10 +174,22 @@ def cpu_baseline(doc, seconds=8.0):
     what = ("oracle/sj_avx512.c (AVX-512 restatement of the reference's 512-bit Java Vector-API stage 1: vpcmpb/kmov classes, "
             "vpshufb nibble tables, two passes like SimdJsonParser.stage1)" if avx else
             "oracle/sj_oracle.c (scalar C port; this host CPU has no AVX-512)")
-    return {"value": round(total / el / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+    port = {"value": round(total / el / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
             "one_core": round(one, 3), "scalar_port_one_core": round(scalar_one, 3),
             "sample": "twitter.json x%d (%d B) per thread, %d threads, %d scans in %.1f s by %s; the reference itself needs a "
                       "JVM: %s" % (reps, base.size, cores, total // base.size, el, what, probe_java())}
+    # the reference itself, the moment a JDK >= 24 and its sources are on the box (java/bench/org/simdjson/RefStage1Bench.java)
+    ref, why = reference_jvm_baseline(doc)
+    if ref is None:
+        port["reference_jvm"] = "not run: " + why
+        return port
+    return {"value": round(ref["stage1_gb_per_s_all_threads"], 3), "unit": "GB/s", "cores": ref["cores"], "kind": "reference",
+            "one_core": round(ref["stage1_gb_per_s_one_thread"], 3),
+            "parse_per_s": round(ref["parse_per_s_all_threads"], 1), "parse_per_s_one_core": round(ref["parse_per_s_one_thread"], 1),
+            "sample": "the reference's own Utf8Validator.validate + StructuralIndexer.index (SimdJsonParser.java:55-58) at %s-bit vectors on "
+                      "JDK %s, one parser per thread over its own %d B slice of twitter.json copies, %.0f s per leg (%s)"
+                      % (ref.get("vector_bits"), ref.get("java"), ref.get("slice_bytes", 0), ref.get("seconds", 0), ref.get("command")),
+            "port": port}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -325,8 +403,9 @@ def check_batch_sample(torch, oracle, shard, offs, sample=10000, seed=20250825):
     return len(ks)
 
 
-BATCH_KERNELS = ("k_batch_sep_check + k_stage1 (one plain pass, accepted on the device) + k_strings + k_doc_prepare + tape-offset scan + "
-                 "k_coop_walk (the per-document passes and the sanitized-copy string pass are queued behind the plain pass and leave at once)")
+BATCH_KERNELS = ("k_stage1_batch (one plain pass with per-block side outputs, accepted on the device) + k_strings<true> + k_doc_prepare "
+                 "(separator check, index ranges, string ordinals, predicted tape lengths) + tape-offset scan + k_tok_walk (token walker; "
+                 "k_coop_walk in list mode behind it for the documents it declines)")
 
 
 def batch_algorithmic_bytes(n, c):

@@ -82,6 +82,7 @@ struct sjmi_ctx {
     HostView views[6];                       // device views of caller buffers that are page-locked and device-visible (zero-copy outputs)
     int view_next = 0;
     const uint32_t* idx_last = nullptr;      // where the last host-form stage-1 call left its indexes (c->d_idx, or the caller's array)
+    const void* idx_last_host = nullptr;     // ... the caller's array as the host sees it (nullptr: c->d_idx)
     void* h_res_dev = nullptr;               // h_res / h_pack as the device sees them
     void* h_pack_dev = nullptr;
     void* s1_zero2 = nullptr;                // one-shot extras of the next stage1_device_impl call (sjmi_parse_document):
@@ -345,6 +346,19 @@ static void drop_stale_views(sjmi_ctx* c) {
     for (auto& v : c->views) v = {};
     c->zc_host = nullptr;
     c->zc_dev = nullptr;
+    // "the indexes of the last call" may sit in a caller array through a view that is gone now (unregistered, maybe unmapped):
+    // the two-call forms (sjmi_unescape, sjmi_match_brackets) must not dereference it -- they ask for a new stage-1 call instead
+    if (c->idx_last && c->idx_last != c->d_idx) {
+        void* dp = nullptr;
+        const bool still = c->idx_last_host && hipHostGetDevicePointer(&dp, const_cast<void*>(c->idx_last_host), 0) == hipSuccess &&
+                           dp == (const void*)c->idx_last;
+        if (!still) {
+            (void)hipGetLastError();
+            c->idx_last = nullptr;
+            c->idx_last_host = nullptr;
+            c->last_valid = false;
+        }
+    }
 }
 static void* device_view(sjmi_ctx* c, const void* host) {
     static const bool off = getenv("SJMI_ZERO_COPY") && atoi(getenv("SJMI_ZERO_COPY")) == 0;
@@ -353,9 +367,9 @@ static void* device_view(sjmi_ctx* c, const void* host) {
     for (const auto& v : c->views)
         if (v.host == host) return v.dev;
     void* dp = nullptr;
-    if (hipHostGetDevicePointer(&dp, const_cast<void*>(host), 0) != hipSuccess) {
-        (void)hipGetLastError();  // (not device-visible: not an error)
-        dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, const_cast<void*>(host), 0) != hipSuccess || !dp) {
+        (void)hipGetLastError();  // (not device-visible: not an error -- and not cached: the buffer may be registered a moment later)
+        return nullptr;
     }
     c->views[c->view_next].host = host;
     c->views[c->view_next].dev = dp;
@@ -404,6 +418,7 @@ int sjmi_stage1(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes
             return SJMI_ERR_CAPACITY;
         }
         c->idx_last = zc_idx;
+        c->idx_last_host = indexes;
         c->last_len = len;
         c->last_count = c->h_res->count;
         c->last_valid = true;
@@ -411,6 +426,7 @@ int sjmi_stage1(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t* indexes
         return SJMI_OK;
     }
     c->idx_last = c->d_idx;
+    c->idx_last_host = nullptr;
     for (int attempt = 0; attempt < 2; ++attempt) {
         // (the device entry point: double-buffered workspace, nothing but the kernel is queued once the context is warm)
         const int rc = stage1_device_impl(c, c->d_in, len, c->d_idx, dev_cap, c->d_res_tmp, c->stream, 0);
@@ -684,6 +700,7 @@ static int unescape_host(sjmi_ctx* c, uint8_t* string_buffer, uint64_t string_ca
 int sjmi_unescape(sjmi_ctx* c, uint8_t* string_buffer, uint64_t string_capacity, uint64_t* total_bytes,
                   uint64_t* first_error_index, uint32_t* first_error_code) {
     if (!c || !string_buffer || !total_bytes || !first_error_index || !first_error_code) return SJMI_ERR_ARG;
+    drop_stale_views(c);  // (the last call's indexes may sit in a caller array that has been unregistered since)
     if (!c->last_valid) {
         c->err = "sjmi_unescape needs a preceding successful sjmi_stage1 on this context";
         return SJMI_ERR_ARG;
@@ -695,6 +712,7 @@ int sjmi_unescape_batch(sjmi_ctx* c, uint8_t* string_buffer, uint64_t string_cap
                         uint64_t* total_bytes, uint64_t* first_error_index, uint32_t* first_error_code) {
     if (!c || !string_buffer || !doc_string_offsets || !total_bytes || !first_error_index || !first_error_code)
         return SJMI_ERR_ARG;
+    drop_stale_views(c);
     if (!c->last_valid || !c->last_batch) {
         c->err = "sjmi_unescape_batch needs a preceding successful sjmi_stage1_batch[_isolated] on this context";
         return SJMI_ERR_ARG;
@@ -755,6 +773,7 @@ int sjmi_stage1_unescape(sjmi_ctx* c, const uint8_t* buf, uint64_t len, uint32_t
     const bool zero_copy = zc_idx && zc_sb && c->h_pack_dev;
     uint32_t* const idx_out = zero_copy ? zc_idx : c->d_idx;
     c->idx_last = idx_out;
+    c->idx_last_host = zero_copy ? indexes : nullptr;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const int s1rc = stage1_device_impl(c, c->d_in, len, idx_out, dev_cap, c->d_res_tmp, c->stream, 0);
         if (s1rc != SJMI_OK) return s1rc;
@@ -1055,6 +1074,8 @@ int sjmi_stage1_batch(sjmi_ctx* c, const uint8_t* buf, uint64_t total_len, const
                                                hipMemcpyDeviceToHost, c->stream)) ||
         fail(c, "sync", hipStreamSynchronize(c->stream)))
         return SJMI_ERR_HIP;
+    c->idx_last = c->d_idx;  // (a batch call's indexes are always in the context's own array, never in a caller's zero-copy view)
+    c->idx_last_host = nullptr;
     c->last_len = total_len;
     c->last_count = c->h_res->count;
     c->last_valid = true;
@@ -1195,6 +1216,8 @@ int sjmi_stage1_batch_isolated(sjmi_ctx* c, const uint8_t* buf, uint64_t total_l
                                                hipMemcpyDeviceToHost, c->stream)) ||
         fail(c, "sync", hipStreamSynchronize(c->stream)))
         return SJMI_ERR_HIP;
+    c->idx_last = c->d_idx;  // (a batch call's indexes are always in the context's own array, never in a caller's zero-copy view)
+    c->idx_last_host = nullptr;
     c->last_len = total_len;
     c->last_count = c->h_res->count;
     c->last_valid = true;
@@ -1448,6 +1471,7 @@ int sjmi_match_brackets_device(sjmi_ctx* c, const void* d_buf, const void* d_ind
 
 int sjmi_match_brackets(sjmi_ctx* c, uint32_t* up, uint32_t* match, uint64_t capacity) {
     if (!c || !up || !match) return SJMI_ERR_ARG;
+    drop_stale_views(c);
     if (!c->last_valid || c->last_batch) {
         c->err = "sjmi_match_brackets needs a preceding successful sjmi_stage1 on this context";
         return SJMI_ERR_ARG;
@@ -1478,15 +1502,19 @@ int sjmi_match_brackets(sjmi_ctx* c, uint32_t* up, uint32_t* match, uint64_t cap
 int sjmi_host_register(sjmi_ctx* c, void* ptr, uint64_t bytes) {
     if (!c || !ptr || !bytes) return SJMI_ERR_ARG;
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
-    g_pin_epoch.fetch_add(1, std::memory_order_acq_rel);
     if (fail(c, "hipHostRegister", hipHostRegister(ptr, bytes, hipHostRegisterDefault))) return SJMI_ERR_HIP;
+    g_pin_epoch.fetch_add(1, std::memory_order_acq_rel);  // (behind the call: a view taken from now on sees the registration)
     return SJMI_OK;
 }
 
 int sjmi_host_unregister(sjmi_ctx* c, void* ptr) {
     if (!c || !ptr) return SJMI_ERR_ARG;
-    g_pin_epoch.fetch_add(1, std::memory_order_acq_rel);  // (every context forgets its zero-copy views, whatever the outcome)
-    if (fail(c, "hipHostUnregister", hipHostUnregister(ptr))) return SJMI_ERR_HIP;
+    // every context forgets its zero-copy views, whatever the outcome -- bumped on BOTH sides of the call: a view another thread
+    // takes between the first bump and hipHostUnregister is dropped again by the second
+    g_pin_epoch.fetch_add(1, std::memory_order_acq_rel);
+    const hipError_t e = hipHostUnregister(ptr);
+    g_pin_epoch.fetch_add(1, std::memory_order_acq_rel);
+    if (fail(c, "hipHostUnregister", e)) return SJMI_ERR_HIP;
     return SJMI_OK;
 }
 

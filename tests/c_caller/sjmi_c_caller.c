@@ -6,6 +6,12 @@
  *                   over every '"' structural that reads the record lengths the GPU wrote (TapeBuilder.visitString); then
  *                   sjmi_parse_document (tape from the device) and sjmi_destroy.  Prints counts and FNV-1a hashes that
  *                   tests/test_gpu_c_caller.py compares with the oracle's.
+ *   engine <file>   what java/org/simdjson/Sjmi.java's Engine does since round 5 (ordinary, non-critical downcalls need off-heap
+ *                   segments): three 64-byte-aligned native buffers (input + padding, index array, string buffer), each
+ *                   sjmi_host_register-ed, the input one also handed to sjmi_set_input_staging; per parse: memcpy of the
+ *                   document into the input buffer, sjmi_stage1_unescape on THOSE buffers (the kernels write indexes and
+ *                   records zero-copy), copies out; twice (the second call uses the cached device views); then
+ *                   sjmi_host_unregister x3 + sjmi_destroy (Engine.close / the Cleaner action).  Same first output line as replay.
  *   guard <file>    the visibility contract of include/sjmi.h ("bytes >= len are never read from buf": what lets Java hand
  *                   over an unpadded byte[]): the document is placed so that byte `len` is the FIRST BYTE OF A PROT_NONE PAGE
  *                   and sjmi_stage1, sjmi_stage1_unescape, sjmi_parser_parse (both placements of stage 2) and sjmi_stream_push
@@ -27,6 +33,7 @@
 SYM(sjmi_create); SYM(sjmi_destroy); SYM(sjmi_last_error); SYM(sjmi_stage1); SYM(sjmi_stage1_unescape); SYM(sjmi_parse_document);
 SYM(sjmi_parser_create); SYM(sjmi_parser_destroy); SYM(sjmi_parser_parse); SYM(sjmi_parser_set_gpu_walk); SYM(sjmi_parser_last_message);
 SYM(sjmi_stream_open); SYM(sjmi_stream_push); SYM(sjmi_stream_close);
+SYM(sjmi_host_register); SYM(sjmi_host_unregister); SYM(sjmi_set_input_staging);
 
 static void* lib;
 #define LOAD(name) do { p_##name = (__typeof__(p_##name))dlsym(lib, #name); if (!p_##name) { fprintf(stderr, "missing %s\n", #name); exit(2); } } while (0)
@@ -88,6 +95,53 @@ static int replay(const char* path) {
            (unsigned long long)fnv(tape, tlen * 8, FNV0), (unsigned long long)slen);
     p_sjmi_destroy(ctx);
     free(tape); free(sb); free(indexes); free(doc);
+    return 0;
+}
+
+static int engine(const char* path) {
+    size_t n;
+    uint8_t* doc = read_file(path, &n);
+    const uint64_t capacity = ((n + 2) * 4 + 4095) / 4096 * 4096;   /* new SimdJsonParser(capacity, maxDepth) */
+    sjmi_ctx* ctx = NULL;
+    if (p_sjmi_create(&ctx, 0, capacity) != SJMI_OK) { fprintf(stderr, "sjmi_create failed\n"); return 1; }
+    void *in = NULL, *indexes = NULL, *strings = NULL;             /* Arena.ofShared().allocate(bytes, 64) */
+    const uint64_t in_bytes = capacity + 64, idx_bytes = 4 * capacity, sb_bytes = capacity;
+    if (posix_memalign(&in, 4096, in_bytes) || posix_memalign(&indexes, 4096, idx_bytes) || posix_memalign(&strings, 4096, sb_bytes)) return 1;
+    void* const pinned[3] = {in, indexes, strings};
+    const uint64_t pinned_bytes[3] = {in_bytes, idx_bytes, sb_bytes};
+    for (int i = 0; i < 3; ++i)
+        if (p_sjmi_host_register(ctx, pinned[i], pinned_bytes[i]) != SJMI_OK) { fprintf(stderr, "sjmi_host_register: %s\n", p_sjmi_last_error(ctx)); return 1; }
+    if (p_sjmi_set_input_staging(ctx, in, in_bytes) != SJMI_OK) { fprintf(stderr, "sjmi_set_input_staging failed\n"); return 1; }
+    uint32_t* heap_idx = (uint32_t*)malloc((n + 2) * 4);              /* BitIndexes.indexes (heap int[]) */
+    uint8_t* heap_sb = (uint8_t*)malloc(capacity);                    /* the parser's stringBuffer (heap byte[]) */
+    for (int pass = 0; pass < 2; ++pass) {
+        uint64_t out[5] = {0, 0, 0, 0, 0};                            /* count | status | total | firstErrorIndex | firstErrorCode */
+        memset(indexes, 0xEE, idx_bytes);
+        memcpy(in, doc, n);                                           /* MemorySegment.copy(buffer, 0, in, JAVA_BYTE, 0, length) */
+        int rc = p_sjmi_stage1_unescape(ctx, (const uint8_t*)in, n, (uint32_t*)indexes, capacity, &out[0], (uint32_t*)&out[1],
+                                        (uint8_t*)strings, capacity, &out[2], &out[3], (uint32_t*)&out[4]);
+        if (rc != SJMI_OK) { fprintf(stderr, "sjmi_stage1_unescape: %d %s\n", rc, p_sjmi_last_error(ctx)); return 1; }
+        const uint64_t count = out[0], total = out[2];
+        const uint32_t status = (uint32_t)out[1];
+        memcpy(heap_idx, indexes, (count + 1) * 4);                   /* MemorySegment.copy(indexes, JAVA_INT, 0, array, 0, count + 1) */
+        if (heap_idx[count] != 0) { fprintf(stderr, "sentinel missing\n"); return 1; }
+        memcpy(heap_sb, strings, total);
+        uint64_t sbi = 0, nstr = 0, bad = 0;
+        for (uint64_t i = 0; i < count && status == 0; ++i) {
+            if (doc[heap_idx[i]] != '"') continue;
+            const uint32_t len = ((uint32_t)heap_sb[sbi] << 24) | ((uint32_t)heap_sb[sbi + 1] << 16) | ((uint32_t)heap_sb[sbi + 2] << 8) | heap_sb[sbi + 3];
+            if ((len & 0xFFFFFF00u) == 0xFFFFFF00u) { ++bad; break; }
+            sbi += 4 + len;
+            ++nstr;
+        }
+        printf("stage1 count=%llu status=%u idxhash=%016llx strings=%llu string_bytes=%llu walked_bytes=%llu sbhash=%016llx bad=%llu\n",
+               (unsigned long long)count, status, (unsigned long long)fnv(heap_idx, count * 4, FNV0), (unsigned long long)nstr,
+               (unsigned long long)total, (unsigned long long)sbi, (unsigned long long)fnv(heap_sb, total, FNV0), (unsigned long long)bad);
+    }
+    for (int i = 0; i < 3; ++i)
+        if (p_sjmi_host_unregister(ctx, pinned[i]) != SJMI_OK) { fprintf(stderr, "sjmi_host_unregister failed\n"); return 1; }
+    p_sjmi_destroy(ctx);
+    free(heap_sb); free(heap_idx); free(strings); free(indexes); free(in); free(doc);
     return 0;
 }
 
@@ -160,13 +214,15 @@ static int guard(const char* path) {
 }
 
 int main(int argc, char** argv) {
-    if (argc != 4) { fprintf(stderr, "usage: %s <libsjmi.so> replay|guard <json file>\n", argv[0]); return 2; }
+    if (argc != 4) { fprintf(stderr, "usage: %s <libsjmi.so> replay|engine|guard <json file>\n", argv[0]); return 2; }
     lib = dlopen(argv[1], RTLD_NOW | RTLD_GLOBAL);
     if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
     LOAD(sjmi_create); LOAD(sjmi_destroy); LOAD(sjmi_last_error); LOAD(sjmi_stage1); LOAD(sjmi_stage1_unescape); LOAD(sjmi_parse_document);
     LOAD(sjmi_parser_create); LOAD(sjmi_parser_destroy); LOAD(sjmi_parser_parse); LOAD(sjmi_parser_set_gpu_walk); LOAD(sjmi_parser_last_message);
     LOAD(sjmi_stream_open); LOAD(sjmi_stream_push); LOAD(sjmi_stream_close);
+    LOAD(sjmi_host_register); LOAD(sjmi_host_unregister); LOAD(sjmi_set_input_staging);
     if (!strcmp(argv[2], "replay")) return replay(argv[3]);
+    if (!strcmp(argv[2], "engine")) return engine(argv[3]);
     if (!strcmp(argv[2], "guard")) return guard(argv[3]);
     return 2;
 }

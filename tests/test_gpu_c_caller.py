@@ -66,6 +66,25 @@ def test_ffm_call_sequence_from_c_equals_the_oracle(name, tmp_path):
     assert int(s2["tapehash"], 16) == _fnv(np.asarray(want.tape, dtype=np.uint64).tobytes())
 
 
+@pytest.mark.parametrize("name", ["twitter.json", "github_events.json"])
+def test_off_heap_engine_sequence_from_c_equals_the_oracle(name, tmp_path):
+    """java/org/simdjson/Sjmi.java's Engine (ordinary downcalls on registered off-heap segments, input segment = staging):
+    both passes -- fresh and cached device views -- give the oracle's indexes and string records"""
+    doc = load_fixture(name)
+    p = tmp_path / name
+    p.write_bytes(doc)
+    out = _run("engine", str(p))
+    lines = out.splitlines()
+    assert len(lines) == 2 and lines[0] == lines[1]
+    s1 = dict(re.findall(r"(\w+)=(\w+)", lines[0]))
+    idx, st = O.stage1(doc)
+    sb = bytes(O.parse(doc).strings)
+    assert int(s1["count"]) == idx.size and int(s1["status"]) == st == 0
+    assert int(s1["idxhash"], 16) == _fnv(idx.astype(np.uint32).tobytes())
+    assert int(s1["string_bytes"]) == int(s1["walked_bytes"]) == len(sb) and int(s1["bad"]) == 0
+    assert int(s1["sbhash"], 16) == _fnv(sb)
+
+
 def test_no_byte_behind_len_is_read_from_the_callers_buffer(tmp_path):
     doc = load_fixture("twitter.json")
     p = tmp_path / "twitter.json"

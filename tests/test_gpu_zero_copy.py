@@ -130,3 +130,38 @@ def test_registration_changes_drop_the_cached_views(ctx):
             if state == "registered":
                 assert lib().sjmi_host_unregister(ctx._h, C.c_void_p(idx.ctypes.data)) == 0
                 assert lib().sjmi_host_unregister(ctx._h, C.c_void_p(sb.ctypes.data)) == 0
+
+
+def test_batch_after_a_zero_copy_call_reads_its_own_indexes(ctx):
+    """a zero-copy sjmi_stage1 leaves 'the last call's indexes' in the CALLER's array; a later host batch call writes
+    the context's own array -- the string pass of that batch must locate a failing string in the batch's indexes, not in the
+    previous call's (the caller's array may even be unregistered by then)."""
+    from simdjson_java_amd.binding import lib
+    single = b'{"first":["call","with","quite","a","few","strings","so","that","the","arrays","differ"]}'
+    idx_host = np.empty(len(single) + 2 + 64, dtype=np.uint32)
+    assert lib().sjmi_host_register(ctx._h, C.c_void_p(idx_host.ctypes.data), C.c_uint64(idx_host.nbytes)) == 0
+    try:
+        got_idx, st = ctx.stage1(single, idx=idx_host)
+        assert st == 0 and np.array_equal(got_idx, O.stage1(single)[0])
+    finally:
+        assert lib().sjmi_host_unregister(ctx._h, C.c_void_p(idx_host.ctypes.data)) == 0
+    idx_host[:] = 0xFFFFFFFF  # (whatever a stale read would find)
+    docs = [b'{"a":"fine"}\n', b'[1,2,3]\n', b'{"k":["x","y","bad \\q escape","z"]}\n', b'"tail"\n']
+    buf = b"".join(docs)
+    offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.uint64)
+    idx, io, ds, st = ctx.stage1_batch_isolated(buf, offs)
+    assert st == 0 and not ds.any()
+    want_idx = O.stage1(buf)[0]
+    assert np.array_equal(idx, want_idx)
+    sb, dso, fei, fec = ctx.unescape_batch(len(buf) * 2 + 64, len(docs))
+    want_sb, _, want_feo, want_code = O.unescape_all(buf + b"\0" * 64, want_idx)
+    quote_positions = [i for i in range(idx.size) if buf[idx[i]] == 0x22]  # oracle: ordinal among strings; GPU: position in indexes[]
+    assert want_feo >= 0 and fei == quote_positions[want_feo]
+    assert buf[idx[fei] + 1:idx[fei] + 5] == b"bad " and fec == want_code
+    # and the single-document two-call form right behind an unregistration refuses instead of reading through a dead view
+    import simdjson_java_amd as S
+    assert lib().sjmi_host_register(ctx._h, C.c_void_p(idx_host.ctypes.data), C.c_uint64(idx_host.nbytes)) == 0
+    ctx.stage1(single, idx=idx_host)
+    assert lib().sjmi_host_unregister(ctx._h, C.c_void_p(idx_host.ctypes.data)) == 0
+    with pytest.raises(S.SjmiError):
+        ctx.unescape(4096)

@@ -31,7 +31,8 @@ def test_patch_applies_to_the_reference_files(tmp_path):
     assert out.returncode == 0, out.stderr
     subprocess.check_call(["git", "apply", "-p1", PATCH], cwd=tmp_path)
     patched = (dst / "SimdJsonParser.java").read_text()
-    assert "Sjmi.STAGE1_UNESCAPE.invokeExact" in patched and "Utf8Validator.validate(buffer, length)" not in patched
+    assert "engine.stage1Unescape(buffer, length, bitIndexes, stringBuffer)" in patched and "Utf8Validator.validate(buffer, length)" not in patched
+    assert "implements AutoCloseable" in patched and "engine.close()" in patched and "new Sjmi.Engine(this," in patched
     assert "setWriteIdx" in (dst / "BitIndexes.java").read_text()
     assert "StringErrors.of" in (dst / "TapeBuilder.java").read_text()
     # the new files sit next to the patched ones
@@ -65,7 +66,7 @@ def _java_handles():
     src = open(SJMI_JAVA).read()
     src = re.sub(r"//[^\n]*", "", src)
     out = {}
-    for m in re.finditer(r"static final MethodHandle (\w+)\s*=\s*h\(\"(sjmi_\w+)\",\s*FunctionDescriptor\.(of|ofVoid)\(([^;]*?)\)\);", src, flags=re.S):
+    for m in re.finditer(r"static final MethodHandle (\w+)\s*=\s*(?:h|critical)\(\"(sjmi_\w+)\",\s*FunctionDescriptor\.(of|ofVoid)\(([^;]*?)\)\);", src, flags=re.S):
         field, name, kind, args = m.group(1), m.group(2), m.group(3), [a.strip() for a in m.group(4).split(",") if a.strip()]
         ret = None if kind == "ofVoid" else args.pop(0)
         out[field] = (name, ret, args)
@@ -92,3 +93,29 @@ def test_integration_md_only_uses_handles_that_exist():
     consts = {"ST_UTF8", "ST_UNCLOSED", "ST_UNESCAPED", "ST_CAPACITY", "ST_INTERNAL", "ST_HALO", "WALK_NEEDS_HOST"}
     missing = sorted(u for u in used if u not in handles and u not in consts)
     assert not missing, "INTEGRATION.md / the patch use Sjmi.%s, which java/org/simdjson/Sjmi.java does not define" % missing
+
+
+def test_heavy_calls_are_not_critical_and_the_context_has_an_owner():
+    """a critical downcall keeps the thread in Java state -- every safepoint (GC) in the JVM waits for it -- so nothing
+    that uploads, launches or synchronises may be linked that way; and a context (device memory + a stream) needs a lifetime."""
+    src = open(SJMI_JAVA).read()
+    code = re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", " ", src, flags=re.S))
+    crit = set(re.findall(r"=\s*critical\(\"(sjmi_\w+)\"", code))
+    assert crit <= {"sjmi_last_error", "sjmi_version"}, crit
+    plain = set(re.findall(r"=\s*h\(\"(sjmi_\w+)\"", code))
+    for name in ("sjmi_create", "sjmi_destroy", "sjmi_stage1", "sjmi_stage1_unescape", "sjmi_parse_document", "sjmi_unescape",
+                 "sjmi_stage1_batch_isolated", "sjmi_unescape_batch", "sjmi_stream_push", "sjmi_host_register", "sjmi_host_unregister"):
+        assert name in plain, name
+    # the ordinary linker call carries no critical option; only the `critical` helper does
+    h_body = re.search(r"MethodHandle h\(String name, FunctionDescriptor descriptor\)\s*\{(.*?)\}", code, flags=re.S).group(1)
+    assert "critical" not in h_body
+    # heap segments cannot cross an ordinary downcall: the heavy call of the parser runs on the Engine's off-heap segments
+    eng = code[code.index("static final class Engine"):]
+    call = re.search(r"STAGE1_UNESCAPE\.invokeExact\((.*?)\);", eng, flags=re.S).group(1)
+    assert "ofArray" not in call and call.split(",")[1].strip() == "in"
+    assert "HOST_REGISTER.invokeExact" in eng and "SET_INPUT_STAGING.invokeExact" in eng
+    # lifetime: AutoCloseable + a Cleaner whose action unregisters, destroys and closes the arena without referencing the Engine
+    assert "implements AutoCloseable" in eng and "CLEANER.register(owner" in eng and "cleanable.clean()" in eng
+    native = eng[eng.index("private static final class Native"):eng.index("private final MemorySegment ctx;", eng.index("private static final class Native") + 200)]
+    assert "HOST_UNREGISTER.invokeExact" in native and "DESTROY.invokeExact" in native and "arena.close()" in native
+    assert "Engine.this" not in native
