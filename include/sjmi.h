@@ -32,6 +32,9 @@ extern "C" {
 #define SJMI_ST_UNESCAPED 4u  /* "Unescaped characters. Within strings, ..."         StructuralIndexer.java:300-302 */
 #define SJMI_ST_CAPACITY 0x100u /* index_capacity < count+1 (the reference throws AIOOBE here) */
 #define SJMI_ST_INTERNAL 0x200u /* engine fault (look-back timeout); results invalid */
+#define SJMI_ST_REJECTED 0x800u /* sjmi_parse_batch_device_optimistic only: the batch is not one the optimistic pipeline can take (a document
+                                 * fails stage 1, a separator is missing, the offsets do not cover the buffer): NO output of the call is
+                                 * valid -- call sjmi_parse_batch_device, which decides every document on its own */
 #define SJMI_ST_HALO 0x400u     /* sjmi_stage1_shard_device / sjmi_stream_push: a backslash run fills the whole left halo, so whether the
                                    byte behind it is escaped cannot be told from what is readable; results invalid -- give more halo */
 
@@ -300,7 +303,8 @@ int sjmi_walk_batch_device(sjmi_ctx* ctx, const void* d_buf, const void* d_doc_o
  * a control-character separator ('\n', '\r', '\t'), the documents cover the buffer exactly (doc_offsets[0] == 0 and
  * doc_offsets[n_docs] == total_len: bytes outside the documents would feed state into them) and the global verdict is
  * clean -- then it is exactly what the per-document passes give; otherwise those run (queued behind it, they leave at once
- * when it was accepted).
+ * when it was accepted).  (Round 5: the separators are checked by k_doc_prepare, which visits every boundary anyway, so the
+ * verdict falls behind the string pass: a rejected batch pays one string pass over the raw batch before its own begins.)
  * Tapes: when the plain pass was accepted the tapes are laid out BEFORE the documents are walked (a document's tape length
  * is a function of its structurals' first bytes: TapeBuilder.java:41-48,191-208, Tape.java:33-43) and written at their final
  * addresses.  A document that then fails stage 2 (doc_errors[k] != 0) keeps its slot: tape_offsets[k + 1] - tape_offsets[k] is
@@ -318,6 +322,17 @@ int sjmi_parse_batch_device(sjmi_ctx* ctx, const void* d_buf, uint64_t total_len
                             void* d_string_buffer, uint64_t string_capacity, void* d_doc_string_offsets, int max_depth,
                             void* d_tape, uint64_t tape_capacity, void* d_tape_offsets, void* d_doc_errors, void* d_result,
                             void* stream);
+/* The same call with ONLY the optimistic pipeline queued (round 5): k_stage1_batch -> k_strings -> k_doc_prepare -> tape layout ->
+ * the token walker (+ the exact walker and the boundary-literal kernel for the documents it lists) -- eight queue entries instead
+ * of thirty, which is what a small batch (one rank's share of a strong-scaled run) is bounded by.  Whether the batch qualified is
+ * decided on the device like before and reported in result.stage1.status: SJMI_ST_REJECTED set = NOTHING this call wrote is
+ * valid; the caller then makes the exact call above (same arguments), off its hot path.  Without that bit the outputs are
+ * exactly those of sjmi_parse_batch_device.  NDJSON whose documents all pass stage 1 is never rejected. */
+int sjmi_parse_batch_device_optimistic(sjmi_ctx* ctx, const void* d_buf, uint64_t total_len, const void* d_doc_offsets, uint64_t n_docs,
+                                       void* d_indexes, uint64_t index_capacity, void* d_index_offsets, void* d_doc_status,
+                                       void* d_string_buffer, uint64_t string_capacity, void* d_doc_string_offsets, int max_depth,
+                                       void* d_tape, uint64_t tape_capacity, void* d_tape_offsets, void* d_doc_errors, void* d_result,
+                                       void* stream);
 
 /* One document, ALL stages on the GPU: stage 1, string records and the cooperative walker (csrc/coop_walk.hip: JsonIterator.
  * walkDocument + TapeBuilder as scans, JsonIterator.java:26-200, TapeBuilder.java:41-217); only the tape (Tape.java:5-47 word

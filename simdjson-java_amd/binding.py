@@ -68,7 +68,7 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_unescape_batch_device", "sjmi_walk_batch_device", "sjmi_stage1_masks", "sjmi_stage1_masks_device",
            "sjmi_parser_root", "sjmi_parser_batch_root", "sjmi_value_type", "sjmi_value_as_long", "sjmi_value_as_double",
            "sjmi_value_as_boolean", "sjmi_value_as_string", "sjmi_value_get", "sjmi_value_size", "sjmi_value_first",
-           "sjmi_value_next", "sjmi_parse_batch_device", "sjmi_parse_document",
+           "sjmi_value_next", "sjmi_parse_batch_device", "sjmi_parse_batch_device_optimistic", "sjmi_parse_document",
            "sjmi_parser_set_gpu_walk", "sjmi_set_auto_safe", "sjmi_match_brackets",
            "sjmi_match_brackets_device", "sjmi_stage1_shard_device", "sjmi_stage1_shard_device2",
            "sjmi_stream_open", "sjmi_stream_push", "sjmi_stream_close", "sjmi_split_open", "sjmi_split_scan", "sjmi_split_resolve", "sjmi_split_close",
@@ -221,6 +221,8 @@ def lib():
         L.sjmi_parse_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p,
                                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sjmi_parse_batch_device_optimistic.restype = C.c_int
+        L.sjmi_parse_batch_device_optimistic.argtypes = L.sjmi_parse_batch_device.argtypes
         L.sjmi_kernel_time.restype = C.c_int
         L.sjmi_kernel_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -419,6 +421,16 @@ class Context:
                                                   d_index_offsets, d_doc_status, d_sb, sb_capacity, d_doc_string_offsets,
                                                   max_depth, d_tape, tape_capacity, d_tape_offsets, d_doc_errors, d_result,
                                                   stream), "sjmi_parse_batch_device")
+
+    def parse_batch_device_optimistic(self, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets,
+                                      d_doc_status, d_sb, sb_capacity, d_doc_string_offsets, max_depth, d_tape, tape_capacity,
+                                      d_tape_offsets, d_doc_errors, d_result, stream=0):
+        """sjmi_parse_batch_device_optimistic: ONLY the optimistic pipeline is queued (eight entries); stage1.status & 0x800
+        (SJMI_ST_REJECTED) in d_result = nothing is valid, make the exact call (parse_batch_device)."""
+        self._check(lib().sjmi_parse_batch_device_optimistic(self._h, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity,
+                                                             d_index_offsets, d_doc_status, d_sb, sb_capacity, d_doc_string_offsets,
+                                                             max_depth, d_tape, tape_capacity, d_tape_offsets, d_doc_errors, d_result,
+                                                             stream), "sjmi_parse_batch_device_optimistic")
 
     def stage1_batch_device(self, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets,
                             d_result, stream=0):

@@ -158,7 +158,12 @@ __device__ __forceinline__ uint32_t prep_words_of(uint32_t c) {  // tape words o
 }
 __global__ void __launch_bounds__(PREP_DOCS)
 k_doc_prepare(DocPrepare a) {
-    if (a.flags[1] == 0) return;
+    // Round 5: this kernel runs BEFORE the acceptance of the plain pass is known -- it contributes to it: every thread looks at
+    // the separator in front of its boundary (what k_batch_sep_check re-read 137 MB for) and ORs a missing one into flags[0];
+    // k_batch_layout (walk.hip), queued behind, decides.  What it can know it checks: a plain pass with any verdict bit is
+    // rejected already.  On a batch that ends up rejected everything written here is overwritten or unused, and every access
+    // below is clamped to the buffer and to the index count whatever the offsets say.
+    if (a.stage1->status != 0) return;
     __shared__ uint32_t s_io[PREP_DOCS + 1], s_pw[PREP_DOCS + 1];
     __shared__ unsigned long long s_sum[PREP_DOCS / 64];
     const uint64_t k0 = (uint64_t)blockIdx.x * PREP_DOCS, k = k0 + threadIdx.x;
@@ -229,6 +234,16 @@ k_doc_prepare(DocPrepare a) {
     uint32_t len = 0;
     if (k < a.n_docs) {
         unsigned long long e = a.doc_offsets[k + 1];
+        {   // the optimistic plain pass is exact only if the documents cover the buffer and each ends in a control-character separator
+            // (see k_batch_sep_check above: the same test, on the boundary this thread reads anyway)
+            const unsigned long long s_raw = a.doc_offsets[k];
+            bool bad = e < s_raw || e > a.total_len || (k == 0 && s_raw != 0) || (k + 1 == a.n_docs && e != a.total_len);
+            if (!bad && k + 1 < a.n_docs) {
+                const uint8_t c = e > s_raw ? a.buf[e - 1] : 0xFF;
+                bad = !(c == 0x0A || c == 0x0D || c == 0x09);
+            }
+            if (bad) atomicOr(&a.flags[0], 1u);
+        }
         if (e > a.total_len) e = a.total_len;
         if (s > e) s = e;
         // whole blocks [bs, be): block bs counted from its start (the part in front of the document comes off again below),

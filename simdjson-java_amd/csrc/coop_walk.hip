@@ -404,6 +404,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
             unsigned long long* __restrict__ ovf, SlowList slow, ExactMode ex) {
     if (run_only_if && *run_only_if == 0) return;   // (the single-wave sweep behind a chunked launch: only on fall-back)
     if (CHUNKED && *cw.fallback != 0) return;
+    if (!CHUNKED && ex.metas && ex.sel && *ex.sel == 0 && !ex.tape_alt) return;  // (optimistic pipeline only, plain pass rejected)
     // LIST MODE (the exact walker behind k_tok_walk): the documents are those the token walker listed; a document's tape goes
     // where its DocMeta says -- the final tape when *ex.sel != 0 (then this kernel also counts the failures), else the scratch tape
     const uint32_t* const list = CHUNKED ? nullptr : ex.list;
@@ -912,6 +913,7 @@ struct __attribute__((aligned(16))) PrimQueue {
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SJMI_TOK_WAVES, SJMI_TOK_WAVES)))
 k_tok_walk(TokArgs a) {
+    if (a.sel && *a.sel == 0 && !a.tape_alt) return;  // (only the optimistic pipeline was queued and its plain pass was rejected)
     __shared__ TokRing rings[4];
     __shared__ PrimQueue queues[4];
     __shared__ TokStack stacks[4];
@@ -1863,8 +1865,10 @@ hipError_t tok_walk_launch(const TokLaunch& t, hipStream_t stream) {
     slow.rec = slow.count + 8;
     slow.cap = CW_SLOW_CAP;
     unsigned long long* const deep = reinterpret_cast<unsigned long long*>(static_cast<uint8_t*>(t.d_deep_ws) + coop_slow_bytes());
-    hipError_t e0 = hipMemsetAsync(slow.count, 0, 64, stream);
-    if (e0 != hipSuccess) return e0;
+    if (!t.header_zeroed) {
+        hipError_t e0 = hipMemsetAsync(slow.count, 0, 64, stream);
+        if (e0 != hipSuccess) return e0;
+    }
     TokArgs a;
     a.buf = t.d_buf;
     a.idx = t.d_idx;

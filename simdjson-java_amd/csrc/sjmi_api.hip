@@ -539,7 +539,7 @@ static int strings_device_impl(sjmi_ctx* c, const void* d_buf, uint64_t len, voi
 static int strings_batch_impl(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_indexes, uint64_t count_bound,
                               const void* d_doc_offsets, const void* d_index_offsets, uint64_t n_docs, bool plain,
                               const uint32_t* d_accept, void* d_string_buffer, uint64_t string_capacity, void* d_doc_str_offsets,
-                              void* d_result, hipStream_t st, bool ordinals_by_prepare = false) {
+                              void* d_result, hipStream_t st) {
     const uint64_t soff_cap = count_bound + 64;
     if (!grow(c, (void**)&c->d_soff, &c->soff_bytes, soff_cap * sizeof(uint32_t), "hipMalloc(soff)") ||
         !grow(c, (void**)&c->d_blk_ord, &c->blk_ord_bytes, (total_len / 64 + 2) * sizeof(uint32_t), "hipMalloc(blk_ord)") ||
@@ -588,7 +588,7 @@ static int strings_batch_impl(sjmi_ctx* c, const void* d_buf, uint64_t total_len
         fail(c, "doc ordinals",
              sjmi::strings_doc_ordinals_launch(buf0, par0, alt, total_len, (const unsigned long long*)d_doc_offsets, n_docs, c->d_blk_ord,
                                                c->d_soff, (const sjmi::UnescapeResult*)d_result, c->d_doc_ord,
-                                               (unsigned long long*)d_doc_str_offsets, st, ordinals_by_prepare ? d_accept : nullptr)))
+                                               (unsigned long long*)d_doc_str_offsets, st, nullptr)))
         return SJMI_ERR_HIP;
     if (!c->d_ures_walk && fail(c, "hipMalloc(ures_walk)", hipMalloc((void**)&c->d_ures_walk, sizeof(sjmi_unescape_result)))) return SJMI_ERR_HIP;
     if (fail(c, "D2D(ures)", hipMemcpyAsync(c->d_ures_walk, d_result, sizeof(sjmi_unescape_result), hipMemcpyDeviceToDevice, st))) return SJMI_ERR_HIP;
@@ -1095,11 +1095,10 @@ static int stage1_batch_isolated_device_impl(sjmi_ctx* c, const void* d_buf, uin
 // verdict is clean (batch.hip: then it is exactly what the per-document passes give); the per-document passes are queued behind
 // it and leave at once if it was accepted.  *d_skip_out = the device flag (!= 0: accepted) or nullptr (not tried); the string
 // pass of the same batch on this context reads it (c->accept_*).  (SJMI_BATCH_OPTIMISTIC=0 switches the plain pass off.)
-// for_pipeline (sjmi_parse_batch_device): the plain launch also leaves the per-block side outputs batch.hip k_doc_prepare reads
-// (queued behind the string pass: it replaces the split and takes over the string ordinals), so no split is queued here.
+// (sjmi_parse_batch_device has its own ordering of the same idea: parse_batch_pipeline below.)
 static int stage1_batch_optimistic(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets, uint64_t n_docs,
                                    void* d_indexes, uint64_t index_capacity, void* d_index_offsets, void* d_doc_status,
-                                   void* d_result, void* stream, const uint32_t** d_skip_out, bool for_pipeline = false) {
+                                   void* d_result, void* stream, const uint32_t** d_skip_out) {
     if (!c || !d_buf || !d_doc_offsets || !d_indexes || !d_index_offsets || !d_doc_status || !d_result) return SJMI_ERR_ARG;
     if (total_len >= (1ull << 32)) return SJMI_ERR_ARG;
     static const bool optimistic = !(getenv("SJMI_BATCH_OPTIMISTIC") && atoi(getenv("SJMI_BATCH_OPTIMISTIC")) == 0);
@@ -1115,14 +1114,7 @@ static int stage1_batch_optimistic(sjmi_ctx* c, const void* d_buf, uint64_t tota
         int rc0;
         {
             const AutoSafeOff plain_only(c);  // (a tripped liveness bound only rejects the plain pass: the per-document passes take over)
-            c->batch_side = for_pipeline;
-            // (experiments: SJMI_BATCH_STEPS = granule of the pipeline's plain pass in units of 4 KiB)
-            static const int batch_steps = getenv("SJMI_BATCH_STEPS") ? atoi(getenv("SJMI_BATCH_STEPS")) : 0;
-            const int keep_steps = c->forced_steps;
-            if (for_pipeline && (batch_steps == 1 || batch_steps == 2 || batch_steps == 4)) c->forced_steps = batch_steps;
             rc0 = stage1_device_impl(c, d_buf, total_len, d_indexes, index_capacity, d_result, stream, 0);
-            c->forced_steps = keep_steps;
-            c->batch_side = false;
         }
         if (rc0 != SJMI_OK) return rc0;
         // (a FAST launch leaves the scanner's per-granule prefixes in its half of the workspace: the split starts from them)
@@ -1132,7 +1124,7 @@ static int stage1_batch_optimistic(sjmi_ctx* c, const void* d_buf, uint64_t tota
         if (fail(c, "plain accept", sjmi::batch_plain_accept_launch((const uint32_t*)d_indexes, (const sjmi::Stage1Result*)d_result,
                                                                     (const unsigned long long*)d_doc_offsets, n_docs,
                                                                     (unsigned long long*)d_index_offsets, (uint32_t*)d_doc_status,
-                                                                    c->d_batch_flags, st0, hint, !for_pipeline)))
+                                                                    c->d_batch_flags, st0, hint, true)))
             return SJMI_ERR_HIP;
         d_skip = c->d_batch_flags + 1;
     }
@@ -1226,56 +1218,160 @@ int sjmi_stage1_batch_isolated(sjmi_ctx* c, const uint8_t* buf, uint64_t total_l
     return SJMI_OK;
 }
 
-int sjmi_parse_batch_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets, uint64_t n_docs,
-                            void* d_indexes, uint64_t index_capacity, void* d_index_offsets, void* d_doc_status,
-                            void* d_string_buffer, uint64_t string_capacity, void* d_doc_string_offsets, int max_depth,
-                            void* d_tape, uint64_t tape_capacity, void* d_tape_offsets, void* d_doc_errors, void* d_result,
-                            void* stream) {
+// The fused batch pipeline (round 5: re-ordered so that an ACCEPTED batch costs eight queue entries).
+//   k_stage1_batch   ONE plain launch over the packed batch, per-block side outputs; its workers zero the string pass's workspace
+//                    on their way out, the acceptance flags sit in the header of its own (zeroed) workspace half
+//   k_strings<true>  over the batch itself, its record inside that workspace
+//   k_doc_prepare    per boundary: the separator check (ORed into flags[0]), index ranges, string ordinals, predicted tape lengths
+//   k_batch_layout   decides: flags[1] = accepted; zeroes the walk's records, hands the string record over, scans the lengths
+//   k_tape_offsets, k_tok_walk, k_coop_walk (list), k_slow_doubles
+// optimistic_only: that is all; a batch that does not qualify comes back with SJMI_ST_REJECTED.  Otherwise the per-document
+// stage-1 passes, the sanitized copy with its parity launch and string pass, and the packing kernels are queued too, each of
+// them leaving at once when flags[1] says accepted -- exact per document whatever the batch contains, no host round trip.
+static int parse_batch_pipeline(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets, uint64_t n_docs,
+                                void* d_indexes, uint64_t index_capacity, void* d_index_offsets, void* d_doc_status,
+                                void* d_string_buffer, uint64_t string_capacity, void* d_doc_string_offsets, int max_depth,
+                                void* d_tape, uint64_t tape_capacity, void* d_tape_offsets, void* d_doc_errors, void* d_result,
+                                void* stream, bool optimistic_only) {
     if (!c || !d_buf || !d_doc_offsets || !d_indexes || !d_index_offsets || !d_doc_status || !d_string_buffer ||
         !d_doc_string_offsets || !d_tape || !d_tape_offsets || !d_doc_errors || !d_result || max_depth < 1 || index_capacity < 1)
         return SJMI_ERR_ARG;
     if (total_len >= (1ull << 32)) return SJMI_ERR_ARG;
+    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
     sjmi_batch_result* r = (sjmi_batch_result*)d_result;
-    // stage 1: ONE plain launch over the packed batch, accepted on the device when it is exact; the per-document passes are queued
-    // behind it and leave at once if it was (stage1_batch_optimistic)
-    const uint32_t* d_skip = nullptr;
-    int rc = stage1_batch_optimistic(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets,
-                                     d_doc_status, &r->stage1, stream, &d_skip, true);
-    if (rc != SJMI_OK) return rc;
-    // string records and the walk: everything queued, nothing comes back to the host in between.  If the optimistic plain
-    // pass was accepted the string pass runs over the batch itself, else over its sanitized copy -- chosen on the device
-    const uint64_t bound = index_capacity - 1;
-    if (!grow(c, &c->d_ws_walk, &c->ws_walk_bytes, sjmi::walk_workspace_bytes(bound, n_docs), "hipMalloc(ws_walk)")) return SJMI_ERR_HIP;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-    rc = strings_batch_impl(c, d_buf, total_len, d_indexes, bound, d_doc_offsets, d_index_offsets, n_docs, false, d_skip, d_string_buffer,
-                            string_capacity, d_doc_string_offsets, &r->strings, st, d_skip != nullptr);
-    if (rc != SJMI_OK) return rc;
-    if (d_skip) {
-        // the accepted plain pass: ONE pass over the documents gives every document its index range, first string, predicted tape
-        // length and walker record (batch.hip k_doc_prepare; leaves at once when the plain pass was rejected)
-        const sjmi::WalkPrepared wp = sjmi::walk_prepared(c->d_ws_walk, bound, n_docs);
-        sjmi::DocPrepare pa;
-        pa.buf = (const uint8_t*)d_buf;
-        pa.idx = (const uint32_t*)d_indexes;
-        pa.doc_offsets = (const unsigned long long*)d_doc_offsets;
-        pa.n_docs = n_docs;
-        pa.total_len = total_len;
-        pa.blkidx = c->d_blkidx;
-        pa.blkw = c->d_blkw;
-        pa.blkpar = c->d_blkpar;
-        pa.blk_ord = c->d_blk_ord;
-        pa.soff = c->d_soff;
-        pa.strings = (const sjmi::UnescapeResult*)&r->strings;
-        pa.stage1 = (const sjmi::Stage1Result*)&r->stage1;
-        pa.flags = c->d_batch_flags;
-        pa.index_offsets = (unsigned long long*)d_index_offsets;
-        pa.doc_status = (uint32_t*)d_doc_status;
-        pa.doc_ord = c->d_doc_ord;
-        pa.doc_str_offsets = (unsigned long long*)d_doc_string_offsets;
-        pa.lens = wp.lens;
-        pa.chunk_sums = wp.chunk_sums;
-        pa.metas = wp.metas;
-        if (fail(c, "prepare launch", sjmi::batch_prepare_launch(pa, st))) return SJMI_ERR_HIP;
+    const uint64_t bound = index_capacity - 1;
+    const uint64_t soff_cap = bound + 64;
+    static const bool optimistic = !(getenv("SJMI_BATCH_OPTIMISTIC") && atoi(getenv("SJMI_BATCH_OPTIMISTIC")) == 0);
+    const bool try_plain = optimistic && n_docs && total_len && !((uintptr_t)d_buf & 15) && !((uintptr_t)d_indexes & 15);
+    if (!grow(c, &c->d_ws_walk, &c->ws_walk_bytes, sjmi::walk_workspace_bytes(bound, n_docs), "hipMalloc(ws_walk)")) return SJMI_ERR_HIP;
+    c->accept_valid = false;
+    if (!try_plain) {
+        if (optimistic_only) {  // (nothing the optimistic pipeline could run on: say so in the record)
+            if (fail(c, "reject", sjmi::batch_reject_launch((sjmi::Stage1Result*)&r->stage1, st))) return SJMI_ERR_HIP;
+            return SJMI_OK;
+        }
+        // the per-document passes only (switched off, misaligned buffers, an empty batch), as the three separate calls would
+        int rc = stage1_batch_isolated_device_impl(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets,
+                                                   d_doc_status, &r->stage1, stream, nullptr);
+        if (rc != SJMI_OK) return rc;
+        rc = strings_batch_impl(c, d_buf, total_len, d_indexes, bound, d_doc_offsets, d_index_offsets, n_docs, false, nullptr, d_string_buffer,
+                                string_capacity, d_doc_string_offsets, &r->strings, st);
+        if (rc != SJMI_OK) return rc;
+        if (fail(c, "walk launch",
+                 sjmi::walk_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs, (const uint32_t*)d_indexes,
+                                   bound, (const unsigned long long*)d_index_offsets, (const uint32_t*)d_doc_status,
+                                   (const uint8_t*)d_string_buffer, c->d_doc_ord, 0, max_depth, (unsigned long long*)d_tape, tape_capacity,
+                                   (unsigned long long*)d_tape_offsets, (int32_t*)d_doc_errors, c->d_ws_walk, (sjmi::WalkResult*)&r->walk, st,
+                                   (const sjmi::Stage1Result*)&r->stage1, (const sjmi::UnescapeResult*)&r->strings, c->d_soff)))
+            return SJMI_ERR_HIP;
+        return SJMI_OK;
+    }
+    const size_t strm_bytes = (sjmi::strings_workspace_bytes(total_len) + 15) & ~(size_t)15;
+    if (!grow(c, (void**)&c->d_soff, &c->soff_bytes, soff_cap * sizeof(uint32_t), "hipMalloc(soff)") ||
+        !grow(c, (void**)&c->d_blk_ord, &c->blk_ord_bytes, (total_len / 64 + 2) * sizeof(uint32_t), "hipMalloc(blk_ord)") ||
+        !grow(c, (void**)&c->d_doc_ord, &c->doc_ord_bytes, (n_docs + 2) * sizeof(unsigned long long), "hipMalloc(doc_ord)") ||
+        !grow(c, &c->d_ws_strm, &c->ws_strm_bytes, strm_bytes, "hipMalloc(ws_strm)"))
+        return SJMI_ERR_HIP;
+    c->soff_idx = nullptr;
+    // ---- (1) the plain pass ----
+    int rc0;
+    {
+        const AutoSafeOff plain_only(c);  // (a tripped liveness bound only rejects the plain pass)
+        c->batch_side = true;
+        c->s1_zero2 = c->d_ws_strm;
+        c->s1_zero2_bytes = strm_bytes;
+        // (experiments: SJMI_BATCH_STEPS = granule of the pipeline's plain pass in units of 4 KiB)
+        static const int batch_steps = getenv("SJMI_BATCH_STEPS") ? atoi(getenv("SJMI_BATCH_STEPS")) : 0;
+        const int keep_steps = c->forced_steps;
+        if (batch_steps == 1 || batch_steps == 2 || batch_steps == 4) c->forced_steps = batch_steps;
+        rc0 = stage1_device_impl(c, d_buf, total_len, d_indexes, index_capacity, &r->stage1, stream, 0);
+        c->forced_steps = keep_steps;
+        c->batch_side = false;
+        c->s1_zero2 = nullptr;
+        c->s1_zero2_bytes = 0;
+    }
+    if (rc0 != SJMI_OK) return rc0;
+    if (!(c->par_valid && c->par_buf == d_buf && c->par_len == total_len) || !c->ws_dev_last) {
+        c->err = "batch pipeline: the plain pass left no block parities";
+        return SJMI_ERR_HIP;
+    }
+    uint32_t* const flags = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(c->ws_dev_last) + sjmi::WS_BATCH_FLAGS_OFFSET);
+    const uint32_t* const d_acc = flags + 1;
+    // ---- (2) the string pass over the batch itself; (3) one pass over the boundaries; (4) the decision and the tape layout ----
+    sjmi::UnescapeResult* const d_u = sjmi::strings_workspace_result(c->d_ws_strm);
+    if (fail(c, "strings launch",
+             sjmi::strings_launch((const uint8_t*)d_buf, total_len, c->d_blkpar, (uint8_t*)d_string_buffer, string_capacity, c->d_soff,
+                                  soff_cap, c->d_blk_ord, c->d_ws_strm, d_u, st, nullptr, nullptr, sjmi::StringsAlt(), true)))
+        return SJMI_ERR_HIP;
+    const sjmi::WalkPrepared wp = sjmi::walk_prepared(c->d_ws_walk, bound, n_docs);
+    sjmi::DocPrepare pa;
+    pa.buf = (const uint8_t*)d_buf;
+    pa.idx = (const uint32_t*)d_indexes;
+    pa.doc_offsets = (const unsigned long long*)d_doc_offsets;
+    pa.n_docs = n_docs;
+    pa.total_len = total_len;
+    pa.blkidx = c->d_blkidx;
+    pa.blkw = c->d_blkw;
+    pa.blkpar = c->d_blkpar;
+    pa.blk_ord = c->d_blk_ord;
+    pa.soff = c->d_soff;
+    pa.strings = d_u;
+    pa.stage1 = (const sjmi::Stage1Result*)&r->stage1;
+    pa.flags = flags;
+    pa.index_offsets = (unsigned long long*)d_index_offsets;
+    pa.doc_status = (uint32_t*)d_doc_status;
+    pa.doc_ord = c->d_doc_ord;
+    pa.doc_str_offsets = (unsigned long long*)d_doc_string_offsets;
+    pa.lens = wp.lens;
+    pa.chunk_sums = wp.chunk_sums;
+    pa.metas = wp.metas;
+    sjmi::BatchLayout bl = {};
+    bl.flags = flags;
+    bl.stage1 = (const sjmi::Stage1Result*)&r->stage1;
+    bl.stage1_out = (sjmi::Stage1Result*)&r->stage1;
+    bl.strings_ws = d_u;
+    bl.strings_out = (sjmi::UnescapeResult*)&r->strings;
+    bl.walk = (sjmi::WalkResult*)&r->walk;
+    bl.chunk_sums = wp.chunk_sums;
+    bl.n_docs = n_docs;
+    bl.tape_capacity = tape_capacity;
+    bl.tape_offsets = (unsigned long long*)d_tape_offsets;
+    bl.optimistic_only = optimistic_only;
+    if (fail(c, "prepare launch", sjmi::batch_prepare_launch(pa, st)) ||
+        fail(c, "layout launch", sjmi::batch_layout_launch(bl, c->d_ws_walk, bound, wp.lens, wp.metas, (int32_t*)d_doc_errors, st)))
+        return SJMI_ERR_HIP;
+    if (!optimistic_only) {
+        // ---- the rejected batch's own path, every kernel gated on flags[1] == 0: per-document stage 1, the sanitized copy, the
+        //      parities of a plain launch over it, the string pass over it (fills the record k_batch_layout zeroed), ordinals ----
+        const int rc = stage1_batch_isolated_device_impl(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity,
+                                                         d_index_offsets, d_doc_status, &r->stage1, stream, d_acc);
+        if (rc != SJMI_OK) return rc;
+        const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(total_len);
+        if (!grow(c, (void**)&c->d_copy, &c->copy_bytes, total_len + 2 * SJMI_PADDING + 64, "hipMalloc(copy)") ||
+            !grow(c, (void**)&c->d_blkpar2, &c->blkpar2_bytes, sjmi::strings_parity_words(total_len) * sizeof(unsigned long long), "hipMalloc(blkpar2)") ||
+            !grow(c, &c->d_ws_par, &c->ws_par_bytes, sjmi::stage1_workspace_bytes(total_len, steps), "hipMalloc(ws_par)"))
+            return SJMI_ERR_HIP;
+        sjmi::Stage1Extras ex;
+        ex.blkpar = c->d_blkpar2;
+        ex.skip = d_acc;
+        if (fail(c, "sanitize", sjmi::strings_sanitize_launch((const uint8_t*)d_buf, total_len, (const unsigned long long*)d_doc_offsets,
+                                                              (const unsigned long long*)d_index_offsets, n_docs, c->d_copy, d_acc, st)) ||
+            fail(c, "parity launch", sjmi::stage1_launch(c->d_copy, total_len, nullptr, 0, c->d_ws_par, steps, st, nullptr, nullptr,
+                                                         (launch_flags(c) & ~sjmi::DBG_NO_LOOKBACK) | sjmi::DBG_NO_WRITE, ex)))
+            return SJMI_ERR_HIP;
+        note_launch(c, st);
+        if (fail(c, "strings launch",
+                 sjmi::strings_launch(c->d_copy, total_len, c->d_blkpar2, (uint8_t*)d_string_buffer, string_capacity, c->d_soff, soff_cap,
+                                      c->d_blk_ord, c->d_ws_strm, (sjmi::UnescapeResult*)&r->strings, st, nullptr, nullptr, sjmi::StringsAlt(),
+                                      false, d_acc)) ||
+            fail(c, "doc ordinals",
+                 sjmi::strings_doc_ordinals_launch(c->d_copy, c->d_blkpar2, sjmi::StringsAlt(), total_len,
+                                                   (const unsigned long long*)d_doc_offsets, n_docs, c->d_blk_ord, c->d_soff,
+                                                   (const sjmi::UnescapeResult*)&r->strings, c->d_doc_ord,
+                                                   (unsigned long long*)d_doc_string_offsets, st, d_acc)))
+            return SJMI_ERR_HIP;
+        c->par_valid = false;  // (the context's parities may be the copy's now: decided on the device)
     }
     if (fail(c, "walk launch",
              sjmi::walk_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs, (const uint32_t*)d_indexes,
@@ -1284,9 +1380,29 @@ int sjmi_parse_batch_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, 
                                (unsigned long long*)d_tape, tape_capacity, (unsigned long long*)d_tape_offsets,
                                (int32_t*)d_doc_errors, c->d_ws_walk, (sjmi::WalkResult*)&r->walk, st,
                                (const sjmi::Stage1Result*)&r->stage1, (const sjmi::UnescapeResult*)&r->strings, c->d_soff, false, false,
-                               sjmi::SingleDocTail(), d_skip)))
+                               sjmi::SingleDocTail(), d_acc, true, optimistic_only)))
         return SJMI_ERR_HIP;
     return SJMI_OK;
+}
+
+int sjmi_parse_batch_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets, uint64_t n_docs,
+                            void* d_indexes, uint64_t index_capacity, void* d_index_offsets, void* d_doc_status,
+                            void* d_string_buffer, uint64_t string_capacity, void* d_doc_string_offsets, int max_depth,
+                            void* d_tape, uint64_t tape_capacity, void* d_tape_offsets, void* d_doc_errors, void* d_result,
+                            void* stream) {
+    return parse_batch_pipeline(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets, d_doc_status,
+                                d_string_buffer, string_capacity, d_doc_string_offsets, max_depth, d_tape, tape_capacity, d_tape_offsets,
+                                d_doc_errors, d_result, stream, false);
+}
+
+int sjmi_parse_batch_device_optimistic(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets, uint64_t n_docs,
+                                       void* d_indexes, uint64_t index_capacity, void* d_index_offsets, void* d_doc_status,
+                                       void* d_string_buffer, uint64_t string_capacity, void* d_doc_string_offsets, int max_depth,
+                                       void* d_tape, uint64_t tape_capacity, void* d_tape_offsets, void* d_doc_errors, void* d_result,
+                                       void* stream) {
+    return parse_batch_pipeline(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets, d_doc_status,
+                                d_string_buffer, string_capacity, d_doc_string_offsets, max_depth, d_tape, tape_capacity, d_tape_offsets,
+                                d_doc_errors, d_result, stream, true);
 }
 
 // (the result records of the three stages come back in one place, sjmi::SingleDocPack, written by the walk's last launch)

@@ -76,6 +76,9 @@ constexpr uint32_t FLAG_ALL_TICKETS = 0x800;
 constexpr size_t WS_RESULT_OFFSET = 0;        // Stage1Result (16 bytes)
 constexpr uint32_t WS_SCANNER_CU_WORD = 8;    // u32 index from the workspace start: id of the scanner's CU
 constexpr size_t WS_TICKET_OFFSET = 64;       // 8 u32 granule tickets, each alone in its 64-byte line
+constexpr size_t WS_BATCH_FLAGS_OFFSET = 576;  // fused batch pipeline: u32 [0] = why the plain pass is rejected (0: it is not), [1] != 0:
+                                               // accepted (written by k_batch_layout).  In the header of the plain pass's OWN workspace
+                                               // half: zero when the launch starts, like the rest of it -- no memset of their own
 constexpr size_t WS_TILE_STATE_OFFSET = 640;   // u64 aggregates[granules], then u64 prefixes[granules]
 
 size_t stage1_workspace_bytes(uint64_t len, int steps);
@@ -129,7 +132,7 @@ struct StringsAlt {
 hipError_t strings_launch(const uint8_t* d_buf, uint64_t len, const unsigned long long* d_blkpar, uint8_t* d_sb, uint64_t sb_cap,
                           uint32_t* d_soff, uint64_t soff_cap, uint32_t* d_blk_ord, void* d_ws, UnescapeResult* d_res,
                           hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
-                          const StringsAlt& alt = StringsAlt(), bool workspace_is_zero = false);
+                          const StringsAlt& alt = StringsAlt(), bool workspace_is_zero = false, const uint32_t* d_skip = nullptr);
 // batches whose documents were indexed one by one: the copy the string pass runs on (failed documents blanked); d_skip != null
 // and *d_skip != 0: nothing to do (the optimistic plain pass was accepted)
 hipError_t strings_sanitize_launch(const uint8_t* d_buf, uint64_t total_len, const unsigned long long* d_doc_offsets,
@@ -183,7 +186,7 @@ struct DocPrepare {
     const uint32_t* soff;
     const UnescapeResult* strings;
     const Stage1Result* stage1;
-    const uint32_t* flags;  // [1] != 0: the plain pass was accepted
+    uint32_t* flags;        // [0]: reject bits -- this kernel adds "a separator is missing / the offsets do not cover the buffer"
     unsigned long long* index_offsets;
     uint32_t* doc_status;
     unsigned long long* doc_ord;
@@ -194,6 +197,28 @@ struct DocPrepare {
 };
 constexpr int PREP_DOCS = 256;  // documents per workgroup of k_doc_prepare = per chunk of the tape-offset scan
 hipError_t batch_prepare_launch(const DocPrepare& a, hipStream_t stream);
+// walk.hip k_batch_layout, queued behind k_doc_prepare: DECIDES whether the plain pass is accepted (flags[0] == 0 and a clean
+// stage-1 verdict) -> flags[1]; zeroes the walk's result record, the literal list's header and the exact walker's list; hands the
+// string pass's record (inside its workspace) to the caller's -- or zeroes that for the per-document string pass to fill;
+// accepted: the scan of the predicted tape lengths (chunk bases, tape_offsets[n_docs], walk.tape_words).  optimistic_only: a
+// rejected batch gets SJMI_ST_REJECTED in the caller's stage-1 record (nothing else is queued for it).
+struct BatchLayout {
+    uint32_t* flags;
+    const Stage1Result* stage1;          // the plain pass's record as the kernel left it
+    Stage1Result* stage1_out;            // the caller's (optimistic_only: |= SJMI_ST_REJECTED)
+    const UnescapeResult* strings_ws;    // the string pass's own record
+    UnescapeResult* strings_out;         // the caller's
+    WalkResult* walk;
+    void* slow_header;                   // 64 bytes
+    uint32_t* list;
+    unsigned long long* chunk_sums;
+    uint64_t n_docs, tape_capacity;
+    unsigned long long* tape_offsets;
+    bool optimistic_only;
+};
+hipError_t batch_reject_launch(Stage1Result* d_stage1, hipStream_t stream);  // sjmi_parse_batch_device_optimistic on a batch it cannot even try
+hipError_t batch_layout_launch(const BatchLayout& a, void* d_ws, uint64_t count, const uint32_t* lens, DocMeta* metas,
+                               int32_t* d_doc_errors, hipStream_t stream);
 // walk.hip: stage 2 of every document of a batch (the cooperative walker + packing of the tapes); d_doc_str_ordinals[k] =
 // ordinal of document k's first string in the record table d_soff of the string pass (strings.hip)
 size_t walk_workspace_bytes(uint64_t count, uint64_t n_docs);
@@ -204,7 +229,9 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
                        int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream,
                        const Stage1Result* dev_count, const UnescapeResult* dev_strings, const uint32_t* d_soff,
                        bool index_from_zero = false, bool results_zeroed = false, const SingleDocTail& tail = SingleDocTail(),
-                       const uint32_t* d_prepared = nullptr);
+                       const uint32_t* d_prepared = nullptr, bool layout_done = false, bool optimistic_only = false);
+// layout_done: batch_layout_launch ran (the tapes ARE laid out when *d_prepared != 0, the result record and list headers are
+// zeroed): nothing of that is queued again.  optimistic_only: only the kernels of the accepted path are queued.
 // d_prepared (the fused batch pipeline): device flag, != 0 = batch.hip k_doc_prepare ran (the accepted plain pass) and left
 // every document's DocMeta / predicted tape length in the walk workspace (walk_prepared): the tapes are laid out before the
 // walk and written at their final addresses -- there a document that fails keeps its (unused) slot: tape_offsets[k + 1] -
@@ -239,6 +266,7 @@ struct TokLaunch {
     const UnescapeResult* dev_strings;
     WalkResult* d_res;
     void* d_deep_ws;
+    bool header_zeroed = false;     // the literal list's 64-byte header is zero already (k_batch_layout)
 };
 hipError_t tok_walk_launch(const TokLaunch& t, hipStream_t stream);
 // coop_walk.hip: the cooperative walker (a wave per document); d_soff = offset of every string's record in d_sb, by ordinal

@@ -113,6 +113,7 @@ struct StrArgs {
     const uint32_t* sel;
     const uint8_t* buf_alt;
     const sj_u64* blkpar_alt;
+    const uint32_t* skip;  // != nullptr and *skip != 0: the launch does nothing (the batch pipeline's per-document string pass behind an accepted plain pass)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -317,6 +318,7 @@ template <bool SOFF>
 __global__ void __launch_bounds__(256)
 k_strings(const StrArgs a0) {
     StrArgs a = a0;
+    if (a.skip && *a.skip != 0) return;
     if (a.sel && *a.sel == 0) {  // (uniform for the whole launch)
         a.buf = a.buf_alt;
         a.blkpar = a.blkpar_alt;
@@ -873,7 +875,8 @@ static hipError_t str_resident(unsigned* out) {
 // string literal of buf[0, len) go to d_sb; optional: d_soff (offset of record k), d_blk_ord (see StrArgs)
 hipError_t strings_launch(const uint8_t* d_buf, uint64_t len, const unsigned long long* d_blkpar, uint8_t* d_sb, uint64_t sb_cap,
                           uint32_t* d_soff, uint64_t soff_cap, uint32_t* d_blk_ord, void* d_ws, UnescapeResult* d_res,
-                          hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, const StringsAlt& alt, bool workspace_is_zero) {
+                          hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, const StringsAlt& alt, bool workspace_is_zero,
+                          const uint32_t* d_skip) {
     const uint64_t ngran = str_granules(len);
     hipError_t e = workspace_is_zero ? hipSuccess : hipMemsetAsync(d_ws, 0, strings_workspace_bytes(len), stream);
     if (e != hipSuccess) return e;
@@ -896,6 +899,7 @@ hipError_t strings_launch(const uint8_t* d_buf, uint64_t len, const unsigned lon
     a.sel = alt.d_sel;
     a.buf_alt = alt.d_buf;
     a.blkpar_alt = reinterpret_cast<const sj_u64*>(alt.d_blkpar);
+    a.skip = d_skip;
     const bool soff = d_soff != nullptr || d_blk_ord != nullptr;
     unsigned resident = 0;
     e = soff ? str_resident<true>(&resident) : str_resident<false>(&resident);

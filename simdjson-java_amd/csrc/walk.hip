@@ -110,6 +110,45 @@ k_tape_compact(const unsigned long long* __restrict__ scratch_tape, const uint32
     }
 }
 
+// ---- the fused batch pipeline's decision + layout (round 5; see BatchLayout in stage1.h): one workgroup behind k_doc_prepare ----
+__global__ void __launch_bounds__(1024)
+k_batch_layout(BatchLayout a, uint64_t nchunks) {
+    __shared__ unsigned long long s_wave[16];
+    __shared__ uint32_t s_acc;
+    if (threadIdx.x == 0) {
+        const uint32_t st = a.stage1->status;
+        const bool acc = a.flags[0] == 0 && st == 0;
+        a.flags[1] = acc ? 1u : 0u;
+        s_acc = acc ? 1u : 0u;
+        WalkResult zw = {};
+        *a.walk = zw;
+        a.list[0] = 0;
+        UnescapeResult u = {};
+        if (acc) u = *a.strings_ws;
+        *a.strings_out = u;
+        if (!acc && a.optimistic_only) a.stage1_out->status = st | SJMI_ST_REJECTED;
+    }
+    if (threadIdx.x < 16) static_cast<uint32_t*>(a.slow_header)[threadIdx.x] = 0;
+    __syncthreads();
+    if (!s_acc) return;
+    unsigned long long carry = 0;
+    for (uint64_t b = 0; b < nchunks; b += 1024) {
+        const uint64_t i = b + threadIdx.x;
+        const unsigned long long v = i < nchunks ? a.chunk_sums[i] : 0ull;
+        unsigned long long total;
+        const unsigned long long ex = block_excl_scan(v, s_wave, &total);
+        if (i < nchunks) a.chunk_sums[i] = carry + ex;
+        carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a.tape_offsets[0] = 0;
+        a.tape_offsets[a.n_docs] = carry;
+        a.walk->tape_words = carry;
+        if (carry > a.tape_capacity) a.walk->flags |= 1u;
+    }
+}
+
 // ---- tapes laid out BEFORE the walk (the accepted plain pass of the fused pipeline: batch.hip k_doc_prepare left every document's
 // predicted length and the sums per PREP_DOCS documents; k_tape_chunk_scan turns those into chunk bases) ----------------------
 __global__ void __launch_bounds__(PREP_DOCS)
@@ -191,14 +230,39 @@ WalkPrepared walk_prepared(void* d_ws, uint64_t count, uint64_t n_docs) {
 
 void* walk_slow_header(void* d_ws, uint64_t count, uint64_t n_docs) { return static_cast<uint8_t*>(d_ws) + walk_deep_offset(count, n_docs); }
 
+__global__ void k_batch_reject(Stage1Result* r) {
+    r->count = 0;
+    r->status = SJMI_ST_REJECTED;
+    r->reserved = 0;
+}
+hipError_t batch_reject_launch(Stage1Result* d_stage1, hipStream_t stream) {
+    hipLaunchKernelGGL(k_batch_reject, dim3(1), dim3(1), 0, stream, d_stage1);
+    return hipGetLastError();
+}
+
+hipError_t batch_layout_launch(const BatchLayout& a0, void* d_ws, uint64_t count, const uint32_t* lens, DocMeta* metas,
+                               int32_t* d_doc_errors, hipStream_t stream) {
+    BatchLayout a = a0;
+    uint8_t* ws = static_cast<uint8_t*>(d_ws);
+    a.slow_header = walk_slow_header(d_ws, count, a.n_docs);
+    a.list = reinterpret_cast<uint32_t*>(ws + walk_list_offset(count, a.n_docs));
+    const uint64_t pchunks = (a.n_docs + PREP_DOCS - 1) / PREP_DOCS;
+    hipLaunchKernelGGL(k_batch_layout, dim3(1), dim3(1024), 0, stream, a, pchunks);
+    hipLaunchKernelGGL(k_tape_offsets, dim3((unsigned)((a.n_docs + 1 + PREP_DOCS - 1) / PREP_DOCS)), dim3(PREP_DOCS), 0, stream, lens,
+                       (const unsigned long long*)a.chunk_sums, a.n_docs, a.tape_capacity, a.tape_offsets, metas, a.list,
+                       (const uint32_t*)(a.flags + 1), d_doc_errors);
+    return hipGetLastError();
+}
+
 hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_idx,
                        uint64_t count, const unsigned long long* d_index_offsets, const uint32_t* d_doc_status,
                        const uint8_t* d_sb, const unsigned long long* d_doc_str_ordinals, uint64_t string_base, int max_depth,
                        unsigned long long* d_tape, uint64_t tape_capacity, unsigned long long* d_tape_offsets,
                        int32_t* d_doc_errors, void* d_ws, WalkResult* d_res, hipStream_t stream, const Stage1Result* dev_count,
                        const UnescapeResult* dev_strings, const uint32_t* d_soff, bool index_from_zero, bool results_zeroed,
-                       const SingleDocTail& tail, const uint32_t* d_prepared) {
+                       const SingleDocTail& tail, const uint32_t* d_prepared, bool layout_done, bool optimistic_only) {
     if (!d_soff) return hipErrorInvalidValue;  // (the record table of the string pass: strings.hip)
+    if (optimistic_only && !(layout_done && d_prepared && n_docs > 1)) return hipErrorInvalidValue;
     uint8_t* ws = static_cast<uint8_t*>(d_ws);
     unsigned long long* scratch = reinterpret_cast<unsigned long long*>(ws);
     // one document whose index range starts at 0 (only sjmi_parse_document knows that: the walker's slot for document 0 is
@@ -207,16 +271,16 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
     if (direct) scratch = d_tape;
     uint32_t* lens = reinterpret_cast<uint32_t*>(ws + walk_lens_offset(count, n_docs));
     unsigned long long* sums = reinterpret_cast<unsigned long long*>(ws + walk_sums_offset(count, n_docs));
-    hipError_t e = results_zeroed ? hipSuccess : hipMemsetAsync(d_res, 0, sizeof(WalkResult), stream);
+    hipError_t e = (results_zeroed || layout_done) ? hipSuccess : hipMemsetAsync(d_res, 0, sizeof(WalkResult), stream);
     if (e != hipSuccess) return e;
     const uint64_t nchunks = (n_docs + PACK_DOCS - 1) / PACK_DOCS;
     static const bool tokens_off = getenv("SJMI_TOKEN_WALK") && atoi(getenv("SJMI_TOKEN_WALK")) == 0;
     const uint32_t* packed_skip = nullptr;  // device flag != 0: the tapes were laid out before the walk, nothing is packed behind it
-    if (n_docs > 1 && !tokens_off) {
+    if (n_docs > 1 && (!tokens_off || optimistic_only)) {
         // ---- a batch: the token walker (coop_walk.hip k_tok_walk) with the exact walker behind it for what it declines ----
         const WalkPrepared wp = walk_prepared(d_ws, count, n_docs);
         uint32_t* list = reinterpret_cast<uint32_t*>(ws + walk_list_offset(count, n_docs));
-        if (d_prepared) {
+        if (d_prepared && !layout_done) {
             // the fused pipeline's accepted plain pass (*d_prepared != 0): batch.hip k_doc_prepare left the predicted lengths, so
             // the tapes are laid out NOW and the walkers store at the final addresses
             const uint64_t pchunks = (n_docs + PREP_DOCS - 1) / PREP_DOCS;
@@ -225,9 +289,10 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
             hipLaunchKernelGGL(k_tape_offsets, dim3((unsigned)((n_docs + 1 + PREP_DOCS - 1) / PREP_DOCS)), dim3(PREP_DOCS), 0, stream,
                                (const uint32_t*)wp.lens, (const unsigned long long*)wp.chunk_sums, n_docs, tape_capacity, d_tape_offsets,
                                wp.metas, list, d_prepared, d_doc_errors);
-            packed_skip = d_prepared;
         }
-        hipLaunchKernelGGL(k_doc_meta, dim3((unsigned)((n_docs + 1 + 255) / 256)), dim3(256), 0, stream, d_doc_offsets, d_index_offsets,
+        if (d_prepared) packed_skip = d_prepared;
+        if (!optimistic_only)
+            hipLaunchKernelGGL(k_doc_meta, dim3((unsigned)((n_docs + 1 + 255) / 256)), dim3(256), 0, stream, d_doc_offsets, d_index_offsets,
                            d_doc_status, d_doc_str_ordinals, n_docs, wp.metas, list, packed_skip, d_doc_errors);
         TokLaunch t;
         t.d_buf = d_buf;
@@ -243,7 +308,8 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
         t.string_base = string_base;
         t.max_depth = max_depth;
         t.d_tape = d_prepared ? d_tape : scratch;
-        t.d_scratch = scratch;
+        t.d_scratch = optimistic_only ? nullptr : scratch;
+        t.header_zeroed = layout_done;
         t.d_sel = d_prepared;
         t.d_tape_lens = lens;
         t.d_doc_errors = d_doc_errors;
@@ -254,6 +320,7 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
         t.d_deep_ws = ws + walk_deep_offset(count, n_docs);
         e = tok_walk_launch(t, stream);
         if (e != hipSuccess) return e;
+        if (optimistic_only) return hipGetLastError();  // (nothing is packed behind tapes that were laid out before the walk)
         hipLaunchKernelGGL(k_tape_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, lens, d_doc_errors, n_docs, sums, d_res, packed_skip);
     } else if (n_docs) {
         // the cooperative walker (coop_walk.hip): a wave per document; STRING payloads from the string pass's record table

@@ -85,8 +85,16 @@ class BatchShard:
         self.max_depth = max_depth
         self._ndocs = torch.tensor([self.n_docs], dtype=torch.int64, device=device)
 
-    def step(self, stream=0):
-        self.engine.parse_batch_device(self.buf.data_ptr(), self.n, self.offs.data_ptr(), self.n_docs, self.idx.data_ptr(),
+    def step(self, stream=0, exact=False):
+        """One step, queued on `stream`.  Default: sjmi_parse_batch_device_optimistic -- only the optimistic pipeline (eight queue
+        entries); a batch it cannot take (a document fails stage 1, a separator is missing) comes back with SJMI_ST_REJECTED in
+        its result record and check() makes the exact call then, off the hot path.  exact=True: sjmi_parse_batch_device,
+        everything queued, every document decided on its own whatever the batch contains."""
+        exact = exact or getattr(self, "rejected_steps", 0) > 0  # (latched: data that was rejected once takes the exact call from then on)
+        fn = self.engine.parse_batch_device if exact or not hasattr(self.engine, "parse_batch_device_optimistic") \
+            else self.engine.parse_batch_device_optimistic
+        self._last_stream = stream
+        fn(self.buf.data_ptr(), self.n, self.offs.data_ptr(), self.n_docs, self.idx.data_ptr(),
                                        self.index_capacity, self.index_offsets.data_ptr(), self.doc_status.data_ptr(),
                                        self.sb.data_ptr(), self.sb_capacity, self.doc_string_offsets.data_ptr(), self.max_depth,
                                        self.tape.data_ptr(), self.tape_capacity, self.tape_offsets.data_ptr(),
@@ -103,6 +111,13 @@ class BatchShard:
         """Host-side verdict of the last step (synchronise first): raises if a capacity was exceeded."""
         r = self.result.cpu().numpy()
         st1, sflags, wflags = int(r[1]) & 0xFFFFFFFF, int(r[4]) & 0xFFFFFFFF, int(r[8]) & 0xFFFFFFFF
+        if st1 & 0x800:  # SJMI_ST_REJECTED: not a batch for the optimistic pipeline -- the exact call, here, off the hot path
+            import torch
+            self.rejected_steps = getattr(self, "rejected_steps", 0) + 1
+            self.step(getattr(self, "_last_stream", 0), exact=True)
+            torch.cuda.synchronize(self.device)
+            r = self.result.cpu().numpy()
+            st1, sflags, wflags = int(r[1]) & 0xFFFFFFFF, int(r[4]) & 0xFFFFFFFF, int(r[8]) & 0xFFFFFFFF
         if st1 & 0x300:
             raise RuntimeError("stage 1 of the shard: capacity / internal error (status 0x%x)" % st1)
         if sflags & 1:

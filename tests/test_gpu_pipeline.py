@@ -92,14 +92,23 @@ def test_capacity_shortfall_is_reported_not_overrun(short):
         ctx.close()
 
 
-def _run_shard(ctx, buf, offs, n):
+def _run_shard(ctx, buf, offs, n, exact=False, want_rejected=None):
+    """exact=False: sjmi_parse_batch_device_optimistic, and check() makes the exact call when the record says SJMI_ST_REJECTED;
+    exact=True: sjmi_parse_batch_device (everything queued)."""
     import torch
     from simdjson_java_amd import sharding
     shard = sharding.BatchShard(ctx, buf, offs, torch.device("cuda", 0))
     for _ in range(2):
-        shard.step(torch.cuda.current_stream().cuda_stream)
+        shard.step(torch.cuda.current_stream().cuda_stream, exact=exact)
         torch.cuda.synchronize()
+    if not exact:
+        st1 = int(shard.result.cpu().numpy()[1]) & 0xFFFFFFFF
+        if want_rejected is not None:
+            assert bool(st1 & 0x800) == want_rejected, hex(st1)
     c = shard.check()
+    assert not (c["stage1_status"] & 0x800)
+    if want_rejected is not None and not exact:
+        assert getattr(shard, "rejected_steps", 0) == (1 if want_rejected else 0)
     to = shard.tape_offsets.cpu().numpy()
     tape = shard.tape.cpu().numpy().view(np.uint64)
     err = shard.doc_errors.cpu().numpy()[:n]
@@ -108,8 +117,9 @@ def _run_shard(ctx, buf, offs, n):
     return c, tape, to, err, bytes(shard.sb[:c["string_bytes"]].cpu().numpy()), io, idx
 
 
+@pytest.mark.parametrize("exact", [False, True], ids=["optimistic_entry", "exact_entry"])
 @pytest.mark.parametrize("separator", [b"\n", b"\r\n", b"\t", b" ", b""], ids=["lf", "crlf", "tab", "space", "none"])
-def test_optimistic_plain_pass_and_its_rejections(separator, monkeypatch):
+def test_optimistic_plain_pass_and_its_rejections(separator, exact, monkeypatch):
     """sjmi_parse_batch_device indexes a batch with ONE plain k_stage1 launch when every document ends in a control-character
     separator and the global verdict is clean; anything else (space / no separators, any broken document) falls to the
     per-document passes.  Either way the outputs equal those of the pipeline with the optimistic pass switched off
@@ -131,7 +141,10 @@ def test_optimistic_plain_pass_and_its_rejections(separator, monkeypatch):
                 continue
             buf = b"".join(d + separator for d in docs)
             offs = np.concatenate([[0], np.cumsum([len(d) + len(separator) for d in docs])]).astype(np.uint64)
-            c, tape, to, err, strings, io, idx = _run_shard(ctx, buf, offs, len(docs))
+            # which batches the optimistic pipeline takes: control-character separators and every document through stage 1
+            # (b"[1 1]" passes stage 1: a grammar error is the walker's business, not a rejection)
+            accepted = separator in (b"\n", b"\r\n", b"\t") and name in ("all valid", "one broken", "empty documents")
+            c, tape, to, err, strings, io, idx = _run_shard(ctx, buf, offs, len(docs), exact=exact, want_rejected=not accepted)
             n_bad = 0
             for k, d in enumerate(docs):
                 # (a document is judged alone: what stands behind it in the batch must not matter -- with space / no
@@ -269,5 +282,45 @@ def test_accepted_batch_delimiters_equal_the_per_document_passes():
         want_dso.append(so)
         assert np.array_equal(got_io, np.asarray(want_io))
         assert np.array_equal(got_dso, np.asarray(want_dso))
+    finally:
+        ctx.close()
+
+
+def test_optimistic_entry_point_equals_the_exact_one_on_an_accepted_batch():
+    """sjmi_parse_batch_device_optimistic (eight queue entries) against sjmi_parse_batch_device (everything queued) on NDJSON
+    that qualifies: every output array byte for byte, the three result records, nothing flagged."""
+    import torch
+    import simdjson_java_amd as S
+    from simdjson_java_amd import sharding
+    rng = random.Random(77)
+    docs = _small_docs(rng, 4000) + [b"[1 1]", b'{"a":tru}', b'["\\q"]']  # (stage-2 / string errors do not reject a batch)
+    rng.shuffle(docs)
+    buf = b"".join(d + b"\n" for d in docs)
+    offs = np.concatenate([[0], np.cumsum([len(d) + 1 for d in docs])]).astype(np.uint64)
+    ctx = S.Context(0, 1 << 20)
+    try:
+        out = []
+        for exact in (False, True):
+            shard = sharding.BatchShard(ctx, buf, offs, torch.device("cuda", 0))
+            for t in (shard.idx, shard.sb, shard.tape):
+                t.zero_()
+            for _ in range(2):
+                shard.step(torch.cuda.current_stream().cuda_stream, exact=exact)
+                torch.cuda.synchronize()
+            r = shard.result.cpu().numpy().copy()
+            assert not (int(r[1]) & 0x800)
+            c = shard.check()
+            assert getattr(shard, "rejected_steps", 0) == 0
+            out.append((r, shard.idx[:c["structurals"] + 1].cpu().numpy(), shard.index_offsets.cpu().numpy(), shard.doc_status.cpu().numpy(),
+                        shard.sb[:c["string_bytes"]].cpu().numpy(), shard.doc_string_offsets.cpu().numpy(),
+                        shard.tape_offsets.cpu().numpy(), shard.doc_errors.cpu().numpy(), shard.tape.cpu().numpy(), c))
+        a, b = out
+        assert a[9] == b[9] and a[9]["failed_documents"] == 3
+        for i in range(8):
+            assert np.array_equal(a[i], b[i]), i
+        to, err = a[6], a[7]
+        for k in range(len(docs)):  # (a failing document's slot holds unspecified words: compare the tapes of the others)
+            if err[k] == 0:
+                assert np.array_equal(a[8][int(to[k]):int(to[k + 1])], b[8][int(to[k]):int(to[k + 1])]), k
     finally:
         ctx.close()
