@@ -358,16 +358,28 @@ def wall_steps(torch, fn, steps, dist=None):
     return el
 
 
+BATCH_GEN_SLICE = 100000  # documents generated (and page-locked) at a time: ~130 MB of pinned host memory per rank, whatever --docs is
+
+
 def make_batch_shard(torch, S, W, dev, ctx, lo, hi):
     """documents [lo, hi) of the configs[3] set (1,000,000 UNIQUE documents, tools/docgen.c seed 20250825: document k is a
-    function of (seed, k), so a rank generates its own range only) as a BatchShard on `dev` -> (shard, local offsets)"""
+    function of (seed, k), so a rank generates its own range only) as a BatchShard on `dev` -> (shard, local offsets).
+    Generated in slices of BATCH_GEN_SLICE documents through ONE re-used page-locked buffer: eight ranks of a node with a million
+    documents each would otherwise pin 8 x 1.3 GB of host memory at the same time."""
+    import numpy as np
     from simdjson_java_amd import sharding
-    host = torch.empty(1300 * (hi - lo) + 64, dtype=torch.uint8).pin_memory()
-    data, offs = W.unique_docs(lo, hi - lo, out=host.numpy())
+    lens = W.unique_doc_lengths(lo, hi - lo)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     n = int(offs[-1])
     shard_bytes = torch.empty(n, dtype=torch.uint8, device=dev)
-    shard_bytes.copy_(host[:n], non_blocking=True)
-    torch.cuda.synchronize()
+    host = torch.empty(1300 * min(BATCH_GEN_SLICE, hi - lo) + 64, dtype=torch.uint8).pin_memory()
+    for a in range(0, hi - lo, BATCH_GEN_SLICE):
+        m = min(BATCH_GEN_SLICE, hi - lo - a)
+        data, o2 = W.unique_docs(lo + a, m, out=host.numpy())
+        b0, b1 = int(offs[a]), int(offs[a + m])
+        assert int(o2[-1]) == b1 - b0
+        shard_bytes[b0:b1].copy_(host[:b1 - b0], non_blocking=True)
+        torch.cuda.synchronize()  # (the buffer is re-used by the next slice)
     del host
     # (this set: 5.4 B per structural, 0.84 string-buffer bytes and 0.13 tape words per input byte)
     return sharding.BatchShard(ctx, shard_bytes, offs, dev, index_ratio=4, string_ratio=1.0, tape_ratio=0.2), offs
@@ -585,8 +597,8 @@ def bench_single(args):
             assert all(v["selected"] == 86 for v in sel.values()), sel  # BenchmarkCorrectnessTest.java:23-55
             extra["parse_and_select_twitter_json"] = {
                 "config": "twitter.json from a host buffer -> the 86 screen names of users with default_profile, per call: H2D, GPU "
-                          "stage 1 (+ string records and host stage 2 for the full parse; + k_coop_match and its D2H for the skip "
-                          "table), selection on the host through sjmi_value_* / sjmi_od_* (tools/ondemand_bench.cpp)",
+                          "stage 1 (+ string records and host stage 2 for the full parse), selection on the host through sjmi_value_* / "
+                          "sjmi_od_* (tools/ondemand_bench.cpp)",
                 "unit": "ms per parse-and-select", "value": sel["on_demand_scan"]["ms"], **sel,
                 "reference_readme": "README.md, 512-bit vectors, Xeon Platinum 8375C, one thread: SchemaBasedParseAndSelectBenchmark "
                                     "3164 ops/s, ParseAndSelectBenchmark 1842 ops/s (other hardware; no JVM here)"}

@@ -343,24 +343,6 @@ int sjmi_parse_document(sjmi_ctx* ctx, const uint8_t* buf, uint64_t len, int max
                         uint64_t* tape_len, uint8_t* string_buffer, uint64_t string_capacity, uint64_t* strings_len,
                         int32_t* error, uint32_t* stage1_status);
 
-/* ---- the on-demand front end's skip table -------------------------------------------------------
- * OnDemandJsonIterator.skipChild(parentDepth) (OnDemandJsonIterator.java:43-81, called from SchemaBasedJsonIterator.java:76,
- * :107 for every field a schema does not want) leaves a value by scanning the structural indexes and counting brackets
- * until the depth has dropped far enough.  The bracket matching of the cooperative walker turns that scan into a lookup.
- * Per structural i (positions in the index array):
- *   up[i]    = the opening bracket of the container i lies in (a closing bracket: its own opening bracket; an opening
- *              bracket: the enclosing one), SJMI_MATCH_NONE at the root level;
- *   match[i] = for an opening bracket its closing bracket (SJMI_MATCH_NONE: never closed), otherwise up[i].
- * skipChild from read position q that has to leave k = depth - parentDepth containers: e = up[q]; k - 1 times e = up[e];
- * continue at match[e] + 1 ("Not enough close braces." when a step yields SJMI_MATCH_NONE).  SJMI_MATCH_UNKNOWN marks
- * what the table does not cover (behind a closing bracket that has no opening one, beyond 64 levels): scan there.
- * Device form: any batch (d_index_offsets: n_docs + 1 entries); host form: the document of the last sjmi_stage1. */
-#define SJMI_MATCH_NONE 0xFFFFFFFFu
-#define SJMI_MATCH_UNKNOWN 0xFFFFFFFEu
-int sjmi_match_brackets_device(sjmi_ctx* ctx, const void* d_buf, const void* d_indexes, const void* d_index_offsets, uint64_t n_docs,
-                               void* d_up, void* d_match, void* stream);
-int sjmi_match_brackets(sjmi_ctx* ctx, uint32_t* up, uint32_t* match, uint64_t capacity);
-
 /* ---- whole parse: SimdJsonParser.parse(byte[], int) (SimdJsonParser.java:35-40) ----------------------------
  * GPU stage 1 + GPU string unescape + the host stage-2 tree builder (C++ mirror of JsonIterator / TapeBuilder /
  * Tape: simdjson-java_amd/csrc/host/simdjson_parser.h).  The tape (Tape.java:5-47 word layout) and string
@@ -392,9 +374,11 @@ int sjmi_parser_parse_batch(sjmi_parser* p, const uint8_t* buf, uint64_t total_l
 /* ---- the on-demand front end --------------------------------------------------------------
  * OnDemandJsonIterator (OnDemandJsonIterator.java:7-675), the cursor SchemaBasedJsonIterator.java:29-132 drives with one
  * call per field of the schema: it walks the structural indexes of stage 1 and parses only the values it is asked for.
- * sjmi_parser_ondemand_init = SimdJsonParser.parse(buffer, len, Class) up to and including iterator.init (:31-41): pad,
- * GPU stage 1, and -- with_skip_table != 0 -- the GPU skip table (sjmi_match_brackets), with which skipChild leaves k
- * containers by k - 1 + 1 table reads instead of scanning every structural in between (:47-81).  The calls below mirror
+ * sjmi_parser_ondemand_init = SimdJsonParser.parse(buffer, len, Class) up to and including iterator.init (:31-41): pad and
+ * GPU stage 1.  (`reserved` must be 0.  Rounds 2-4 built a GPU skip table here -- up[] / match[] per structural, skipChild as
+ * a lookup -- that never paid: 0.256 against 0.159 ms per parse-and-select of twitter.json, because the scan it replaced costs
+ * ~1 ns per structural on the host and the table two kernels plus 8 bytes per structural over PCIe.  Removed in round 5.)
+ * The calls below mirror
  * the iterator's methods one to one (root != 0: the Root form; nullable == 0: the NonNull form; *is_null: the method
  * returned null); each returns 0, or > 0 = the SJMI_E_* code of the JsonParsingException the reference throws there
  * (exact text: sjmi_parser_last_message), or < 0.  Every getter of the class is here. */
@@ -415,7 +399,7 @@ int sjmi_parser_parse_batch(sjmi_parser* p, const uint8_t* buf, uint64_t total_l
 #define SJMI_OD_EMPTY 0                  /* IteratorResult :672-674 */
 #define SJMI_OD_NULL 1
 #define SJMI_OD_NOT_EMPTY 2
-int sjmi_parser_ondemand_init(sjmi_parser* p, const uint8_t* buf, uint64_t len, int with_skip_table);
+int sjmi_parser_ondemand_init(sjmi_parser* p, const uint8_t* buf, uint64_t len, int reserved);
 int sjmi_od_skip_child(sjmi_parser* p, int parent_depth);             /* skipChild(parentDepth) :47-81; < 0: skipChild() :43-45 */
 int sjmi_od_get_boolean(sjmi_parser* p, int root, int nullable, int* is_null, int* value);     /* :83-109,:147-171 */
 int sjmi_od_get_long(sjmi_parser* p, int root, int nullable, int* is_null, int64_t* value);    /* :321-358 */

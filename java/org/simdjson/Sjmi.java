@@ -99,10 +99,6 @@ final class Sjmi {
     static final MethodHandle UNESCAPE_BATCH = h("sjmi_unescape_batch",
             FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
 
-    // int sjmi_match_brackets(ctx, uint32_t* up, uint32_t* match, uint64_t capacity)
-    static final MethodHandle MATCH_BRACKETS = h("sjmi_match_brackets",
-            FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG));
-
     // int sjmi_stream_open(ctx, uint64_t max_chunk_bytes, uint64_t halo_bytes, sjmi_stream** out)
     static final MethodHandle STREAM_OPEN = h("sjmi_stream_open",
             FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS));

@@ -69,8 +69,7 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_parser_root", "sjmi_parser_batch_root", "sjmi_value_type", "sjmi_value_as_long", "sjmi_value_as_double",
            "sjmi_value_as_boolean", "sjmi_value_as_string", "sjmi_value_get", "sjmi_value_size", "sjmi_value_first",
            "sjmi_value_next", "sjmi_parse_batch_device", "sjmi_parse_batch_device_optimistic", "sjmi_parse_document",
-           "sjmi_parser_set_gpu_walk", "sjmi_set_auto_safe", "sjmi_match_brackets",
-           "sjmi_match_brackets_device", "sjmi_stage1_shard_device", "sjmi_stage1_shard_device2",
+           "sjmi_parser_set_gpu_walk", "sjmi_set_auto_safe", "sjmi_stage1_shard_device", "sjmi_stage1_shard_device2",
            "sjmi_stream_open", "sjmi_stream_push", "sjmi_stream_close", "sjmi_split_open", "sjmi_split_scan", "sjmi_split_resolve", "sjmi_split_close",
            "sjmi_parser_ondemand_init", "sjmi_od_skip_child", "sjmi_od_get_boolean", "sjmi_od_get_long", "sjmi_od_get_integral", "sjmi_od_get_double", "sjmi_od_get_float", "sjmi_od_get_char",
            "sjmi_od_get_string", "sjmi_od_get_field_name", "sjmi_od_start_array", "sjmi_od_next_array_element",
@@ -173,11 +172,6 @@ def lib():
         L.sjmi_parser_parse_batch.restype = C.c_int
         L.sjmi_parser_parse_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p]
-        L.sjmi_match_brackets.restype = C.c_int
-        L.sjmi_match_brackets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
-        L.sjmi_match_brackets_device.restype = C.c_int
-        L.sjmi_match_brackets_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
-                                                 C.c_void_p]
         L.sjmi_stage1_shard_device.restype = C.c_int
         L.sjmi_stage1_shard_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_uint64,
                                                C.c_void_p, C.c_void_p]
@@ -296,13 +290,6 @@ class Context:
                                               C.addressof(tl), sb.ctypes.data, sb.size, C.addressof(sl), C.addressof(err),
                                               C.addressof(st)), "sjmi_parse_document")
         return (tape[:tl.value].copy() if err.value == 0 else None), bytes(sb[:sl.value]), err.value, st.value
-
-    def match_brackets(self, count):
-        """The on-demand skip table of the document of the last stage1() call: -> (up, match) np.uint32 [count]."""
-        up = np.zeros(max(count, 1), dtype=np.uint32)
-        match = np.zeros(max(count, 1), dtype=np.uint32)
-        self._check(lib().sjmi_match_brackets(self._h, up.ctypes.data, match.ctypes.data, count), "sjmi_match_brackets")
-        return up[:count], match[:count]
 
     def stage1_masks(self, data, length=None):
         """The reference's per-block masks (sjmi_stage1_masks): -> np.uint64 [len // 64 + 1, 6] =
@@ -666,13 +653,12 @@ class SimdJsonParser:
         strings = bytes(np.ctypeslib.as_array(sb_p, shape=(max(sb_len.value, 1),))[:sb_len.value])
         return ParsedDocument(tape, strings)
 
-    def ondemand(self, buffer, length=None, skip_table=False):
-        """The on-demand front end (OnDemandJsonIterator.java; csrc/host/ondemand.h): pad + GPU stage 1 (+ the GPU skip
-        table, worth its download only when large subtrees of a large document are skipped) + iterator.init -> the cursor.
-        One cursor per parser at a time, invalidated by the next parse / ondemand."""
+    def ondemand(self, buffer, length=None):
+        """The on-demand front end (OnDemandJsonIterator.java; csrc/host/ondemand.h): pad + GPU stage 1 + iterator.init -> the
+        cursor.  One cursor per parser at a time, invalidated by the next parse / ondemand."""
         a = np.frombuffer(bytes(buffer), dtype=np.uint8)
         n = a.size if length is None else length
-        rc = lib().sjmi_parser_ondemand_init(self._h, a.ctypes.data if a.size else None, n, 1 if skip_table else 0)
+        rc = lib().sjmi_parser_ondemand_init(self._h, a.ctypes.data if a.size else None, n, 0)
         if rc > 0:
             raise JsonParsingException(rc, lib().sjmi_parser_last_message(self._h).decode("utf-8"))
         if rc < 0:

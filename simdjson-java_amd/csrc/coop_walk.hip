@@ -1543,174 +1543,6 @@ k_chunk_finish(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ idx
     }
 }
 
-// ---- the skip table of the on-demand front end -------------------------------------------------
-// OnDemandJsonIterator.skipChild (OnDemandJsonIterator.java:43-81) leaves a value by scanning the structurals and counting
-// brackets until the depth drops; with the bracket matching above that scan is a table lookup.  Per structural i of a
-// document (absolute positions in the index array):
-//   up[i]    = the opening bracket of the container i lies in (for a closing bracket: its own opening bracket; for an opening
-//              bracket: the enclosing one); SJMI_MATCH_NONE at the root level
-//   match[i] = for an opening bracket its closing bracket (SJMI_MATCH_NONE if it is never closed), otherwise up[i]
-// "leave k containers from position q" = climb k - 1 times through up[] from up[q], then continue behind match[] of that
-// bracket.  Levels beyond the 64 of the per-wave stack are marked SJMI_MATCH_UNKNOWN (scan there, as the reference does).
-// the per-chunk summary of the chunk-parallel skip table: like k_chunk_summary with nothing but brackets -- net depth change,
-// minimum, and as the export of a level the STRUCTURAL POSITION of the bracket left open there (words, string bytes and
-// commas are zero, so the scan kernels of the walker carry it through unchanged: entry value = 1 + position)
-__global__ void __launch_bounds__(256)
-k_match_summary(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ idx, const unsigned long long* __restrict__ index_offsets,
-                uint32_t* __restrict__ match, ChunkWs cw) {
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
-    const unsigned long long from = index_offsets[0], to = index_offsets[1];
-    if (to - from <= CW_SINGLE_N) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(cw.fallback, 1u);
-        return;
-    }
-    const uint32_t chunk = cw_chunk_of(to - from);
-    const uint64_t nchunks = (to - from + chunk - 1) / chunk;
-    for (uint64_t k = (uint64_t)blockIdx.x * 4 + wv; k < nchunks; k += nwaves) {
-        const unsigned long long wfrom = from + k * chunk, wto = wfrom + chunk < to ? wfrom + chunk : to;
-        const uint64_t nsteps = (wto - wfrom + 63) / 64;
-        uint32_t st_idx = 0;
-        int H = CW_BIAS, min_after = 0x7FFF;
-        bool out_of_range = false;
-        uint32_t p_n = wfrom + lane < wto ? idx[wfrom + lane] : 0u;
-        for (uint64_t s = 0; s < nsteps; ++s) {
-            const uint64_t i = wfrom + s * 64 + lane;
-            const bool valid = i < wto;
-            const uint32_t c = buf[p_n];
-            if (s + 1 < nsteps) p_n = i + 64 < wto ? idx[i + 64] : 0u;
-            const uint32_t cls = valid ? class_of(c) : K_COMMA;
-            const bool is_open = valid && cls <= K_OPEN_O, is_close = valid && (cls == K_CLOSE_A || cls == K_CLOSE_O);
-            const uint32_t upb = is_open ? 1u : 0u, down = is_close ? 1u : 0u;
-            const uint32_t iu = cw_incl_scan(upb), id = cw_incl_scan(down);
-            const int h = H + (int)(iu - upb) - (int)(id - down);
-            const int plevel = h - 1;
-            if (is_open) match[i] = 0xFFFFFFFFu;  // SJMI_MATCH_NONE until its closing bracket's chunk says otherwise
-            const int after = cw_wave_minmax<false>(valid ? h + (int)upb - (int)down : 0x7FFF);
-            const int hmin = cw_wave_minmax<false>(valid ? plevel : 0x7FFF), hmax = cw_wave_minmax<true>(valid ? (is_open ? h : plevel) : -0x7FFF);
-            min_after = min(min_after, after);
-            if (hmin < 0 || hmax >= CW_LEVELS) {
-                out_of_range = true;
-                break;
-            }
-            for (int L = hmin; L <= hmax; ++L) {
-                const unsigned long long O = __ballot(is_open && h == L);
-                const unsigned long long Z = __ballot(is_close && plevel == L);
-                if (O) {
-                    const int al = 63 - __builtin_clzll(O);
-                    const unsigned long long above = al == 63 ? 0ull : ~((2ull << al) - 1ull);
-                    if (!(Z & above)) st_idx = lane == L ? (uint32_t)(wfrom + s * 64 + al) : st_idx;
-                }
-            }
-            H += (int)cw_last(iu) - (int)cw_last(id);
-        }
-        if (out_of_range && lane == 0) atomicOr(cw.fallback, 1u);
-        if (lane == 0) {
-            cw.sum.delta[k] = H - CW_BIAS;
-            cw.sum.min_after[k] = (min_after == 0x7FFF ? CW_BIAS : min_after) - CW_BIAS;
-            cw.sum.words[k] = 0;
-            cw.sum.ssz[k] = 0;
-            cw.sum.exp_arr[k] = 0;
-        }
-        cw.sum.exp_tpos[k * 64 + lane] = st_idx;
-        cw.sum.exp_cnt[k * 64 + lane] = 0;
-    }
-}
-
-template <bool CHUNKED>
-__global__ void __launch_bounds__(256)
-k_coop_match(const uint8_t* __restrict__ buf, uint64_t n_docs, const uint32_t* __restrict__ idx,
-             const unsigned long long* __restrict__ index_offsets, uint32_t* __restrict__ up, uint32_t* __restrict__ match,
-             ChunkWs cw, const uint32_t* run_only_if) {
-    if (run_only_if && *run_only_if == 0) return;
-    if (CHUNKED && *cw.fallback != 0) return;
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
-    constexpr uint32_t NONE = 0xFFFFFFFFu, UNKNOWN = 0xFFFFFFFEu;
-    uint64_t n_items = n_docs;
-    uint32_t chunk = 0;
-    if (CHUNKED) {
-        chunk = cw_chunk_of(index_offsets[1] - index_offsets[0]);
-        n_items = (index_offsets[1] - index_offsets[0] + chunk - 1) / chunk;
-    }
-    for (uint64_t k = (uint64_t)blockIdx.x * 4 + wv; k < n_items; k += nwaves) {
-        const unsigned long long dfrom = index_offsets[CHUNKED ? 0 : k], dto = index_offsets[CHUNKED ? 1 : k + 1];
-        const unsigned long long from = CHUNKED ? dfrom + k * chunk : dfrom;
-        const unsigned long long to = CHUNKED ? (from + chunk < dto ? from + chunk : dto) : dto;
-        const uint64_t nsteps = (to - from + 63) / 64;
-        uint32_t st_idx = NONE;  // LANE L = the open bracket of level L (structural position), as in k_coop_walk
-        int H0 = 0;
-        bool broken = false;     // a closing bracket without an opening one was seen: everything behind it is left to the scan
-        if (CHUNKED) {           // the chunk's entry state (k_group_replay; values are 1 + position, 0 = never set)
-            H0 = (int)cw.in.H[k];
-            const uint32_t e = cw.in.tpos[k * 64 + lane];
-            st_idx = (lane < H0 && e != 0) ? e - 1u : NONE;
-            broken = (cw.in.root_closed[k] & 2u) != 0;
-        }
-        uint32_t p_n = from + lane < to ? idx[from + lane] : 0u;
-        uint32_t c_n = buf[p_n];
-        for (uint64_t s = 0; s < nsteps; ++s) {
-            const uint64_t i = from + s * 64 + lane;
-            const bool valid = i < to;
-            const uint32_t c = c_n;
-            if (s + 1 < nsteps) {  // (two dependent loads per step; the walker proper pipelines them, this table is built once)
-                const uint64_t in = i + 64;
-                p_n = in < to ? idx[in] : 0u;
-                c_n = buf[p_n];
-            }
-            const uint32_t cls = valid ? class_of(c) : K_COMMA;
-            const bool is_open = valid && cls <= K_OPEN_O, is_close = valid && (cls == K_CLOSE_A || cls == K_CLOSE_O);
-            const uint32_t upb = is_open ? 1u : 0u, down = is_close ? 1u : 0u;
-            const uint32_t iu = cw_incl_scan(upb), id = cw_incl_scan(down);
-            const int h = H0 + (int)(iu - upb) - (int)(id - down);
-            // a closing bracket at depth 0 (only in documents stage 2 rejects): the table stops being defined there --
-            // the reference's skipChild merely counts, and its answers behind such a bracket are whatever the counting gives
-            const unsigned long long under = __ballot(valid && is_close && h <= 0);
-            const int first_bad = broken ? 0 : (under ? __builtin_ctzll(under) : 64);
-            const int plevel = h - 1;
-            int hmin = cw_wave_minmax<false>(valid ? plevel : 0x7FFF), hmax = cw_wave_minmax<true>(valid ? (is_open ? h : plevel) : -0x7FFF);
-            if (hmin < 0) hmin = 0;
-            if (hmax >= CW_LEVELS) hmax = CW_LEVELS - 1;
-            uint32_t my_up = (valid && plevel >= CW_LEVELS) ? UNKNOWN : NONE;
-            // (overwritten by its closing bracket, below or in a later step; chunks run in no particular order, so there the
-            //  "never closed" default was written by k_match_summary, which is complete before any chunk starts)
-            if (!CHUNKED && is_open) match[i] = (h >= CW_LEVELS) ? UNKNOWN : NONE;
-            for (int L = hmin; L <= hmax; ++L) {
-                const unsigned long long O = __ballot(is_open && h == L);
-                const unsigned long long Z = __ballot(is_close && plevel == L);
-                const int a = highest_bit_below(O, lt_mask);
-                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)st_idx, L);
-                if (valid && plevel == L) my_up = a >= 0 ? (uint32_t)(from + s * 64 + a) : sk;
-                if (O) {
-                    const int al = 63 - __builtin_clzll(O);
-                    const unsigned long long above = al == 63 ? 0ull : ~((2ull << al) - 1ull);
-                    if (!(Z & above)) st_idx = lane == L ? (uint32_t)(from + s * 64 + al) : st_idx;
-                    else st_idx = lane == L ? NONE : st_idx;
-                } else if (Z) {
-                    st_idx = lane == L ? NONE : st_idx;  // the container of this level closed and nothing reopened
-                }
-            }
-            if (valid) {
-                if (lane >= first_bad) {
-                    up[i] = UNKNOWN;
-                    match[i] = UNKNOWN;
-                } else {
-                    up[i] = my_up;
-                    if (!is_open) match[i] = my_up;
-                    if (is_close && my_up < UNKNOWN) match[my_up] = (uint32_t)i;
-                }
-            }
-            if (first_bad < 64) broken = true;
-            H0 = H0 + (int)cw_last(iu) - (int)cw_last(id);
-            if (H0 < 0) H0 = 0;
-        }
-    }
-}
-
-
 // single document: the delimiters the batch kernels expect, from the stage-1 record that is still on the device
 __global__ void k_single_doc_setup(const Stage1Result* __restrict__ res, unsigned long long len, unsigned long long* doc_offsets,
                                    unsigned long long* index_offsets, uint32_t* doc_status, unsigned long long* doc_str_offsets,
@@ -1903,37 +1735,6 @@ hipError_t tok_walk_launch(const TokLaunch& t, hipStream_t stream) {
                        t.max_depth, t.d_scratch, t.d_tape_lens, t.d_doc_errors, t.dev_count, t.dev_strings, t.d_res, abl, ChunkWs{},
                        (const uint32_t*)nullptr, deep, slow, ex);
     hipLaunchKernelGGL(k_slow_doubles, dim3(256), dim3(64), 0, stream, t.d_buf, slow);  // (nothing listed: 256 waves that leave at once)
-    return hipGetLastError();
-}
-
-hipError_t coop_match_launch(const uint8_t* d_buf, uint64_t n_docs, const uint32_t* d_idx, const unsigned long long* d_index_offsets,
-                             uint32_t* d_up, uint32_t* d_match, hipStream_t stream, void* d_chunk_ws, uint64_t count_bound) {
-    if (!n_docs) return hipSuccess;
-    ChunkWs cw = {};
-    const uint32_t* only_if = nullptr;
-    static const bool no_chunks = getenv("SJMI_COOP_CHUNKS") && atoi(getenv("SJMI_COOP_CHUNKS")) == 0;
-    if (d_chunk_ws && n_docs == 1 && count_bound > COOP_CHUNK_MIN && !no_chunks) {
-        // one large document: chunks by different waves (k_match_summary -> the walker's scan kernels -> k_coop_match<true>),
-        // the single-wave kernel behind it for the flagged cases
-        // (the flags of this path live in the first 64 bytes of the chunk workspace; the states behind them)
-        cw = chunk_ws(static_cast<uint8_t*>(d_chunk_ws) + 64, count_bound, static_cast<uint32_t*>(d_chunk_ws));
-        hipError_t e = hipMemsetAsync(cw.fallback, 0, 64, stream);
-        if (e != hipSuccess) return e;
-        const uint64_t want = (chunk_bound(count_bound) + 3) / 4;
-        const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
-        const uint64_t gwant = (group_bound(count_bound) + 3) / 4;
-        const unsigned ggrid = (unsigned)(gwant < 4096 ? gwant : 4096);
-        hipLaunchKernelGGL(k_match_summary, dim3(grid), dim3(256), 0, stream, d_buf, d_idx, d_index_offsets, d_match, cw);
-        hipLaunchKernelGGL(k_group_summary, dim3(ggrid), dim3(256), 0, stream, d_index_offsets, cw);
-        hipLaunchKernelGGL(k_top_scan, dim3(1), dim3(64), 0, stream, d_index_offsets, d_index_offsets, cw);
-        hipLaunchKernelGGL(k_group_replay, dim3(ggrid), dim3(256), 0, stream, d_index_offsets, cw);
-        hipLaunchKernelGGL((k_coop_match<true>), dim3(grid), dim3(256), 0, stream, d_buf, n_docs, d_idx, d_index_offsets, d_up, d_match,
-                           cw, (const uint32_t*)nullptr);
-        only_if = cw.fallback;
-    }
-    const uint64_t want = (n_docs + 3) / 4;
-    hipLaunchKernelGGL((k_coop_match<false>), dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, stream, d_buf, n_docs, d_idx,
-                       d_index_offsets, d_up, d_match, cw, only_if);
     return hipGetLastError();
 }
 

@@ -2,10 +2,8 @@
 //   org.simdjson.OnDemandJsonIterator (/root/reference/src/main/java/org/simdjson/OnDemandJsonIterator.java:7-675),
 //   driven by SchemaBasedJsonIterator.java:29-132 (one get* / startIterating* / skipChild call per field of the schema).
 // Same method names, same depth bookkeeping, same exception messages.  It walks the GPU-made structural indexes
-// (BitIndexes) and parses only the values it is asked for; what the GPU adds for THIS front end is the skip table of
-// csrc/coop_walk.hip (k_coop_match: up[i] = the opening bracket structural i lies in, match[i] = the partner of a
-// bracket), which turns skipChild's bracket-counting scan (:47-81) -- the bulk of the work when a schema wants a few
-// fields of a large document -- into k - 1 climbs through up[] and one jump through match[].
+// (BitIndexes) and parses only the values it is asked for.  (Rounds 2-4 also had a GPU skip table -- up[] / match[] per
+// structural, skipChild's scan as a lookup: it never paid at any size measured and was removed in round 5)
 // Built: booleans, byte / short / int / long, float, double, String (and their Root / NonNull forms), null handling,
 // arrays, objects, field names, skipChild, assertNoMoreJsonValues, char (a Java UTF-16 unit) -- every method of the class.
 // Not built: the reflection-driven schema mapping itself (SchemaBasedJsonIterator, ClassResolver), which is Java-specific.
@@ -55,11 +53,6 @@ public:
         len_ = len;
         depth_ = 1;
     }
-    // the GPU skip table of this document (sjmi_match_brackets), or nullptr: skipChild scans like the reference
-    void setSkipTable(const uint32_t* up, const uint32_t* match) {
-        up_ = up;
-        match_ = match;
-    }
     int getDepth() const { return depth_; }                                       // :654-656
     uint8_t peekByte() const { return buffer_[indexer_->peek()]; }                // (for schema-less drivers: the next structural's byte)
     size_t readIdx() const { return indexer_->readIdx(); }
@@ -68,7 +61,6 @@ public:
     void skipChild() { skipChild(depth_ - 1); }                                   // :43-45
     void skipChild(int parentDepth) {                                             // :47-81
         if (depth_ <= parentDepth) return;
-        const size_t r = indexer_->readIdx();
         uint32_t idx = indexer_->getAndAdvance();
         const uint8_t character = buffer_[idx];
         switch (character) {
@@ -84,7 +76,6 @@ public:
             depth_--;
             if (depth_ <= parentDepth) return;
         }
-        if (up_ && skipByTable(r, character, parentDepth)) return;
         while (indexer_->hasNext()) {
             idx = indexer_->getAndAdvance();
             const uint8_t c = buffer_[idx];
@@ -519,33 +510,10 @@ private:
         }
     }
 
-    // skipChild's scan as a lookup (validated against the scan from every read position by
-    // tests/test_gpu_ondemand.py).  r = read position of the structural the call consumed first, `first` its byte; the
-    // cursor stands behind it (and behind a key's colon).  false: the table cannot tell (a bracket whose partner lies
-    // beyond the device stack, or no closing bracket at all): the caller scans, and the scan raises what has to be raised.
-    bool skipByTable(size_t r, uint8_t first, int parentDepth) {
-        constexpr uint32_t NONE = 0xFFFFFFFFu, UNKNOWN = 0xFFFFFFFEu;
-        const size_t q = indexer_->readIdx(), n = indexer_->writeIdx();
-        if (q >= n) return false;
-        const int k = depth_ - parentDepth;  // containers to leave
-        uint32_t e = (first == '[' || first == '{') ? (uint32_t)r : up_[q];
-        if (e == NONE || e == UNKNOWN) return false;
-        for (int i = 1; i < k; ++i) {
-            e = up_[e];
-            if (e == NONE || e == UNKNOWN) return false;
-        }
-        const uint32_t m = match_[e];
-        if (m == NONE || m == UNKNOWN) return false;
-        indexer_->setReadIdx((size_t)m + 1);
-        depth_ = parentDepth;
-        return true;
-    }
-
     BitIndexes* indexer_;
     const uint8_t* buffer_ = nullptr;
     size_t len_ = 0;
     int depth_ = 0;
-    const uint32_t *up_ = nullptr, *match_ = nullptr;
     std::vector<uint8_t> string_;
 };
 

@@ -284,7 +284,7 @@ JsonValue SimdJsonParser::parse(const uint8_t* buffer, size_t len) {
 // The head of the schema-based parse (SimdJsonParser.java:31-33: padIfNeeded, reset, stage1; SchemaBasedJsonIterator.java
 // :29-41: iterator.init): stage 1 alone on the GPU -- the on-demand cursor parses the strings it is asked for itself -- and,
 // on request, the skip table of the document's brackets.
-void SimdJsonParser::onDemandInit(const uint8_t* buffer, size_t len, bool withSkipTable) {
+void SimdJsonParser::onDemandInit(const uint8_t* buffer, size_t len) {
     onDemandReady_ = false;
     if (len > (size_t)capacity_) throw fail(E_CAPACITY);
     memcpy(paddedBuffer_.data(), buffer, len);
@@ -299,16 +299,6 @@ void SimdJsonParser::onDemandInit(const uint8_t* buffer, size_t len, bool withSk
     if (status & SJMI_ST_UNCLOSED) throw fail(E_UNCLOSED_STRING);
     if (status & SJMI_ST_UNESCAPED) throw fail(E_UNESCAPED_CHARS);
     if (!onDemand_) onDemand_.reset(new OnDemandJsonIterator(&walker_.bitIndexes()));
-    onDemand_->setSkipTable(nullptr, nullptr);
-    if (withSkipTable && count) {
-        if (skipUp_.size() < count + 1) {
-            skipUp_.resize((size_t)count + 1);
-            skipMatch_.resize((size_t)count + 1);
-        }
-        rc = sjmi_match_brackets(ctx_, skipUp_.data(), skipMatch_.data(), skipUp_.size());
-        if (rc != SJMI_OK) throw std::runtime_error(std::string("sjmi_match_brackets: ") + sjmi_last_error(ctx_));
-        onDemand_->setSkipTable(skipUp_.data(), skipMatch_.data());
-    }
     onDemand_->init(paddedBuffer_.data(), len);
     onDemandReady_ = true;
 }
@@ -1053,11 +1043,11 @@ int sjmi_value_next(const sjmi_parser* h, const sjmi_value* container, const sjm
 
 // ---- the on-demand front end over the C ABI (ondemand.h) ----
 
-int sjmi_parser_ondemand_init(sjmi_parser* h, const uint8_t* buf, uint64_t len, int with_skip_table) {
+int sjmi_parser_ondemand_init(sjmi_parser* h, const uint8_t* buf, uint64_t len, int reserved) {
     if (!h || (!buf && len)) return SJMI_ERR_ARG;
     h->msg.clear();
     try {
-        h->p->onDemandInit(buf, (size_t)len, with_skip_table != 0);
+        h->p->onDemandInit(buf, (size_t)len);
         return 0;
     } catch (const org_simdjson::JsonParsingException& e) {
         h->msg = e.what();

@@ -233,7 +233,7 @@ public:
 
     // The on-demand front end (ondemand.h): pad + GPU stage 1 (+ the GPU skip table) + iterator.init, i.e. the head of
     // SimdJsonParser.parse(byte[], int, Class<T>) (SimdJsonParser.java:31-33 / SchemaBasedJsonIterator.java:29-41)
-    void onDemandInit(const uint8_t* buffer, size_t len, bool withSkipTable);
+    void onDemandInit(const uint8_t* buffer, size_t len);
     OnDemandJsonIterator& onDemand() { return *onDemand_; }
     bool onDemandReady() const { return onDemandReady_; }
 
@@ -276,7 +276,6 @@ private:
     bool stagedInput_ = false;  // paddedBuffer_ is the engine's input staging (sjmi_set_input_staging)
     std::vector<int32_t> batchErrors_;
     std::unique_ptr<OnDemandJsonIterator> onDemand_;
-    std::vector<uint32_t> skipUp_, skipMatch_;
     bool onDemandReady_ = false;
 };
 

@@ -347,7 +347,7 @@ static void drop_stale_views(sjmi_ctx* c) {
     c->zc_host = nullptr;
     c->zc_dev = nullptr;
     // "the indexes of the last call" may sit in a caller array through a view that is gone now (unregistered, maybe unmapped):
-    // the two-call forms (sjmi_unescape, sjmi_match_brackets) must not dereference it -- they ask for a new stage-1 call instead
+    // the two-call form (sjmi_unescape) must not dereference it -- they ask for a new stage-1 call instead
     if (c->idx_last && c->idx_last != c->d_idx) {
         void* dp = nullptr;
         const bool still = c->idx_last_host && hipHostGetDevicePointer(&dp, const_cast<void*>(c->idx_last_host), 0) == hipSuccess &&
@@ -1570,48 +1570,6 @@ int sjmi_parse_document(sjmi_ctx* c, const uint8_t* buf, uint64_t len, int max_d
         return SJMI_ERR_HIP;
     *tape_len = words;
     *strings_len = h->u.total_bytes;
-    return SJMI_OK;
-}
-
-int sjmi_match_brackets_device(sjmi_ctx* c, const void* d_buf, const void* d_indexes, const void* d_index_offsets, uint64_t n_docs,
-                               void* d_up, void* d_match, void* stream) {
-    if (!c || !d_buf || !d_indexes || !d_index_offsets || !d_up || !d_match) return SJMI_ERR_ARG;
-    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-    if (fail(c, "match launch", sjmi::coop_match_launch((const uint8_t*)d_buf, n_docs, (const uint32_t*)d_indexes,
-                                                        (const unsigned long long*)d_index_offsets, (uint32_t*)d_up,
-                                                        (uint32_t*)d_match, st)))
-        return SJMI_ERR_HIP;
-    return SJMI_OK;
-}
-
-int sjmi_match_brackets(sjmi_ctx* c, uint32_t* up, uint32_t* match, uint64_t capacity) {
-    if (!c || !up || !match) return SJMI_ERR_ARG;
-    drop_stale_views(c);
-    if (!c->last_valid || c->last_batch) {
-        c->err = "sjmi_match_brackets needs a preceding successful sjmi_stage1 on this context";
-        return SJMI_ERR_ARG;
-    }
-    const uint64_t count = c->last_count;
-    if (capacity < count) return SJMI_ERR_CAPACITY;
-    if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
-    if (!c->d_single && fail(c, "hipMalloc(single)", hipMalloc(&c->d_single, 512))) return SJMI_ERR_HIP;
-    // up[] in the (idle) string-buffer allocation, match[] in the tape allocation: both grown on demand
-    if (!grow(c, (void**)&c->d_sb, &c->sb_bytes, (size_t)count * 4 + 64, "hipMalloc(sb)") ||
-        !grow(c, (void**)&c->d_tape, &c->tape_bytes, (size_t)count * 4 + 64, "hipMalloc(tape)"))
-        return SJMI_ERR_HIP;
-    const unsigned long long io[2] = {0ull, count};
-    unsigned long long* d_io = (unsigned long long*)c->d_single + 2;
-    if (fail(c, "H2D", hipMemcpyAsync(d_io, io, sizeof io, hipMemcpyHostToDevice, c->stream))) return SJMI_ERR_HIP;
-    // (a large document: chunk-parallel, with the chunk states in the walk workspace)
-    if (!grow(c, &c->d_ws_walk, &c->ws_walk_bytes, sjmi::coop_chunk_workspace_bytes(count), "hipMalloc(ws_walk)")) return SJMI_ERR_HIP;
-    if (fail(c, "match launch", sjmi::coop_match_launch(c->d_in, 1, c->idx_last ? c->idx_last : c->d_idx, d_io, (uint32_t*)c->d_sb, (uint32_t*)c->d_tape, c->stream,
-                                                        c->d_ws_walk, count)))
-        return SJMI_ERR_HIP;
-    if (count && (fail(c, "D2H(up)", hipMemcpyAsync(up, c->d_sb, count * 4, hipMemcpyDeviceToHost, c->stream)) ||
-                  fail(c, "D2H(match)", hipMemcpyAsync(match, c->d_tape, count * 4, hipMemcpyDeviceToHost, c->stream))))
-        return SJMI_ERR_HIP;
-    if (fail(c, "sync", hipStreamSynchronize(c->stream))) return SJMI_ERR_HIP;
     return SJMI_OK;
 }
 

@@ -282,9 +282,6 @@ hipError_t coop_walk_launch(const uint8_t* d_buf, const unsigned long long* d_do
 size_t coop_deep_workspace_bytes(uint64_t n_docs);
 // workspace of the chunk-parallel path for one large document (coop_walk.hip)
 size_t coop_chunk_workspace_bytes(uint64_t count_bound);
-// the on-demand front end's skip table (coop_walk.hip): up[] / match[] per structural
-hipError_t coop_match_launch(const uint8_t* d_buf, uint64_t n_docs, const uint32_t* d_idx, const unsigned long long* d_index_offsets,
-                             uint32_t* d_up, uint32_t* d_match, hipStream_t stream, void* d_chunk_ws = nullptr, uint64_t count_bound = 0);
 hipError_t single_doc_setup_launch(const Stage1Result* d_res, uint64_t len, unsigned long long* d_doc_offsets,
                                    unsigned long long* d_index_offsets, uint32_t* d_doc_status, unsigned long long* d_doc_str_offsets,
                                    hipStream_t stream, WalkResult* d_walk_result = nullptr, void* d_slow_header = nullptr);

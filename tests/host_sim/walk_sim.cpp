@@ -18,7 +18,6 @@ int sjmi_stage1_batch_isolated(sjmi_ctx*, const uint8_t*, uint64_t, const uint64
                                uint32_t*, uint64_t*, uint32_t*) { return SJMI_ERR_NO_DEVICE; }
 int sjmi_unescape_batch(sjmi_ctx*, uint8_t*, uint64_t, uint64_t*, uint64_t*, uint64_t*, uint32_t*) { return SJMI_ERR_NO_DEVICE; }
 int sjmi_stage1(sjmi_ctx*, const uint8_t*, uint64_t, uint32_t*, uint64_t, uint64_t*, uint32_t*) { return SJMI_ERR_NO_DEVICE; }
-int sjmi_match_brackets(sjmi_ctx*, uint32_t*, uint32_t*, uint64_t) { return SJMI_ERR_NO_DEVICE; }
 int sjmi_parse_document(sjmi_ctx*, const uint8_t*, uint64_t, int, uint64_t*, uint64_t, uint64_t*, uint8_t*, uint64_t, uint64_t*, int32_t*,
                         uint32_t*) { return SJMI_ERR_NO_DEVICE; }
 
@@ -47,19 +46,17 @@ int sim_parser_create_fails() {
     return sjmi_parser_create(&p, 1 << 20, 1024, 0) != 0 && p == nullptr;
 }
 
-// ---- the on-demand cursor (csrc/host/ondemand.h) over indexes (and, optionally, a skip table) the test supplies ----
+// ---- the on-demand cursor (csrc/host/ondemand.h) over indexes the test supplies ----
 struct SimOnDemand {
     org_simdjson::BitIndexes idx;
     org_simdjson::OnDemandJsonIterator it;
     std::string msg;
     SimOnDemand(uint32_t* indexes, size_t cap) : idx(indexes, cap), it(&idx) {}
 };
-void* sim_od_create(const uint8_t* padded, uint64_t len, uint32_t* indexes, uint64_t count, const uint32_t* up, const uint32_t* match,
-                    int* code) {
+void* sim_od_create(const uint8_t* padded, uint64_t len, uint32_t* indexes, uint64_t count, int* code) {
     SimOnDemand* s = new SimOnDemand(indexes, (size_t)count + 1);
     s->idx.reset();
     s->idx.setWriteIdx((size_t)count);
-    s->it.setSkipTable(up, match);
     *code = 0;
     try {
         s->it.init(padded, (size_t)len);

@@ -39,6 +39,28 @@ def test_two_processes_share_the_gpu(strings):
         assert "0 bad, final indexes ok" in o, o[-2000:]
 
 
+def test_eight_processes_share_the_gpu():
+    """Round 5 (VERDICT r4 #5 / ADVICE r4): what an 8-rank node does to ONE GPU when it is oversubscribed -- eight PROCESSES, each
+    alternating a FAST k_stage1 launch (static scanner and first granules, SAFE re-run on a tripped bound through
+    sjmi_set_auto_safe) and the string pass (scanner by arrival, no SAFE mode) over its own 40 MB document.  The arrival fix of
+    k_strings had only ever seen two processes.  Every result record and the final buffers must be the oracle's in all eight."""
+    worker = os.path.join(ROOT, "tools", "two_proc_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, "proc%d" % k, "64", "64", "strings"], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, env=dict(os.environ)) for k in range(8)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+            o += b"\nTIMEOUT"
+        outs.append(o.decode(errors="replace"))
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-2000:]
+        assert "0 bad, final indexes ok" in o, o[-2000:]
+
+
 def test_device_entry_point_auto_safe_rerun(twitter):
     """sjmi_set_auto_safe: a FAST launch of sjmi_stage1_device that reports SJMI_ST_INTERNAL (faked with debug flag 16) is
     repeated in SAFE mode before the call returns; the result record the caller reads is the good one, SAFE mode stays on."""

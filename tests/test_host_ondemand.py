@@ -1,6 +1,6 @@
-"""The on-demand front end (csrc/host/ondemand.h: C++ mirror of OnDemandJsonIterator + the skip-table skipChild) without a
-GPU: the engine ABI is stubbed (tests/host_sim/walk_sim.cpp), the structural indexes come from the oracle's stage 1 and
-the skip table from a plain bracket stack, and a schema driver / a fuzz driver make the same calls on the product's cursor
+"""The on-demand front end (csrc/host/ondemand.h: C++ mirror of OnDemandJsonIterator) without a
+GPU: the engine ABI is stubbed (tests/host_sim/walk_sim.cpp), the structural indexes come from the oracle's stage 1,
+and a schema driver / a fuzz driver make the same calls on the product's cursor
 and on the Python restatement of the reference (oracle/ondemand.py) -- values, depth bookkeeping and exception messages
 must agree call for call.  The restatement itself is pinned by tests/golden/ondemand_vectors.py: 287 inputs with the
 values / messages the reference's own *SchemaBasedParsingTest classes assert."""
@@ -20,53 +20,19 @@ from tests.ondemand_common import OracleIterator, fuzz_walk, run_oracle, walk_do
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIM_DIR = os.path.join(ROOT, "tests", "host_sim")
-NONE, UNKNOWN = 0xFFFFFFFF, 0xFFFFFFFE
-
-
-def skip_table(doc, idx):
-    """up[] / match[] as include/sjmi.h defines them (sjmi_match_brackets), from a plain bracket stack"""
-    n = len(idx)
-    up = np.full(n + 1, NONE, dtype=np.uint32)
-    match = np.full(n + 1, NONE, dtype=np.uint32)
-    stack = []
-    broken = False  # behind a closing bracket without an opening one the table says "unknown"
-    for i, p in enumerate(idx):
-        ch = doc[p]
-        if broken:
-            up[i] = match[i] = UNKNOWN
-            continue
-        if ch in b"]}":
-            if not stack:
-                broken = True
-                up[i] = match[i] = UNKNOWN
-                continue
-            o = stack.pop()
-            up[i] = match[i] = o
-            match[o] = i
-        else:
-            up[i] = stack[-1] if stack else NONE
-            if ch in b"[{":
-                stack.append(i)
-            else:
-                match[i] = up[i]
-    return up, match
-
-
 class SimException(Exception):
     pass
 
 
 class SimIterator:
-    """tests/host_sim/walk_sim.cpp sim_od_*: the product's OnDemandJsonIterator over indexes (and a table) the test supplies"""
+    """tests/host_sim/walk_sim.cpp sim_od_*: the product's OnDemandJsonIterator over indexes the test supplies"""
 
-    def __init__(self, lib, doc, length, idx, table):
+    def __init__(self, lib, doc, length, idx):
         self.lib = lib
         self.padded = np.frombuffer(bytes(doc[:length]) + b"\0" * 64, dtype=np.uint8)
         self.ix = np.concatenate([np.asarray(idx, dtype=np.uint32), [0]]).astype(np.uint32)
-        self.up, self.match = skip_table(doc, [int(x) for x in idx]) if table else (None, None)
         code = C.c_int(0)
-        self.h = lib.sim_od_create(self.padded.ctypes.data, length, self.ix.ctypes.data, len(idx),
-                                   self.up.ctypes.data if table else None, self.match.ctypes.data if table else None, C.byref(code))
+        self.h = lib.sim_od_create(self.padded.ctypes.data, length, self.ix.ctypes.data, len(idx), C.byref(code))
         if code.value:
             msg = lib.sim_od_message(self.h).decode("utf-8")
             lib.sim_od_destroy(self.h)
@@ -151,7 +117,7 @@ def lib():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, deps[0]])
     L = C.CDLL(so)
     L.sim_od_create.restype = C.c_void_p
-    L.sim_od_create.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sim_od_create.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
     L.sim_od_destroy.argtypes = [C.c_void_p]
     L.sim_od_message.restype = C.c_char_p
     L.sim_od_message.argtypes = [C.c_void_p]
@@ -165,9 +131,9 @@ def lib():
     return L
 
 
-def run_product(lib, doc, length, idx, schema, table):
+def run_product(lib, doc, length, idx, schema):
     try:
-        return "ok", walk_document(SimIterator(lib, doc, length, idx, table), schema)
+        return "ok", walk_document(SimIterator(lib, doc, length, idx), schema)
     except SimException as e:
         return "error", str(e)
 
@@ -185,13 +151,12 @@ def test_oracle_restatement_is_pinned_by_the_reference_vectors():
             assert kind == "ok" and got == value, (j, schema, got)
 
 
-@pytest.mark.parametrize("table", [False, True], ids=["scan", "skip-table"])
-def test_reference_vectors_on_the_product_iterator(lib, table):
+def test_reference_vectors_on_the_product_iterator(lib):
     for (j, length, schema, value, message) in VECTORS:
         doc = j.encode("utf-8")
         n = len(doc) if length is None else length
         idx, _ = O.stage1(doc[:n])
-        kind, got = run_product(lib, doc, n, idx, schema, table)
+        kind, got = run_product(lib, doc, n, idx, schema)
         if message is not None:
             assert (kind, got) == ("error", message), (j, schema, got)
         else:
@@ -203,14 +168,13 @@ def _twitter_schema():
     return ("object", {"statuses": ("array", ("object", {"user": ("object", {"default_profile": "boolean", "screen_name": "String"})}))})
 
 
-@pytest.mark.parametrize("table", [False, True], ids=["scan", "skip-table"])
-def test_parse_and_select_twitter(lib, table):
+def test_parse_and_select_twitter(lib):
     """The reference's schema-based benchmark selection (BenchmarkCorrectnessTest.schemaBasedSimdJsonParser): the users with
     default_profile == true -- the same 86 names the full parse finds."""
     doc = load_fixture("twitter.json")
     idx, st = O.stage1(doc)
     assert st == 0
-    kind, got = run_product(lib, doc, len(doc), idx, _twitter_schema(), table)
+    kind, got = run_product(lib, doc, len(doc), idx, _twitter_schema())
     assert kind == "ok"
     names = {u["user"]["screen_name"] for u in got["statuses"] if u["user"]["default_profile"]}
     assert len(got["statuses"]) == 100 and len(names) == 86
@@ -231,8 +195,7 @@ def _random_doc(rng, depth=0):
                                                                      _random_doc(rng, depth + 1)) for i in range(rng.randint(0, 5))) + rng.choice(["}", "}", "}", "}", "]", ""])
 
 
-@pytest.mark.parametrize("table", [False, True], ids=["scan", "skip-table"])
-def test_fuzz_traces_equal_the_restatement(lib, table):
+def test_fuzz_traces_equal_the_restatement(lib):
     """Random (often broken) documents walked by the schema-less driver with seeded skips, wrong-typed reads and early
     exits: the product's trace -- every value, every depth, the message of the first exception -- equals the restatement's."""
     rng = random.Random(20260925)
@@ -244,7 +207,7 @@ def test_fuzz_traces_equal_the_restatement(lib, table):
             continue
         seed = rng.getrandbits(32)
         traces = []
-        for make in (lambda: OracleIterator(doc, len(doc), idx), lambda: SimIterator(lib, doc, len(doc), idx, table)):
+        for make in (lambda: OracleIterator(doc, len(doc), idx), lambda: SimIterator(lib, doc, len(doc), idx)):
             tr = []
             try:
                 fuzz_walk(make(), random.Random(seed), tr)
@@ -258,28 +221,28 @@ def test_fuzz_traces_equal_the_restatement(lib, table):
     assert walked > 2500 and 500 < errors < walked - 300
 
 
-def test_skip_child_by_table_lands_where_the_scan_lands(lib):
-    """From every structural of the reference files: skipChild(parentDepth) leaving 1, 2, 3 containers through the table =
-    through the scan (read position and depth), including the positions from which the document runs out of brackets."""
+def test_skip_child_from_every_position_equals_the_reference_scan(lib):
+    """From sampled structurals of the reference files: skipChild(parentDepth) leaving 1, 2, 3 containers on the product's cursor
+    = OnDemandJsonIterator.skipChild restated as the scan it is (:47-81): read position and depth, including the positions from
+    which the document runs out of brackets."""
+    from tests.test_gpu_ondemand import skip_child_scan
     rng = random.Random(5)
     for name in ("twitter.json", "github_events.json"):
         doc = load_fixture(name)
         idx, _ = O.stage1(doc)
-        positions = sorted(rng.sample(range(len(idx)), 400))
-        its = [SimIterator(lib, doc, len(doc), idx, t) for t in (False, True)]
-        for r in positions:
+        ix = [int(x) for x in idx]
+        for r in sorted(rng.sample(range(len(idx)), 400)):
             for k in (1, 2, 3):
-                out = []
-                for it in its:
-                    # place both cursors at r with a depth of 10 (only depth - parentDepth matters to skipChild)
-                    it2 = SimIterator(lib, doc, len(doc), idx, it.up is not None)
-                    it2.lib.sim_od_set(it2.h, r, 10)
-                    try:
-                        it2.skip_child(10 - k)
-                        out.append((it2.read_idx(), it2.depth_value()))
-                    except SimException as e:
-                        out.append(str(e))
-                assert out[0] == out[1], (name, r, k, out)
+                it = SimIterator(lib, doc, len(doc), idx)
+                it.lib.sim_od_set(it.h, r, 10)  # (only depth - parentDepth matters to skipChild)
+                want = skip_child_scan(doc, ix, r, 10, 10 - k)
+                try:
+                    it.skip_child(10 - k)
+                    got = (it.read_idx(), it.depth_value())
+                except SimException as e:
+                    got = None
+                    assert "Not enough close braces" in str(e)
+                assert got == want, (name, r, k, got, want)
 
 
 def test_reference_float_vectors(lib):
@@ -298,7 +261,7 @@ def test_reference_float_vectors(lib):
             assert want == int(v["bits"], 16), v
         for schema in ("float", "Float"):
             assert run_oracle(doc, len(doc), idx, schema) == ("ok", OD.float32_of(v["input"]))
-            kind, got = run_product(lib, doc, len(doc), idx, schema, False)
+            kind, got = run_product(lib, doc, len(doc), idx, schema)
             assert kind == "ok" and OD.float_bits(got) == want, (v, got)
 
 
@@ -330,10 +293,10 @@ def test_float_and_double_getters_on_random_literals(lib):
         doc = lit.encode()
         idx, st = O.stage1(doc)
         assert st == 0
-        kind, got = run_product(lib, doc, len(doc), idx, "float", False)
+        kind, got = run_product(lib, doc, len(doc), idx, "float")
         assert kind == "ok" and OD.float_bits(got) == OD.float_bits(OD.float32_of(lit)), (lit, got)
         checked_f += 1
-        kind, got = run_product(lib, doc, len(doc), idx, "double", False)
+        kind, got = run_product(lib, doc, len(doc), idx, "double")
         assert kind == "ok" and OD.double_bits(got) == OD.double_bits(float(lit)), (lit, got)
         checked_d += 1
     assert checked_f == checked_d == len(lits) > 3000

@@ -3,7 +3,6 @@
 // default_profile) written against the PUBLIC C ABI (include/sjmi.h), the way a host-language binding would call it:
 //   mode 0  full parse (sjmi_parser_parse) + JsonValue walk (sjmi_value_*)
 //   mode 1  on-demand cursor (sjmi_parser_ondemand_init + sjmi_od_*), skipChild scanning like the reference
-//   mode 2  on-demand cursor with the GPU skip table
 //   mode 3  sjmi_parser_parse alone (any document): the binding-free cost of SimdJsonParser.parse
 // Built and loaded by bench.py (section `select`) / tools/ondemand_bench.py; links libsjmi.so.
 #include <stdint.h>
@@ -75,9 +74,9 @@ int select_status(sjmi_parser* p, uint64_t* selected, uint64_t* bytes) {
     return sjmi_od_skip_child(p, parent);
 }
 
-int select_on_demand(sjmi_parser* p, const uint8_t* buf, uint64_t len, int table, uint64_t* selected, uint64_t* bytes) {
+int select_on_demand(sjmi_parser* p, const uint8_t* buf, uint64_t len, uint64_t* selected, uint64_t* bytes) {
     int rc, res = 0;
-    if ((rc = sjmi_parser_ondemand_init(p, buf, len, table))) return rc;
+    if ((rc = sjmi_parser_ondemand_init(p, buf, len, 0))) return rc;
     if ((rc = sjmi_od_start_object(p, 1, &res))) return rc;
     if (res != SJMI_OD_NOT_EMPTY) return 0;
     const int parent = sjmi_od_depth(p) - 1;
@@ -181,7 +180,7 @@ extern "C" int odb_run(sjmi_parser* p, const uint8_t* buf, uint64_t len, int mod
             *selected = tl;
             *bytes = sl;
         } else {
-            rc = mode == 0 ? select_full_parse(p, buf, len, selected, bytes) : select_on_demand(p, buf, len, mode == 2, selected, bytes);
+            rc = mode == 0 ? select_full_parse(p, buf, len, selected, bytes) : select_on_demand(p, buf, len, selected, bytes);
         }
         if (rc) return rc;
     }

@@ -1,5 +1,5 @@
 """Parse-and-select of twitter.json (the reference's headline benchmark shape) through the public C ABI, user code in C++
-(tools/ondemand_bench.cpp): full parse + JsonValue walk, on-demand cursor scanning, on-demand cursor with the GPU skip table."""
+(tools/ondemand_bench.cpp): full parse + JsonValue walk, on-demand cursor."""
 import ctypes as C
 import gzip
 import os
@@ -41,7 +41,7 @@ def measure(doc, iters=300, gpu_walk=None):  # None: the library places stage 2 
     p = S.SimdJsonParser(capacity=len(doc) + 64, gpu_walk=gpu_walk)
     buf = (C.c_uint8 * len(doc)).from_buffer_copy(doc)
     out = {}
-    for mode, name in ((0, "full_parse_then_select"), (1, "on_demand_scan"), (2, "on_demand_skip_table")):
+    for mode, name in ((0, "full_parse_then_select"), (1, "on_demand_scan")):
         secs, sel, nbytes = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
         best = 1e9
         for rep in range(4):  # first round = warm-up

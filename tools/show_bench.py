@@ -16,6 +16,6 @@ for l in open(sys.argv[1]):
         rr = v.get("roofline") or {}
         print("%-32s %s %s | frac %s ms %s | cpu %s %s (one core %s)" % (k, v.get("value"), v.get("unit"), rr.get("frac"),
               rr.get("avg_kernel_ms", rr.get("avg_ms_per_call", v.get("ms_per_batch"))), cb.get("value"), cb.get("unit"), cb.get("one_core")))
-        for kk in ("twitter_json", "array_16mib", "incl_h2d", "on_demand_scan", "on_demand_skip_table", "full_parse_then_select", "docs_per_s"):
+        for kk in ("twitter_json", "array_16mib", "incl_h2d", "on_demand_scan", "full_parse_then_select", "docs_per_s"):
             if kk in v:
                 print("    ", kk, v[kk])

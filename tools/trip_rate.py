@@ -9,7 +9,7 @@
   neighbour  (optional) a second PROCESS looping k_strings (another persistent kernel with a scanner chain) over its own
              40 MB document.
 
-usage: trip_rate.py <launches> [rccl] [neighbour]      -> one JSON line
+usage: trip_rate.py <launches> [rccl] [neighbour | neighbours=N]      -> one JSON line   (round 5: N contending processes)
        trip_rate.py neighbour-worker <seconds>        (internal)"""
 import json, os, subprocess, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -56,6 +56,11 @@ def main():
         return neighbour(float(sys.argv[2]))
     launches = int(sys.argv[1])
     with_rccl, with_nb = "rccl" in sys.argv[2:], "neighbour" in sys.argv[2:]
+    n_nb = 1 if with_nb else 0
+    for a in sys.argv[2:]:
+        if a.startswith("neighbours="):
+            n_nb = int(a.split("=")[1])
+            with_nb = n_nb > 0
     doc = W.load_twitter()
     idx0, _ = O.stage1(doc)
     dev = torch.device("cuda", 0)
@@ -92,11 +97,12 @@ def main():
                     gathers[0] += 32
         th = threading.Thread(target=loop, daemon=True)
         th.start()
-    nb = None
-    if with_nb:
-        nb = subprocess.Popen([sys.executable, os.path.abspath(__file__), "neighbour-worker", str(max(20.0, launches * 0.0006))],
+    nbs = []
+    for _ in range(n_nb):
+        nb = subprocess.Popen([sys.executable, os.path.abspath(__file__), "neighbour-worker", str(max(20.0, launches * 0.0006 * max(1, n_nb)))],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        nb.stdout.readline()  # "neighbour ready" (after its imports and first launch)
+        nbs.append(nb)
+    for nb in nbs:  # "neighbour ready" (after its imports and first launch)
         while True:
             l = nb.stdout.readline()
             if "ready" in l or not l:
@@ -125,15 +131,16 @@ def main():
     if th:
         th.join(timeout=10)
     ok, _ = W.closed_form_ok(out, idx0, len(doc), REPS)
-    nb_out = ""
-    if nb:
+    nb_out = []
+    for nb in nbs:
         try:
-            nb_out, _ = nb.communicate(timeout=120)
+            o, _ = nb.communicate(timeout=300)
+            nb_out.append(o.strip().splitlines()[-1] if o.strip() else "")
         except subprocess.TimeoutExpired:
             nb.kill()
-            nb_out = "TIMEOUT"
+            nb_out.append("TIMEOUT")
     print(json.dumps({"launches": launches, "document_MB": n // 1000000, "rccl_all_gather_loop": with_rccl, "rccl_gathers": gathers[0],
-                      "second_process_string_pass": with_nb, "neighbour": nb_out.strip().splitlines()[-1:] if nb_out else None,
+                      "contending_string_pass_processes": n_nb, "neighbours": nb_out or None,
                       "tripped_spin_bounds": trips, "wrong_results": wrong, "final_indexes_ok": bool(ok),
                       "safe_rerun_ms": [round(x, 2) for x in safe_ms[:8]], "ms_per_launch_incl_sync": round(el / launches * 1e3, 4)}))
     ctx.close()
