@@ -657,6 +657,7 @@ def bench_single(args):
     put("parse_twitter_json_all_device_ms", "parse_single_document", "twitter_json", "gpu_walker", "ms")
     put("parse_twitter_json_host_walker_ms", "parse_single_document", "twitter_json", "host_walker", "ms")
     put("configs4_1024_trees_ms", "twitter_x1024_as_1024_trees", "value")
+    put("configs4_1024_trees_pcie_floor_ms", "twitter_x1024_as_1024_trees", "pcie_floor_ms")
     put("select_on_demand_ms", "parse_and_select_twitter_json", "value")
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(doc)
@@ -744,7 +745,12 @@ def trees_1024(S, doc, reps=1024, iters=3):
                       "over sub-batches (sjmi_parser_parse_batch, timed from C++); every tree walked through sjmi_value_*: %d statuses "
                       "with default_profile each (the oracle's count); word-for-word tree equality: tests/test_gpu_fullscale.py"
                       % (reps, reps, host.size, reps, want_users),
-            "value": round(best, 3), "unit": "ms per batch", "docs_per_s": round(reps / best * 1e3, 1), "GB_per_s": round(host.size / best / 1e6, 3)}
+            "value": round(best, 3), "unit": "ms per batch", "docs_per_s": round(reps / best * 1e3, 1), "GB_per_s": round(host.size / best / 1e6, 3),
+            # what the link alone costs: the batch in, indexes (4 B per structural) + string records out, one direction at a time
+            # at the ~57 GB/s tools/pcie.py measures on these boxes (both directions at once halve each): NOT GPU time
+            "pcie_floor_ms": round((host.size + 4 * 55263 * reps + 440313 * reps) / 57e9 * 1e3, 2),
+            "pcie_floor": "bytes in + uint32 indexes + string records out = %d MB at 57 GB/s one way at a time (tools/pcie.py); the "
+                          "GPU kernels of this batch take ~1 ms" % ((host.size + 4 * 55263 * reps + 440313 * reps) // 1000000)}
 
 
 def batch_single_gpu(torch, S, W, dev, work, args, with_h2d=True, n_docs=None, check=True):

@@ -324,3 +324,52 @@ def test_optimistic_entry_point_equals_the_exact_one_on_an_accepted_batch():
                 assert np.array_equal(a[8][int(to[k]):int(to[k + 1])], b[8][int(to[k]):int(to[k + 1])]), k
     finally:
         ctx.close()
+
+
+_TOKEN_WALK_OFF = r"""
+import random, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+import simdjson_java_amd as S
+from simdjson_java_amd import sharding
+from oracle import oracle as O
+from tests.test_gpu_batch import _small_docs
+rng = random.Random(31)
+docs = _small_docs(rng, 1500) + [b"[1 1]", b'{"a":tru}', b'["\\q"]', b"[" * 70 + b"]" * 70, b"7"]
+rng.shuffle(docs)
+buf = b"".join(d + b"\n" for d in docs)
+offs = np.concatenate([[0], np.cumsum([len(d) + 1 for d in docs])]).astype(np.uint64)
+ctx = S.Context(0, 1 << 20)
+shard = sharding.BatchShard(ctx, buf, offs, torch.device("cuda", 0))
+for _ in range(2):
+    shard.step(torch.cuda.current_stream().cuda_stream, exact=True)
+    torch.cuda.synchronize()
+c = shard.check()
+to = shard.tape_offsets.cpu().numpy(); tape = shard.tape.cpu().numpy().view(np.uint64); err = shard.doc_errors.cpu().numpy()
+strings = bytes(shard.sb[:c["string_bytes"]].cpu().numpy())
+bad = 0
+for k, d in enumerate(docs):
+    want = O.parse(d + b"\n")
+    assert int(err[k]) == want.error, (k, d[:40], int(err[k]), want.error)
+    if want.error:
+        bad += 1
+    else:
+        assert O.Parsed(tape[int(to[k]):int(to[k + 1])], strings, 0, 0, 0).to_python() == want.to_python(), k
+assert c["failed_documents"] == bad == 3, (c, bad)
+ctx.close()
+print("TOKEN_WALK_OFF_OK", len(docs))
+"""
+
+
+def test_whole_batch_through_the_exact_walker_in_a_fresh_process():
+    """SJMI_TOKEN_WALK=0 (read once per process) puts k_coop_walk<false> back on EVERY document of a batch -- the dispatch branch
+    of walk.hip that the suite otherwise only reaches through the token walker's list.  A fresh process with the switch set: the
+    exact entry point on an accepted batch with grammar errors, a string error, nesting beyond the LDS stack and a scalar root,
+    every document against the oracle."""
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    env = dict(os.environ, SJMI_TOKEN_WALK="0")
+    out = subprocess.run([sys.executable, "-c", _TOKEN_WALK_OFF % ROOT], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0 and "TOKEN_WALK_OFF_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
