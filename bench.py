@@ -372,7 +372,7 @@ def make_batch_shard(torch, S, W, dev, ctx, lo, hi):
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     n = int(offs[-1])
     shard_bytes = torch.empty(n, dtype=torch.uint8, device=dev)
-    host = torch.empty(1300 * min(BATCH_GEN_SLICE, hi - lo) + 64, dtype=torch.uint8).pin_memory()
+    host = torch.empty(1300 * int(os.environ.get("SJMI_DOC_SCALE", "1")) * min(BATCH_GEN_SLICE, hi - lo) + 64, dtype=torch.uint8).pin_memory()
     for a in range(0, hi - lo, BATCH_GEN_SLICE):
         m = min(BATCH_GEN_SLICE, hi - lo - a)
         data, o2 = W.unique_docs(lo + a, m, out=host.numpy())

@@ -83,10 +83,13 @@ static uint8_t* put_string(uint8_t* p, Rng* r, uint32_t n_chars, uint32_t esc_pm
 // document k of the set: -> bytes written (without the separator); out needs 2048 bytes of room.  Fields are drawn until
 // the next one would not fit; the last field "z" is a plain ASCII string that brings the document to exactly the drawn
 // length (so the lengths ARE uniform in [768, 1280]).
+#ifndef DOC_SCALE
+#define DOC_SCALE 1  /* experiments only (tools/r5_doc_scale.sh): documents DOC_SCALE times as long; the configs[3] set is scale 1 */
+#endif
 static uint32_t one_doc(uint64_t seed, uint64_t k, uint8_t* out) {
     uint64_t sm = seed ^ (k * 0xD1342543DE82EF95ull);
     Rng r = {splitmix(&sm) | 1ull};
-    const uint32_t target = range(&r, 768, 1280);
+    const uint32_t target = range(&r, 768 * DOC_SCALE, 1280 * DOC_SCALE);
     uint8_t* p = out;
     *p++ = '{';
     for (uint32_t i = 0;; ++i) {
@@ -130,12 +133,12 @@ static uint32_t one_doc(uint64_t seed, uint64_t k, uint8_t* out) {
 
 // lengths (incl. the '\n' separator) of documents [first, first + n)
 void docgen_lengths(uint64_t seed, uint64_t first, uint64_t n, uint64_t* lens) {
-    uint8_t tmp[2048];
+    uint8_t tmp[2048 * DOC_SCALE];
     for (uint64_t i = 0; i < n; ++i) lens[i] = (uint64_t)one_doc(seed, first + i, tmp) + 1;
 }
 // documents [first, first + n) at out + offsets[i] (offsets relative to `out`; each followed by '\n')
 void docgen_fill(uint64_t seed, uint64_t first, uint64_t n, uint8_t* out, const uint64_t* offsets) {
-    uint8_t tmp[2048];
+    uint8_t tmp[2048 * DOC_SCALE];
     for (uint64_t i = 0; i < n; ++i) {
         const uint32_t len = one_doc(seed, first + i, tmp);
         memcpy(out + offsets[i], tmp, len);

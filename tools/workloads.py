@@ -97,7 +97,7 @@ def _docgen():
     global _DOCGEN
     if _DOCGEN is None:
         import ctypes
-        L = ctypes.CDLL(build_docgen())
+        L = ctypes.CDLL(os.environ.get("SJMI_DOCGEN_LIB") or build_docgen())  # (SJMI_DOCGEN_LIB: an experiment build, e.g. -DDOC_SCALE=4)
         L.docgen_lengths.argtypes = [ctypes.c_uint64] * 3 + [ctypes.c_void_p]
         L.docgen_lengths.restype = None
         L.docgen_fill.argtypes = [ctypes.c_uint64] * 3 + [ctypes.c_void_p, ctypes.c_void_p]
