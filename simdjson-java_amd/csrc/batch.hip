@@ -176,36 +176,91 @@ k_doc_prepare(DocPrepare a) {
         const unsigned long long b = pos >> 6;
         unsigned long long j = a.blkidx[b];
         uint32_t w = 0, q = 0;
-        // the block's first 16 structurals and their first bytes in TWO round trips (all loads of a stage are independent); a
-        // boundary has ~6 structurals of its block in front of it, so the one-by-one loop behind this is rarely entered
-        uint32_t e[16];
+        // Round 5: the kernel is bound by L2 REQUESTS, not bytes -- every lane works on cache lines of its own, so each load
+        // instruction of a wave is 64 requests (round 4: 16 index loads + 16 first-byte loads + ~13 others per boundary).  The
+        // boundary's block is loaded ONCE (4 x 16 bytes) and everything about its bytes is SWAR algebra on those registers: which
+        // bytes are quotes / backslashes (the strings opened in front of the boundary) and which are ',' ':' '-' digits (the
+        // tape words of the structurals in front of it); the block's first 16 index entries come as 4 x 16 bytes.
+        const unsigned long long start = b << 6;
+        const uint32_t upto = (uint32_t)(pos & 63);
+        if (upto) {
+            struct alignas(16) Q4 { uint32_t a, b, c, d; };
+            struct __attribute__((packed, aligned(4))) I4 { uint32_t a, b, c, d; };
+            uint32_t w16[16], e[16];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) e[t] = j + t < count ? a.idx[j + t] : 0xFFFFFFFFu;
-        uint32_t c16[16];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) c16[t] = (unsigned long long)e[t] < pos ? (uint32_t)a.buf[e[t]] : 0x2Cu;  // (',' = no word, no quote)
-        uint32_t nb = 0;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            nb += (unsigned long long)e[t] < pos ? 1u : 0u;
-            w += prep_words_of(c16[t]);
-        }
-        j += nb;
-        if (nb == 16u) {
-            for (int t = 16; t < 64 && j < count; ++t, ++j) {  // (a block has at most 64 structurals)
-                const uint32_t p = a.idx[j];
-                if ((unsigned long long)p >= pos) break;
-                w += prep_words_of(a.buf[p]);
+            for (int v = 0; v < 4; ++v) {
+                const Q4 q4 = reinterpret_cast<const Q4*>(a.buf + start)[v];
+                w16[4 * v] = q4.a;
+                w16[4 * v + 1] = q4.b;
+                w16[4 * v + 2] = q4.c;
+                w16[4 * v + 3] = q4.d;
             }
-        }
-        // the strings opened in the block in front of the boundary: counted on the BYTES (the '"' structurals would miss a quote
-        // directly behind a primitive -- 1"abc" -- which opens a string for the string pass all the same: a malformed document,
-        // but the documents behind it in the same block need their ordinals right)
-        if (pos & 63) {
-            const unsigned long long start = b << 6;
+            // (the array holds count + 1 entries, sentinel included: a group of four is read at most from its last in-bounds
+            //  position and shifted; fewer than four entries in all: one by one)
+            const unsigned long long last4 = count + 1 >= 4 ? count + 1 - 4 : 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const unsigned long long g = j + 4 * v, jj = g < last4 ? g : last4;
+                uint32_t x[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                if (count + 1 >= 4) {
+                    const I4 i4 = *reinterpret_cast<const I4*>(a.idx + jj);
+                    x[0] = i4.a; x[1] = i4.b; x[2] = i4.c; x[3] = i4.d;
+                } else {
+                    for (int t = 0; t < 4; ++t) x[t] = (unsigned long long)t < count ? a.idx[t] : 0xFFFFFFFFu;
+                }
+                const uint32_t sh = (uint32_t)(g - jj);  // (only a clamped group is shifted; g >= count + 1: nothing of it is valid)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    uint32_t val = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) val = (uint32_t)(t + (int)sh) == (uint32_t)u ? x[u] : val;
+                    e[4 * v + t] = g + t < count ? val : 0xFFFFFFFFu;
+                }
+            }
+            unsigned long long qm = 0, bm = 0, sepm = 0, numm = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t x = w16[i];
+                auto eq = [&](uint32_t c4) -> uint32_t {  // 0x80 in every byte of x that equals the byte repeated in c4
+                    const uint32_t z = x ^ c4;
+                    return ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
+                };
+                auto nib = [](uint32_t f) -> unsigned long long { return (unsigned long long)((((f >> 7) * 0x00204081u) >> 21) & 0xFu); };
+                const uint32_t ge30 = ((x | 0x80808080u) - 0x30303030u) & 0x80808080u;
+                const uint32_t lt3a = ~((x & 0x7F7F7F7Fu) + 0x46464646u) & 0x80808080u;
+                const uint32_t digit = ge30 & lt3a & ~x;
+                qm |= nib(eq(0x22222222u)) << (4 * i);
+                bm |= nib(eq(0x5C5C5C5Cu)) << (4 * i);
+                sepm |= nib(eq(0x2C2C2C2Cu) | eq(0x3A3A3A3Au)) << (4 * i);
+                numm |= nib(digit | eq(0x2D2D2D2Du)) << (4 * i);
+            }
+            // the structurals of the block in front of the boundary, as a mask of their positions
+            unsigned long long M = 0;
+            uint32_t nb = 0;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const bool in = (unsigned long long)e[t] < pos;
+                M |= in ? 1ull << (e[t] & 63u) : 0ull;
+                nb += in ? 1u : 0u;
+            }
+            w = (uint32_t)__popcll(M & ~sepm) + (uint32_t)__popcll(M & numm);  // (bracket / string / atom 1 word, number 2, ',' ':' 0)
+            j += nb;
+            if (nb == 16u) {
+                for (int t = 16; t < 64 && j < count; ++t, ++j) {  // (a block has at most 64 structurals)
+                    const uint32_t p = a.idx[j];
+                    if ((unsigned long long)p >= pos) break;
+                    w += prep_words_of(a.buf[p]);
+                }
+            }
+            // the strings opened in the block in front of the boundary: counted on the BYTES (the '"' structurals would miss a quote
+            // directly behind a primitive -- 1"abc" -- which opens a string for the string pass all the same: a malformed document,
+            // but the documents behind it in the same block need their ordinals right); sj_str_opens_before's algebra on the masks
             const uint32_t in_str = (uint32_t)(a.blkpar[b >> 6] >> (b & 63)) & 1u;
             const uint32_t e_in = b ? sj_backslash_run_parity(a.buf, 0, start) : 0u;
-            q = sj_str_opens_before(a.buf, start, (uint32_t)(pos & 63), in_str, e_in);
+            const sj_u64 quote = qm & ~sj_escaped_mask<sj_u64>(bm, e_in);
+            const sj_u64 in0 = sj_prefix_xor(quote);
+            const sj_u64 opens = quote & (in_str ? ~in0 : in0);
+            q = (uint32_t)__popcll(opens & ((1ull << upto) - 1ull));
         }
         *io = (uint32_t)j;
         *pw = w;

@@ -794,8 +794,8 @@ k_strings(const StrArgs a0) {
                         lo = reinterpret_cast<const StrU4B*>(src - 3)->a;
                         if (is_pair) hi = reinterpret_cast<const StrU4B*>(src - 9)->a;
                     }
-                    uint32_t cp = (uint32_t)sj_hex4_word(lo);
-                    if (is_pair) cp = ((((uint32_t)sj_hex4_word(hi) - 0xD800u) << 10) | (cp - 0xDC00u)) + 0x10000u;
+                    uint32_t cp = sj_hex4_valid_word(lo);  // (items exist only for sequences whose digits the plane algebra found valid)
+                    if (is_pair) cp = (((sj_hex4_valid_word(hi) - 0xD800u) << 10) | (cp - 0xDC00u)) + 0x10000u;
                     uint32_t L;
                     const uint32_t nb = sj_utf8_bytes(cp, &L);
                     uint32_t old = L == 4 ? lo : (lo >> (8u * (4u - L)));

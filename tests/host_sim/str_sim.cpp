@@ -93,11 +93,13 @@ extern "C" int sim_strings(const uint8_t* buf, uint64_t len, uint8_t* sb, uint64
             const uint32_t e = (uint32_t)__builtin_ctzll(x);
             uint32_t lo;
             memcpy(&lo, buf + start + e - 3, 4);
-            uint32_t cp = (uint32_t)sj_hex4_word(lo);
+            uint32_t cp = sj_hex4_valid_word(lo);
+            if (cp != (uint32_t)sj_hex4_word(lo)) return -7;  // (the fast form on digits the planes found valid == the checking form)
             if ((m.pair >> e) & 1) {
                 uint32_t hi;
                 memcpy(&hi, buf + start + e - 9, 4);
-                cp = ((((uint32_t)sj_hex4_word(hi) - 0xD800u) << 10) | (cp - 0xDC00u)) + 0x10000u;
+                if (sj_hex4_valid_word(hi) != (uint32_t)sj_hex4_word(hi)) return -7;
+                cp = (((sj_hex4_valid_word(hi) - 0xD800u) << 10) | (cp - 0xDC00u)) + 0x10000u;
             }
             uint32_t L;
             const uint32_t nb = sj_utf8_bytes(cp, &L);
