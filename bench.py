@@ -38,7 +38,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable)
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r4")
+PROFILE_ROUND = "r5"
+PROFILE_DIR = os.path.join(ROOT, "profiles", PROFILE_ROUND)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -224,8 +225,8 @@ def pmc_source():
     try:
         with open(os.path.join(PROFILE_DIR, "pmc_summary.json")) as f:
             meta = json.load(f).get("_collected", {})
-        return "profiles/r4/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_r4.sh, calibrated: " \
-               "pmc_calibration.json; collected at commit %s)" % meta.get("commit", "unknown")
+        return "profiles/%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_round.sh, calibrated: " \
+               "pmc_calibration.json; collected at commit %s)" % (PROFILE_ROUND, meta.get("commit", "unknown"))
     except (OSError, ValueError):
         return None
 

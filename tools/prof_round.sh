@@ -1,12 +1,14 @@
 #!/bin/bash
-# Round-3 rocprofv3 collection (run on the GPU box via gpurun): tools/prof_r3.sh
+# A round's rocprofv3 collection (run on the GPU box via gpurun): tools/prof_round.sh r5
 #   1. --kernel-trace --stats of the DEFAULT bench command (python bench.py --no-cpu-baseline): every kernel the bench line quotes
 #   2. FETCH_SIZE and WRITE_SIZE, separate passes (never combined with trace domains), one bench section per pass so that
 #      the k_stage1 dispatches of the three workloads cannot be confused; SQ counters for the unescape and batch kernels
 #   3. the calibration kernels (tools/pmc_calibrate.py) under the same two counters
-# Output: gpurun_out/prof_r3/... ; tools/summarize_prof_r3.py turns it into profiles/r2/.
+# Output: gpurun_out/prof_<round>/... ; tools/summarize_prof_round.py turns it into gpurun_out/profiles_<round>/, tools/install_prof.py
+# <round> (in the build container) into the tracked profiles/<round>/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-out=$R/gpurun_out/prof_r3
+RD=${1:-r5}
+out=$R/gpurun_out/prof_$RD
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline"
@@ -28,4 +30,4 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --kernel-trace --output-format csv --pmc $ctr -d $out/cal_$ctr -o p -- python $R/tools/pmc_calibrate.py > $out/cal_$ctr.log 2>&1
   echo "cal $ctr rc=$?"
 done
-python $R/tools/summarize_prof_r3.py $out $R/gpurun_out/profiles_r3
+python $R/tools/summarize_prof_round.py $out $R/gpurun_out/profiles_$RD

@@ -5,5 +5,5 @@ cd $R
 for v in "$@"; do
   if [ "$v" != "base" ]; then export SJMI_LIB=$R/tools/variants/libsjmi_$v.so; else unset SJMI_LIB; fi
   echo "== $v"
-  bash tools/pmc_batch_r4.sh r5_$v 2>&1 | grep -v "^pmc rc"
+  bash tools/pmc_batch.sh r5_$v 2>&1 | grep -v "^pmc rc"
 done

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""gpurun_out/prof_r2 (tools/prof_r2.sh) -> the tracked summaries of profiles/r2/:
+"""gpurun_out/prof_<round> (tools/prof_round.sh) -> the tracked summaries of profiles/<round>/:
   kernel_stats.csv          rocprofv3 --kernel-trace --stats of the default bench command
   kernel_durations.json     per-kernel launch durations from the same trace (first / last launches apart: clock ramp)
   pmc_calibration.json      FETCH_SIZE / WRITE_SIZE of known copy / read / fill kernels -> correction factors
@@ -77,21 +77,27 @@ json.dump(cal, open(os.path.join(dst, "pmc_calibration.json"), "w"), indent=1)
 # ---- per section ----
 KEY = {"main": "stage1_twitter_4g", "x1024": "stage1_twitter_x1024", "unescape": "unescape_twitter_x1024", "synth": "stage1_synthetic_4g",
        "batch": "batch_1m_docs"}
-WANT = {"main": ["k_stage1"], "x1024": ["k_stage1"], "synth": ["k_stage1"], "unescape": ["k_str_", "k_scan_sums"],
-        "batch": ["k_doc_", "k_str_", "k_scan_sums", "k_tape_", "k_coop"]}
+WANT = {"main": ["k_stage1"], "x1024": ["k_stage1"], "synth": ["k_stage1"], "unescape": ["k_strings"],
+        # (round 5: the batch step holds no plain k_stage1 launch any more -- the section's k_stage1 dispatches are the primary
+        #  workload's parity-check launches and must not be counted)
+        "batch": ["k_doc_", "k_strings", "k_stage1_batch", "k_split", "k_batch", "k_tape_", "k_coop", "k_tok_", "k_slow_"]}
 summary = {}
 for sec, key in KEY.items():
     f, w = counters("pmc_%s_FETCH_SIZE" % sec), counters("pmc_%s_WRITE_SIZE" % sec)
     sq = counters("pmc_%s_SQ" % sec)
     kernels = {}
-    tot_f = tot_w = 0.0
+    tot_f = tot_w = tot_f_raw = 0.0
     for k in sorted(set(f) | set(w)):
         if not any(p in k for p in WANT[sec]):
             continue
         vf, vw = f.get(k, {}).get("FETCH_SIZE", []), w.get(k, {}).get("WRITE_SIZE", [])
         # the LAST dispatches are the timed ones (earlier ones: parity check launch, warmup; for k_stage1 of an extra
-        # section the first dispatch is the primary workload's check launch)
-        lf, lw = vf[-2:], vw[-2:]
+        # section the first dispatch is the primary workload's check launch).  k_stage1 in the batch section: two launches
+        # per step, the plain pass and the (skipped, empty) parity pass of the sanitized copy -- a whole step = the last two
+        per_step = 1  # (round 4: the batch's plain pass is its own kernel, k_stage1_batch; the skipped parity pass k_stage1)
+        lf, lw = vf[-2 * per_step:], vw[-2 * per_step:]
+        if per_step == 2:
+            lf, lw = [sum(lf) / 2.0] if lf else [], [sum(lw) / 2.0] if lw else []
         af, aw = (sum(lf) / len(lf) if lf else 0.0), (sum(lw) / len(lw) if lw else 0.0)
         kernels[k] = {"FETCH_SIZE_KiB_per_launch": round(af, 1), "WRITE_SIZE_KiB_per_launch": round(aw, 1), "dispatches_seen": len(vf),
                       "fetch_bytes_corrected": int(af * 1024 * ff), "write_bytes_corrected": int(aw * 1024 * wf)}
@@ -99,10 +105,16 @@ for sec, key in KEY.items():
             kernels[k]["sq_per_launch"] = {c: round(sum(v[-2:]) / len(v[-2:]), 1) for c, v in sq[k].items()}
         tot_f += af * 1024 * ff
         tot_w += aw * 1024 * wf
+        # (kernels whose loads are narrow gathers -- the walkers, the per-boundary pass -- report FETCH_SIZE at factor ~1.0, like the
+        #  calibration's narrow read: for them the raw counter is the better figure, the corrected one an upper bound)
+        narrow = any(p in k for p in ("k_tok_", "k_coop", "k_doc_prepare", "k_tape_", "k_batch"))
+        tot_f_raw += af * 1024 * (1.0 if narrow else ff)
     summary[key] = {"kernels": kernels,
                     "hbm_traffic_bytes_per_launch": {"fetch_bytes": int(tot_f), "write_bytes": int(tot_w), "total": int(tot_f + tot_w),
+                                                     "total_lower_bound": int(tot_f_raw + tot_w),
                                                      "fetch_factor": ff, "write_factor": wf,
-                                                     "note": "sum over the kernels of one step of this section; counters in KiB x calibration factor"}}
+                                                     "note": "sum over the kernels of one step of this section; counters in KiB x calibration factor; total = every FETCH "
+                                                             "counter x the wide-read factor (upper bound), total_lower_bound = raw counter for the kernels with narrow loads"}}
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps({k: v["hbm_traffic_bytes_per_launch"]["total"] for k, v in summary.items()}))
 print(json.dumps(cal["applied"]))
