@@ -373,3 +373,72 @@ def test_whole_batch_through_the_exact_walker_in_a_fresh_process():
     env = dict(os.environ, SJMI_TOKEN_WALK="0")
     out = subprocess.run([sys.executable, "-c", _TOKEN_WALK_OFF % ROOT], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0 and "TOKEN_WALK_OFF_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+def test_pipeline_in_safe_mode_with_a_faked_timeout_and_with_misaligned_buffers():
+    """The corners of the re-ordered pipeline (round 5): (a) SAFE liveness mode -- no scanner, so the plain pass's record comes by a
+    queued copy and the string workspace is still zeroed by the workers; (b) a FAST plain pass that reports a tripped spin bound
+    (debug flag 16): the batch is rejected on the device (stage-1 status != 0) -- the optimistic call says SJMI_ST_REJECTED, the
+    exact call decides every document by the per-document passes; (c) a misaligned batch buffer: the plain pass cannot even be
+    tried -- rejected / per-document passes.  Every case against the oracle."""
+    import torch
+    import simdjson_java_amd as S
+    from simdjson_java_amd import sharding
+    rng = random.Random(41)
+    docs = _small_docs(rng, 1200) + [b"[1 1]"]
+    buf = b"".join(d + b"\n" for d in docs)
+    offs = np.concatenate([[0], np.cumsum([len(d) + 1 for d in docs])]).astype(np.uint64)
+    want = [O.parse(d + b"\n") for d in docs]
+
+    def verify(shard, label):
+        c = shard.check()
+        to = shard.tape_offsets.cpu().numpy()
+        tape = shard.tape.cpu().numpy().view(np.uint64)
+        err = shard.doc_errors.cpu().numpy()
+        strings = bytes(shard.sb[:c["string_bytes"]].cpu().numpy())
+        for k, w in enumerate(want):
+            assert int(err[k]) == w.error, (label, k)
+            if not w.error:
+                assert O.Parsed(tape[int(to[k]):int(to[k + 1])], strings, 0, 0, 0).to_python() == w.to_python(), (label, k)
+        assert c["failed_documents"] == 1, (label, c)
+        return c
+
+    st = torch.cuda.current_stream().cuda_stream
+    ctx = S.Context(0, 1 << 20)
+    try:
+        # (a) SAFE mode
+        ctx.set_tile_mode(True)
+        for exact in (False, True):
+            shard = sharding.BatchShard(ctx, buf, offs, torch.device("cuda", 0))
+            for _ in range(2):
+                shard.step(st, exact=exact)
+                torch.cuda.synchronize()
+            assert not (int(shard.result.cpu().numpy()[1]) & 0x800)
+            verify(shard, "safe exact=%s" % exact)
+        ctx.set_tile_mode(False)
+        # (b) a faked liveness trip of the FAST plain pass
+        ctx.debug_set_flags(16)
+        shard = sharding.BatchShard(ctx, buf, offs, torch.device("cuda", 0))
+        shard.step(st)
+        torch.cuda.synchronize()
+        assert int(shard.result.cpu().numpy()[1]) & 0x800, "the optimistic call must report the rejected plain pass"
+        ctx.debug_set_flags(0)
+        shard2 = sharding.BatchShard(ctx, buf, offs, torch.device("cuda", 0))
+        ctx.debug_set_flags(16)
+        shard2.step(st, exact=True)
+        torch.cuda.synchronize()
+        ctx.debug_set_flags(0)
+        verify(shard2, "faked timeout, exact call")
+        # (c) a batch buffer that is not 16-byte aligned
+        shard3 = sharding.BatchShard(ctx, buf, offs, torch.device("cuda", 0))
+        moved = torch.zeros(shard3.n + 256, dtype=torch.uint8, device="cuda")
+        moved[1:1 + shard3.n] = shard3.buf[:shard3.n]
+        shard3.buf = moved[1:]
+        assert shard3.buf.data_ptr() % 16 != 0
+        shard3.step(st)
+        torch.cuda.synchronize()
+        assert int(shard3.result.cpu().numpy()[1]) & 0x800
+        verify(shard3, "misaligned (check() makes the exact call)")
+        assert shard3.rejected_steps == 1
+    finally:
+        ctx.close()
