@@ -416,6 +416,30 @@ def check_batch_sample(torch, oracle, shard, offs, sample=10000, seed=20250825):
     return len(ks)
 
 
+def check_batch_all(torch, oracle, shard, offs):
+    """EVERY document of the batch against the oracle, outside every timed region: per document a digest of its tape (every word;
+    STRING words by the record's bytes instead of the buffer offset: oracle/sj_oracle.c sjo_tape_digest), a hash of its structural
+    indexes relative to its first byte, the structural count and the error code -- the oracle's from its own per-document parse
+    (sjo_digest_many, on the host's cores), the engine's from the batch's output arrays (sjo_digest_outputs)."""
+    import numpy as np
+    c = shard.check()
+    n_docs = shard.n_docs
+    host_buf = shard.buf[:shard.n].cpu().numpy()
+    want_dig, want_err, want_ih, want_cnt = oracle.digest_many(host_buf, np.asarray(offs, dtype=np.uint64))
+    to = shard.tape_offsets.cpu().numpy().view(np.uint64)
+    io = shard.index_offsets.cpu().numpy().view(np.uint64)
+    err = shard.doc_errors.cpu().numpy()[:n_docs]
+    tape = shard.tape[:int(to[-1])].cpu().numpy().view(np.uint64)
+    sb = shard.sb[:c["string_bytes"]].cpu().numpy()
+    idx = shard.idx[:c["structurals"]].cpu().numpy().view(np.uint32)
+    got_dig, got_ih, got_cnt = oracle.digest_outputs(tape, to, sb, idx, io, np.asarray(offs, dtype=np.uint64), err)
+    assert np.array_equal(err, want_err), "document verdicts differ from the oracle's at %s" % np.flatnonzero(err != want_err)[:5]
+    assert np.array_equal(got_cnt, want_cnt) and np.array_equal(got_ih, want_ih), \
+        "structural indexes differ from the oracle's at documents %s" % np.flatnonzero((got_cnt != want_cnt) | (got_ih != want_ih))[:5]
+    assert np.array_equal(got_dig, want_dig), "tapes / string records differ from the oracle's at documents %s" % np.flatnonzero(got_dig != want_dig)[:5]
+    return n_docs
+
+
 BATCH_KERNELS = ("k_stage1_batch (one plain pass with per-block side outputs, accepted on the device) + k_strings<true> + k_doc_prepare "
                  "(separator check, index ranges, string ordinals, predicted tape lengths) + tape-offset scan + k_tok_walk (token walker; "
                  "k_coop_walk in list mode behind it for the documents it declines)")
@@ -654,6 +678,7 @@ def bench_single(args):
     put("configs3_batch_frac", "batch_1m_docs", "roofline", "frac")
     put("configs3_batch_documents", "batch_1m_docs", "documents")
     put("configs3_batch_oracle_checked_documents", "batch_1m_docs", "oracle_checked_documents")
+    put("configs3_batch_oracle_digest_checked_documents", "batch_1m_docs", "oracle_digest_checked_documents")
     put("configs3_batch_docs_per_s_incl_h2d", "batch_1m_docs", "incl_h2d", "value")
     put("parse_twitter_json_all_device_ms", "parse_single_document", "twitter_json", "gpu_walker", "ms")
     put("parse_twitter_json_host_walker_ms", "parse_single_document", "twitter_json", "host_walker", "ms")
@@ -766,15 +791,17 @@ def batch_single_gpu(torch, S, W, dev, work, args, with_h2d=True, n_docs=None, c
     c = shard.check()
     assert c["failed_documents"] == 0 and c["host_documents"] == 0 and c["stage1_status"] == 0, c
     checked = check_batch_sample(torch, oracle, shard, offs, args.sample) if check else 0
+    checked_all = check_batch_all(torch, oracle, shard, offs) if check else 0
     el = wall_steps(torch, lambda: shard.step(st), args.batch_steps)
     ms = el / args.batch_steps * 1e3
     alg = batch_algorithmic_bytes(shard.n, c)
     out = {"config": "configs[3] on one GPU: %d UNIQUE documents (tools/docgen.c, seed 20250825, lengths uniform in [768, 1280] B, %d B, "
                      "%.1f structurals per document), device-resident: stage 1 (per-document verdicts) -> string records -> GPU walk "
-                     "(tapes), sjmi_parse_batch_device; %d seeded sample documents checked against the oracle before timing (indexes + tree)"
-                     % (n_docs, shard.n, c["structurals"] / n_docs, checked),
+                     "(tapes), sjmi_parse_batch_device_optimistic; before timing ALL %d documents compared per document with the oracle (tape digest incl. "
+                     "string bytes, index hash, verdict) and %d seeded sample documents as trees"
+                     % (n_docs, shard.n, c["structurals"] / n_docs, checked_all, checked),
            "value": round(n_docs / (ms / 1e3), 1), "unit": "docs/s", "ms_per_batch": round(ms, 3), "counts": c,
-           "documents": n_docs, "oracle_checked_documents": checked,
+           "documents": n_docs, "oracle_checked_documents": checked, "oracle_digest_checked_documents": checked_all,
            "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("batch_1m_docs"),
                         "traffic_source": pmc_source(),

@@ -194,6 +194,58 @@ def parse_many(packed, offsets, loops=1, avx=False, max_depth=1024):
     return int(ok), tw.value, sbytes.value
 
 
+def digest_many(packed, offsets, max_depth=1024, threads=None):
+    """Every document packed[offsets[k]:offsets[k+1]] through the restatement -> (digests u64[n] (0 where the document fails),
+    errors i32[n], index hashes u64[n], structural counts u32[n]); sj_oracle.c sjo_digest_many, on `threads` host threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    a = np.frombuffer(bytes(packed) + b"\0" * 64, dtype=np.uint8) if not isinstance(packed, np.ndarray) else packed
+    offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = offs.size - 1
+    dig, err = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.int32)
+    ih, cnt = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint32)
+    L = lib()
+    L.sjo_digest_many.restype = None
+    L.sjo_digest_many.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    threads = threads or min(64, os.cpu_count() or 1)
+    step = max(1, (n + threads - 1) // threads)
+
+    def part(lo):
+        m = min(step, n - lo)
+        L.sjo_digest_many(_ptr(a), offs[lo:].ctypes.data, m, max_depth, dig[lo:].ctypes.data, err[lo:].ctypes.data, ih[lo:].ctypes.data,
+                          cnt[lo:].ctypes.data)
+    with ThreadPoolExecutor(threads) as ex:  # (ctypes releases the GIL)
+        list(ex.map(part, range(0, n, step)))
+    return dig, err, ih, cnt
+
+
+def digest_outputs(tape, tape_offsets, strings, indexes, index_offsets, doc_offsets, errors, threads=None):
+    """The same four arrays from the ENGINE's outputs of a batch (one tape array, one string buffer, one index array)."""
+    from concurrent.futures import ThreadPoolExecutor
+    tape = np.ascontiguousarray(tape, dtype=np.uint64)
+    to = np.ascontiguousarray(tape_offsets, dtype=np.uint64)
+    sb = np.ascontiguousarray(strings, dtype=np.uint8)
+    ix = np.ascontiguousarray(indexes, dtype=np.uint32)
+    io = np.ascontiguousarray(index_offsets, dtype=np.uint64)
+    do = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+    er = np.ascontiguousarray(errors, dtype=np.int32)
+    n = do.size - 1
+    dig, ih, cnt = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint32)
+    L = lib()
+    L.sjo_digest_outputs.restype = None
+    L.sjo_digest_outputs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    threads = threads or min(64, os.cpu_count() or 1)
+    step = max(1, (n + threads - 1) // threads)
+
+    def part(lo):
+        m = min(step, n - lo)
+        L.sjo_digest_outputs(tape.ctypes.data, to[lo:].ctypes.data, sb.ctypes.data, sb.size, ix.ctypes.data, io[lo:].ctypes.data,
+                             do[lo:].ctypes.data, m, er[lo:].ctypes.data, dig[lo:].ctypes.data, ih[lo:].ctypes.data, cnt[lo:].ctypes.data)
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(part, range(0, n, step)))
+    return dig, ih, cnt
+
+
 def unescape_loop(padded, indexes, loops=1, sb=None):
     """Timing loop: StringParser.parseString for every string of one indexed document, `loops` times, in C -> record bytes."""
     a = _as_u8(padded)

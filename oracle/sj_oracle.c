@@ -886,3 +886,87 @@ int sjo_avx512_supported(void) {
     return 0;
 #endif
 }
+
+/* ---- per-document DIGESTS: every document of a large batch against the engine, not a sample (round 5) ------------------------
+ * A tape is position-independent except for its STRING words, whose payload is an offset into whichever string buffer the
+ * producer used (the oracle's is per document, the engine's one buffer per batch).  The digest walks the words linearly
+ * (Tape.java:28-43): FNV-1a over every word as it is -- type, container payloads (positions inside the document's own tape),
+ * element counts, the raw second word of a number -- and, for a STRING word, over its type byte, the record's be32 length and
+ * its bytes instead of the offset.  Equal digests <=> equal trees in the sense of SURVEY.md 8(c) (type, int64, raw double bits,
+ * UTF-8 bytes, order, sizes) and equal word-for-word tape layout. */
+static uint64_t fnv_mix(uint64_t h, const uint8_t *p, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) h = (h ^ p[i]) * 0x100000001B3ull;
+    return h;
+}
+uint64_t sjo_tape_digest(const uint64_t *tape, uint64_t n, const uint8_t *strings, uint64_t strings_len) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t w = tape[i];
+        const uint8_t t = (uint8_t)(w >> 56);
+        if (t == '"') {
+            const uint64_t off = w & 0x00FFFFFFFFFFFFFFull;
+            if (off + 4 > strings_len) return ~0ull - 1;  /* (a record outside the buffer: never equal to a real digest) */
+            const uint32_t len = ((uint32_t)strings[off] << 24) | ((uint32_t)strings[off + 1] << 16) | ((uint32_t)strings[off + 2] << 8) | strings[off + 3];
+            if (off + 4 + (uint64_t)len > strings_len) return ~0ull - 1;
+            h = fnv_mix(h, &t, 1);
+            h = fnv_mix(h, strings + off, 4 + (uint64_t)len);
+        } else {
+            h = fnv_mix(h, (const uint8_t *)&w, 8);
+            if ((t == 'l' || t == 'd') && i + 1 < n) {
+                ++i;
+                h = fnv_mix(h, (const uint8_t *)&tape[i], 8);
+            }
+        }
+    }
+    return h;
+}
+/* documents [0, n) of a packed batch through the restatement (scalar stage 1 + stage 2): digests[k] (0 for a failing document),
+ * errors[k] (enum sjo_error; stage-1 verdicts included the way sjo_parse reports them), idx_hash[k] = FNV-1a of the document's
+ * structural indexes relative to its first byte, counts[k] = their number */
+void sjo_digest_many(const uint8_t *buf, const uint64_t *offsets, uint64_t n, int max_depth, uint64_t *digests, int32_t *errors,
+                     uint64_t *idx_hash, uint32_t *counts) {
+    uint64_t maxlen = 0;
+    for (uint64_t k = 0; k < n; k++)
+        if (offsets[k + 1] - offsets[k] > maxlen) maxlen = offsets[k + 1] - offsets[k];
+    uint32_t *ix = (uint32_t *)malloc((maxlen + 2 + 64) * 4);
+    uint8_t *padded = (uint8_t *)calloc(maxlen + 128, 1);
+    for (uint64_t k = 0; k < n; k++) {
+        const uint64_t len = offsets[k + 1] - offsets[k];
+        memcpy(padded, buf + offsets[k], len);
+        memset(padded + len, 0, 64);
+        uint64_t count = 0;
+        uint32_t st = 0;
+        sjo_doc d;
+        memset(&d, 0, sizeof d);
+        sjo_stage1(padded, len, ix, maxlen + 2, &count, &st);
+        counts[k] = (uint32_t)count;
+        idx_hash[k] = fnv_mix(0xCBF29CE484222325ull, (const uint8_t *)ix, count * 4);
+        digests[k] = 0;
+        if (st != 0) {
+            errors[k] = (st & 1) ? SJO_E_UTF8 : ((st & 2) ? SJO_E_UNCLOSED_STRING : SJO_E_UNESCAPED_CHARS);
+        } else {
+            errors[k] = sjo_stage2(padded, len, ix, count, max_depth, &d);
+            if (errors[k] == 0) digests[k] = sjo_tape_digest(d.tape, d.tape_len, d.string_buffer, d.string_len);
+        }
+        sjo_doc_free(&d);
+    }
+    free(ix);
+    free(padded);
+}
+/* the engine's outputs of a batch, the same way: digests of the tapes tape[tape_offsets[k], tape_offsets[k + 1]) over ONE string
+ * buffer, hashes of the index ranges indexes[index_offsets[k], index_offsets[k + 1]) made relative to doc_offsets[k] */
+void sjo_digest_outputs(const uint64_t *tape, const uint64_t *tape_offsets, const uint8_t *strings, uint64_t strings_len,
+                        const uint32_t *indexes, const uint64_t *index_offsets, const uint64_t *doc_offsets, uint64_t n,
+                        const int32_t *errors, uint64_t *digests, uint64_t *idx_hash, uint32_t *counts) {
+    for (uint64_t k = 0; k < n; k++) {
+        digests[k] = errors[k] == 0 ? sjo_tape_digest(tape + tape_offsets[k], tape_offsets[k + 1] - tape_offsets[k], strings, strings_len) : 0;
+        uint64_t h = 0xCBF29CE484222325ull;
+        const uint32_t base = (uint32_t)doc_offsets[k];
+        for (uint64_t i = index_offsets[k]; i < index_offsets[k + 1]; i++) {
+            const uint32_t rel = indexes[i] - base;
+            h = fnv_mix(h, (const uint8_t *)&rel, 4);
+        }
+        idx_hash[k] = h;
+        counts[k] = (uint32_t)(index_offsets[k + 1] - index_offsets[k]);
+    }
+}

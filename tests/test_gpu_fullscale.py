@@ -210,3 +210,30 @@ def test_128k_document_batch_full_device_pipeline():
         assert torch.equal(tp - shift, tp[:1].expand(reps, t0n))
     finally:
         ctx.close()
+
+
+def test_one_million_unique_documents_every_document_against_the_oracle():
+    """configs[3] at full size, EVERY document (round 5: the bench checked a 10,000-document sample, the suite 128,000): the
+    1,000,000 unique ~1 KB documents of tools/docgen.c through sjmi_parse_batch_device_optimistic; per document the digest of its
+    tape (every word, STRING words by their record's bytes), the hash of its structural indexes, its count and its verdict
+    against the oracle's own per-document parse (oracle/sj_oracle.c sjo_digest_many / sjo_digest_outputs)."""
+    import sys
+    import torch
+    import simdjson_java_amd as S
+    from tests.conftest import ROOT
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench
+    import workloads as W
+    W.build_docgen()
+    dev = torch.device("cuda", 0)
+    ctx = S.Context(0, 1 << 20)
+    try:
+        shard, offs = bench.make_batch_shard(torch, S, W, dev, ctx, 0, 1000000)
+        shard.step(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        c = shard.check()
+        assert c["failed_documents"] == 0 and c["host_documents"] == 0 and getattr(shard, "rejected_steps", 0) == 0
+        assert bench.check_batch_all(torch, O, shard, offs) == 1000000
+    finally:
+        ctx.close()

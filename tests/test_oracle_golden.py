@@ -372,3 +372,57 @@ def test_avx512_restatement_equals_the_scalar_one():
         else:
             d = bytes(rng.getrandbits(8) for _ in range(n))
         _avx_same(d)
+
+
+def test_per_document_digests_see_every_kind_of_difference():
+    """oracle.digest_many / digest_outputs (the all-documents check of bench.py and tests/test_gpu_fullscale.py): outputs assembled
+    from the oracle's own per-document parses digest equal; one changed tape word, string byte, number bit, index or verdict does not."""
+    import random
+    from tests.test_gpu_batch import _small_docs
+    rng = random.Random(3)
+    docs = _small_docs(rng, 200) + [b"[1 1]", b'{"a":"\\u00e9\\n","b":[1.5,-2,true,null,{"c":"d"}]}']
+    buf = b"".join(d + b"\n" for d in docs)
+    offs = np.concatenate([[0], np.cumsum([len(d) + 1 for d in docs])]).astype(np.uint64)
+    dig, err, ih, cnt = O.digest_many(buf, offs, threads=3)
+    tapes, sbs, to, idxs, io, errs, sb_off = [], [], [0], [], [0], [], 0
+    for k, d in enumerate(docs):
+        p = O.parse(d + b"\n")
+        errs.append(p.error)
+        ix, _ = O.stage1(d + b"\n")
+        idxs.append(ix.astype(np.uint32) + np.uint32(int(offs[k])))
+        io.append(io[-1] + ix.size)
+        if p.error:
+            to.append(to[-1])
+            continue
+        tp = np.array(p.tape, dtype=np.uint64)
+        i = 0
+        while i < tp.size:
+            t = int(tp[i]) >> 56
+            if t == 0x22:
+                tp[i] = np.uint64((t << 56) | ((int(tp[i]) & 0xFFFFFFFFFFFFFF) + sb_off))
+            i += 2 if t in (0x6C, 0x64) else 1
+        tapes.append(tp)
+        sbs.append(bytes(p.strings))
+        sb_off += len(p.strings)
+        to.append(to[-1] + tp.size)
+    tape, sb, idx = np.concatenate(tapes), np.frombuffer(b"".join(sbs), dtype=np.uint8).copy(), np.concatenate(idxs)
+    to, io, errs = np.array(to, dtype=np.uint64), np.array(io, dtype=np.uint64), np.array(errs, dtype=np.int32)
+    assert np.array_equal(errs, err) and errs[len(docs) - 2] != 0
+
+    def run():
+        return O.digest_outputs(tape, to, sb, idx, io, offs, errs, threads=2)
+    g = run()
+    assert np.array_equal(g[0], dig) and np.array_equal(g[1], ih) and np.array_equal(g[2], cnt)
+    last = len(docs) - 1
+    for what in ("tape word", "string byte", "index"):
+        keep = (tape.copy(), sb.copy(), idx.copy())
+        if what == "tape word":
+            tape[int(to[last]) + 1] ^= np.uint64(1 << 33)       # the element count of the root object
+        elif what == "string byte":
+            sb[sb.size - 1] ^= 1
+        else:
+            idx[int(io[last]) + 3] += 1
+        g = run()
+        changed = (g[0] != dig) | (g[1] != ih)
+        assert changed[last] and not changed[:last].any(), what
+        tape[:], sb[:], idx[:] = keep
