@@ -38,7 +38,7 @@
 #include "stage1.h"
 
 #ifndef SJMI_STR_ABL
-#define SJMI_STR_ABL 0  // ablation experiments only (results invalid): 1 no headers, 2 no copy, 4 no stores
+#define SJMI_STR_ABL 0  // ablation experiments only (results invalid): 1 no headers, 2 no copy, 4 no stores, 8 no \\u patches
 #endif
 
 namespace sjmi {
@@ -306,6 +306,8 @@ struct __attribute__((packed, aligned(1))) StrU4B { uint32_t a; };
 #endif
 constexpr uint32_t STR_TICKET_CLASSES = SJMI_STR_CLASSES;
 
+constexpr uint32_t STR_UQ_ITEMS = 128;  // sequences of one granule that are decoded densely (more: the lane-local loop)
+
 template <bool SOFF>
 struct StrWaveLds {
     alignas(16) uint32_t tile[STR_TILE_DW];
@@ -324,6 +326,7 @@ k_strings(const StrArgs a0) {
         a.blkpar = a.blkpar_alt;
     }
     __shared__ StrWaveLds<SOFF> sh[4];
+    __shared__ uint32_t s_uq[4][STR_UQ_ITEMS];  // the \uXXXX sequences of a wave's granule: tile offset | position << 14 | pair << 26
     __shared__ uint32_t s_lut[16];
     __shared__ StrHand hand;
     const int lane = threadIdx.x & 63;
@@ -541,18 +544,46 @@ k_strings(const StrArgs a0) {
         if (have && retire != 0) nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk) * NC + cls;
         // \uXXXX: the hex digits of a lane's first two sequences are requested now and used behind the flush and the copy
         // (a request per trip of the loop there costs a memory round trip per trip)
+        // Round 5: the sequences are patched DENSELY.  A lane-local loop over its own sequences runs to the busiest lane's count (3-4
+        // for a mean of 0.5 on the documents of configs[3]) at ~85 instructions a trip -- 12 % of the pass there.  Now each lane only
+        // queues {where its UTF-8 bytes go in the tile, where its digits are, pair?} in LDS, and the decoding runs with one lane per
+        // sequence (up to 64 at a time; their digits requested here and used behind the flush and the copy).
         uint32_t it_lo[2] = {0, 0}, it_hi[2] = {0, 0};
+        uint32_t u_n = 0, u_ent = 0, u_lo = 0, u_hi = 0;
         const sj_u64 items = have ? (m.l1 | m.l2 | m.l3 | m.pair) : 0ull;
         const bool any_items = __ballot(items != 0) != 0;
+        bool u_dense = false;
         if (any_items) {
-            sj_u64 x = items;
+            const uint32_t n_it = (uint32_t)__popcll(items);
+            const uint32_t sc = str_incl_scan(n_it);
+            const uint32_t tot_it = (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+            u_dense = tot_it <= STR_UQ_ITEMS;
+            if (u_dense) {
+                uint32_t* const uq = s_uq[wave];
+                uint32_t i = sc - n_it;
+                for (sj_u64 x = items; x; x &= x - 1, ++i) {
+                    const uint32_t e = (uint32_t)__builtin_ctzll(x);
+                    const uint32_t dest = base + sj_str_offset(m, e);  // (< STR_TILE_BYTES: 14 bits)
+                    uq[i] = dest | ((((uint32_t)lane << 6) | e) << 14) | ((uint32_t)((m.pair >> e) & 1ull) << 26);
+                }
+                str_lds_fence();
+                u_n = tot_it;
+                if ((uint32_t)lane < u_n) {
+                    u_ent = uq[lane];
+                    const uint8_t* src = a.buf + (sj_u64)cur * 4096 + ((u_ent >> 14) & 0xFFFu);
+                    u_lo = reinterpret_cast<const StrU4B*>(src - 3)->a;
+                    if (u_ent >> 26) u_hi = reinterpret_cast<const StrU4B*>(src - 9)->a;
+                }
+            } else {  // (more sequences than the queue holds: the lane-local loop, its first two items' digits requested here)
+                sj_u64 x = items;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (x) {
-                    const uint8_t* src = a.buf + blk * 64 + (uint32_t)__builtin_ctzll(x);
-                    it_lo[t] = reinterpret_cast<const StrU4B*>(src - 3)->a;
-                    if (m.pair & x & (0 - x)) it_hi[t] = reinterpret_cast<const StrU4B*>(src - 9)->a;
-                    x &= x - 1;
+                for (int t = 0; t < 2; ++t) {
+                    if (x) {
+                        const uint8_t* src = a.buf + blk * 64 + (uint32_t)__builtin_ctzll(x);
+                        it_lo[t] = reinterpret_cast<const StrU4B*>(src - 3)->a;
+                        if (m.pair & x & (0 - x)) it_hi[t] = reinterpret_cast<const StrU4B*>(src - 9)->a;
+                        x &= x - 1;
+                    }
                 }
             }
         }
@@ -777,7 +808,31 @@ k_strings(const StrArgs a0) {
                     }
                 }
             }
-            if (any_items) {  // \uXXXX: the UTF-8 bytes over the last hex digits (StringParser.java:126-153)
+            if (any_items && u_dense && !(SJMI_STR_ABL & 8)) {  // \uXXXX: the UTF-8 bytes over the last hex digits (StringParser.java:126-153)
+                const uint32_t* const uq = s_uq[wave];
+                for (uint32_t c0 = 0; c0 < u_n; c0 += 64) {
+                    const uint32_t it = c0 + (uint32_t)lane;
+                    uint32_t ent = u_ent, lo = u_lo, hi = u_hi;
+                    if (c0) {  // (more than 64 sequences in 4 KiB: their digits are fetched now)
+                        ent = it < u_n ? uq[it] : 0u;
+                        const uint8_t* src = a.buf + (sj_u64)cur * 4096 + ((ent >> 14) & 0xFFFu);
+                        lo = it < u_n ? reinterpret_cast<const StrU4B*>(src - 3)->a : 0u;
+                        hi = (it < u_n && (ent >> 26)) ? reinterpret_cast<const StrU4B*>(src - 9)->a : 0u;
+                    }
+                    if (it < u_n) {
+                        const uint32_t e = (ent >> 14) & 63u;
+                        const bool is_pair = (ent >> 26) != 0;
+                        uint32_t cp = sj_hex4_valid_word(lo);  // (items exist only for sequences whose digits the plane algebra found valid)
+                        if (is_pair) cp = (((sj_hex4_valid_word(hi) - 0xD800u) << 10) | (cp - 0xDC00u)) + 0x10000u;
+                        uint32_t L;
+                        const uint32_t nb = sj_utf8_bytes(cp, &L);
+                        uint32_t old = L == 4 ? lo : (lo >> (8u * (4u - L)));
+                        const uint32_t spilled = L - 1u > e ? L - 1u - e : 0u;  // slots in front of the block: nothing was copied there
+                        if (spilled) old &= ~0u << (8u * spilled);
+                        tile_xor(tile, (ent & 0x3FFFu) - (L - 1u), old ^ nb);
+                    }
+                }
+            } else if (any_items && !(SJMI_STR_ABL & 8)) {
                 int t = 0;
                 for (sj_u64 x = items; x; x &= x - 1, ++t) {
                     const uint32_t e = (uint32_t)__builtin_ctzll(x);
@@ -794,12 +849,12 @@ k_strings(const StrArgs a0) {
                         lo = reinterpret_cast<const StrU4B*>(src - 3)->a;
                         if (is_pair) hi = reinterpret_cast<const StrU4B*>(src - 9)->a;
                     }
-                    uint32_t cp = sj_hex4_valid_word(lo);  // (items exist only for sequences whose digits the plane algebra found valid)
+                    uint32_t cp = sj_hex4_valid_word(lo);
                     if (is_pair) cp = (((sj_hex4_valid_word(hi) - 0xD800u) << 10) | (cp - 0xDC00u)) + 0x10000u;
                     uint32_t L;
                     const uint32_t nb = sj_utf8_bytes(cp, &L);
                     uint32_t old = L == 4 ? lo : (lo >> (8u * (4u - L)));
-                    const uint32_t spilled = L - 1u > e ? L - 1u - e : 0u;  // slots in front of the block: nothing was copied there
+                    const uint32_t spilled = L - 1u > e ? L - 1u - e : 0u;
                     if (spilled) old &= ~0u << (8u * spilled);
                     tile_xor(tile, base + sj_str_offset(m, e) - (L - 1u), old ^ nb);
                 }
