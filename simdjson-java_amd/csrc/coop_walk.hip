@@ -911,6 +911,9 @@ struct __attribute__((aligned(16))) PrimQueue {
 #ifndef SJMI_TOK_WAVES
 #define SJMI_TOK_WAVES 7
 #endif
+#ifndef SJMI_TOK_ABL
+#define SJMI_TOK_ABL 0   // (measurement only, tools/abl_tok.sh: 1 no literal parsing, 2 no container resolution, 4 no grammar, 8 no bracket / string words, 16 no step body)
+#endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SJMI_TOK_WAVES, SJMI_TOK_WAVES)))
 k_tok_walk(TokArgs a_by_value) {
     // The kernel is VALU-bound and was spilling ~40 SGPRs -- on gfx950 every spilled SGPR is a v_writelane / v_readlane pair in
@@ -955,7 +958,9 @@ k_tok_walk(TokArgs a_by_value) {
         if (live) {
             uint32_t ptype = 0;
             unsigned long long praw = 0;
-            if (cw_primitive(a.buf, win, p, false, 0u, &ptype, &praw) == 0) {
+            if (SJMI_TOK_ABL & 1) {
+                dst[0] = tape_word('n', win.a & 1u);
+            } else if (cw_primitive(a.buf, win, p, false, 0u, &ptype, &praw) == 0) {
                 dst[0] = tape_word(ptype, 0);
                 if (ptype == 'l' || ptype == 'd') dst[1] = praw;
             } else {
@@ -1066,6 +1071,12 @@ k_tok_walk(TokArgs a_by_value) {
                     ok = false;
                     break;
                 }
+                if (SJMI_TOK_ABL & 16) {
+                    head += nv;
+                    T0 += nv + (p & 1u) + (info & 1u) + (ninfo & 1u);
+                    if (c == nchunks && head == tail) root_closed = true;
+                    continue;
+                }
                 const uint32_t ch = (info >> 8) & 0xFFu;
                 const uint32_t cls = info & 7u, pre = (info >> 3) & 3u;
                 const uint32_t cls_next = ninfo & 7u, pre_next = (ninfo >> 3) & 3u;
@@ -1103,12 +1114,17 @@ k_tok_walk(TokArgs a_by_value) {
                 if (hmax >= CW_LEVELS) hmax = CW_LEVELS - 1;  // (deeper: handed to the exact walker below)
                 const bool comma_in_front = valid && pre == 1u;
                 int par_lane = -1;
+                if (SJMI_TOK_ABL & 2) hmax = hmin - 1;
                 for (int L = hmin; L <= hmax; ++L) {
                     const unsigned long long O = cw_ballot(is_open && h == L);  // opens of level L
                     if (plevel == L) par_lane = highest_bit_below(O, lt_mask);
                 }
                 const bool par_in_wave = par_lane >= 0, has_par = valid && plevel >= 0;
                 const uint32_t lvl = (uint32_t)plevel & 63u;
+#if (SJMI_TOK_ABL & 2)
+                const uint2 se = make_uint2(h, 0x80000000u);
+                const uint32_t pcnt = lvl, own = 0;
+#else
                 st.cnt[lane] = 0;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -1124,6 +1140,7 @@ k_tok_walk(TokArgs a_by_value) {
                 __builtin_amdgcn_wave_barrier();
                 if (is_open && !empty_open && !(own & 0x40000000u) && h < CW_LEVELS)
                     st.stk[h & 63] = make_uint2(tpos, (own & 0x3FFFFFFFu) | (cls == K_OPEN_A ? 0x80000000u : 0u));
+#endif
                 const int pl = par_in_wave ? par_lane : 0;
                 const uint32_t s_tpos = (uint32_t)__shfl((int)tpos, pl);
                 const uint32_t s_arr = (uint32_t)__shfl((int)(cls == K_OPEN_A ? 1u : 0u), pl);
@@ -1161,13 +1178,15 @@ k_tok_walk(TokArgs a_by_value) {
                 const unsigned long long rc = cw_ballot(closes_root);
                 const int rc_lane = rc ? __builtin_ctzll(rc) : 64;
                 if (valid && lane > rc_lane) good = false;  // trailing content
-                if (cw_ballot(!good)) {
+                if (!(SJMI_TOK_ABL & 6) && cw_ballot(!good)) {
                     ok = false;
                     break;
                 }
-                if (rc) root_closed = true;
+                if (SJMI_TOK_ABL & 6) {
+                    if (c == nchunks && head + nv == tail) root_closed = true;
+                } else if (rc) root_closed = true;
                 // (7) the tape words of this step
-                if (pq_live && pq_tpos < room) T[pq_tpos] = tape_word('"', a.string_base + pq_off);  // the previous step's strings
+                if (!(SJMI_TOK_ABL & 8) && pq_live && pq_tpos < room) T[pq_tpos] = tape_word('"', a.string_base + pq_off);  // the previous step's strings
                 pq_live = valid && cls == K_QUOTE;
                 pq_tpos = tpos;
                 pq_off = rec_off;
@@ -1185,10 +1204,10 @@ k_tok_walk(TokArgs a_by_value) {
                 }
                 {   // brackets: an empty pair is two self-contained words (TapeBuilder.java:205-208); a closing bracket writes its own
                     // word and its container's opening word (:197-203: element count = commas + 1, saturated)
-                    const bool w1 = valid && (empty_open || is_close) && tpos < room;
+                    const bool w1 = !(SJMI_TOK_ABL & 8) && valid && (empty_open || is_close) && tpos < room;
                     const uint32_t pay1 = empty_open ? tpos + 2u : (empty_close ? tpos : par_tpos);
                     if (w1) T[tpos] = tape_word(ch, pay1);
-                    const bool w2 = is_close && !empty_close && par_tpos < room;
+                    const bool w2 = !(SJMI_TOK_ABL & 8) && is_close && !empty_close && par_tpos < room;
                     uint32_t cnt = par_cnt + 1u;
                     if (cnt > 0xFFFFFFu) cnt = 0xFFFFFFu;
                     if (w2) T[par_tpos] = tape_word(ch - 2, (unsigned long long)(tpos + 1) | ((unsigned long long)cnt << 32));
