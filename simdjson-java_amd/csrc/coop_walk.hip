@@ -891,11 +891,12 @@ struct TokArgs {
     const UnescapeResult* dev_strings;
 };
 struct __attribute__((aligned(8))) TokRing {
-    uint2 e[128];  // .x = position, .y = class | pre << 3 (0 none, 1 ',', 2 ':') | two separators in front << 5 | first byte << 8
+    uint2 e[128];  // .x = position, .y = class (K_*, a number: K_PRIM | 8) | first byte << 8 | in front: ',' 1 / ':' 2 << 29 | two separators in front << 31
 };
-struct __attribute__((aligned(8))) TokStack {
-    uint2 stk[64];      // the open containers of the wave's document by level: .x = tape position of the opening word, .y = commas so far | is-array << 31
-    uint32_t cnt[64];   // per token of the current step: an opening bracket's commas so far | closed-in-this-step << 30
+struct __attribute__((aligned(8))) TokLevels {
+    unsigned long long open[64];  // per level: the lanes of this step's opening brackets with that depth in front of them
+    uint2 stk[64];                // the open containers of the wave's document by level: .x = tape position of the opening word | is-array << 31, .y = commas so far
+    uint32_t cnt[64];             // per token of the current step: an opening bracket's commas so far | closed-in-this-step << 31
 };
 constexpr int32_t CW_NEEDS_EXACT = -100;  // (internal, overwritten by the exact walker)
 // Primitives are parsed DENSELY: a token step only queues its atoms and numbers (window, position, where the words go, which
@@ -907,20 +908,30 @@ constexpr int32_t CW_NEEDS_EXACT = -100;  // (internal, overwritten by the exact
 struct __attribute__((aligned(16))) PrimQueue {
     uint4 e[128];  // .x = position (its 16-byte window is loaded when the queue is flushed: 64 dense loads), .y = document, .zw = where the words go
 };
+// LANE MASKS.  The kernel is bound by VALU issue (91 % of the SIMD cycles, profiles/r5/README.md), and most of what a token
+// step decides is boolean: a predicate of a token is kept as a 64-bit lane mask in SGPRs, "my predecessor / successor has it"
+// is a scalar shift of the mask with the carry of the neighbouring step, the grammar is scalar and / or / andn2, and a mask
+// comes back to the lanes only as the condition of a select or of a store (inverse ballot: the mask IS the condition, no
+// instruction); "how many lanes below me" is v_mbcnt.  Round 5: 887 -> see profiles/r5/README.md VALU instructions per document.
+__device__ __forceinline__ bool cw_lanes(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+__device__ __forceinline__ uint32_t cw_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ unsigned long long cw_first(uint32_t n) { return n >= 64u ? ~0ull : (1ull << n) - 1ull; }
+__device__ __forceinline__ uint32_t cw_bit(unsigned long long m, uint32_t i) { return (uint32_t)(m >> i) & 1u; }
 
 #ifndef SJMI_TOK_WAVES
 #define SJMI_TOK_WAVES 7
 #endif
 #ifndef SJMI_TOK_ABL
-#define SJMI_TOK_ABL 0   // (measurement only, tools/abl_tok.sh: 1 no literal parsing, 2 no container resolution, 4 no grammar, 8 no bracket / string words, 16 no step body)
+#define SJMI_TOK_ABL 0   // (measurement only, tools/abl_tok.sh: 1 no literal parsing, 16 no step body)
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SJMI_TOK_WAVES, SJMI_TOK_WAVES)))
 k_tok_walk(TokArgs a_by_value) {
-    // The kernel is VALU-bound and was spilling ~40 SGPRs -- on gfx950 every spilled SGPR is a v_writelane / v_readlane pair in
-    // the VALU.  Its sixteen arguments are 30 SGPRs that would live for the whole kernel although most are rarely used (the
-    // exact walker's list, the error array, the string buffer that is only looked at behind a string error ...): they are read
-    // from the kernarg segment where they are needed instead (the compiler repeats such a scalar load rather than spill its
-    // value): 39 -> 15 spilled SGPRs, SQ_INSTS_VALU 9.22e8 -> 8.87e8 per launch, 1.99 -> 1.93 ms (round 5).
+    // The kernel's sixteen arguments are 30 SGPRs that would live for the whole kernel although most are rarely used (the
+    // exact walker's list, the error array, the string buffer that is only looked at behind a string error ...), and on gfx950
+    // every spilled SGPR is a v_writelane / v_readlane pair in the VALU: they are read from the kernarg segment where they are
+    // needed instead (the compiler repeats such a scalar load rather than spill its value).
 #if defined(__HIP_DEVICE_COMPILE__)
     const TokArgs& a = *(const TokArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // (the kernel's only argument: offset 0 of the segment)
     (void)a_by_value;
@@ -930,12 +941,18 @@ k_tok_walk(TokArgs a_by_value) {
     if (a.sel && *a.sel == 0 && !a.tape_alt) return;  // (only the optimistic pipeline was queued and its plain pass was rejected)
     __shared__ TokRing rings[4];
     __shared__ PrimQueue queues[4];
-    __shared__ TokStack stacks[4];
+    __shared__ TokLevels levels[4];
+    __shared__ uint8_t first_byte_class[256];  // class_of() | 8 for the first byte of a number: one LDS read per structural
+    {
+        const uint32_t b = threadIdx.x;
+        first_byte_class[b] = (uint8_t)(class_of(b) | ((b == '-' || b - '0' <= 9u) ? 8u : 0u));
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     TokRing& ring = rings[wv];
     PrimQueue& pq = queues[wv];
-    TokStack& st = stacks[wv];
+    TokLevels& lv = levels[wv];
     uint32_t qhead = 0, qtail = 0;
     // a document for the exact walker: listed once, whoever finds out first (doc_errors[] starts at 0: k_doc_prepare / k_doc_meta)
     auto send_to_exact = [&](uint32_t doc) {
@@ -969,12 +986,14 @@ k_tok_walk(TokArgs a_by_value) {
         }
         qhead += nq;
     };
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const unsigned long long lane_bit = 1ull << lane;
+    const uint32_t below_lo = (uint32_t)(lane_bit - 1ull), below_hi = (uint32_t)((lane_bit - 1ull) >> 32);
     const uint32_t nwaves = gridDim.x * 4u;
     unsigned long long* const tape = (a.sel && *a.sel == 0) ? a.tape_alt : a.tape;
     const bool upstream_failed = (a.dev_count && (a.dev_count->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL))) ||
                                  (a.dev_strings && (a.dev_strings->flags & 0xFu));
     const bool string_errors = a.dev_strings && a.dev_strings->first_error_inv != 0;
+    const int depth_limit = (a.max_depth < CW_LEVELS ? a.max_depth : CW_LEVELS) - 1;  // an opening bracket with this depth in front of it is one too deep
     auto load_pos = [&](uint32_t from, uint32_t to, uint32_t c, uint32_t dflt) -> uint32_t {
         const uint32_t i = from + c * 64u + (uint32_t)lane;
         return i < to ? a.idx[i] : dflt;
@@ -990,8 +1009,8 @@ k_tok_walk(TokArgs a_by_value) {
         p1 = load_pos(m.from, m.to, 1, m.doc_start);
     }
     for (; k < a.n_docs; k += nwaves) {
-        const bool more = a.n_docs - k > nwaves;
-        if (more) {
+        const bool more_docs = a.n_docs - k > nwaves;
+        if (more_docs) {
             m_next = a.metas[k + nwaves];
             t_end_next = ((unsigned long long)a.metas[k + nwaves + 1].tape_hi << 32) | a.metas[k + nwaves + 1].tape_lo;
         }
@@ -999,233 +1018,226 @@ k_tok_walk(TokArgs a_by_value) {
         const unsigned long long t_off = ((unsigned long long)m.tape_hi << 32) | m.tape_lo;
         unsigned long long* const T = tape + t_off;
         const unsigned long long room64 = t_end - t_off;
-        const uint32_t room = room64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)room64;
-        // (more than 2^30 structurals: the comma counters keep two flag bits -- such a document goes to the exact walker)
+        const uint32_t room = room64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)room64;
+        // (more than 2^30 structurals: tape positions keep a flag bit, the comma counters too -- such a document goes to the exact walker)
         bool ok = !upstream_failed && m.st == 0 && n != 0 && n < (1u << 30) && to <= 0xFFFFFF00u;
         uint32_t tlen = 0;
         if (ok) {
             const uint32_t doc_start = m.doc_start;
             const uint32_t nchunks = (n + 63u) / 64u;
             // ---- running state (wave-uniform) ----
-            uint32_t H0 = 0, T0 = 1, S0 = m.dso;
-            uint32_t prev_cls = K_COMMA;
-            bool prev_empty_open = false, prev_is_key = false, root_closed = false, at_start = true;
+            int H0 = 0;
+            uint32_t T0 = 1, S0 = m.dso;
+            uint32_t c_open_a = 0, c_open_o = 0, c_empty_open = 0, c_is_key = 0;  // of the last token of the previous step
+            bool root_closed = false, at_start = true;
             uint32_t pq_tpos = 0, pq_off = 0;
-            bool pq_live = false;
+            unsigned long long PQ = 0;  // the lanes whose string word is still to be written (its record offset was requested a step ago)
             // ingest state
             uint32_t c = 0, head = 0, tail = 0;
-            uint32_t sep1 = 0, sep2 = 0, colon1 = 0;
+            unsigned long long SEPp = 0, COLp = 0;  // separators / colons of the previous chunk (only the last chunk is partial)
             // positions are requested two chunks ahead of their use, first bytes one chunk ahead
             uint32_t p_cur = p0, p_nxt = p1;
             uint32_t b_cur = a.buf[p_cur], b_nxt = nchunks > 1u ? (uint32_t)a.buf[p_nxt] : 0u;
             uint32_t p_nn = nchunks > 2u ? load_pos(from, to, 2, doc_start) : doc_start;
             while (ok) {
-                // ---- ingest chunks of 64 structurals until a token step has its 64 tokens and one to look ahead at ----
-                while (c < nchunks && tail - head < 65u) {
-                    const uint32_t base = from + c * 64u;
-                    const uint32_t nvl = to - base < 64u ? to - base : 64u;
-                    const bool valid = (uint32_t)lane < nvl;
+                // ---- ingest chunks of 64 structurals until a token step has its 64 tokens ----
+                while (c < nchunks && tail - head < 64u) {
+                    const uint32_t nvl = n - c * 64u < 64u ? n - c * 64u : 64u;
+                    const unsigned long long VL = cw_first(nvl);
                     const uint32_t p = p_cur, b0 = b_cur;
                     p_cur = p_nxt;
                     b_cur = b_nxt;
                     p_nxt = p_nn;
                     if (c + 2 < nchunks) b_nxt = a.buf[p_nxt];
                     p_nn = c + 3 < nchunks ? load_pos(from, to, c + 3, doc_start) : doc_start;
-                    const uint32_t cls = valid ? class_of(b0) : K_QUOTE;
-                    const bool sep = valid && (cls == K_COMMA || cls == K_COLON);
-                    const unsigned long long S = cw_ballot(sep), CO = cw_ballot(valid && cls == K_COLON);
-                    const unsigned long long S1 = (S << 1) | sep1, S2 = (S << 2) | ((unsigned long long)sep1 << 1) | sep2;
-                    const unsigned long long C1 = (CO << 1) | colon1;
-                    const uint32_t pre_sep = (uint32_t)(S1 >> lane) & 1u, pre_colon = (uint32_t)(C1 >> lane) & 1u;
-                    const uint32_t two = pre_sep & ((uint32_t)(S2 >> lane) & 1u);
-                    const uint32_t info = cls | ((pre_sep ? (pre_colon ? 2u : 1u) : 0u) << 3) | (two << 5) | (b0 << 8);
-                    const bool tok = valid && !sep;
-                    const unsigned long long TM = cw_ballot(tok);
-                    const uint32_t slot = (tail + (uint32_t)__popcll(TM & lt_mask)) & 127u;
-                    if (tok) ring.e[slot] = make_uint2(p, info);
-                    tail += (uint32_t)__popcll(TM);
-                    // carries into the next chunk: are the last / the last but one structural separators, is the last a ':'
-                    const uint32_t lb = nvl - 1u;
-                    const uint32_t s_last = (uint32_t)(S >> lb) & 1u;
-                    sep2 = lb ? (uint32_t)(S >> (lb - 1u)) & 1u : sep1;
-                    sep1 = s_last;
-                    colon1 = (uint32_t)(CO >> lb) & 1u;
+                    const uint32_t kind = first_byte_class[b0];
+                    const unsigned long long COL = cw_ballot(b0 == ':') & VL;
+                    const unsigned long long SEP = (cw_ballot(b0 == ',') & VL) | COL;
+                    // what stands in front of a structural: the masks moved up by one / two lanes, the previous chunk's last bits carried in
+                    const unsigned long long S1 = (SEP << 1) | (SEPp >> 63), S2 = (SEP << 2) | (SEPp >> 62), C1 = (COL << 1) | (COLp >> 63);
+                    uint32_t pre = cw_lanes(S1) ? 0x20000000u : 0u;
+                    pre = cw_lanes(C1) ? 0x40000000u : pre;
+                    const uint32_t two = cw_lanes(S1 & S2) ? 0x80000000u : 0u;
+                    const uint32_t info = kind | (b0 << 8) | pre | two;
+                    const unsigned long long TOK = VL & ~SEP;
+                    const uint32_t slot = (tail + cw_below(TOK)) & 127u;
+                    if (cw_lanes(TOK)) ring.e[slot] = make_uint2(p, info);
+                    tail += (uint32_t)__popcll(TOK);
+                    SEPp = SEP;
+                    COLp = COL;
                     ++c;
-                    if (c == nchunks && s_last) ok = false;  // a separator behind the last token
+                    if (c == nchunks && cw_bit(SEP, nvl - 1u)) ok = false;  // a separator behind the last token
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const uint32_t avail = tail - head;
                 if (avail == 0u || !ok) break;
-                const uint32_t nv = avail < 64u ? avail : 64u;
-                // ---- one token step ----
-                const bool valid = (uint32_t)lane < nv;
-                const uint32_t e = (head + (uint32_t)lane) & 127u;
-                const uint2 re = ring.e[e];
-                const uint32_t p = re.x, info = valid ? re.y : (uint32_t)K_COMMA;
-                const bool has_next = (uint32_t)lane + 1u < avail;
-                const uint32_t ninfo = has_next ? ring.e[(e + 1u) & 127u].y : (uint32_t)K_COMMA;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
                 if (root_closed) {  // something follows the root value (JsonIterator.java:196-198)
                     ok = false;
                     break;
                 }
+                // ---- one token step ----
+                const uint32_t na = avail < 64u ? avail : 64u;
+                const unsigned long long VA = cw_first(na);   // the tokens at hand
+                const uint2 re = ring.e[(head + (uint32_t)lane) & 127u];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t p = re.x, info = re.y;
                 if (SJMI_TOK_ABL & 16) {
-                    head += nv;
-                    T0 += nv + (p & 1u) + (info & 1u) + (ninfo & 1u);
+                    head += na;
+                    T0 += na + (p & 1u) + (info & 1u);
                     if (c == nchunks && head == tail) root_closed = true;
                     continue;
                 }
-                const uint32_t ch = (info >> 8) & 0xFFu;
-                const uint32_t cls = info & 7u, pre = (info >> 3) & 3u;
-                const uint32_t cls_next = ninfo & 7u, pre_next = (ninfo >> 3) & 3u;
-                const bool is_open = valid && cls <= K_OPEN_O, is_close = valid && (cls == K_CLOSE_A || cls == K_CLOSE_O);
-                uint32_t cls_prev = (uint32_t)__shfl_up((int)cls, 1);
-                if (lane == 0) cls_prev = prev_cls;
-                const bool first = at_start && lane == 0;
+                const uint32_t kind = info & 15u;
+                const unsigned long long OAa = cw_ballot(kind == K_OPEN_A) & VA, OOa = cw_ballot(kind == K_OPEN_O) & VA;
+                const unsigned long long CAa = cw_ballot(kind == K_CLOSE_A) & VA, CCa = cw_ballot(kind == K_CLOSE_O) & VA;
+                // a step ends in front of an opening bracket whose successor is not at hand (is it an empty container?)
+                const bool more = c < nchunks || avail > 64u;
+                const uint32_t nv = (more && cw_bit(OAa | OOa, 63)) ? 63u : na;
+                const unsigned long long V = cw_first(nv);
+                const unsigned long long OA = OAa & V, OO = OOa & V, CA = CAa & V, CC = CCa & V;
+                const unsigned long long Q = cw_ballot(kind == K_QUOTE) & V;
+                const unsigned long long NUM = cw_ballot(kind == (K_PRIM | 8u)) & V, PRIM = (cw_ballot(kind == K_PRIM) & V) | NUM;
+                const unsigned long long PRE0a = cw_ballot(info < 0x20000000u) & VA;           // nothing in front
+                const unsigned long long PRE2 = cw_ballot(info >= 0x40000000u) & V;            // ':' in front (or two separators: not good anyway)
+                const unsigned long long TWO = cw_ballot((int32_t)info < 0) & V;
+                const unsigned long long PRE0 = PRE0a & V, PRE1 = V & ~PRE0 & ~PRE2;           // ',' in front
+                const unsigned long long OPEN = OA | OO, CLOSE = CA | CC;
+                const unsigned long long FIRST = at_start ? 1ull : 0ull;
                 // (1) empty containers: an opening bracket directly followed by its closing bracket is ONE value (TapeBuilder.java:205-208)
-                const bool empty_open = is_open && has_next && cls_next == cls + 2u && pre_next == 0u;
-                int eo_prev = __shfl_up((int)empty_open, 1);
-                if (lane == 0) eo_prev = prev_empty_open;
-                const bool empty_close = is_close && eo_prev && !first;
-                // (2) depth and (3) tape position in front of every token: one ladder, three fields
-                const uint32_t up = is_open ? 1u : 0u, down = is_close ? 1u : 0u;
-                const bool is_num = valid && cls == K_PRIM && (ch == '-' || ch - '0' <= 9u);
-                const uint32_t words = !valid ? 0u : (is_num ? 2u : 1u);
-                const uint32_t scan3 = cw_incl_scan(up | (down << 8) | (words << 16));
-                const uint32_t iu = scan3 & 0xFFu, id = (scan3 >> 8) & 0xFFu, iw = scan3 >> 16;
-                const int h = (int)H0 + (int)(iu - up) - (int)(id - down);
-                const uint32_t tpos = T0 + iw - words;
-                const bool is_str = valid && cls == K_QUOTE;
-                const unsigned long long qm = cw_ballot(is_str);
-                const uint32_t sord = S0 + (uint32_t)__popcll(qm & lt_mask);
-                const uint32_t rec_off = is_str ? a.soff[sord] : 0u;  // (used one step later)
-                // (4) the container of every token.  One trip per depth level present in the step finds the opening bracket of
-                // a token's container among the step's own 64 tokens (the last open of that level in front of it); a container
-                // opened in an earlier step sits on the wave's STACK IN LDS, entry = level: {tape position of its opening word,
-                // commas so far | is-array << 31}.  Comma counts are LDS atomics -- every token that follows a ',' adds one to its
-                // container's counter (the opener's slot of this step, or the stack entry), every closing bracket marks its
-                // opener's slot closed -- so the level loop carries no per-level scalar bookkeeping at all, and what the next
-                // steps need is three LDS operations: the openers that were not closed push themselves.
-                const int plevel = h - 1;
-                int hmin = cw_wave_minmax<false>(valid ? plevel : 0x7FFF), hmax = cw_wave_minmax<true>(valid ? (is_open ? h : plevel) : -0x7FFF);
-                if (hmin < 0) hmin = 0;
-                if (hmax >= CW_LEVELS) hmax = CW_LEVELS - 1;  // (deeper: handed to the exact walker below)
-                const bool comma_in_front = valid && pre == 1u;
-                int par_lane = -1;
-                if (SJMI_TOK_ABL & 2) hmax = hmin - 1;
-                for (int L = hmin; L <= hmax; ++L) {
-                    const unsigned long long O = cw_ballot(is_open && h == L);  // opens of level L
-                    if (plevel == L) par_lane = highest_bit_below(O, lt_mask);
-                }
-                const bool par_in_wave = par_lane >= 0, has_par = valid && plevel >= 0;
-                const uint32_t lvl = (uint32_t)plevel & 63u;
-#if (SJMI_TOK_ABL & 2)
-                const uint2 se = make_uint2(h, 0x80000000u);
-                const uint32_t pcnt = lvl, own = 0;
-#else
-                st.cnt[lane] = 0;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                uint32_t* const my_counter = par_in_wave ? &st.cnt[par_lane] : &st.stk[lvl].y;
-                if (has_par && comma_in_front) atomicAdd(my_counter, 1u);
-                if (is_close && !empty_close && par_in_wave) atomicOr(&st.cnt[par_lane], 0x40000000u);  // (its opener does not stay open)
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const uint2 se = st.stk[lvl];          // the stack entry of my level (as the earlier steps left it + this step's commas)
-                const uint32_t pcnt = *my_counter;     // my container's commas (all of them lie in front of its closing bracket)
-                const uint32_t own = st.cnt[lane];     // an opening bracket's own slot
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (is_open && !empty_open && !(own & 0x40000000u) && h < CW_LEVELS)
-                    st.stk[h & 63] = make_uint2(tpos, (own & 0x3FFFFFFFu) | (cls == K_OPEN_A ? 0x80000000u : 0u));
-#endif
-                const int pl = par_in_wave ? par_lane : 0;
-                const uint32_t s_tpos = (uint32_t)__shfl((int)tpos, pl);
-                const uint32_t s_arr = (uint32_t)__shfl((int)(cls == K_OPEN_A ? 1u : 0u), pl);
-                const bool par_is_array_ = par_in_wave ? s_arr != 0 : (plevel >= 0 && (se.y >> 31) != 0);
-                const uint32_t par_tpos = par_in_wave ? s_tpos : se.x;
-                const uint32_t par_cnt = pcnt & 0x3FFFFFFFu;
-                // (5) the token grammar
-                const bool prev_open_ne = cls_prev <= K_OPEN_O && !eo_prev && !first;
-                const bool par_is_array = prev_open_ne ? cls_prev == K_OPEN_A : par_is_array_;
-                const bool key_pos = prev_open_ne ? cls_prev == K_OPEN_O : (pre == 1u && !par_is_array);
-                // is_key needs "my predecessor is not a key" only for the comma case, where the predecessor ended a value or it is an error anyway
-                const bool is_key = valid && !first && !empty_close && cls == K_QUOTE && key_pos;
-                int ik_prev = __shfl_up((int)is_key, 1);
-                if (lane == 0) ik_prev = prev_is_key;
-                bool good = true;
-                if (valid) {
-                    if (info & 32u) good = false;                                   // two separators in a row
-                    else if (first) good = is_open && pre == 0u;                      // (a root that is not a container: the exact walker)
-                    else if (empty_close) good = true;
-                    else if (prev_open_ne) good = pre == 0u && (cls_prev == K_OPEN_A ? !is_close : cls == K_QUOTE);   // :68-77
-                    else if (ik_prev) good = pre == 2u && !is_close;                  // :84-86
-                    else if (pre == 1u) good = par_is_array ? !is_close : cls == K_QUOTE;                             // :121-123
-                    else if (pre == 0u) good = cls == (par_is_array ? (uint32_t)K_CLOSE_A : (uint32_t)K_CLOSE_O) && plevel >= 0;  // :131,:189
-                    else good = false;
-                    if (is_open && !empty_open && (h + 1 >= a.max_depth || h + 1 >= CW_LEVELS)) good = false;        // :69-70 / deeper than the stack
-                }
-                if (valid && good && cls == K_QUOTE && string_errors) {
-                    // a string the reference's StringParser would have thrown on: record header FF FF FF <code>
-                    const uint8_t* hh = a.sb + rec_off;
-                    if (hh[0] == 0xFF && hh[1] == 0xFF && hh[2] == 0xFF) good = false;
-                }
-                if (valid && cls == K_PRIM && tpos + words > room) good = false;  // (no room for its words: the exact walker reports it)
-                // (6) where the root value ends
-                const bool closes_root = is_close && h == 1;
-                const unsigned long long rc = cw_ballot(closes_root);
-                const int rc_lane = rc ? __builtin_ctzll(rc) : 64;
-                if (valid && lane > rc_lane) good = false;  // trailing content
-                if (!(SJMI_TOK_ABL & 6) && cw_ballot(!good)) {
+                const unsigned long long EO = ((OA & (CAa >> 1)) | (OO & (CCa >> 1))) & (PRE0a >> 1);
+                const unsigned long long EOP = (EO << 1) | c_empty_open;
+                const unsigned long long EC = CLOSE & EOP & ~FIRST;
+                // (2) depth and (3) tape position in front of every token: one ladder, two fields (1 + up - down | words << 16)
+                uint32_t inc = cw_lanes(NUM) ? 0x00020001u : 0x00010001u;
+                inc = cw_lanes(OPEN) ? 0x00010002u : inc;
+                inc = cw_lanes(CLOSE) ? 0x00010000u : inc;
+                inc = cw_lanes(V) ? inc : 0u;
+                const uint32_t scan2 = cw_incl_scan(inc);
+                const uint32_t tot2 = cw_last(scan2);
+                if (T0 + (tot2 >> 16) > room) {  // no room for this step's words: the exact walker reports it
                     ok = false;
                     break;
                 }
-                if (SJMI_TOK_ABL & 6) {
-                    if (c == nchunks && head + nv == tail) root_closed = true;
-                } else if (rc) root_closed = true;
+                const uint32_t excl = scan2 - inc;
+                const int h = H0 + (int)(excl & 0xFFFFu) - lane;
+                const uint32_t tpos = T0 + (excl >> 16);
+                const uint32_t sord = S0 + cw_below(Q);
+                const uint32_t rec_off = cw_lanes(Q) ? a.soff[sord] : 0u;  // (used one step later)
+                const unsigned long long HAS_PAR = cw_ballot(h >= 1) & V;
+                const unsigned long long DEEP = cw_ballot(h >= depth_limit);
+                const unsigned long long ROOT_END = cw_ballot(h == 1) & CLOSE;
+                // (4) the container of every token.  The opening brackets of the step put their lane into the word of their level
+                // (LDS, atomic or); a token reads the word of ITS level: the last opening bracket in front of it there is its
+                // container -- or, if there is none, a container opened in an earlier step, which sits on the wave's STACK IN LDS,
+                // entry = level.  Comma counts are LDS atomics -- every token that follows a ',' adds one to its container's counter
+                // (the opener's slot of this step, or the stack entry), every closing bracket marks its opener's slot closed --
+                // and what the next steps need is one LDS write: the openers that were not closed push themselves.
+                const uint32_t lvl = (uint32_t)(h - 1) & 63u;
+                lv.open[lane] = 0ull;
+                lv.cnt[lane] = 0u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (cw_lanes(OPEN)) atomicOr(&lv.open[(uint32_t)h & 63u], lane_bit);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const unsigned long long om = lv.open[lvl];
+                const uint32_t om_lo = (uint32_t)om & below_lo, om_hi = (uint32_t)(om >> 32) & below_hi;
+                // (v_ffbh_u32: leading zeros, ~0 for 0)
+                const uint32_t lz_hi = om_hi ? (uint32_t)__builtin_clz(om_hi) : 0xFFFFFFFFu;
+                const uint32_t lz_lo = (om_lo ? (uint32_t)__builtin_clz(om_lo) : 0xFFFFFFFFu) | 32u;
+                const uint32_t lz = lz_hi < lz_lo ? lz_hi : lz_lo;
+                const unsigned long long IN_STEP = cw_ballot((int32_t)lz >= 0);  // my container was opened in this step
+                const uint32_t par_lane = 63u - lz;
+                uint32_t* const my_counter = cw_lanes(IN_STEP) ? &lv.cnt[par_lane & 63u] : &lv.stk[lvl].y;
+                if (cw_lanes(PRE1 & HAS_PAR)) atomicAdd(my_counter, 1u);
+                if (cw_lanes(CLOSE & ~EC & IN_STEP)) atomicOr(my_counter, 0x80000000u);  // (its opener does not stay open)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t se_x = lv.stk[lvl].x;   // the stack entry of my level as the earlier steps left it
+                const uint32_t pcnt = *my_counter;     // my container's commas (all of them lie in front of its closing bracket)
+                const uint32_t own = lv.cnt[lane];     // an opening bracket's own slot
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t opener = tpos | (cw_lanes(OA) ? 0x80000000u : 0u);
+                if (cw_lanes(OPEN & ~EO & ~cw_ballot((int32_t)own < 0))) lv.stk[(uint32_t)h & 63u] = make_uint2(opener, own);
+                const uint32_t from_step = (uint32_t)__shfl((int)opener, (int)(par_lane & 63u));
+                const uint32_t par = cw_lanes(IN_STEP) ? from_step : se_x;
+                const unsigned long long PAR_ARR = cw_ballot((int32_t)par < 0) & HAS_PAR;
+                const uint32_t par_tpos = par & 0x7FFFFFFFu;
+                const uint32_t par_cnt = pcnt & 0x3FFFFFFFu;
+                // (5) the token grammar (JsonIterator.java:68-193, in masks)
+                const unsigned long long OAP = (OA << 1) | c_open_a, OOP = (OO << 1) | c_open_o;     // my predecessor is '[' / '{'
+                const unsigned long long PON = (OAP | OOP) & ~EOP & ~FIRST;                             // ... and not an empty one
+                const unsigned long long ARR = (PON & OAP) | (~PON & PAR_ARR);                          // my container is an array
+                const unsigned long long KEYPOS = (PON & OOP) | (~PON & PRE1 & ~ARR);
+                // is_key needs "my predecessor is not a key" only for the comma case, where the predecessor ended a value or it is an error anyway
+                const unsigned long long KEY = Q & KEYPOS & ~FIRST & ~EC;
+                const unsigned long long KEYP = (KEY << 1) | c_is_key;
+                const unsigned long long R1 = V & ~TWO & ~FIRST & ~EC;                                  // two separators in a row: never
+                const unsigned long long R3 = R1 & ~PON, R4 = R3 & ~KEYP;
+                const unsigned long long GOOD =
+                    (FIRST & OPEN & PRE0 & ~TWO) |                                                      // (a root that is not a container: the exact walker)
+                    (V & ~TWO & ~FIRST & EC) |
+                    (R1 & PON & PRE0 & ((OAP & ~CLOSE) | (~OAP & Q))) |                                // :68-77
+                    (R3 & KEYP & PRE2 & ~CLOSE) |                                                       // :84-86
+                    (R4 & PRE1 & ((ARR & ~CLOSE) | (~ARR & Q))) |                                      // :121-123
+                    (R4 & PRE0 & ((ARR & CA) | (~ARR & CC)) & HAS_PAR);                                // :131,:189
+                unsigned long long BAD = (V & ~GOOD) | (OPEN & ~EO & DEEP);                            // :69-70 / deeper than the stack
+                if (string_errors) {
+                    // a string the reference's StringParser would have thrown on: record header FF FF FF <code>
+                    bool bad_string = false;
+                    if (cw_lanes(Q)) {
+                        const uint8_t* hh = a.sb + rec_off;
+                        bad_string = hh[0] == 0xFF && hh[1] == 0xFF && hh[2] == 0xFF;
+                    }
+                    BAD |= cw_ballot(bad_string);
+                }
+                // (6) where the root value ends: nothing may follow
+                if (ROOT_END) BAD |= V & ~((ROOT_END & (0ull - ROOT_END)) * 2ull - 1ull);
+                if (BAD) {
+                    ok = false;
+                    break;
+                }
+                if (ROOT_END) root_closed = true;
                 // (7) the tape words of this step
-                if (!(SJMI_TOK_ABL & 8) && pq_live && pq_tpos < room) T[pq_tpos] = tape_word('"', a.string_base + pq_off);  // the previous step's strings
-                pq_live = valid && cls == K_QUOTE;
+                if (cw_lanes(PQ)) T[pq_tpos] = tape_word('"', a.string_base + pq_off);  // the previous step's strings
+                PQ = Q;
                 pq_tpos = tpos;
                 pq_off = rec_off;
-                {   // atoms and numbers: queued, parsed 64 at a time (flush_primitives)
-                    const bool is_prim = valid && cls == K_PRIM;
-                    const unsigned long long PM = cw_ballot(is_prim);
-                    if (PM) {
-                        const uint32_t qs = (qtail + (uint32_t)__popcll(PM & lt_mask)) & 127u;
-                        if (is_prim) {
-                            const unsigned long long d = reinterpret_cast<unsigned long long>(T + tpos);
-                            pq.e[qs] = make_uint4(p, k, (uint32_t)d, (uint32_t)(d >> 32));
-                        }
-                        qtail += (uint32_t)__popcll(PM);
+                if (PRIM) {  // atoms and numbers: queued, parsed 64 at a time (flush_primitives)
+                    const uint32_t qs = (qtail + cw_below(PRIM)) & 127u;
+                    if (cw_lanes(PRIM)) {
+                        const unsigned long long d = reinterpret_cast<unsigned long long>(T + tpos);
+                        pq.e[qs] = make_uint4(p, k, (uint32_t)d, (uint32_t)(d >> 32));
                     }
+                    qtail += (uint32_t)__popcll(PRIM);
                 }
                 {   // brackets: an empty pair is two self-contained words (TapeBuilder.java:205-208); a closing bracket writes its own
                     // word and its container's opening word (:197-203: element count = commas + 1, saturated)
-                    const bool w1 = !(SJMI_TOK_ABL & 8) && valid && (empty_open || is_close) && tpos < room;
-                    const uint32_t pay1 = empty_open ? tpos + 2u : (empty_close ? tpos : par_tpos);
-                    if (w1) T[tpos] = tape_word(ch, pay1);
-                    const bool w2 = !(SJMI_TOK_ABL & 8) && is_close && !empty_close && par_tpos < room;
+                    const uint32_t type_hi = __builtin_amdgcn_perm(info, 0u, 0x050C0C0Cu);  // the bracket itself << 24
+                    uint32_t pay1 = cw_lanes(EC) ? tpos : par_tpos;
+                    pay1 = cw_lanes(EO) ? tpos + 2u : pay1;
+                    if (cw_lanes(EO | CLOSE)) T[tpos] = ((unsigned long long)type_hi << 32) | pay1;
                     uint32_t cnt = par_cnt + 1u;
                     if (cnt > 0xFFFFFFu) cnt = 0xFFFFFFu;
-                    if (w2) T[par_tpos] = tape_word(ch - 2, (unsigned long long)(tpos + 1) | ((unsigned long long)cnt << 32));
+                    if (cw_lanes(CLOSE & ~EC)) T[par_tpos] = ((unsigned long long)((type_hi - 0x02000000u) | cnt) << 32) | (tpos + 1u);
                 }
                 // (8) carries
-                const uint32_t tot3 = cw_last(scan3);
-                H0 = (uint32_t)((int)H0 + (int)(tot3 & 0xFFu) - (int)((tot3 >> 8) & 0xFFu));
-                T0 += tot3 >> 16;
-                S0 += (uint32_t)__popcll(qm);
-                const int lastv = (int)nv - 1;
-                prev_cls = (uint32_t)__builtin_amdgcn_readlane((int)cls, lastv);
-                prev_empty_open = __builtin_amdgcn_readlane((int)empty_open, lastv) != 0;
-                prev_is_key = __builtin_amdgcn_readlane((int)is_key, lastv) != 0;
+                const uint32_t lastv = nv - 1u;
+                H0 += (int)(tot2 & 0xFFFFu) - (int)nv;
+                T0 += tot2 >> 16;
+                S0 += (uint32_t)__popcll(Q);
+                c_open_a = cw_bit(OA, lastv);
+                c_open_o = cw_bit(OO, lastv);
+                c_empty_open = cw_bit(EO, lastv);
+                c_is_key = cw_bit(KEY, lastv);
                 at_start = false;
                 head += nv;
                 if (qtail - qhead >= 64u) flush_primitives(64u);
             }
-            if (pq_live && pq_tpos < room) T[pq_tpos] = tape_word('"', a.string_base + pq_off);  // the last step's strings
+            if (cw_lanes(PQ)) T[pq_tpos] = tape_word('"', a.string_base + pq_off);  // the last step's strings
             if (ok && !root_closed) ok = false;  // the root container is never closed (JsonIterator.java:39-41,:51-53)
             if (ok) {
                 tlen = T0 + 1;  // + the closing root word
@@ -1246,7 +1258,7 @@ k_tok_walk(TokArgs a_by_value) {
         }
         m = m_next;
         t_end = t_end_next;
-        if (more) {
+        if (more_docs) {
             p0 = load_pos(m.from, m.to, 0, m.doc_start);
             p1 = load_pos(m.from, m.to, 1, m.doc_start);
         }
