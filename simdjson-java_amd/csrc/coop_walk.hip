@@ -890,8 +890,12 @@ struct TokArgs {
     const Stage1Result* dev_count;
     const UnescapeResult* dev_strings;
 };
+// Token kinds of the batch walker (its own numbering: what a token step needs is a compare or a table index away)
+enum : uint32_t { TK_OPEN_A = 0, TK_OPEN_O = 1, TK_CLOSE_A = 2, TK_CLOSE_O = 3, TK_STRING = 4, TK_NONE = 5, TK_ATOM = 6, TK_NUMBER = 7 };
+// A token as the ring holds it: TK_* | ',' in front << 3 | ':' in front << 4 | depth field of the scan (1 + up - down) << 5 | first byte << 8 | its tape words << 21
+constexpr uint32_t TOK_COMMA = 8u, TOK_COLON = 16u, TOK_SCAN_FIELDS = 0x00600060u;
 struct __attribute__((aligned(8))) TokRing {
-    uint2 e[128];  // .x = position, .y = class (K_*, a number: K_PRIM | 8) | first byte << 8 | in front: ',' 1 / ':' 2 << 29 | two separators in front << 31
+    uint2 e[128];  // .x = position, .y = the token
 };
 struct __attribute__((aligned(8))) TokLevels {
     unsigned long long open[64];  // per level: the lanes of this step's opening brackets with that depth in front of them
@@ -908,17 +912,52 @@ constexpr int32_t CW_NEEDS_EXACT = -100;  // (internal, overwritten by the exact
 struct __attribute__((aligned(16))) PrimQueue {
     uint4 e[128];  // .x = position (its 16-byte window is loaded when the queue is flushed: 64 dense loads), .y = document, .zw = where the words go
 };
-// LANE MASKS.  The kernel is bound by VALU issue (91 % of the SIMD cycles, profiles/r5/README.md), and most of what a token
-// step decides is boolean: a predicate of a token is kept as a 64-bit lane mask in SGPRs, "my predecessor / successor has it"
-// is a scalar shift of the mask with the carry of the neighbouring step, the grammar is scalar and / or / andn2, and a mask
-// comes back to the lanes only as the condition of a select or of a store (inverse ballot: the mask IS the condition, no
-// instruction); "how many lanes below me" is v_mbcnt.  Round 5: 887 -> see profiles/r5/README.md VALU instructions per document.
+// LANE MASKS AND TABLES.  The kernel was bound by VALU issue (91 % of the SIMD cycles, 887 instructions per document), then --
+// with its predicates as 64-bit lane masks in SGPRs -- by the scalar unit (profiles/r5/README.md).  What is left on either side:
+//   * a predicate that gates a store, an LDS operation or a select is a lane mask from ONE v_cmp; it comes back to the lanes
+//     as the condition itself (inverse ballot: no instruction); "how many lanes below me" is v_mbcnt;
+//   * "my predecessor / successor" is one DPP move of the token word (wave_shr / wave_shl), the carry of the neighbouring step
+//     in the lane that has no neighbour;
+//   * everything a token is by itself (kind, its fields of the scan, its byte) is ONE LDS read of a 256-entry table in the ingest;
+//   * the token grammar (JsonIterator.java:68-193) is ONE LDS read of a 2048-entry table: token, what stands in front of it,
+//     the previous token, is my container an array.
 __device__ __forceinline__ bool cw_lanes(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 __device__ __forceinline__ uint32_t cw_below(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
-__device__ __forceinline__ unsigned long long cw_first(uint32_t n) { return n >= 64u ? ~0ull : (1ull << n) - 1ull; }
+__device__ __forceinline__ unsigned long long cw_first(uint32_t n) { return ~0ull >> (64u - n); }  // lanes [0, n), 1 <= n <= 64
 __device__ __forceinline__ uint32_t cw_bit(unsigned long long m, uint32_t i) { return (uint32_t)(m >> i) & 1u; }
+// the token of a structural's first byte (separators: TK_NONE, they never reach the ring)
+__device__ inline uint32_t tok_of_first_byte(uint32_t b) {
+    const uint32_t k = class_of(b);
+    const bool num = b == '-' || b - '0' <= 9u;
+    const uint32_t tk = k <= K_CLOSE_O ? k : (k == K_QUOTE ? (uint32_t)TK_STRING : (k == K_PRIM ? (num ? (uint32_t)TK_NUMBER : (uint32_t)TK_ATOM) : (uint32_t)TK_NONE));
+    if (tk == TK_NONE) return tk;
+    const uint32_t field = tk <= TK_OPEN_O ? 2u : (tk <= TK_CLOSE_O ? 0u : 1u), words = tk == TK_NUMBER ? 2u : 1u;
+    return tk | (field << 5) | (b << 8) | (words << 21);
+}
+// The token grammar, JsonIterator.java:68-193 re-keyed for tokens: i = token (TK_* | TOK_COMMA | TOK_COLON) | the same five bits
+// of the previous token << 5 | my container is an array << 10.  Every earlier token of the document was good (one bad token
+// fails the document), so what came before is known from the previous token alone:
+//     nothing (TK_NONE)            the root: an opening bracket, nothing in front (any other root: the exact walker)
+//     '['                          no separator; a value, or ']' (the empty array, TapeBuilder.java:205-208)
+//     '{'                          no separator; a key, or '}'
+//     a key                        ':' and a value      (a string is a key: in an object, and no ':' in front of it)
+//     a value                      ',' and a value (array) / a key (object), or no separator and the container's own closing bracket
+__device__ inline uint32_t tok_grammar(uint32_t i) {
+    const uint32_t tk = i & 7u, prev = (i >> 5) & 7u;
+    const bool comma = (i & TOK_COMMA) != 0, colon = (i & TOK_COLON) != 0, prev_colon = ((i >> 5) & TOK_COLON) != 0, arr = ((i >> 10) & 1u) != 0;
+    const bool close = tk == TK_CLOSE_A || tk == TK_CLOSE_O;
+    if (tk == TK_NONE) return 1u;  // (a lane without a token)
+    if (comma && colon) return 0u;
+    if (prev == TK_NONE) return (tk <= TK_OPEN_O && !comma && !colon) ? 1u : 0u;
+    if (prev == TK_OPEN_A) return (!comma && !colon && tk != TK_CLOSE_O) ? 1u : 0u;                     // :68-77
+    if (prev == TK_OPEN_O) return (!comma && !colon && (tk == TK_STRING || tk == TK_CLOSE_O)) ? 1u : 0u;
+    if (prev == TK_STRING && !arr && !prev_colon) return (colon && !close) ? 1u : 0u;                    // :84-86
+    if (comma) return (arr ? !close : tk == TK_STRING) ? 1u : 0u;                                        // :121-123
+    if (colon) return 0u;
+    return tk == (arr ? (uint32_t)TK_CLOSE_A : (uint32_t)TK_CLOSE_O) ? 1u : 0u;                          // :131,:189
+}
 
 #ifndef SJMI_TOK_WAVES
 #define SJMI_TOK_WAVES 7
@@ -942,11 +981,10 @@ k_tok_walk(TokArgs a_by_value) {
     __shared__ TokRing rings[4];
     __shared__ PrimQueue queues[4];
     __shared__ TokLevels levels[4];
-    __shared__ uint8_t first_byte_class[256];  // class_of() | 8 for the first byte of a number: one LDS read per structural
-    {
-        const uint32_t b = threadIdx.x;
-        first_byte_class[b] = (uint8_t)(class_of(b) | ((b == '-' || b - '0' <= 9u) ? 8u : 0u));
-    }
+    __shared__ uint32_t first_byte_token[256];
+    __shared__ uint8_t grammar[2048];
+    first_byte_token[threadIdx.x] = tok_of_first_byte(threadIdx.x);
+    for (uint32_t i = threadIdx.x; i < 2048u; i += 256u) grammar[i] = (uint8_t)tok_grammar(i);
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1028,13 +1066,14 @@ k_tok_walk(TokArgs a_by_value) {
             // ---- running state (wave-uniform) ----
             int H0 = 0;
             uint32_t T0 = 1, S0 = m.dso;
-            uint32_t c_open_a = 0, c_open_o = 0, c_empty_open = 0, c_is_key = 0;  // of the last token of the previous step
-            bool root_closed = false, at_start = true;
+            uint32_t c_token = TK_NONE, c_empty_open = 0;  // of the last token of the previous step
+            bool root_closed = false;
             uint32_t pq_tpos = 0, pq_off = 0;
             unsigned long long PQ = 0;  // the lanes whose string word is still to be written (its record offset was requested a step ago)
             // ingest state
             uint32_t c = 0, head = 0, tail = 0;
             unsigned long long SEPp = 0, COLp = 0;  // separators / colons of the previous chunk (only the last chunk is partial)
+            unsigned long long sep_twice = 0;       // a separator behind a separator: never valid
             // positions are requested two chunks ahead of their use, first bytes one chunk ahead
             uint32_t p_cur = p0, p_nxt = p1;
             uint32_t b_cur = a.buf[p_cur], b_nxt = nchunks > 1u ? (uint32_t)a.buf[p_nxt] : 0u;
@@ -1050,27 +1089,27 @@ k_tok_walk(TokArgs a_by_value) {
                     p_nxt = p_nn;
                     if (c + 2 < nchunks) b_nxt = a.buf[p_nxt];
                     p_nn = c + 3 < nchunks ? load_pos(from, to, c + 3, doc_start) : doc_start;
-                    const uint32_t kind = first_byte_class[b0];
+                    const uint32_t token = first_byte_token[b0];
                     const unsigned long long COL = cw_ballot(b0 == ':') & VL;
                     const unsigned long long SEP = (cw_ballot(b0 == ',') & VL) | COL;
-                    // what stands in front of a structural: the masks moved up by one / two lanes, the previous chunk's last bits carried in
-                    const unsigned long long S1 = (SEP << 1) | (SEPp >> 63), S2 = (SEP << 2) | (SEPp >> 62), C1 = (COL << 1) | (COLp >> 63);
-                    uint32_t pre = cw_lanes(S1) ? 0x20000000u : 0u;
-                    pre = cw_lanes(C1) ? 0x40000000u : pre;
-                    const uint32_t two = cw_lanes(S1 & S2) ? 0x80000000u : 0u;
-                    const uint32_t info = kind | (b0 << 8) | pre | two;
+                    // what stands in front of a structural: the masks moved up by one lane, the previous chunk's last bit carried in
+                    const unsigned long long S1 = (SEP << 1) | (SEPp >> 63), C1 = (COL << 1) | (COLp >> 63);
+                    sep_twice |= SEP & S1;
+                    uint32_t pre = cw_lanes(S1) ? TOK_COMMA : 0u;
+                    pre = cw_lanes(C1) ? TOK_COLON : pre;
                     const unsigned long long TOK = VL & ~SEP;
                     const uint32_t slot = (tail + cw_below(TOK)) & 127u;
-                    if (cw_lanes(TOK)) ring.e[slot] = make_uint2(p, info);
+                    if (cw_lanes(TOK)) ring.e[slot] = make_uint2(p, token | pre);
                     tail += (uint32_t)__popcll(TOK);
                     SEPp = SEP;
                     COLp = COL;
                     ++c;
-                    if (c == nchunks && cw_bit(SEP, nvl - 1u)) ok = false;  // a separator behind the last token
+                    if (c == nchunks) sep_twice |= SEP >> (nvl - 1u);  // a separator behind the last token
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const uint32_t avail = tail - head;
+                if (sep_twice) ok = false;
                 if (avail == 0u || !ok) break;
                 if (root_closed) {  // something follows the root value (JsonIterator.java:196-198)
                     ok = false;
@@ -1078,42 +1117,31 @@ k_tok_walk(TokArgs a_by_value) {
                 }
                 // ---- one token step ----
                 const uint32_t na = avail < 64u ? avail : 64u;
-                const unsigned long long VA = cw_first(na);   // the tokens at hand
                 const uint2 re = ring.e[(head + (uint32_t)lane) & 127u];
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const uint32_t p = re.x, info = re.y;
+                // a step ends in front of an opening bracket whose successor is not at hand (is it an empty container?)
+                const bool more = c < nchunks || avail > 64u;
+                const uint32_t nv = (more && ((uint32_t)__builtin_amdgcn_readlane((int)re.y, 63) & 7u) <= TK_OPEN_O) ? 63u : na;
+                const unsigned long long V = cw_first(nv);
+                const uint32_t p = re.x, token = cw_lanes(V) ? re.y : (uint32_t)TK_NONE;
                 if (SJMI_TOK_ABL & 16) {
-                    head += na;
-                    T0 += na + (p & 1u) + (info & 1u);
+                    head += nv;
+                    T0 += nv + (p & 1u) + (token & 1u);
                     if (c == nchunks && head == tail) root_closed = true;
                     continue;
                 }
-                const uint32_t kind = info & 15u;
-                const unsigned long long OAa = cw_ballot(kind == K_OPEN_A) & VA, OOa = cw_ballot(kind == K_OPEN_O) & VA;
-                const unsigned long long CAa = cw_ballot(kind == K_CLOSE_A) & VA, CCa = cw_ballot(kind == K_CLOSE_O) & VA;
-                // a step ends in front of an opening bracket whose successor is not at hand (is it an empty container?)
-                const bool more = c < nchunks || avail > 64u;
-                const uint32_t nv = (more && cw_bit(OAa | OOa, 63)) ? 63u : na;
-                const unsigned long long V = cw_first(nv);
-                const unsigned long long OA = OAa & V, OO = OOa & V, CA = CAa & V, CC = CCa & V;
-                const unsigned long long Q = cw_ballot(kind == K_QUOTE) & V;
-                const unsigned long long NUM = cw_ballot(kind == (K_PRIM | 8u)) & V, PRIM = (cw_ballot(kind == K_PRIM) & V) | NUM;
-                const unsigned long long PRE0a = cw_ballot(info < 0x20000000u) & VA;           // nothing in front
-                const unsigned long long PRE2 = cw_ballot(info >= 0x40000000u) & V;            // ':' in front (or two separators: not good anyway)
-                const unsigned long long TWO = cw_ballot((int32_t)info < 0) & V;
-                const unsigned long long PRE0 = PRE0a & V, PRE1 = V & ~PRE0 & ~PRE2;           // ',' in front
-                const unsigned long long OPEN = OA | OO, CLOSE = CA | CC;
-                const unsigned long long FIRST = at_start ? 1ull : 0ull;
+                const uint32_t tk = token & 7u;
+                const unsigned long long OPEN = cw_ballot(tk <= TK_OPEN_O), CLOSE = cw_ballot(tk <= TK_CLOSE_O) & ~OPEN;
+                const unsigned long long Q = cw_ballot(tk == TK_STRING), PRIM = cw_ballot(tk >= TK_ATOM);
+                // my neighbours' tokens
+                const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)c_token, (int)token, 0x138, 0xf, 0xf, false);       // wave_shr:1
+                const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp((int)TK_NONE, (int)token, 0x130, 0xf, 0xf, false);       // wave_shl:1
                 // (1) empty containers: an opening bracket directly followed by its closing bracket is ONE value (TapeBuilder.java:205-208)
-                const unsigned long long EO = ((OA & (CAa >> 1)) | (OO & (CCa >> 1))) & (PRE0a >> 1);
-                const unsigned long long EOP = (EO << 1) | c_empty_open;
-                const unsigned long long EC = CLOSE & EOP & ~FIRST;
+                const unsigned long long EO = cw_ballot(((next ^ (tk + 2u)) & (7u | TOK_COMMA | TOK_COLON)) == 0u) & OPEN;
+                const unsigned long long EC = CLOSE & ((EO << 1) | c_empty_open);
                 // (2) depth and (3) tape position in front of every token: one ladder, two fields (1 + up - down | words << 16)
-                uint32_t inc = cw_lanes(NUM) ? 0x00020001u : 0x00010001u;
-                inc = cw_lanes(OPEN) ? 0x00010002u : inc;
-                inc = cw_lanes(CLOSE) ? 0x00010000u : inc;
-                inc = cw_lanes(V) ? inc : 0u;
+                const uint32_t inc = (token & TOK_SCAN_FIELDS) >> 5;
                 const uint32_t scan2 = cw_incl_scan(inc);
                 const uint32_t tot2 = cw_last(scan2);
                 if (T0 + (tot2 >> 16) > room) {  // no room for this step's words: the exact walker reports it
@@ -1125,7 +1153,6 @@ k_tok_walk(TokArgs a_by_value) {
                 const uint32_t tpos = T0 + (excl >> 16);
                 const uint32_t sord = S0 + cw_below(Q);
                 const uint32_t rec_off = cw_lanes(Q) ? a.soff[sord] : 0u;  // (used one step later)
-                const unsigned long long HAS_PAR = cw_ballot(h >= 1) & V;
                 const unsigned long long DEEP = cw_ballot(h >= depth_limit);
                 const unsigned long long ROOT_END = cw_ballot(h == 1) & CLOSE;
                 // (4) the container of every token.  The opening brackets of the step put their lane into the word of their level
@@ -1144,15 +1171,16 @@ k_tok_walk(TokArgs a_by_value) {
                 __builtin_amdgcn_wave_barrier();
                 const unsigned long long om = lv.open[lvl];
                 const uint32_t om_lo = (uint32_t)om & below_lo, om_hi = (uint32_t)(om >> 32) & below_hi;
-                // (v_ffbh_u32: leading zeros, ~0 for 0)
-                const uint32_t lz_hi = om_hi ? (uint32_t)__builtin_clz(om_hi) : 0xFFFFFFFFu;
+                const uint32_t lz_hi = om_hi ? (uint32_t)__builtin_clz(om_hi) : 0xFFFFFFFFu;          // (v_ffbh_u32: ~0 for 0)
                 const uint32_t lz_lo = (om_lo ? (uint32_t)__builtin_clz(om_lo) : 0xFFFFFFFFu) | 32u;
                 const uint32_t lz = lz_hi < lz_lo ? lz_hi : lz_lo;
                 const unsigned long long IN_STEP = cw_ballot((int32_t)lz >= 0);  // my container was opened in this step
-                const uint32_t par_lane = 63u - lz;
-                uint32_t* const my_counter = cw_lanes(IN_STEP) ? &lv.cnt[par_lane & 63u] : &lv.stk[lvl].y;
-                if (cw_lanes(PRE1 & HAS_PAR)) atomicAdd(my_counter, 1u);
-                if (cw_lanes(CLOSE & ~EC & IN_STEP)) atomicOr(my_counter, 0x80000000u);  // (its opener does not stay open)
+                const uint32_t par_lane = (63u - lz) & 63u;
+                uint32_t* const my_counter = cw_lanes(IN_STEP) ? &lv.cnt[par_lane] : &lv.stk[lvl].y;
+                // one atomic add: 1 for a ',' in front of me, bit 31 from the closing bracket of a container of this step (it does not stay open)
+                uint32_t add = (token >> 3) & 1u;
+                add = cw_lanes(CLOSE & ~EC & IN_STEP) ? add | 0x80000000u : add;
+                atomicAdd(my_counter, add);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const uint32_t se_x = lv.stk[lvl].x;   // the stack entry of my level as the earlier steps left it
@@ -1160,31 +1188,15 @@ k_tok_walk(TokArgs a_by_value) {
                 const uint32_t own = lv.cnt[lane];     // an opening bracket's own slot
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const uint32_t opener = tpos | (cw_lanes(OA) ? 0x80000000u : 0u);
+                const uint32_t opener = tpos | ((tk - 1u) & 0x80000000u);  // is-array << 31 (TK_OPEN_A = 0)
                 if (cw_lanes(OPEN & ~EO & ~cw_ballot((int32_t)own < 0))) lv.stk[(uint32_t)h & 63u] = make_uint2(opener, own);
-                const uint32_t from_step = (uint32_t)__shfl((int)opener, (int)(par_lane & 63u));
+                const uint32_t from_step = (uint32_t)__shfl((int)opener, (int)par_lane);
                 const uint32_t par = cw_lanes(IN_STEP) ? from_step : se_x;
-                const unsigned long long PAR_ARR = cw_ballot((int32_t)par < 0) & HAS_PAR;
                 const uint32_t par_tpos = par & 0x7FFFFFFFu;
                 const uint32_t par_cnt = pcnt & 0x3FFFFFFFu;
-                // (5) the token grammar (JsonIterator.java:68-193, in masks)
-                const unsigned long long OAP = (OA << 1) | c_open_a, OOP = (OO << 1) | c_open_o;     // my predecessor is '[' / '{'
-                const unsigned long long PON = (OAP | OOP) & ~EOP & ~FIRST;                             // ... and not an empty one
-                const unsigned long long ARR = (PON & OAP) | (~PON & PAR_ARR);                          // my container is an array
-                const unsigned long long KEYPOS = (PON & OOP) | (~PON & PRE1 & ~ARR);
-                // is_key needs "my predecessor is not a key" only for the comma case, where the predecessor ended a value or it is an error anyway
-                const unsigned long long KEY = Q & KEYPOS & ~FIRST & ~EC;
-                const unsigned long long KEYP = (KEY << 1) | c_is_key;
-                const unsigned long long R1 = V & ~TWO & ~FIRST & ~EC;                                  // two separators in a row: never
-                const unsigned long long R3 = R1 & ~PON, R4 = R3 & ~KEYP;
-                const unsigned long long GOOD =
-                    (FIRST & OPEN & PRE0 & ~TWO) |                                                      // (a root that is not a container: the exact walker)
-                    (V & ~TWO & ~FIRST & EC) |
-                    (R1 & PON & PRE0 & ((OAP & ~CLOSE) | (~OAP & Q))) |                                // :68-77
-                    (R3 & KEYP & PRE2 & ~CLOSE) |                                                       // :84-86
-                    (R4 & PRE1 & ((ARR & ~CLOSE) | (~ARR & Q))) |                                      // :121-123
-                    (R4 & PRE0 & ((ARR & CA) | (~ARR & CC)) & HAS_PAR);                                // :131,:189
-                unsigned long long BAD = (V & ~GOOD) | (OPEN & ~EO & DEEP);                            // :69-70 / deeper than the stack
+                // (5) the token grammar: one table entry
+                const uint32_t gi = (token & 0x1Fu) | ((prev & 0x17u) << 5) | ((par >> 21) & 0x400u);
+                unsigned long long BAD = cw_ballot(grammar[gi] == 0) | (OPEN & ~EO & DEEP);            // :69-70 / deeper than the stack
                 if (string_errors) {
                     // a string the reference's StringParser would have thrown on: record header FF FF FF <code>
                     bool bad_string = false;
@@ -1216,7 +1228,7 @@ k_tok_walk(TokArgs a_by_value) {
                 }
                 {   // brackets: an empty pair is two self-contained words (TapeBuilder.java:205-208); a closing bracket writes its own
                     // word and its container's opening word (:197-203: element count = commas + 1, saturated)
-                    const uint32_t type_hi = __builtin_amdgcn_perm(info, 0u, 0x050C0C0Cu);  // the bracket itself << 24
+                    const uint32_t type_hi = __builtin_amdgcn_perm(token, 0u, 0x050C0C0Cu);  // the bracket itself << 24
                     uint32_t pay1 = cw_lanes(EC) ? tpos : par_tpos;
                     pay1 = cw_lanes(EO) ? tpos + 2u : pay1;
                     if (cw_lanes(EO | CLOSE)) T[tpos] = ((unsigned long long)type_hi << 32) | pay1;
@@ -1229,11 +1241,8 @@ k_tok_walk(TokArgs a_by_value) {
                 H0 += (int)(tot2 & 0xFFFFu) - (int)nv;
                 T0 += tot2 >> 16;
                 S0 += (uint32_t)__popcll(Q);
-                c_open_a = cw_bit(OA, lastv);
-                c_open_o = cw_bit(OO, lastv);
+                c_token = (uint32_t)__builtin_amdgcn_readlane((int)token, (int)lastv);
                 c_empty_open = cw_bit(EO, lastv);
-                c_is_key = cw_bit(KEY, lastv);
-                at_start = false;
                 head += nv;
                 if (qtail - qhead >= 64u) flush_primitives(64u);
             }
