@@ -894,8 +894,10 @@ struct TokArgs {
 enum : uint32_t { TK_OPEN_A = 0, TK_OPEN_O = 1, TK_CLOSE_A = 2, TK_CLOSE_O = 3, TK_STRING = 4, TK_NONE = 5, TK_ATOM = 6, TK_NUMBER = 7 };
 // A token as the ring holds it: TK_* | ',' in front << 3 | ':' in front << 4 | depth field of the scan (1 + up - down) << 5 | first byte << 8 | its tape words << 21
 constexpr uint32_t TOK_COMMA = 8u, TOK_COLON = 16u, TOK_SCAN_FIELDS = 0x00600060u;
+constexpr uint32_t TOK_RING = 256u;   // a document of up to 256 structurals is ingested whole, before its first token step
+constexpr uint32_t TOK_AHEAD = 4u;    // chunks of 64 structurals whose positions / first bytes are requested a document ahead
 struct __attribute__((aligned(8))) TokRing {
-    uint2 e[128];  // .x = position, .y = the token
+    uint2 e[TOK_RING];  // .x = position, .y = the token
 };
 struct __attribute__((aligned(8))) TokLevels {
     unsigned long long open[64];  // per level: the lanes of this step's opening brackets with that depth in front of them
@@ -960,10 +962,20 @@ __device__ inline uint32_t tok_grammar(uint32_t i) {
 }
 
 #ifndef SJMI_TOK_WAVES
-#define SJMI_TOK_WAVES 7
+#define SJMI_TOK_WAVES 6
 #endif
 #ifndef SJMI_TOK_ABL
-#define SJMI_TOK_ABL 0   // (measurement only, tools/abl_tok.sh: 1 no literal parsing, 16 no step body)
+#define SJMI_TOK_ABL 0   // (measurement only, tools/abl_tok.sh: 1 no literal parsing, 8 no bracket / string words, 16 no step body, 32 no literal words, 64 no string record offsets)
+#endif
+#ifdef SJMI_TOK_PROF   // (measurement only: where a wave's cycles go, tools/tok_prof.py)
+__device__ unsigned long long g_tok_prof[16];
+#define TOK_PROF_DECL uint32_t tp_acc[8] = {}; uint32_t tp_t0 = (uint32_t)__builtin_readcyclecounter(); const uint32_t tp_start = tp_t0;
+#define TOK_PROF(i) { const uint32_t tp_t1 = (uint32_t)__builtin_readcyclecounter(); tp_acc[i] += tp_t1 - tp_t0; tp_t0 = tp_t1; }
+#define TOK_PROF_END if (lane == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&g_tok_prof[i], (unsigned long long)tp_acc[i]); atomicAdd(&g_tok_prof[8], (unsigned long long)((uint32_t)__builtin_readcyclecounter() - tp_start)); atomicAdd(&g_tok_prof[9], 1ull); }
+#else
+#define TOK_PROF_DECL
+#define TOK_PROF(i)
+#define TOK_PROF_END
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SJMI_TOK_WAVES, SJMI_TOK_WAVES)))
 k_tok_walk(TokArgs a_by_value) {
@@ -1014,10 +1026,12 @@ k_tok_walk(TokArgs a_by_value) {
             uint32_t ptype = 0;
             unsigned long long praw = 0;
             if (SJMI_TOK_ABL & 1) {
-                dst[0] = tape_word('n', win.a & 1u);
+                if (!(SJMI_TOK_ABL & 32) || win.a == 0x12345678u) dst[0] = tape_word('n', win.a & 1u);
             } else if (cw_primitive(a.buf, win, p, false, 0u, &ptype, &praw) == 0) {
+                if (!(SJMI_TOK_ABL & 32) || praw == 0x12345678u) {
                 dst[0] = tape_word(ptype, 0);
                 if (ptype == 'l' || ptype == 'd') dst[1] = praw;
+                }
             } else {
                 send_to_exact(doc);
             }
@@ -1036,29 +1050,57 @@ k_tok_walk(TokArgs a_by_value) {
         const uint32_t i = from + c * 64u + (uint32_t)lane;
         return i < to ? a.idx[i] : dflt;
     };
+    // (the index entries of any other document may be anything: its bytes are not looked at)
+    auto walkable = [&](const DocMeta& d) { return !upstream_failed && d.st == 0 && d.to != d.from && d.to - d.from < (1u << 30) && d.to <= 0xFFFFFF00u; };
     uint32_t k = blockIdx.x * 4u + (uint32_t)wv;
-    DocMeta m = {}, m_next = {};
-    unsigned long long t_end = 0, t_end_next = 0;
-    uint32_t p0 = 0, p1 = 0;  // positions of the document's first two chunks of structurals (requested a document ahead)
+    // (the DocMeta records are not written while this kernel runs: constant address space = scalar loads, the kernarg reference
+    //  alone leaves the compiler with vector loads of a uniform address; a record is read TWO documents ahead, so that the
+    //  requests for the next document's positions never wait for it)
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const DocMeta __attribute__((address_space(4)))* MetaPtr;
+    const MetaPtr metas = (MetaPtr)(unsigned long long)a.metas;
+#else
+    const DocMeta* const metas = a.metas;
+#endif
+    auto load_meta = [&](uint32_t d, DocMeta& out, unsigned long long& end) {
+        out.from = metas[d].from; out.to = metas[d].to; out.dso = metas[d].dso; out.doc_start = metas[d].doc_start;
+        out.doc_end = metas[d].doc_end; out.st = metas[d].st; out.tape_lo = metas[d].tape_lo; out.tape_hi = metas[d].tape_hi;
+        end = ((unsigned long long)metas[d + 1].tape_hi << 32) | metas[d + 1].tape_lo;
+    };
+    DocMeta m = {}, m_next = {}, m_after = {};
+    unsigned long long t_end = 0, t_end_next = 0, t_end_after = 0;
+    // MEMORY.  The walker's loads are short dependent chains (index entry -> first byte), and a wave that waits for each chunk's
+    // round trip spends most of its time waiting.  So a document's positions are requested while the document in front of it is
+    // ingested, its first bytes inside that document's first token step, TOK_AHEAD chunks at a time: a document of up to 256
+    // structurals finds everything in registers.
+    uint32_t P[TOK_AHEAD] = {}, B[TOK_AHEAD] = {}, PN[TOK_AHEAD] = {}, BN[TOK_AHEAD] = {};
     if (k < a.n_docs) {
-        m = a.metas[k];
-        t_end = ((unsigned long long)a.metas[k + 1].tape_hi << 32) | a.metas[k + 1].tape_lo;
-        p0 = load_pos(m.from, m.to, 0, m.doc_start);
-        p1 = load_pos(m.from, m.to, 1, m.doc_start);
-    }
-    for (; k < a.n_docs; k += nwaves) {
-        const bool more_docs = a.n_docs - k > nwaves;
-        if (more_docs) {
-            m_next = a.metas[k + nwaves];
-            t_end_next = ((unsigned long long)a.metas[k + nwaves + 1].tape_hi << 32) | a.metas[k + nwaves + 1].tape_lo;
+        load_meta(k, m, t_end);
+        if (a.n_docs - k > nwaves) load_meta(k + nwaves, m_next, t_end_next);
+#pragma unroll
+        for (uint32_t j = 0; j < TOK_AHEAD; ++j) P[j] = load_pos(m.from, m.to, j, m.doc_start);
+        if (walkable(m)) {
+#pragma unroll
+            for (uint32_t j = 0; j < TOK_AHEAD; ++j) B[j] = a.buf[P[j]];
         }
+    }
+    TOK_PROF_DECL
+    for (; k < a.n_docs; k += nwaves) {
+        TOK_PROF(7)
+        const bool more_docs = a.n_docs - k > nwaves;
+        if (a.n_docs - k > 2u * nwaves) load_meta(k + 2u * nwaves, m_after, t_end_after);
+        if (more_docs) {
+#pragma unroll
+            for (uint32_t j = 0; j < TOK_AHEAD; ++j) PN[j] = load_pos(m_next.from, m_next.to, j, m_next.doc_start);
+        }
+        bool bytes_requested = !more_docs;
         const uint32_t from = m.from, to = m.to, n = to - from;
         const unsigned long long t_off = ((unsigned long long)m.tape_hi << 32) | m.tape_lo;
         unsigned long long* const T = tape + t_off;
         const unsigned long long room64 = t_end - t_off;
         const uint32_t room = room64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)room64;
         // (more than 2^30 structurals: tape positions keep a flag bit, the comma counters too -- such a document goes to the exact walker)
-        bool ok = !upstream_failed && m.st == 0 && n != 0 && n < (1u << 30) && to <= 0xFFFFFF00u;
+        bool ok = walkable(m);
         uint32_t tlen = 0;
         if (ok) {
             const uint32_t doc_start = m.doc_start;
@@ -1074,37 +1116,37 @@ k_tok_walk(TokArgs a_by_value) {
             uint32_t c = 0, head = 0, tail = 0;
             unsigned long long SEPp = 0, COLp = 0;  // separators / colons of the previous chunk (only the last chunk is partial)
             unsigned long long sep_twice = 0;       // a separator behind a separator: never valid
-            // positions are requested two chunks ahead of their use, first bytes one chunk ahead
-            uint32_t p_cur = p0, p_nxt = p1;
-            uint32_t b_cur = a.buf[p_cur], b_nxt = nchunks > 1u ? (uint32_t)a.buf[p_nxt] : 0u;
-            uint32_t p_nn = nchunks > 2u ? load_pos(from, to, 2, doc_start) : doc_start;
+            // one chunk of 64 structurals: the separators are folded into the token behind them, the tokens compacted into the ring
+            auto ingest = [&](uint32_t p, uint32_t b0) {
+                const uint32_t nvl = n - c * 64u < 64u ? n - c * 64u : 64u;
+                const unsigned long long VL = cw_first(nvl);
+                const uint32_t token = first_byte_token[b0];
+                const unsigned long long COL = cw_ballot(b0 == ':') & VL;
+                const unsigned long long SEP = (cw_ballot(b0 == ',') & VL) | COL;
+                // what stands in front of a structural: the masks moved up by one lane, the previous chunk's last bit carried in
+                const unsigned long long S1 = (SEP << 1) | (SEPp >> 63), C1 = (COL << 1) | (COLp >> 63);
+                sep_twice |= SEP & S1;
+                uint32_t pre = cw_lanes(S1) ? TOK_COMMA : 0u;
+                pre = cw_lanes(C1) ? TOK_COLON : pre;
+                const unsigned long long TOK = VL & ~SEP;
+                const uint32_t slot = (tail + cw_below(TOK)) & (TOK_RING - 1u);
+                if (cw_lanes(TOK)) ring.e[slot] = make_uint2(p, token | pre);
+                tail += (uint32_t)__popcll(TOK);
+                SEPp = SEP;
+                COLp = COL;
+                ++c;
+                if (c == nchunks) sep_twice |= SEP >> (nvl - 1u);  // a separator behind the last token
+            };
+            TOK_PROF(1)
+#pragma unroll
+            for (uint32_t j = 0; j < TOK_AHEAD; ++j)
+                if (j < nchunks) ingest(P[j], B[j]);
+            TOK_PROF(2)
             while (ok) {
-                // ---- ingest chunks of 64 structurals until a token step has its 64 tokens ----
-                while (c < nchunks && tail - head < 64u) {
-                    const uint32_t nvl = n - c * 64u < 64u ? n - c * 64u : 64u;
-                    const unsigned long long VL = cw_first(nvl);
-                    const uint32_t p = p_cur, b0 = b_cur;
-                    p_cur = p_nxt;
-                    b_cur = b_nxt;
-                    p_nxt = p_nn;
-                    if (c + 2 < nchunks) b_nxt = a.buf[p_nxt];
-                    p_nn = c + 3 < nchunks ? load_pos(from, to, c + 3, doc_start) : doc_start;
-                    const uint32_t token = first_byte_token[b0];
-                    const unsigned long long COL = cw_ballot(b0 == ':') & VL;
-                    const unsigned long long SEP = (cw_ballot(b0 == ',') & VL) | COL;
-                    // what stands in front of a structural: the masks moved up by one lane, the previous chunk's last bit carried in
-                    const unsigned long long S1 = (SEP << 1) | (SEPp >> 63), C1 = (COL << 1) | (COLp >> 63);
-                    sep_twice |= SEP & S1;
-                    uint32_t pre = cw_lanes(S1) ? TOK_COMMA : 0u;
-                    pre = cw_lanes(C1) ? TOK_COLON : pre;
-                    const unsigned long long TOK = VL & ~SEP;
-                    const uint32_t slot = (tail + cw_below(TOK)) & 127u;
-                    if (cw_lanes(TOK)) ring.e[slot] = make_uint2(p, token | pre);
-                    tail += (uint32_t)__popcll(TOK);
-                    SEPp = SEP;
-                    COLp = COL;
-                    ++c;
-                    if (c == nchunks) sep_twice |= SEP >> (nvl - 1u);  // a separator behind the last token
+                // (a longer document: the rest of its chunks as the ring has room for them, each one a round trip of its own)
+                while (c < nchunks && tail - head <= TOK_RING - 64u) {
+                    const uint32_t p = load_pos(from, to, c, doc_start);
+                    ingest(p, a.buf[p]);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -1117,7 +1159,7 @@ k_tok_walk(TokArgs a_by_value) {
                 }
                 // ---- one token step ----
                 const uint32_t na = avail < 64u ? avail : 64u;
-                const uint2 re = ring.e[(head + (uint32_t)lane) & 127u];
+                const uint2 re = ring.e[(head + (uint32_t)lane) & (TOK_RING - 1u)];
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 // a step ends in front of an opening bracket whose successor is not at hand (is it an empty container?)
@@ -1148,11 +1190,12 @@ k_tok_walk(TokArgs a_by_value) {
                     ok = false;
                     break;
                 }
+                TOK_PROF(3)
                 const uint32_t excl = scan2 - inc;
                 const int h = H0 + (int)(excl & 0xFFFFu) - lane;
                 const uint32_t tpos = T0 + (excl >> 16);
                 const uint32_t sord = S0 + cw_below(Q);
-                const uint32_t rec_off = cw_lanes(Q) ? a.soff[sord] : 0u;  // (used one step later)
+                const uint32_t rec_off = (SJMI_TOK_ABL & 64) ? sord : (cw_lanes(Q) ? a.soff[sord] : 0u);  // (used one step later)
                 const unsigned long long DEEP = cw_ballot(h >= depth_limit);
                 const unsigned long long ROOT_END = cw_ballot(h == 1) & CLOSE;
                 // (4) the container of every token.  The opening brackets of the step put their lane into the word of their level
@@ -1213,7 +1256,18 @@ k_tok_walk(TokArgs a_by_value) {
                     break;
                 }
                 if (ROOT_END) root_closed = true;
+                TOK_PROF(4)
+                if (!bytes_requested) {
+                    // the next document's first bytes: its positions have had this document's ingest and most of a step to arrive,
+                    // and nothing younger than this step's record offsets is in flight (a wait here also waits for every store issued so far)
+                    bytes_requested = true;
+                    if (walkable(m_next)) {
+#pragma unroll
+                        for (uint32_t j = 0; j < TOK_AHEAD; ++j) BN[j] = a.buf[PN[j]];
+                    }
+                }
                 // (7) the tape words of this step
+                if (!(SJMI_TOK_ABL & 8) || pq_off == 0x12345678u)
                 if (cw_lanes(PQ)) T[pq_tpos] = tape_word('"', a.string_base + pq_off);  // the previous step's strings
                 PQ = Q;
                 pq_tpos = tpos;
@@ -1231,9 +1285,11 @@ k_tok_walk(TokArgs a_by_value) {
                     const uint32_t type_hi = __builtin_amdgcn_perm(token, 0u, 0x050C0C0Cu);  // the bracket itself << 24
                     uint32_t pay1 = cw_lanes(EC) ? tpos : par_tpos;
                     pay1 = cw_lanes(EO) ? tpos + 2u : pay1;
+                    if (!(SJMI_TOK_ABL & 8) || pay1 == 0x12345678u)
                     if (cw_lanes(EO | CLOSE)) T[tpos] = ((unsigned long long)type_hi << 32) | pay1;
                     uint32_t cnt = par_cnt + 1u;
                     if (cnt > 0xFFFFFFu) cnt = 0xFFFFFFu;
+                    if (!(SJMI_TOK_ABL & 8) || cnt == 0x12345678u)
                     if (cw_lanes(CLOSE & ~EC)) T[par_tpos] = ((unsigned long long)((type_hi - 0x02000000u) | cnt) << 32) | (tpos + 1u);
                 }
                 // (8) carries
@@ -1244,14 +1300,15 @@ k_tok_walk(TokArgs a_by_value) {
                 c_token = (uint32_t)__builtin_amdgcn_readlane((int)token, (int)lastv);
                 c_empty_open = cw_bit(EO, lastv);
                 head += nv;
-                if (qtail - qhead >= 64u) flush_primitives(64u);
+                TOK_PROF(5)
+                if (qtail - qhead >= 64u) { flush_primitives(64u); TOK_PROF(6) }
             }
             if (cw_lanes(PQ)) T[pq_tpos] = tape_word('"', a.string_base + pq_off);  // the last step's strings
             if (ok && !root_closed) ok = false;  // the root container is never closed (JsonIterator.java:39-41,:51-53)
             if (ok) {
                 tlen = T0 + 1;  // + the closing root word
                 if (tlen <= room) {
-                    if (lane == 0) {
+                    if (lane == 0 && (!(SJMI_TOK_ABL & 128) || tlen == 0x12345678u)) {
                         T[T0] = tape_word('r', 0);      // visitDocumentEnd, TapeBuilder.java:45-48
                         T[0] = tape_word('r', tlen);
                     }
@@ -1262,17 +1319,25 @@ k_tok_walk(TokArgs a_by_value) {
             }
         }
         if (lane == 0) {
-            if (a.tape_lens) a.tape_lens[k] = ok ? tlen : 0u;
+            if (a.tape_lens && (!(SJMI_TOK_ABL & 128) || tlen == 0x12345678u)) a.tape_lens[k] = ok ? tlen : 0u;
             if (!ok) send_to_exact(k);
+        }
+        if (!bytes_requested && walkable(m_next)) {
+#pragma unroll
+            for (uint32_t j = 0; j < TOK_AHEAD; ++j) BN[j] = a.buf[PN[j]];
         }
         m = m_next;
         t_end = t_end_next;
-        if (more_docs) {
-            p0 = load_pos(m.from, m.to, 0, m.doc_start);
-            p1 = load_pos(m.from, m.to, 1, m.doc_start);
+        m_next = m_after;
+        t_end_next = t_end_after;
+#pragma unroll
+        for (uint32_t j = 0; j < TOK_AHEAD; ++j) {
+            P[j] = PN[j];
+            B[j] = BN[j];
         }
     }
     if (qtail != qhead) flush_primitives(qtail - qhead);  // (fewer than 64 by construction)
+    TOK_PROF_END
 }
 
 // ---- the chunk passes around k_coop_walk<true> --------------------------------------------------------------------------
@@ -1790,3 +1855,14 @@ hipError_t tok_walk_launch(const TokLaunch& t, hipStream_t stream) {
 }
 
 }  // namespace sjmi
+
+#ifdef SJMI_TOK_PROF
+extern "C" int sjmi_debug_tok_prof(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(sjmi::g_tok_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sjmi::g_tok_prof), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
