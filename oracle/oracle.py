@@ -16,14 +16,32 @@ _AVX_PATH = os.path.join(_HERE, "liboracle_avx512.so")
 ST_UTF8, ST_UNCLOSED, ST_UNESCAPED = 1, 2, 4
 
 
+def _stale(target, deps):
+    return not os.path.exists(target) or os.path.getmtime(target) < max(os.path.getmtime(d) for d in deps)
+
+
 def build(force=False):
-    """Compile liboracle.so with gcc (portable flags so the .so also runs on the GPU box)."""
-    srcs = [os.path.join(_HERE, f) for f in ("sj_oracle.c", "sj_oracle.h", "sj_tables.h", "sj_avx512.c", "Makefile")]
-    newest = max(os.path.getmtime(f) for f in srcs)
-    if (not force and os.path.exists(_LIB_PATH) and os.path.exists(_AVX_PATH)
-            and min(os.path.getmtime(_LIB_PATH), os.path.getmtime(_AVX_PATH)) >= newest):
+    """Compile liboracle.so / liboracle_avx512.so with gcc (portable flags so that the .so also runs on the GPU box; the same commands
+    as `make portable`).  Each library is checked against ITS sources, compiled into a temporary file and renamed into place under a
+    file lock: N ranks of a node that find something stale at the same time must never see (or write) half a library."""
+    import fcntl
+    src = lambda *names: [os.path.join(_HERE, f) for f in names]
+    jobs = [(_LIB_PATH, src("sj_oracle.c", "sj_oracle.h", "sj_tables.h"), ["-O3", "-std=gnu11", "-fPIC", "-shared"]),
+            (_AVX_PATH, src("sj_avx512.c", "sj_oracle.h", "sj_tables.h"),
+             ["-O3", "-std=gnu11", "-fPIC", "-mavx512f", "-mavx512bw", "-mbmi", "-mbmi2", "-mlzcnt", "-mpopcnt", "-shared"])]
+    if not force and not any(_stale(t, d) for t, d, _ in jobs):
         return _LIB_PATH
-    subprocess.check_call(["make", "-C", _HERE, "portable"], stdout=subprocess.DEVNULL)
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            for target, deps, flags in jobs:
+                if not force and not _stale(target, deps):
+                    continue  # (another process built it while this one waited for the lock)
+                tmp = "%s.tmp.%d" % (target, os.getpid())
+                subprocess.check_call([os.environ.get("CC", "gcc")] + flags + ["-o", tmp, deps[0]], stdout=subprocess.DEVNULL)
+                os.replace(tmp, target)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return _LIB_PATH
 
 

@@ -48,11 +48,13 @@ def build(force=False, verbose=False):
         [os.path.join(_ROOT, "include", "sjmi.h")]
     if not force and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= max(os.path.getmtime(d) for d in deps):
         return _LIB
+    tmp = "%s.tmp.%d" % (_LIB, os.getpid())  # (renamed into place: a process that loads the library never sees half of it)
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-           "-I", os.path.join(_ROOT, "include")] + srcs + ["-o", _LIB]
+           "-I", os.path.join(_ROOT, "include")] + srcs + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    os.replace(tmp, _LIB)
     return _LIB
 
 

@@ -88,8 +88,16 @@ def build_docgen(force=False):
     """gcc -> tools/libdocgen.so (in-tree, travels to the GPU box; __graft_entry__.build() calls this)"""
     import subprocess
     src, lib = os.path.join(ROOT, "tools", "docgen.c"), os.path.join(ROOT, "tools", "libdocgen.so")
-    if force or not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", lib, src])
+    stale = lambda: not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src)
+    if force or stale():
+        import fcntl
+        # (compiled into a temporary file and renamed into place under a lock: several ranks may get here at once)
+        with open(os.path.join(ROOT, "tools", ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or stale():
+                tmp = "%s.tmp.%d" % (lib, os.getpid())
+                subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", tmp, src])
+                os.replace(tmp, lib)
     return lib
 
 
