@@ -1308,10 +1308,8 @@ k_tok_walk(TokArgs a_by_value) {
             if (ok) {
                 tlen = T0 + 1;  // + the closing root word
                 if (tlen <= room) {
-                    if (lane == 0 && (!(SJMI_TOK_ABL & 128) || tlen == 0x12345678u)) {
-                        T[T0] = tape_word('r', 0);      // visitDocumentEnd, TapeBuilder.java:45-48
-                        T[0] = tape_word('r', tlen);
-                    }
+                    // visitDocumentEnd, TapeBuilder.java:45-48: both root words in ONE store (lane 0 the closing one, lane 1 the opening one)
+                    if (lane < 2 && (!(SJMI_TOK_ABL & 128) || tlen == 0x12345678u)) T[lane == 0 ? T0 : 0u] = tape_word('r', lane == 0 ? 0u : tlen);
                 } else {
                     ok = false;  // (no room: the exact walker reports it)
                     tlen = 0;

@@ -311,7 +311,7 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
         t.d_scratch = optimistic_only ? nullptr : scratch;
         t.header_zeroed = layout_done;
         t.d_sel = d_prepared;
-        t.d_tape_lens = lens;
+        t.d_tape_lens = optimistic_only ? nullptr : lens;  // (read by the passes that pack scratch tapes: none of them behind tapes laid out in advance)
         t.d_doc_errors = d_doc_errors;
         t.d_list = list;
         t.dev_count = dev_count;
