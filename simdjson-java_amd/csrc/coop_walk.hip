@@ -42,6 +42,7 @@
 
 #include "sj_number.h"
 #include "sj_bigdec.h"
+#include "sj_tokens.h"
 #include "stage1.h"
 
 namespace sjmi {
@@ -890,10 +891,7 @@ struct TokArgs {
     const Stage1Result* dev_count;
     const UnescapeResult* dev_strings;
 };
-// Token kinds of the batch walker (its own numbering: what a token step needs is a compare or a table index away)
-enum : uint32_t { TK_OPEN_A = 0, TK_OPEN_O = 1, TK_CLOSE_A = 2, TK_CLOSE_O = 3, TK_STRING = 4, TK_NONE = 5, TK_ATOM = 6, TK_NUMBER = 7 };
-// A token as the ring holds it: TK_* | ',' in front << 3 | ':' in front << 4 | depth field of the scan (1 + up - down) << 5 | first byte << 8 | its tape words << 21
-constexpr uint32_t TOK_COMMA = 8u, TOK_COLON = 16u, TOK_SCAN_FIELDS = 0x00600060u;
+// (token kinds, the first-byte table and the grammar table: sj_tokens.h, shared with the CPU test)
 constexpr uint32_t TOK_RING = 256u;   // a document of up to 256 structurals is ingested whole, before its first token step
 constexpr uint32_t TOK_AHEAD = 4u;    // chunks of 64 structurals whose positions / first bytes are requested a document ahead
 struct __attribute__((aligned(8))) TokRing {
@@ -929,38 +927,6 @@ __device__ __forceinline__ uint32_t cw_below(unsigned long long m) {
 }
 __device__ __forceinline__ unsigned long long cw_first(uint32_t n) { return ~0ull >> (64u - n); }  // lanes [0, n), 1 <= n <= 64
 __device__ __forceinline__ uint32_t cw_bit(unsigned long long m, uint32_t i) { return (uint32_t)(m >> i) & 1u; }
-// the token of a structural's first byte (separators: TK_NONE, they never reach the ring)
-__device__ inline uint32_t tok_of_first_byte(uint32_t b) {
-    const uint32_t k = class_of(b);
-    const bool num = b == '-' || b - '0' <= 9u;
-    const uint32_t tk = k <= K_CLOSE_O ? k : (k == K_QUOTE ? (uint32_t)TK_STRING : (k == K_PRIM ? (num ? (uint32_t)TK_NUMBER : (uint32_t)TK_ATOM) : (uint32_t)TK_NONE));
-    if (tk == TK_NONE) return tk;
-    const uint32_t field = tk <= TK_OPEN_O ? 2u : (tk <= TK_CLOSE_O ? 0u : 1u), words = tk == TK_NUMBER ? 2u : 1u;
-    return tk | (field << 5) | (b << 8) | (words << 21);
-}
-// The token grammar, JsonIterator.java:68-193 re-keyed for tokens: i = token (TK_* | TOK_COMMA | TOK_COLON) | the same five bits
-// of the previous token << 5 | my container is an array << 10.  Every earlier token of the document was good (one bad token
-// fails the document), so what came before is known from the previous token alone:
-//     nothing (TK_NONE)            the root: an opening bracket, nothing in front (any other root: the exact walker)
-//     '['                          no separator; a value, or ']' (the empty array, TapeBuilder.java:205-208)
-//     '{'                          no separator; a key, or '}'
-//     a key                        ':' and a value      (a string is a key: in an object, and no ':' in front of it)
-//     a value                      ',' and a value (array) / a key (object), or no separator and the container's own closing bracket
-__device__ inline uint32_t tok_grammar(uint32_t i) {
-    const uint32_t tk = i & 7u, prev = (i >> 5) & 7u;
-    const bool comma = (i & TOK_COMMA) != 0, colon = (i & TOK_COLON) != 0, prev_colon = ((i >> 5) & TOK_COLON) != 0, arr = ((i >> 10) & 1u) != 0;
-    const bool close = tk == TK_CLOSE_A || tk == TK_CLOSE_O;
-    if (tk == TK_NONE) return 1u;  // (a lane without a token)
-    if (comma && colon) return 0u;
-    if (prev == TK_NONE) return (tk <= TK_OPEN_O && !comma && !colon) ? 1u : 0u;
-    if (prev == TK_OPEN_A) return (!comma && !colon && tk != TK_CLOSE_O) ? 1u : 0u;                     // :68-77
-    if (prev == TK_OPEN_O) return (!comma && !colon && (tk == TK_STRING || tk == TK_CLOSE_O)) ? 1u : 0u;
-    if (prev == TK_STRING && !arr && !prev_colon) return (colon && !close) ? 1u : 0u;                    // :84-86
-    if (comma) return (arr ? !close : tk == TK_STRING) ? 1u : 0u;                                        // :121-123
-    if (colon) return 0u;
-    return tk == (arr ? (uint32_t)TK_CLOSE_A : (uint32_t)TK_CLOSE_O) ? 1u : 0u;                          // :131,:189
-}
-
 #ifndef SJMI_TOK_WAVES
 #define SJMI_TOK_WAVES 6
 #endif
@@ -994,9 +960,9 @@ k_tok_walk(TokArgs a_by_value) {
     __shared__ PrimQueue queues[4];
     __shared__ TokLevels levels[4];
     __shared__ uint32_t first_byte_token[256];
-    __shared__ uint8_t grammar[2048];
+    __shared__ uint8_t grammar[TOK_GRAMMAR_ENTRIES];
     first_byte_token[threadIdx.x] = tok_of_first_byte(threadIdx.x);
-    for (uint32_t i = threadIdx.x; i < 2048u; i += 256u) grammar[i] = (uint8_t)tok_grammar(i);
+    for (uint32_t i = threadIdx.x; i < TOK_GRAMMAR_ENTRIES; i += 256u) grammar[i] = (uint8_t)tok_grammar(i);
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
