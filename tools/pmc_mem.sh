@@ -1,12 +1,12 @@
 #!/bin/bash
-# memory-pipeline counters of k_tok_walk (TA / TCP / LDS), tools/batch_nocheck.py; run on the GPU box: tools/pmc_mem.sh lib ...
+# memory-pipeline counters of k_tok_walk (VMEM issue, LDS), tools/batch_nocheck.py; run on the GPU box: tools/pmc_mem.sh lib ...
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 K=${PMC_KERNEL:-k_tok}
 for lib in "$@"; do
   if [ "$lib" = base ]; then unset SJMI_LIB; else export SJMI_LIB=$R/tools/variants/libsjmi_$lib.so; fi
-  for set in "TA_BUSY_avr TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE" \
-             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_GATE_EN1_sum" \
+  # (TA_* and TCP_* counter sets hung rocprofv3 on these boxes -- two 200 s timeouts -- and were taken out)
+  for set in \
              "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM SQ_WAVE_CYCLES" \
              "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS_ATOMIC SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_LDS SQ_BUSY_CYCLES"; do
   rm -rf /tmp/pm_$lib
