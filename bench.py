@@ -775,8 +775,9 @@ def trees_1024(S, doc, reps=1024, iters=3):
             # what the link alone costs: the batch in, indexes (4 B per structural) + string records out, one direction at a time
             # at the ~57 GB/s tools/pcie.py measures on these boxes (both directions at once halve each): NOT GPU time
             "pcie_floor_ms": round((host.size + 4 * 55263 * reps + 440313 * reps) / 57e9 * 1e3, 2),
-            "pcie_floor": "bytes in + uint32 indexes + string records out = %d MB at 57 GB/s one way at a time (tools/pcie.py); the "
-                          "GPU kernels of this batch take ~1 ms" % ((host.size + 4 * 55263 * reps + 440313 * reps) // 1000000)}
+            "pcie_floor": "bytes in + uint32 indexes + string records out = %d MB at 57 GB/s one way at a time (tools/pcie.py; the "
+                          "link's rate differs by +-5 %% between boxes, so a batch can come in just under this figure); the GPU kernels "
+                          "of this batch take ~1 ms" % ((host.size + 4 * 55263 * reps + 440313 * reps) // 1000000)}
 
 
 def batch_single_gpu(torch, S, W, dev, work, args, with_h2d=True, n_docs=None, check=True):
