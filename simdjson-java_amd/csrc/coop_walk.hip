@@ -930,6 +930,9 @@ __device__ __forceinline__ uint32_t cw_bit(unsigned long long m, uint32_t i) { r
 #ifndef SJMI_TOK_WAVES
 #define SJMI_TOK_WAVES 6
 #endif
+// (measurement builds only: TOK_KEPT(bit, v) is false when `bit` of SJMI_TOK_ABL compiles a store out -- unless its value is a number
+//  it never is, so that whatever computes the value stays in the kernel; in the product build it is the constant true)
+#define TOK_KEPT(bit, v) (!(SJMI_TOK_ABL & (bit)) || (v) == 0x12345678u)
 #ifndef SJMI_TOK_ABL
 #define SJMI_TOK_ABL 0   // (measurement only, tools/abl_tok.sh: 1 no literal parsing, 8 no bracket / string words, 16 no step body, 32 no literal words, 64 no string record offsets)
 #endif
@@ -992,11 +995,11 @@ k_tok_walk(TokArgs a_by_value) {
             uint32_t ptype = 0;
             unsigned long long praw = 0;
             if (SJMI_TOK_ABL & 1) {
-                if (!(SJMI_TOK_ABL & 32) || win.a == 0x12345678u) dst[0] = tape_word('n', win.a & 1u);
+                if (TOK_KEPT(32, win.a)) dst[0] = tape_word('n', win.a & 1u);
             } else if (cw_primitive(a.buf, win, p, false, 0u, &ptype, &praw) == 0) {
-                if (!(SJMI_TOK_ABL & 32) || praw == 0x12345678u) {
-                dst[0] = tape_word(ptype, 0);
-                if (ptype == 'l' || ptype == 'd') dst[1] = praw;
+                if (TOK_KEPT(32, praw)) {
+                    dst[0] = tape_word(ptype, 0);
+                    if (ptype == 'l' || ptype == 'd') dst[1] = praw;
                 }
             } else {
                 send_to_exact(doc);
@@ -1233,8 +1236,7 @@ k_tok_walk(TokArgs a_by_value) {
                     }
                 }
                 // (7) the tape words of this step
-                if (!(SJMI_TOK_ABL & 8) || pq_off == 0x12345678u)
-                if (cw_lanes(PQ)) T[pq_tpos] = tape_word('"', a.string_base + pq_off);  // the previous step's strings
+                if (cw_lanes(PQ) && TOK_KEPT(8, pq_off)) T[pq_tpos] = tape_word('"', a.string_base + pq_off);  // the previous step's strings
                 PQ = Q;
                 pq_tpos = tpos;
                 pq_off = rec_off;
@@ -1251,12 +1253,10 @@ k_tok_walk(TokArgs a_by_value) {
                     const uint32_t type_hi = __builtin_amdgcn_perm(token, 0u, 0x050C0C0Cu);  // the bracket itself << 24
                     uint32_t pay1 = cw_lanes(EC) ? tpos : par_tpos;
                     pay1 = cw_lanes(EO) ? tpos + 2u : pay1;
-                    if (!(SJMI_TOK_ABL & 8) || pay1 == 0x12345678u)
-                    if (cw_lanes(EO | CLOSE)) T[tpos] = ((unsigned long long)type_hi << 32) | pay1;
+                    if (cw_lanes(EO | CLOSE) && TOK_KEPT(8, pay1)) T[tpos] = ((unsigned long long)type_hi << 32) | pay1;
                     uint32_t cnt = par_cnt + 1u;
                     if (cnt > 0xFFFFFFu) cnt = 0xFFFFFFu;
-                    if (!(SJMI_TOK_ABL & 8) || cnt == 0x12345678u)
-                    if (cw_lanes(CLOSE & ~EC)) T[par_tpos] = ((unsigned long long)((type_hi - 0x02000000u) | cnt) << 32) | (tpos + 1u);
+                    if (cw_lanes(CLOSE & ~EC) && TOK_KEPT(8, cnt)) T[par_tpos] = ((unsigned long long)((type_hi - 0x02000000u) | cnt) << 32) | (tpos + 1u);
                 }
                 // (8) carries
                 const uint32_t lastv = nv - 1u;
@@ -1275,7 +1275,7 @@ k_tok_walk(TokArgs a_by_value) {
                 tlen = T0 + 1;  // + the closing root word
                 if (tlen <= room) {
                     // visitDocumentEnd, TapeBuilder.java:45-48: both root words in ONE store (lane 0 the closing one, lane 1 the opening one)
-                    if (lane < 2 && (!(SJMI_TOK_ABL & 128) || tlen == 0x12345678u)) T[lane == 0 ? T0 : 0u] = tape_word('r', lane == 0 ? 0u : tlen);
+                    if (lane < 2 && TOK_KEPT(128, tlen)) T[lane == 0 ? T0 : 0u] = tape_word('r', lane == 0 ? 0u : tlen);
                 } else {
                     ok = false;  // (no room: the exact walker reports it)
                     tlen = 0;
@@ -1283,7 +1283,7 @@ k_tok_walk(TokArgs a_by_value) {
             }
         }
         if (lane == 0) {
-            if (a.tape_lens && (!(SJMI_TOK_ABL & 128) || tlen == 0x12345678u)) a.tape_lens[k] = ok ? tlen : 0u;
+            if (a.tape_lens && TOK_KEPT(128, tlen)) a.tape_lens[k] = ok ? tlen : 0u;
             if (!ok) send_to_exact(k);
         }
         if (!bytes_requested && walkable(m_next)) {
