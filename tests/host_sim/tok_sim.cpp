@@ -67,3 +67,7 @@ int sim_tok_walk(const uint8_t* doc, const uint32_t* structurals, uint32_t n, in
     return 1;
 }
 }
+
+// the two tables themselves, for the lane-level model of the kernel (tools/tok_walk_model.py)
+extern "C" uint32_t sim_tok_of_first_byte(uint32_t b) { return tok_of_first_byte(b); }
+extern "C" uint32_t sim_tok_grammar(uint32_t i) { return tok_grammar(i); }
