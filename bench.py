@@ -207,6 +207,7 @@ def roofline(alg_bytes, ms, input_bytes, kernel, launches, traffic=None, **more)
          "frac_all_algorithmic_bytes": round(alg_bytes / s / 1e9 / HBM_PEAK_GBS, 4)}
     if traffic is not None:
         r["traffic_source"] = pmc_source()
+        r["traffic_stale"] = pmc_stale()
     r.update(more)
     return r
 
@@ -218,6 +219,17 @@ def pmc_traffic(key):
             return int(json.load(f)[key]["hbm_traffic_bytes_per_launch"]["total"])
     except (OSError, KeyError, ValueError, TypeError):
         return None
+
+
+def pmc_stale():
+    """True when the kernels' sources have changed since the PMC summary was collected (tools/csrc_digest.py): `traffic` then
+    describes other kernels than the ones this run timed."""
+    import csrc_digest
+    try:
+        with open(os.path.join(PROFILE_DIR, "pmc_summary.json")) as f:
+            return bool(csrc_digest.traffic_stale(json.load(f), ROOT)[0])
+    except (OSError, ValueError):
+        return True
 
 
 def pmc_source():
@@ -573,7 +585,7 @@ def bench_single(args):
             "value": round(n1 / ums / 1e6, 2), "unit": "GB/s of document",
             "roofline": {"bound": "hbm", "achieved": round(ualg / ums / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ualg / ums / 1e6 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("unescape_twitter_x1024"),
-                         "traffic_source": pmc_source(),
+                         "traffic_source": pmc_source(), "traffic_stale": pmc_stale(),
                          "kernel": "k_strings (one streaming pass; + the memsets of its chain state and result record)", "avg_ms_per_call": round(ums, 4),
                          "algorithmic_bytes_per_launch": ualg,
                          "algorithmic_bytes": "string bytes incl. quotes read (%d) + 4 B index word per string + records written (%d), per copy"
@@ -680,6 +692,10 @@ def bench_single(args):
     put("configs3_batch_oracle_checked_documents", "batch_1m_docs", "oracle_checked_documents")
     put("configs3_batch_oracle_digest_checked_documents", "batch_1m_docs", "oracle_digest_checked_documents")
     put("configs3_batch_docs_per_s_incl_h2d", "batch_1m_docs", "incl_h2d", "value")
+    put("configs3_batch_exact_ms", "batch_1m_docs", "rejected_path", "exact_ms")
+    put("configs3_batch_one_bad_doc_ms", "batch_1m_docs", "rejected_path", "one_bad_doc_ms")
+    put("configs3_batch_one_bad_doc_stage2_ms", "batch_1m_docs", "rejected_path", "one_bad_doc_stage2_ms")
+    put("configs3_batch_no_separator_ms", "batch_1m_docs", "rejected_path", "no_separator_ms")
     put("parse_twitter_json_all_device_ms", "parse_single_document", "twitter_json", "gpu_walker", "ms")
     put("parse_twitter_json_host_walker_ms", "parse_single_document", "twitter_json", "host_walker", "ms")
     put("configs4_1024_trees_ms", "twitter_x1024_as_1024_trees", "value")
@@ -805,10 +821,12 @@ def batch_single_gpu(torch, S, W, dev, work, args, with_h2d=True, n_docs=None, c
            "documents": n_docs, "oracle_checked_documents": checked, "oracle_digest_checked_documents": checked_all,
            "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("batch_1m_docs"),
-                        "traffic_source": pmc_source(),
+                        "traffic_source": pmc_source(), "traffic_stale": pmc_stale(),
                         "kernel": BATCH_KERNELS,
                         "algorithmic_bytes_per_launch": alg,
                         "algorithmic_bytes": "input read once + uint32 indexes + string records + tape words written once"}}
+    if check:
+        out["rejected_path"] = batch_rejected_path(torch, oracle, shard, offs, st, ms, max(3, args.batch_steps // 4))
     if with_h2d:
         host = torch.empty(shard.n, dtype=torch.uint8).pin_memory()
         host.copy_(shard.buf[:shard.n])
@@ -824,6 +842,79 @@ def batch_single_gpu(torch, S, W, dev, work, args, with_h2d=True, n_docs=None, c
                            "note": "pinned host buffer -> HBM copy of the batch inside every step (outputs stay on the device)"}
     ctx.close()
     return out
+
+
+def batch_rejected_path(torch, oracle, shard, offs, st, accepted_ms, steps):
+    """What a batch costs that the optimistic pipeline does NOT take (the reference isolates a bad document for free: one
+    JsonParsingException per parse, SimdJsonParser.java:35-40).  Same documents as the accepted figure, every variant compared per
+    document with the oracle (check_batch_all) before it is timed:
+      exact           sjmi_parse_batch_device on the unchanged batch (everything queued, the device decides);
+      one_bad_doc     ONE document of the batch fails stage 1 (a 0xFF byte inside its last string): optimistic call ->
+                      SJMI_ST_REJECTED -> BatchShard.check() makes the exact call -- the whole cliff, both calls and the host
+                      round trip between them, per batch;
+      one_bad_doc_stage2   ONE document fails stage 2 only (its last '}' replaced by ']'): the plain pass is accepted, the token
+                      walker declines the document, the exact walker (list mode) reports its error -- no rejection;
+      no_separator    the '\\n' behind every document replaced by a space: no control-character separators -> rejected -> exact."""
+    import numpy as np
+    n_docs = shard.n_docs
+    res = {}
+
+    def timed(fn):
+        fn()
+        el = wall_steps(torch, fn, steps)
+        return round(el / steps * 1e3, 3)
+
+    def cliff():
+        shard.rejected_steps = 0
+        shard.step(st)
+        torch.cuda.synchronize()
+        return shard.check()
+
+    def verified(label, want_failed):
+        c = shard.check()
+        assert c["failed_documents"] == want_failed and c["host_documents"] == 0, (label, c)
+        return check_batch_all(torch, oracle, shard, offs)
+
+    # exact call, unchanged batch
+    shard.step(st, exact=True)
+    torch.cuda.synchronize()
+    verified("exact", 0)
+    res["exact_ms"] = timed(lambda: shard.step(st, exact=True))
+    k = n_docs // 2
+    end = int(offs[k + 1])
+    # one document fails stage 2 only: "...}\n" -> "...]\n"
+    keep = shard.buf[end - 2].clone()
+    shard.buf[end - 2] = 0x5D
+    shard.rejected_steps = 0
+    c = cliff()
+    assert getattr(shard, "rejected_steps", 0) == 0, "a stage-2 failure must not reject the batch"
+    verified("one_bad_doc_stage2", 1)
+    res["one_bad_doc_stage2_ms"] = timed(lambda: shard.step(st))
+    shard.buf[end - 2] = keep
+    # one document fails stage 1: 0xFF inside the filler string ("...x\"}\n": the byte in front of the closing quote)
+    keep = shard.buf[end - 4].clone()
+    shard.buf[end - 4] = 0xFF
+    cliff()
+    assert shard.rejected_steps == 1
+    verified("one_bad_doc", 1)
+    res["one_bad_doc_ms"] = timed(cliff)
+    shard.buf[end - 4] = keep
+    # no separators
+    sep = torch.from_numpy(np.asarray(offs[1:], dtype=np.int64) - 1).to(shard.buf.device)
+    shard.buf[sep] = 0x20
+    cliff()
+    assert shard.rejected_steps == 1
+    verified("no_separator", 0)
+    res["no_separator_ms"] = timed(cliff)
+    shard.buf[sep] = 0x0A
+    shard.rejected_steps = 0
+    shard.step(st)
+    torch.cuda.synchronize()
+    verified("restored", 0)
+    res["accepted_ms"] = accepted_ms
+    res["one_bad_doc_over_accepted"] = round(res["one_bad_doc_ms"] / accepted_ms, 2)
+    res["oracle_checked"] = "every variant: all %d documents per document against the oracle before timing" % n_docs
+    return res
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -179,7 +179,8 @@ typedef struct sjmi_unescape_result {
     uint64_t first_error_inv;  /* 0 = every string is fine; else ~((p << 8) | SJMI_E_* code) of the first failing string, p = byte
                                   offset of the offending escape in the document (sjmi_unescape_device, sjmi_parse_*), or the
                                   string's position in indexes[] (sjmi_unescape_batch_device) */
-    uint32_t flags;            /* bit 0: string_buffer capacity exceeded; bits 2-3: engine fault (results invalid) */
+    uint32_t flags;            /* bit 0: string_buffer capacity exceeded; bit 1: more strings than the record table holds
+                                * (index_capacity - 1 + 64 entries: raise index_capacity; no tape is built); bits 2-3: engine fault (results invalid) */
     uint32_t n_strings;        /* string literals of the document (sjmi_unescape_device) */
 } sjmi_unescape_result;
 

@@ -180,6 +180,9 @@ final class Sjmi {
             this.capacity = capacity;
             Arena arena = Arena.ofShared();
             MemorySegment c = null;
+            // the segments page-locked so far: a failure half way through must unregister exactly these before the arena frees
+            // their memory (memory freed while still registered leaks the pin and leaves a stale registration behind)
+            java.util.ArrayList<MemorySegment> registered = new java.util.ArrayList<>(3);
             try {
                 c = create(device, capacity);
                 in = arena.allocate((long) capacity + padding, 64);
@@ -189,29 +192,31 @@ final class Sjmi {
                 MemorySegment[] pinned = {in, indexes, strings};
                 for (MemorySegment p : pinned) {
                     check((int) HOST_REGISTER.invokeExact(c, p, p.byteSize()), "sjmi_host_register", c);
+                    registered.add(p);
                 }
                 check((int) SET_INPUT_STAGING.invokeExact(c, in, in.byteSize()), "sjmi_set_input_staging", c);
                 ctx = c;
                 cleanable = CLEANER.register(owner, new Native(arena, c, pinned));
             } catch (RuntimeException | Error e) {
-                destroyQuietly(c, arena);
+                destroyQuietly(c, arena, registered);
                 throw e;
             } catch (Throwable t) {
-                destroyQuietly(c, arena);
+                destroyQuietly(c, arena, registered);
                 throw new IllegalStateException(t);
             }
         }
 
-        private static void destroyQuietly(MemorySegment c, Arena arena) {
+        private static void destroyQuietly(MemorySegment c, Arena arena, java.util.List<MemorySegment> registered) {
             try {
                 if (c != null) {
-                    DESTROY.invokeExact(c);
+                    // (the partially built state goes through the same action the Cleaner would run for a complete one)
+                    new Native(arena, c, registered.toArray(new MemorySegment[0])).run();
+                    return;
                 }
             } catch (Throwable ignored) {
                 // keep the original failure
-            } finally {
-                arena.close();
             }
+            arena.close();
         }
 
         /**

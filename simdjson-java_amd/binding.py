@@ -41,20 +41,49 @@ def lib_path():
 
 
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> simdjson-java_amd/libsjmi.so (in-tree; cross-compiles without a GPU)."""
+    """hipcc --offload-arch=gfx950 -> simdjson-java_amd/libsjmi.so (in-tree; cross-compiles without a GPU).  Under a file lock
+    with the staleness check repeated behind it (N ranks of a node that find the library stale at the same time: one builds, the
+    others wait and load its result); every source compiled to an object of its own (in parallel, only what changed), then linked
+    into a temporary file that is renamed into place -- a process that loads the library never sees half of it."""
+    import fcntl
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(_CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(_CSRC, h) for h in os.listdir(_CSRC) if h.endswith(".h")] + \
-        [os.path.join(_CSRC, "host", "simdjson_parser.h")] + \
+    headers = [os.path.join(_CSRC, h) for h in os.listdir(_CSRC) if h.endswith(".h")] + \
+        [os.path.join(_CSRC, "host", h) for h in os.listdir(os.path.join(_CSRC, "host")) if h.endswith(".h")] + \
         [os.path.join(_ROOT, "include", "sjmi.h")]
-    if not force and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= max(os.path.getmtime(d) for d in deps):
+    newest = max(os.path.getmtime(d) for d in srcs + headers)
+    fresh = lambda: os.path.exists(_LIB) and os.path.getmtime(_LIB) >= newest
+    if not force and fresh():
         return _LIB
-    tmp = "%s.tmp.%d" % (_LIB, os.getpid())  # (renamed into place: a process that loads the library never sees half of it)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-           "-I", os.path.join(_ROOT, "include")] + srcs + ["-o", tmp]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(tmp, _LIB)
+    objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and fresh():
+                return _LIB  # (another process built it while this one waited for the lock)
+            newest_h = max(os.path.getmtime(h) for h in headers)
+            flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-I", os.path.join(_ROOT, "include")]
+
+            def compile_one(src):
+                obj = os.path.join(objdir, os.path.basename(src) + ".o")
+                if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_h):
+                    cmd = ["hipcc"] + flags + ["-c", src, "-o", obj]
+                    if verbose:
+                        print(" ".join(cmd))
+                    subprocess.check_call(cmd)
+                return obj
+
+            with ThreadPoolExecutor(min(len(srcs), os.cpu_count() or 1)) as ex:
+                objs = list(ex.map(compile_one, srcs))
+            tmp = "%s.tmp.%d" % (_LIB, os.getpid())
+            cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread"] + objs + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(tmp, _LIB)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return _LIB
 
 

@@ -1243,7 +1243,10 @@ static int parse_batch_pipeline(sjmi_ctx* c, const void* d_buf, uint64_t total_l
     const uint64_t bound = index_capacity - 1;
     const uint64_t soff_cap = bound + 64;
     static const bool optimistic = !(getenv("SJMI_BATCH_OPTIMISTIC") && atoi(getenv("SJMI_BATCH_OPTIMISTIC")) == 0);
-    const bool try_plain = optimistic && n_docs && total_len && !((uintptr_t)d_buf & 15) && !((uintptr_t)d_indexes & 15);
+    // (a batch of ONE document has no token-walker path behind tapes laid out in advance -- walk_launch takes the cooperative
+    //  walker for it -- so the optimistic entry rejects it like any other batch it cannot take; the exact entry serves it)
+    const bool try_plain = optimistic && n_docs && total_len && !((uintptr_t)d_buf & 15) && !((uintptr_t)d_indexes & 15) &&
+                           !(optimistic_only && n_docs < 2);
     if (!grow(c, &c->d_ws_walk, &c->ws_walk_bytes, sjmi::walk_workspace_bytes(bound, n_docs), "hipMalloc(ws_walk)")) return SJMI_ERR_HIP;
     c->accept_valid = false;
     if (!try_plain) {

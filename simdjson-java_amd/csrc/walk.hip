@@ -79,7 +79,9 @@ k_tape_chunk_scan(unsigned long long* __restrict__ chunk_sums, uint64_t nchunks,
         tape_offsets[0] = 0;  // (the others: k_tape_compact; a single document written in place has no other)
         tape_offsets[n_docs] = carry;
         res->tape_words = carry;
-        if (carry > tape_capacity) res->flags |= 1u;
+        // (assigned, not OR-ed: behind k_batch_layout -- which judged the PREDICTED lengths of an accepted batch -- this pass
+        //  packs by the ACTUAL lengths of the cooperative walker, and a document that failed stage 2 has no tape at all)
+        res->flags = (res->flags & ~1u) | (carry > tape_capacity ? 1u : 0u);
     }
 }
 

@@ -122,6 +122,10 @@ class BatchShard:
             raise RuntimeError("stage 1 of the shard: capacity / internal error (status 0x%x)" % st1)
         if sflags & 1:
             raise RuntimeError("string buffer capacity exceeded")
+        if sflags & 2:  # (the walkers read record offsets by string ordinal: with the table short they walk nothing)
+            raise RuntimeError("more strings than the record table holds: index capacity exceeded")
+        if sflags & 0xC:
+            raise RuntimeError("string pass: engine fault (flags 0x%x)" % sflags)
         if wflags & 1:
             raise RuntimeError("tape capacity exceeded")
         return {"documents": self.n_docs, "structurals": int(r[0]), "string_bytes": int(r[2]), "tape_words": int(r[5]),

@@ -161,6 +161,27 @@ def test_optimistic_plain_pass_and_its_rejections(separator, exact, monkeypatch)
         ctx.close()
 
 
+@pytest.mark.parametrize("exact", [False, True], ids=["optimistic_entry", "exact_entry"])
+def test_a_batch_of_one_document(exact):
+    """A shard that holds ONE document (a rank's share of a tiny batch): the optimistic entry has no token-walker path for it and
+    must say SJMI_ST_REJECTED -- not fail with a HIP error and a half-written record (round 5's advisor finding) -- so that
+    check() makes the exact call; the exact entry serves it directly.  Valid, failing stage 2, failing stage 1."""
+    import simdjson_java_amd as S
+    ctx = S.Context(0, 1 << 20)
+    try:
+        for d in (b'{"a":[1,2.5,"x\\n"],"b":{"c":null}}', b"[1 1]", b'["abc', b"7"):
+            buf = d + b"\n"
+            offs = np.array([0, len(buf)], dtype=np.uint64)
+            c, tape, to, err, strings, io, idx = _run_shard(ctx, buf, offs, 1, exact=exact, want_rejected=True)
+            want = O.parse(buf)
+            assert int(err[0]) == want.error, (d, int(err[0]), want.error)
+            assert c["failed_documents"] == (1 if want.error else 0) and c["host_documents"] == 0
+            if not want.error:
+                assert O.Parsed(tape[int(to[0]):int(to[1])], strings, 0, 0, 0).to_python() == want.to_python(), d
+    finally:
+        ctx.close()
+
+
 def test_accepted_batch_with_strings_that_are_not_structurals():
     """A quote directly behind a primitive (1"abc", true"x") opens a string for the string pass without being a structural
     (StructuralIndexer.java:243-248: a scalar start needs a non-scalar in front of it).  Such a document passes stage 1 and fails

@@ -12,7 +12,8 @@ for f in ("kernel_stats.csv", "kernel_durations.json", "pmc_calibration.json", "
     shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 p = os.path.join(dst, "pmc_summary.json")
 d = json.load(open(p))
-d["_collected"] = {"commit": commit, "date": time.strftime("%Y-%m-%d"), "by": "tools/prof_round.sh %s on one MI355X via gpurun" % rd,
+stamp = d.get("_collected", {})
+d["_collected"] = {"csrc_digest": stamp.get("csrc_digest"), "commit": commit, "date": time.strftime("%Y-%m-%d"), "by": "tools/prof_round.sh %s on one MI355X via gpurun" % rd,
                    "note": "kernels of this commit; later commits of the round that do not touch csrc/ leave the figures valid"}
 json.dump(d, open(p, "w"), indent=1)
 print("installed", dst, "commit", commit)

@@ -115,6 +115,9 @@ for sec, key in KEY.items():
                                                      "fetch_factor": ff, "write_factor": wf,
                                                      "note": "sum over the kernels of one step of this section; counters in KiB x calibration factor; total = every FETCH "
                                                              "counter x the wide-read factor (upper bound), total_lower_bound = raw counter for the kernels with narrow loads"}}
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import csrc_digest  # (the sources these counters were collected from: bench.py's traffic_stale compares)
+summary["_collected"] = {"csrc_digest": csrc_digest.csrc_digest()}
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
-print(json.dumps({k: v["hbm_traffic_bytes_per_launch"]["total"] for k, v in summary.items()}))
+print(json.dumps({k: v["hbm_traffic_bytes_per_launch"]["total"] for k, v in summary.items() if not k.startswith("_")}))
 print(json.dumps(cal["applied"]))
