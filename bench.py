@@ -446,8 +446,12 @@ def check_batch_all(torch, oracle, shard, offs):
     idx = shard.idx[:c["structurals"]].cpu().numpy().view(np.uint32)
     got_dig, got_ih, got_cnt = oracle.digest_outputs(tape, to, sb, idx, io, np.asarray(offs, dtype=np.uint64), err)
     assert np.array_equal(err, want_err), "document verdicts differ from the oracle's at %s" % np.flatnonzero(err != want_err)[:5]
-    assert np.array_equal(got_cnt, want_cnt) and np.array_equal(got_ih, want_ih), \
-        "structural indexes differ from the oracle's at documents %s" % np.flatnonzero((got_cnt != want_cnt) | (got_ih != want_ih))[:5]
+    # (a document that fails stage 1 -- codes 1..3 -- has NO structurals in the engine's isolated mode, include/sjmi.h; the
+    #  reference throws before anyone sees its indexes, SimdJsonParser.java:55-58)
+    s1 = (want_err >= 1) & (want_err <= 3)
+    assert not got_cnt[s1].any(), "a document that failed stage 1 has structurals"
+    assert np.array_equal(got_cnt[~s1], want_cnt[~s1]) and np.array_equal(got_ih[~s1], want_ih[~s1]), \
+        "structural indexes differ from the oracle's at documents %s" % np.flatnonzero(~s1 & ((got_cnt != want_cnt) | (got_ih != want_ih)))[:5]
     assert np.array_equal(got_dig, want_dig), "tapes / string records differ from the oracle's at documents %s" % np.flatnonzero(got_dig != want_dig)[:5]
     return n_docs
 

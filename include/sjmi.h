@@ -34,7 +34,7 @@ extern "C" {
 #define SJMI_ST_INTERNAL 0x200u /* engine fault (look-back timeout); results invalid */
 #define SJMI_ST_REJECTED 0x800u /* sjmi_parse_batch_device_optimistic only: the batch is not one the optimistic pipeline can take (a document
                                  * fails stage 1, a separator is missing, the offsets do not cover the buffer): NO output of the call is
-                                 * valid -- call sjmi_parse_batch_device, which decides every document on its own */
+                                 * valid -- call sjmi_parse_batch_device_rejected (or sjmi_parse_batch_device), which decide every document on its own */
 #define SJMI_ST_HALO 0x400u     /* sjmi_stage1_shard_device / sjmi_stream_push: a backslash run fills the whole left halo, so whether the
                                    byte behind it is escaped cannot be told from what is readable; results invalid -- give more halo */
 
@@ -311,8 +311,9 @@ int sjmi_walk_batch_device(sjmi_ctx* ctx, const void* d_buf, const void* d_doc_o
  * addresses.  A document that then fails stage 2 (doc_errors[k] != 0) keeps its slot: tape_offsets[k + 1] - tape_offsets[k] is
  * its PREDICTED length and the words there are unspecified; walk.tape_words counts the slots.  Every well-formed document's
  * tape is where and what it always was, and a batch without failing documents is packed exactly as before.  (When the plain
- * pass was rejected -- some document fails stage 1, a separator is missing -- the tapes are packed behind the walk and a
- * failing document's range is empty, as with sjmi_walk_batch_device.) */
+ * pass was rejected -- some document fails stage 1, a separator is missing -- the REPAIR stage described at
+ * sjmi_parse_batch_device_rejected takes the batch and reports like an accepted one; only behind a batch it cannot take either are
+ * the tapes packed behind the walk and a failing document's range empty, as with sjmi_walk_batch_device.) */
 typedef struct sjmi_batch_result {
     sjmi_stage1_result stage1;
     sjmi_unescape_result strings;
@@ -334,6 +335,23 @@ int sjmi_parse_batch_device_optimistic(sjmi_ctx* ctx, const void* d_buf, uint64_
                                        void* d_string_buffer, uint64_t string_capacity, void* d_doc_string_offsets, int max_depth,
                                        void* d_tape, uint64_t tape_capacity, void* d_tape_offsets, void* d_doc_errors, void* d_result,
                                        void* stream);
+
+/* The call to make after sjmi_parse_batch_device_optimistic came back with SJMI_ST_REJECTED (round 6; same arguments, same outputs as
+ * sjmi_parse_batch_device -- which is this call behind one more attempt at the plain pass).  The reference isolates a malformed
+ * document for free -- one JsonParsingException per SimdJsonParser.parse, SimdJsonParser.java:35-40, the neighbours never see it --
+ * so a batch with ONE bad document in a million must not cost a multiple of a clean one.  On the device, no host round trip:
+ * every document gets its own stage-1 verdict (16 lanes per document, all carries from zero), the documents that fail are
+ * blanked in a sanitized copy, and the optimistic pipeline runs over that copy (REPAIR) -- exact, because every surviving
+ * document begins and ends outside a string; documents that are not separated at all are taken too as long as no scalar can run
+ * on across a boundary (the last byte of every document is whitespace, an operator or a quote).  Only a batch that fails that
+ * rule falls to the per-document index passes.  A repaired batch reports like an accepted one: a document that failed stage 1
+ * has doc_status[k] / doc_errors[k] set, no structurals and a two-word tape slot with unspecified contents; stage1.status is the
+ * OR of the documents' verdicts.  (SJMI_BATCH_REPAIR=0 switches the repair stage off.) */
+int sjmi_parse_batch_device_rejected(sjmi_ctx* ctx, const void* d_buf, uint64_t total_len, const void* d_doc_offsets, uint64_t n_docs,
+                                     void* d_indexes, uint64_t index_capacity, void* d_index_offsets, void* d_doc_status,
+                                     void* d_string_buffer, uint64_t string_capacity, void* d_doc_string_offsets, int max_depth,
+                                     void* d_tape, uint64_t tape_capacity, void* d_tape_offsets, void* d_doc_errors, void* d_result,
+                                     void* stream);
 
 /* One document, ALL stages on the GPU: stage 1, string records and the cooperative walker (csrc/coop_walk.hip: JsonIterator.
  * walkDocument + TapeBuilder as scans, JsonIterator.java:26-200, TapeBuilder.java:41-217); only the tape (Tape.java:5-47 word

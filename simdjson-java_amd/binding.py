@@ -99,7 +99,7 @@ EXPORTS = ["sjmi_create", "sjmi_destroy", "sjmi_last_error", "sjmi_version", "sj
            "sjmi_unescape_batch_device", "sjmi_walk_batch_device", "sjmi_stage1_masks", "sjmi_stage1_masks_device",
            "sjmi_parser_root", "sjmi_parser_batch_root", "sjmi_value_type", "sjmi_value_as_long", "sjmi_value_as_double",
            "sjmi_value_as_boolean", "sjmi_value_as_string", "sjmi_value_get", "sjmi_value_size", "sjmi_value_first",
-           "sjmi_value_next", "sjmi_parse_batch_device", "sjmi_parse_batch_device_optimistic", "sjmi_parse_document",
+           "sjmi_value_next", "sjmi_parse_batch_device", "sjmi_parse_batch_device_optimistic", "sjmi_parse_batch_device_rejected", "sjmi_parse_document",
            "sjmi_parser_set_gpu_walk", "sjmi_set_auto_safe", "sjmi_stage1_shard_device", "sjmi_stage1_shard_device2",
            "sjmi_stream_open", "sjmi_stream_push", "sjmi_stream_close", "sjmi_split_open", "sjmi_split_scan", "sjmi_split_resolve", "sjmi_split_close",
            "sjmi_parser_ondemand_init", "sjmi_od_skip_child", "sjmi_od_get_boolean", "sjmi_od_get_long", "sjmi_od_get_integral", "sjmi_od_get_double", "sjmi_od_get_float", "sjmi_od_get_char",
@@ -248,6 +248,8 @@ def lib():
                                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sjmi_parse_batch_device_optimistic.restype = C.c_int
         L.sjmi_parse_batch_device_optimistic.argtypes = L.sjmi_parse_batch_device.argtypes
+        L.sjmi_parse_batch_device_rejected.restype = C.c_int
+        L.sjmi_parse_batch_device_rejected.argtypes = L.sjmi_parse_batch_device.argtypes
         L.sjmi_kernel_time.restype = C.c_int
         L.sjmi_kernel_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -449,6 +451,17 @@ class Context:
                                                              d_index_offsets, d_doc_status, d_sb, sb_capacity, d_doc_string_offsets,
                                                              max_depth, d_tape, tape_capacity, d_tape_offsets, d_doc_errors, d_result,
                                                              stream), "sjmi_parse_batch_device_optimistic")
+
+    def parse_batch_device_rejected(self, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets,
+                                    d_doc_status, d_sb, sb_capacity, d_doc_string_offsets, max_depth, d_tape, tape_capacity,
+                                    d_tape_offsets, d_doc_errors, d_result, stream=0):
+        """sjmi_parse_batch_device_rejected: the call behind SJMI_ST_REJECTED -- per-document verdicts, the failing documents
+        blanked in a copy, the optimistic pipeline over the copy (repair); the per-document passes only for a batch that cannot
+        take either.  Outputs as parse_batch_device."""
+        self._check(lib().sjmi_parse_batch_device_rejected(self._h, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity,
+                                                           d_index_offsets, d_doc_status, d_sb, sb_capacity, d_doc_string_offsets,
+                                                           max_depth, d_tape, tape_capacity, d_tape_offsets, d_doc_errors, d_result,
+                                                           stream), "sjmi_parse_batch_device_rejected")
 
     def stage1_batch_device(self, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets,
                             d_result, stream=0):

@@ -163,6 +163,7 @@ k_doc_prepare(DocPrepare a) {
     // k_batch_layout (walk.hip), queued behind, decides.  What it can know it checks: a plain pass with any verdict bit is
     // rejected already.  On a batch that ends up rejected everything written here is overwritten or unused, and every access
     // below is clamped to the buffer and to the index count whatever the offsets say.
+    if (a.gate && *a.gate != 0) return;
     if (a.stage1->status != 0) return;
     __shared__ uint32_t s_io[PREP_DOCS + 1], s_pw[PREP_DOCS + 1];
     __shared__ unsigned long long s_sum[PREP_DOCS / 64];
@@ -294,8 +295,21 @@ k_doc_prepare(DocPrepare a) {
             const unsigned long long s_raw = a.doc_offsets[k];
             bool bad = e < s_raw || e > a.total_len || (k == 0 && s_raw != 0) || (k + 1 == a.n_docs && e != a.total_len);
             if (!bad && k + 1 < a.n_docs) {
-                const uint8_t c = e > s_raw ? a.buf[e - 1] : 0xFF;
-                bad = !(c == 0x0A || c == 0x0D || c == 0x09);
+                uint8_t c = e > s_raw ? a.buf[e - 1] : (a.relaxed ? 0x20 : 0xFF);
+                // (the repair pass reads the COPY -- a failing document is blank there -- except for a surviving document's trailing
+                //  backslash, which the copy has lost: the sanitizer shortens an odd run by one for the string pass)
+                if (a.boundary_buf && e > s_raw && a.boundary_buf[e - 1] == 0x5C && !(a.status_in && a.status_in[k] != 0)) c = 0x5C;
+                if (!a.relaxed) {
+                    bad = !(c == 0x0A || c == 0x0D || c == 0x09);
+                } else {
+                    // the repair pass: every document has its own verdict and the failing ones are blank, so no string is open at
+                    // a boundary; what is left to rule out is a scalar running ON across it -- StructuralIndexer.java:243-248: a
+                    // scalar (or a quote) is a structural only behind a byte that is not a non-quote scalar character, i.e.
+                    // behind whitespace, an operator or a quote
+                    const bool ws = c == 0x20 || c == 0x0A || c == 0x0D || c == 0x09;
+                    const bool op = c == '{' || c == '}' || c == '[' || c == ']' || c == ':' || c == ',';
+                    bad = !(ws || op || c == '"');
+                }
             }
             if (bad) atomicOr(&a.flags[0], 1u);
         }
@@ -327,14 +341,15 @@ k_doc_prepare(DocPrepare a) {
         const uint32_t to = s_io[threadIdx.x + 1];
         len = sum - pw + s_pw[threadIdx.x + 1] + 2u;  // + the two root words (TapeBuilder.java:41-48)
         a.lens[k] = len;
-        a.doc_status[k] = 0;
+        const uint32_t st_k = a.status_in ? a.status_in[k] : 0u;  // (status_in may BE doc_status: read before it is written)
+        a.doc_status[k] = st_k;
         DocMeta m;
         m.from = io;
         m.to = to;
         m.dso = (uint32_t)ord;
         m.doc_start = (uint32_t)s;
         m.doc_end = (uint32_t)e;
-        m.st = 0;
+        m.st = st_k;
         m.tape_lo = m.tape_hi = 0;  // (k_tape_offsets)
         a.metas[k] = m;
     }
@@ -383,8 +398,9 @@ __global__ void __launch_bounds__(256)
 k_doc_pass(const uint8_t* __restrict__ buf, const unsigned long long* __restrict__ doc_offsets, uint64_t n_docs,
            uint32_t* __restrict__ counts, uint32_t* __restrict__ doc_status,
            const unsigned long long* __restrict__ index_offsets, uint32_t* __restrict__ out, uint64_t out_cap,
-           sj_u64 total_len, const uint32_t* __restrict__ skip) {
+           sj_u64 total_len, const uint32_t* __restrict__ skip, uint32_t* __restrict__ status_or) {
     if (skip && *skip) return;  // (the optimistic plain pass of the fused pipeline was accepted: k_batch_plain_accept)
+    uint32_t seen = 0;          // (WRITE = false: the OR of this thread's documents' verdicts, for status_or)
     const int lane = threadIdx.x & 63;
     const int rl = lane & 15;         // lane inside the row
     const int rshift = lane & ~15;    // first lane of the row
@@ -471,9 +487,11 @@ k_doc_pass(const uint8_t* __restrict__ buf, const unsigned long long* __restrict
             if (rl == 0 && k < n_docs) {
                 doc_status[k] = all;
                 counts[k] = all ? 0u : (uint32_t)cnt;
+                seen |= all;
             }
         }
     }
+    if (!WRITE && status_or && seen) atomicOr(status_or, seen);  // (rare: only the threads that saw a failing document)
 }
 
 // ---- index_offsets = exclusive scan of counts: chunk sums, scan of the chunk sums (one workgroup), chunk scans ----
@@ -582,33 +600,54 @@ size_t batch_isolated_workspace_bytes(uint64_t n_docs) {
     return iso_chunks_offset(n_docs) + ((size_t)(n_docs / SCAN_CHUNK) + 2) * sizeof(unsigned long long);
 }
 
-hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs,
-                                 uint32_t* d_out, uint64_t out_cap, unsigned long long* d_index_offsets,
-                                 uint32_t* d_doc_status, uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream,
-                                 uint64_t total_len, const uint32_t* d_skip) {
+const uint32_t* batch_status_or(const uint32_t* d_counts, uint64_t n_docs) {
+    return reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(d_counts) + iso_status_offset(n_docs));
+}
+static unsigned doc_pass_grid(uint64_t n_docs) {
+    const uint64_t want = (n_docs + 15) / 16;  // 16 documents per workgroup and trip
+    return (unsigned)(want < 8192 ? want : 8192);  // grid-stride over the documents
+}
+hipError_t batch_verdicts_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint32_t* d_doc_status,
+                                 uint32_t* d_counts, hipStream_t stream, uint64_t total_len, const uint32_t* d_skip) {
+    uint8_t* ws = reinterpret_cast<uint8_t*>(d_counts);
+    uint32_t* status_or = reinterpret_cast<uint32_t*>(ws + iso_status_offset(n_docs));
+    hipError_t e = hipMemsetAsync(status_or, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    if (n_docs)
+        hipLaunchKernelGGL(k_doc_pass<false>, dim3(doc_pass_grid(n_docs)), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_counts,
+                           d_doc_status, (const unsigned long long*)nullptr, (uint32_t*)nullptr, (uint64_t)0, (sj_u64)total_len, d_skip,
+                           status_or);
+    return hipGetLastError();
+}
+hipError_t batch_indexes_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint32_t* d_out,
+                                uint64_t out_cap, unsigned long long* d_index_offsets, uint32_t* d_doc_status, uint32_t* d_counts,
+                                Stage1Result* d_res, hipStream_t stream, uint64_t total_len, const uint32_t* d_skip) {
     uint8_t* ws = reinterpret_cast<uint8_t*>(d_counts);
     uint32_t* status_or = reinterpret_cast<uint32_t*>(ws + iso_status_offset(n_docs));
     unsigned long long* chunk_sums = reinterpret_cast<unsigned long long*>(ws + iso_chunks_offset(n_docs));
     const uint64_t nchunks = (n_docs + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    hipError_t e = hipMemsetAsync(status_or, 0, sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    const uint64_t want = (n_docs + 15) / 16;  // 16 documents per workgroup and trip
-    const unsigned grid = (unsigned)(want < 8192 ? want : 8192);  // grid-stride over the documents
-    if (n_docs) {
-        hipLaunchKernelGGL(k_doc_pass<false>, dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_counts,
-                           d_doc_status, (const unsigned long long*)nullptr, (uint32_t*)nullptr, (uint64_t)0, (sj_u64)total_len, d_skip);
+    if (n_docs)
         hipLaunchKernelGGL(k_doc_chunk_sums, dim3((unsigned)nchunks), dim3(1024), 0, stream, d_counts, d_doc_status, n_docs,
                            chunk_sums, status_or, d_skip);
-    }
     hipLaunchKernelGGL(k_doc_scan, dim3(1), dim3(1024), 0, stream, chunk_sums, nchunks, status_or, n_docs, d_index_offsets,
                        d_out, out_cap, d_res, d_skip);
     if (n_docs) {
         hipLaunchKernelGGL(k_doc_offsets, dim3((unsigned)nchunks), dim3(1024), 0, stream, d_counts, n_docs, chunk_sums,
                            d_index_offsets, d_skip);
-        hipLaunchKernelGGL(k_doc_pass<true>, dim3(grid), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_counts,
-                           d_doc_status, (const unsigned long long*)d_index_offsets, d_out, out_cap, (sj_u64)total_len, d_skip);
+        hipLaunchKernelGGL(k_doc_pass<true>, dim3(doc_pass_grid(n_docs)), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_counts,
+                           d_doc_status, (const unsigned long long*)d_index_offsets, d_out, out_cap, (sj_u64)total_len, d_skip,
+                           (uint32_t*)nullptr);
     }
     return hipGetLastError();
+}
+hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs,
+                                 uint32_t* d_out, uint64_t out_cap, unsigned long long* d_index_offsets,
+                                 uint32_t* d_doc_status, uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream,
+                                 uint64_t total_len, const uint32_t* d_skip) {
+    const hipError_t e = batch_verdicts_launch(d_buf, d_doc_offsets, n_docs, d_doc_status, d_counts, stream, total_len, d_skip);
+    if (e != hipSuccess) return e;
+    return batch_indexes_launch(d_buf, d_doc_offsets, n_docs, d_out, out_cap, d_index_offsets, d_doc_status, d_counts, d_res, stream,
+                                total_len, d_skip);
 }
 
 }  // namespace sjmi

@@ -1218,38 +1218,55 @@ int sjmi_stage1_batch_isolated(sjmi_ctx* c, const uint8_t* buf, uint64_t total_l
     return SJMI_OK;
 }
 
-// The fused batch pipeline (round 5: re-ordered so that an ACCEPTED batch costs eight queue entries).
-//   k_stage1_batch   ONE plain launch over the packed batch, per-block side outputs; its workers zero the string pass's workspace
-//                    on their way out, the acceptance flags sit in the header of its own (zeroed) workspace half
-//   k_strings<true>  over the batch itself, its record inside that workspace
-//   k_doc_prepare    per boundary: the separator check (ORed into flags[0]), index ranges, string ordinals, predicted tape lengths
-//   k_batch_layout   decides: flags[1] = accepted; zeroes the walk's records, hands the string record over, scans the lengths
-//   k_tape_offsets, k_tok_walk, k_coop_walk (list), k_slow_doubles
-// optimistic_only: that is all; a batch that does not qualify comes back with SJMI_ST_REJECTED.  Otherwise the per-document
-// stage-1 passes, the sanitized copy with its parity launch and string pass, and the packing kernels are queued too, each of
-// them leaving at once when flags[1] says accepted -- exact per document whatever the batch contains, no host round trip.
+// The fused batch pipeline (round 5: re-ordered so that an ACCEPTED batch costs eight queue entries; round 6: a REPAIR stage
+// between the plain pass and the per-document passes).
+//   stage A   k_stage1_batch   ONE plain launch over the packed batch, per-block side outputs; its workers zero the string pass's
+//                              workspace on their way out, the acceptance flags sit in the header of its own (zeroed) workspace half
+//             k_strings<true>  over the batch itself, its record inside that workspace (leaves at once behind a stage-1 verdict)
+//             k_doc_prepare    per boundary: the separator check (ORed into flags[0]), index ranges, string ordinals, predicted tape lengths
+//             k_batch_layout   decides: accepted?  zeroes the walk's records, hands the string record over, scans the lengths
+//             k_tape_offsets
+//   stage B   (round 6; every kernel leaves at once when A was accepted)  A batch A rejects -- ONE document in a million fails
+//             stage 1, or the documents are not separated by control characters -- used to fall to stage C, 2.2 x the cost of an
+//             accepted batch.  Now: k_doc_pass<false> gives every document ITS verdict (16 lanes per document, every carry from
+//             zero: StructuralIndexer.java:196-303 per document), the sanitized copy blanks the failing documents, and the SAME
+//             five kernels of stage A run over the copy -- exact there, because every surviving document begins and ends outside a
+//             string whatever separates it from its neighbours; the only thing a missing separator can still do is let a scalar
+//             run on across a boundary, which k_doc_prepare's relaxed rule rules out (else: stage C).  A failing document keeps
+//             its verdict, has no structurals and a two-word tape slot.
+//   stage C   (every kernel leaves at once when A or B was accepted)  the per-document stage-1 passes with their index arrays,
+//             the string pass over the sanitized copy, ordinals, the walk into scratch tapes + packing.
+//   k_tok_walk, k_coop_walk (list), k_slow_doubles: ONE set of walkers behind all three (a device flag says where the tapes go).
+// PIPE_OPTIMISTIC: stage A and the walkers, nothing else; a batch that does not qualify comes back with SJMI_ST_REJECTED.
+// PIPE_EXACT: A, B, C.  PIPE_REJECTED: B, C -- the call to make after SJMI_ST_REJECTED.  No host round trip in any of them.
+enum PipeMode { PIPE_OPTIMISTIC, PIPE_EXACT, PIPE_REJECTED };
 static int parse_batch_pipeline(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets, uint64_t n_docs,
                                 void* d_indexes, uint64_t index_capacity, void* d_index_offsets, void* d_doc_status,
                                 void* d_string_buffer, uint64_t string_capacity, void* d_doc_string_offsets, int max_depth,
                                 void* d_tape, uint64_t tape_capacity, void* d_tape_offsets, void* d_doc_errors, void* d_result,
-                                void* stream, bool optimistic_only) {
+                                void* stream, PipeMode mode) {
     if (!c || !d_buf || !d_doc_offsets || !d_indexes || !d_index_offsets || !d_doc_status || !d_string_buffer ||
         !d_doc_string_offsets || !d_tape || !d_tape_offsets || !d_doc_errors || !d_result || max_depth < 1 || index_capacity < 1)
         return SJMI_ERR_ARG;
     if (total_len >= (1ull << 32)) return SJMI_ERR_ARG;
     if (fail(c, "hipSetDevice", hipSetDevice(c->device))) return SJMI_ERR_HIP;
+    const bool optimistic_only = mode == PIPE_OPTIMISTIC;
     sjmi_batch_result* r = (sjmi_batch_result*)d_result;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     const uint64_t bound = index_capacity - 1;
     const uint64_t soff_cap = bound + 64;
     static const bool optimistic = !(getenv("SJMI_BATCH_OPTIMISTIC") && atoi(getenv("SJMI_BATCH_OPTIMISTIC")) == 0);
+    static const bool repair_on = !(getenv("SJMI_BATCH_REPAIR") && atoi(getenv("SJMI_BATCH_REPAIR")) == 0);
     // (a batch of ONE document has no token-walker path behind tapes laid out in advance -- walk_launch takes the cooperative
     //  walker for it -- so the optimistic entry rejects it like any other batch it cannot take; the exact entry serves it)
-    const bool try_plain = optimistic && n_docs && total_len && !((uintptr_t)d_buf & 15) && !((uintptr_t)d_indexes & 15) &&
-                           !(optimistic_only && n_docs < 2);
+    const bool aligned = optimistic && n_docs && total_len && !((uintptr_t)d_buf & 15) && !((uintptr_t)d_indexes & 15);
+    const bool try_plain = aligned && mode != PIPE_REJECTED && !(optimistic_only && n_docs < 2);
+    // stage B needs the FAST kernel (its scanner writes the caller's record: a SAFE launch's record is copied out behind the
+    // kernel whether it ran or not) and more than one document
+    const bool try_repair = aligned && repair_on && !optimistic_only && n_docs > 1 && !(launch_flags(c) & (sjmi::FLAG_SAFE | sjmi::DBG_NO_LOOKBACK));
     if (!grow(c, &c->d_ws_walk, &c->ws_walk_bytes, sjmi::walk_workspace_bytes(bound, n_docs), "hipMalloc(ws_walk)")) return SJMI_ERR_HIP;
     c->accept_valid = false;
-    if (!try_plain) {
+    if (!try_plain && !try_repair) {
         if (optimistic_only) {  // (nothing the optimistic pipeline could run on: say so in the record)
             if (fail(c, "reject", sjmi::batch_reject_launch((sjmi::Stage1Result*)&r->stage1, st))) return SJMI_ERR_HIP;
             return SJMI_OK;
@@ -1276,52 +1293,21 @@ static int parse_batch_pipeline(sjmi_ctx* c, const void* d_buf, uint64_t total_l
         !grow(c, (void**)&c->d_doc_ord, &c->doc_ord_bytes, (n_docs + 2) * sizeof(unsigned long long), "hipMalloc(doc_ord)") ||
         !grow(c, &c->d_ws_strm, &c->ws_strm_bytes, strm_bytes, "hipMalloc(ws_strm)"))
         return SJMI_ERR_HIP;
+    if (!c->d_batch_flags && fail(c, "hipMalloc(batch flags)", hipMalloc((void**)&c->d_batch_flags, 64))) return SJMI_ERR_HIP;
+    // the pipeline's stage flags: pf[0] != 0 = stage A accepted, pf[1] != 0 = A or B accepted (the tapes are laid out in advance)
+    uint32_t* const pf = c->d_batch_flags + 8;
     c->soff_idx = nullptr;
-    // ---- (1) the plain pass ----
-    int rc0;
-    {
-        const AutoSafeOff plain_only(c);  // (a tripped liveness bound only rejects the plain pass)
-        c->batch_side = true;
-        c->s1_zero2 = c->d_ws_strm;
-        c->s1_zero2_bytes = strm_bytes;
-        // (experiments: SJMI_BATCH_STEPS = granule of the pipeline's plain pass in units of 4 KiB)
-        static const int batch_steps = getenv("SJMI_BATCH_STEPS") ? atoi(getenv("SJMI_BATCH_STEPS")) : 0;
-        const int keep_steps = c->forced_steps;
-        if (batch_steps == 1 || batch_steps == 2 || batch_steps == 4) c->forced_steps = batch_steps;
-        rc0 = stage1_device_impl(c, d_buf, total_len, d_indexes, index_capacity, &r->stage1, stream, 0);
-        c->forced_steps = keep_steps;
-        c->batch_side = false;
-        c->s1_zero2 = nullptr;
-        c->s1_zero2_bytes = 0;
-    }
-    if (rc0 != SJMI_OK) return rc0;
-    if (!(c->par_valid && c->par_buf == d_buf && c->par_len == total_len) || !c->ws_dev_last) {
-        c->err = "batch pipeline: the plain pass left no block parities";
-        return SJMI_ERR_HIP;
-    }
-    uint32_t* const flags = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(c->ws_dev_last) + sjmi::WS_BATCH_FLAGS_OFFSET);
-    const uint32_t* const d_acc = flags + 1;
-    // ---- (2) the string pass over the batch itself; (3) one pass over the boundaries; (4) the decision and the tape layout ----
     sjmi::UnescapeResult* const d_u = sjmi::strings_workspace_result(c->d_ws_strm);
-    if (fail(c, "strings launch",
-             sjmi::strings_launch((const uint8_t*)d_buf, total_len, c->d_blkpar, (uint8_t*)d_string_buffer, string_capacity, c->d_soff,
-                                  soff_cap, c->d_blk_ord, c->d_ws_strm, d_u, st, nullptr, nullptr, sjmi::StringsAlt(), true)))
-        return SJMI_ERR_HIP;
     const sjmi::WalkPrepared wp = sjmi::walk_prepared(c->d_ws_walk, bound, n_docs);
     sjmi::DocPrepare pa;
-    pa.buf = (const uint8_t*)d_buf;
     pa.idx = (const uint32_t*)d_indexes;
     pa.doc_offsets = (const unsigned long long*)d_doc_offsets;
     pa.n_docs = n_docs;
     pa.total_len = total_len;
-    pa.blkidx = c->d_blkidx;
-    pa.blkw = c->d_blkw;
-    pa.blkpar = c->d_blkpar;
     pa.blk_ord = c->d_blk_ord;
     pa.soff = c->d_soff;
     pa.strings = d_u;
     pa.stage1 = (const sjmi::Stage1Result*)&r->stage1;
-    pa.flags = flags;
     pa.index_offsets = (unsigned long long*)d_index_offsets;
     pa.doc_status = (uint32_t*)d_doc_status;
     pa.doc_ord = c->d_doc_ord;
@@ -1330,7 +1316,6 @@ static int parse_batch_pipeline(sjmi_ctx* c, const void* d_buf, uint64_t total_l
     pa.chunk_sums = wp.chunk_sums;
     pa.metas = wp.metas;
     sjmi::BatchLayout bl = {};
-    bl.flags = flags;
     bl.stage1 = (const sjmi::Stage1Result*)&r->stage1;
     bl.stage1_out = (sjmi::Stage1Result*)&r->stage1;
     bl.strings_ws = d_u;
@@ -1341,41 +1326,145 @@ static int parse_batch_pipeline(sjmi_ctx* c, const void* d_buf, uint64_t total_l
     bl.tape_capacity = tape_capacity;
     bl.tape_offsets = (unsigned long long*)d_tape_offsets;
     bl.optimistic_only = optimistic_only;
-    if (fail(c, "prepare launch", sjmi::batch_prepare_launch(pa, st)) ||
-        fail(c, "layout launch", sjmi::batch_layout_launch(bl, c->d_ws_walk, bound, wp.lens, wp.metas, (int32_t*)d_doc_errors, st)))
+    bl.pipe_flags = optimistic_only ? nullptr : pf;
+    const uint32_t* d_laid_out = nullptr;  // device flag != 0: the tapes are laid out (what the walkers and the packing kernels ask)
+    if (try_plain) {
+        // ---- stage A (1): the plain pass ----
+        int rc0;
+        {
+            const AutoSafeOff plain_only(c);  // (a tripped liveness bound only rejects the plain pass)
+            c->batch_side = true;
+            c->s1_zero2 = c->d_ws_strm;
+            c->s1_zero2_bytes = strm_bytes;
+            // (experiments: SJMI_BATCH_STEPS = granule of the pipeline's plain pass in units of 4 KiB)
+            static const int batch_steps = getenv("SJMI_BATCH_STEPS") ? atoi(getenv("SJMI_BATCH_STEPS")) : 0;
+            const int keep_steps = c->forced_steps;
+            if (batch_steps == 1 || batch_steps == 2 || batch_steps == 4) c->forced_steps = batch_steps;
+            rc0 = stage1_device_impl(c, d_buf, total_len, d_indexes, index_capacity, &r->stage1, stream, 0);
+            c->forced_steps = keep_steps;
+            c->batch_side = false;
+            c->s1_zero2 = nullptr;
+            c->s1_zero2_bytes = 0;
+        }
+        if (rc0 != SJMI_OK) return rc0;
+        if (!(c->par_valid && c->par_buf == d_buf && c->par_len == total_len) || !c->ws_dev_last) {
+            c->err = "batch pipeline: the plain pass left no block parities";
+            return SJMI_ERR_HIP;
+        }
+        uint32_t* const flags = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(c->ws_dev_last) + sjmi::WS_BATCH_FLAGS_OFFSET);
+        // ---- (2) the string pass over the batch itself (not behind a stage-1 verdict: nothing would use it);
+        //      (3) one pass over the boundaries; (4) the decision and the tape layout ----
+        if (fail(c, "strings launch",
+                 sjmi::strings_launch((const uint8_t*)d_buf, total_len, c->d_blkpar, (uint8_t*)d_string_buffer, string_capacity, c->d_soff,
+                                      soff_cap, c->d_blk_ord, c->d_ws_strm, d_u, st, nullptr, nullptr, sjmi::StringsAlt(), true,
+                                      &r->stage1.status)))
+            return SJMI_ERR_HIP;
+        pa.buf = (const uint8_t*)d_buf;
+        pa.blkidx = c->d_blkidx;
+        pa.blkw = c->d_blkw;
+        pa.blkpar = c->d_blkpar;
+        pa.flags = flags;
+        bl.flags = flags;
+        bl.stage = 0;
+        if (fail(c, "prepare launch", sjmi::batch_prepare_launch(pa, st)) ||
+            fail(c, "layout launch", sjmi::batch_layout_launch(bl, c->d_ws_walk, bound, wp.lens, wp.metas, (int32_t*)d_doc_errors, st)))
+            return SJMI_ERR_HIP;
+        d_laid_out = optimistic_only ? flags + 1 : pf + 1;
+    } else if (fail(c, "memset(pipe flags)", hipMemsetAsync(pf, 0, 8, st))) {  // (PIPE_REJECTED: stage A is known to fail)
         return SJMI_ERR_HIP;
+    }
     if (!optimistic_only) {
-        // ---- the rejected batch's own path, every kernel gated on flags[1] == 0: per-document stage 1, the sanitized copy, the
-        //      parities of a plain launch over it, the string pass over it (fills the record k_batch_layout zeroed), ordinals ----
-        const int rc = stage1_batch_isolated_device_impl(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity,
-                                                         d_index_offsets, d_doc_status, &r->stage1, stream, d_acc);
-        if (rc != SJMI_OK) return rc;
         const int steps = c->forced_steps ? c->forced_steps : sjmi::stage1_pick_steps(total_len);
-        if (!grow(c, (void**)&c->d_copy, &c->copy_bytes, total_len + 2 * SJMI_PADDING + 64, "hipMalloc(copy)") ||
+        if (!grow(c, (void**)&c->d_doccnt, &c->doccnt_bytes, sjmi::batch_isolated_workspace_bytes(n_docs), "hipMalloc(doccnt)") ||
+            !grow(c, (void**)&c->d_copy, &c->copy_bytes, total_len + 2 * SJMI_PADDING + 64, "hipMalloc(copy)") ||
             !grow(c, (void**)&c->d_blkpar2, &c->blkpar2_bytes, sjmi::strings_parity_words(total_len) * sizeof(unsigned long long), "hipMalloc(blkpar2)") ||
             !grow(c, &c->d_ws_par, &c->ws_par_bytes, sjmi::stage1_workspace_bytes(total_len, steps), "hipMalloc(ws_par)"))
             return SJMI_ERR_HIP;
-        sjmi::Stage1Extras ex;
-        ex.blkpar = c->d_blkpar2;
-        ex.skip = d_acc;
-        if (fail(c, "sanitize", sjmi::strings_sanitize_launch((const uint8_t*)d_buf, total_len, (const unsigned long long*)d_doc_offsets,
-                                                              (const unsigned long long*)d_index_offsets, n_docs, c->d_copy, d_acc, st)) ||
-            fail(c, "parity launch", sjmi::stage1_launch(c->d_copy, total_len, nullptr, 0, c->d_ws_par, steps, st, nullptr, nullptr,
-                                                         (launch_flags(c) & ~sjmi::DBG_NO_LOOKBACK) | sjmi::DBG_NO_WRITE, ex)))
+        const uint32_t* const skip_b = pf;      // stages B and the verdicts: not behind an accepted A
+        const uint32_t* const skip_c = pf + 1;  // stage C: not behind an accepted A or B
+        // ---- every document's own stage-1 verdict (B needs nothing else of the per-document passes; C the rest) ----
+        if (fail(c, "verdicts launch", sjmi::batch_verdicts_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs,
+                                                                   (uint32_t*)d_doc_status, c->d_doccnt, st, total_len, skip_b)))
             return SJMI_ERR_HIP;
-        note_launch(c, st);
-        if (fail(c, "strings launch",
-                 sjmi::strings_launch(c->d_copy, total_len, c->d_blkpar2, (uint8_t*)d_string_buffer, string_capacity, c->d_soff, soff_cap,
+        c->par_valid = false;  // (whose parities the context holds is decided on the device from here on)
+        // ---- the sanitized copy: failing documents blank (by verdict) ----
+        if (fail(c, "sanitize", sjmi::strings_sanitize_launch((const uint8_t*)d_buf, total_len, (const unsigned long long*)d_doc_offsets,
+                                                              nullptr, n_docs, c->d_copy, skip_b, st, (const uint32_t*)d_doc_status)))
+            return SJMI_ERR_HIP;
+        const unsigned long long* copy_par = c->d_blkpar2;  // the copy's block parities: from B's plain pass, or a parity-only launch
+        if (try_repair) {
+            // ---- stage B: the plain pipeline over the copy.  Its stage-1 launch has a workspace of its own (a launch that may
+            //      leave at once cannot take part in the context's two alternating halves) and its string pass a zeroed one ----
+            if (!grow(c, (void**)&c->d_blkidx, &c->blkidx_bytes, sjmi::stage1_block_entries(total_len) * sizeof(uint32_t), "hipMalloc(blkidx)") ||
+                !grow(c, (void**)&c->d_blkw, &c->blkw_bytes, sjmi::stage1_block_entries(total_len) * sizeof(uint16_t), "hipMalloc(blkw)"))
+                return SJMI_ERR_HIP;
+            sjmi::Stage1Extras ex;
+            ex.blkpar = c->d_blkpar2;
+            ex.skip = skip_b;
+            ex.blkidx = c->d_blkidx;
+            ex.blkw = c->d_blkw;
+            ex.result_out = &r->stage1;
+            const uint64_t dev_cap = index_capacity;
+            if (fail(c, "repair: plain pass", sjmi::stage1_launch(c->d_copy, total_len, (uint32_t*)d_indexes, dev_cap, c->d_ws_par, steps, st,
+                                                                  nullptr, nullptr, launch_flags(c), ex)))
+                return SJMI_ERR_HIP;
+            note_launch(c, st);
+            uint32_t* const flags_b = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(c->d_ws_par) + sjmi::WS_BATCH_FLAGS_OFFSET);
+            if (fail(c, "repair: strings launch",
+                     sjmi::strings_launch(c->d_copy, total_len, c->d_blkpar2, (uint8_t*)d_string_buffer, string_capacity, c->d_soff, soff_cap,
+                                          c->d_blk_ord, c->d_ws_strm, d_u, st, nullptr, nullptr, sjmi::StringsAlt(), false, skip_b)))
+                return SJMI_ERR_HIP;
+            sjmi::DocPrepare pb = pa;
+            pb.buf = c->d_copy;
+            pb.boundary_buf = (const uint8_t*)d_buf;
+            pb.blkidx = c->d_blkidx;
+            pb.blkw = c->d_blkw;
+            pb.blkpar = c->d_blkpar2;
+            pb.flags = flags_b;
+            pb.gate = skip_b;
+            pb.status_in = (const uint32_t*)d_doc_status;
+            pb.relaxed = true;
+            sjmi::BatchLayout lb = bl;
+            lb.flags = flags_b;
+            lb.stage = 1;
+            lb.gate = skip_b;
+            lb.status_or = sjmi::batch_status_or(c->d_doccnt, n_docs);
+            if (fail(c, "repair: prepare launch", sjmi::batch_prepare_launch(pb, st)) ||
+                fail(c, "repair: layout launch", sjmi::batch_layout_launch(lb, c->d_ws_walk, bound, wp.lens, wp.metas, (int32_t*)d_doc_errors, st)))
+                return SJMI_ERR_HIP;
+            d_laid_out = pf + 1;
+        } else {
+            // (no stage B: the copy's parities from a parity-only launch, as before round 6)
+            sjmi::Stage1Extras ex;
+            ex.blkpar = c->d_blkpar2;
+            ex.skip = skip_c;
+            if (fail(c, "parity launch", sjmi::stage1_launch(c->d_copy, total_len, nullptr, 0, c->d_ws_par, steps, st, nullptr, nullptr,
+                                                             (launch_flags(c) & ~sjmi::DBG_NO_LOOKBACK) | sjmi::DBG_NO_WRITE, ex)))
+                return SJMI_ERR_HIP;
+            note_launch(c, st);
+            if (!try_plain) {  // (neither A nor B ran: nobody zeroed the records stage C accumulates into)
+                if (fail(c, "memset(results)", hipMemsetAsync(&r->strings, 0, sizeof(sjmi_unescape_result) + sizeof(sjmi_walk_result), st)))
+                    return SJMI_ERR_HIP;
+            }
+        }
+        // ---- stage C, every kernel gated on pf[1] == 0: the per-document index arrays, the string pass over the copy (fills the
+        //      record k_batch_layout zeroed), ordinals ----
+        if (fail(c, "indexes launch", sjmi::batch_indexes_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs,
+                                                                 (uint32_t*)d_indexes, index_capacity, (unsigned long long*)d_index_offsets,
+                                                                 (uint32_t*)d_doc_status, c->d_doccnt, (sjmi::Stage1Result*)&r->stage1, st,
+                                                                 total_len, skip_c)) ||
+            fail(c, "strings launch",
+                 sjmi::strings_launch(c->d_copy, total_len, copy_par, (uint8_t*)d_string_buffer, string_capacity, c->d_soff, soff_cap,
                                       c->d_blk_ord, c->d_ws_strm, (sjmi::UnescapeResult*)&r->strings, st, nullptr, nullptr, sjmi::StringsAlt(),
-                                      false, d_acc)) ||
+                                      false, skip_c)) ||
             fail(c, "doc ordinals",
-                 sjmi::strings_doc_ordinals_launch(c->d_copy, c->d_blkpar2, sjmi::StringsAlt(), total_len,
+                 sjmi::strings_doc_ordinals_launch(c->d_copy, copy_par, sjmi::StringsAlt(), total_len,
                                                    (const unsigned long long*)d_doc_offsets, n_docs, c->d_blk_ord, c->d_soff,
                                                    (const sjmi::UnescapeResult*)&r->strings, c->d_doc_ord,
-                                                   (unsigned long long*)d_doc_string_offsets, st, d_acc)))
+                                                   (unsigned long long*)d_doc_string_offsets, st, skip_c)))
             return SJMI_ERR_HIP;
-        c->par_valid = false;  // (the context's parities may be the copy's now: decided on the device)
     }
+    const bool layout_done = try_plain || try_repair;
     if (fail(c, "walk launch",
              sjmi::walk_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs, (const uint32_t*)d_indexes,
                                bound, (const unsigned long long*)d_index_offsets, (const uint32_t*)d_doc_status,
@@ -1383,7 +1472,7 @@ static int parse_batch_pipeline(sjmi_ctx* c, const void* d_buf, uint64_t total_l
                                (unsigned long long*)d_tape, tape_capacity, (unsigned long long*)d_tape_offsets,
                                (int32_t*)d_doc_errors, c->d_ws_walk, (sjmi::WalkResult*)&r->walk, st,
                                (const sjmi::Stage1Result*)&r->stage1, (const sjmi::UnescapeResult*)&r->strings, c->d_soff, false, false,
-                               sjmi::SingleDocTail(), d_acc, true, optimistic_only)))
+                               sjmi::SingleDocTail(), layout_done ? d_laid_out : nullptr, layout_done, optimistic_only)))
         return SJMI_ERR_HIP;
     return SJMI_OK;
 }
@@ -1395,7 +1484,7 @@ int sjmi_parse_batch_device(sjmi_ctx* c, const void* d_buf, uint64_t total_len, 
                             void* stream) {
     return parse_batch_pipeline(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets, d_doc_status,
                                 d_string_buffer, string_capacity, d_doc_string_offsets, max_depth, d_tape, tape_capacity, d_tape_offsets,
-                                d_doc_errors, d_result, stream, false);
+                                d_doc_errors, d_result, stream, PIPE_EXACT);
 }
 
 int sjmi_parse_batch_device_optimistic(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets, uint64_t n_docs,
@@ -1405,7 +1494,17 @@ int sjmi_parse_batch_device_optimistic(sjmi_ctx* c, const void* d_buf, uint64_t 
                                        void* stream) {
     return parse_batch_pipeline(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets, d_doc_status,
                                 d_string_buffer, string_capacity, d_doc_string_offsets, max_depth, d_tape, tape_capacity, d_tape_offsets,
-                                d_doc_errors, d_result, stream, true);
+                                d_doc_errors, d_result, stream, PIPE_OPTIMISTIC);
+}
+
+int sjmi_parse_batch_device_rejected(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets, uint64_t n_docs,
+                                     void* d_indexes, uint64_t index_capacity, void* d_index_offsets, void* d_doc_status,
+                                     void* d_string_buffer, uint64_t string_capacity, void* d_doc_string_offsets, int max_depth,
+                                     void* d_tape, uint64_t tape_capacity, void* d_tape_offsets, void* d_doc_errors, void* d_result,
+                                     void* stream) {
+    return parse_batch_pipeline(c, d_buf, total_len, d_doc_offsets, n_docs, d_indexes, index_capacity, d_index_offsets, d_doc_status,
+                                d_string_buffer, string_capacity, d_doc_string_offsets, max_depth, d_tape, tape_capacity, d_tape_offsets,
+                                d_doc_errors, d_result, stream, PIPE_REJECTED);
 }
 
 // (the result records of the three stages come back in one place, sjmi::SingleDocPack, written by the walk's last launch)

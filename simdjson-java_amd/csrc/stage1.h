@@ -137,7 +137,9 @@ hipError_t strings_launch(const uint8_t* d_buf, uint64_t len, const unsigned lon
 // and *d_skip != 0: nothing to do (the optimistic plain pass was accepted)
 hipError_t strings_sanitize_launch(const uint8_t* d_buf, uint64_t total_len, const unsigned long long* d_doc_offsets,
                                    const unsigned long long* d_index_offsets, uint64_t n_docs, uint8_t* d_copy, const uint32_t* d_skip,
-                                   hipStream_t stream);
+                                   hipStream_t stream, const uint32_t* d_doc_status = nullptr);
+// (d_doc_status != nullptr: a document is blanked when its stage-1 verdict is not 0 -- the repair pass, which has no index offsets
+//  yet; else when it has no structurals)
 // per document: ordinal of its first string in the record table (and, optionally, that record's offset)
 hipError_t strings_doc_ordinals_launch(const uint8_t* d_buf, const unsigned long long* d_blkpar, const StringsAlt& alt, uint64_t len,
                                        const unsigned long long* d_doc_offsets, uint64_t n_docs, const uint32_t* d_blk_ord,
@@ -194,6 +196,15 @@ struct DocPrepare {
     uint32_t* lens;
     unsigned long long* chunk_sums;
     DocMeta* metas;
+    // the REPAIR pass (round 6, sjmi_api.hip parse_batch_pipeline stage B): the same kernel over the sanitized copy of a batch
+    // whose plain pass was rejected -- the documents that failed stage 1 (status_in[k] != 0, from the verdict pass
+    // k_doc_pass<false>) are blank there, so every surviving document begins and ends outside a string whatever separates them
+    const uint32_t* gate = nullptr;       // device flag: != 0 -> nothing to do
+    const uint32_t* status_in = nullptr;  // per-document stage-1 verdicts to keep (nullptr: every document passed)
+    const uint8_t* boundary_buf = nullptr;  // the ORIGINAL batch: a surviving document that ends in a backslash there fails the boundary
+                                          // rule (the sanitized copy has an odd trailing backslash run shortened by one)
+    bool relaxed = false;                 // boundary rule: the last byte of a document must not be a non-quote scalar character
+                                          // (instead of: must be a control-character separator)
 };
 constexpr int PREP_DOCS = 256;  // documents per workgroup of k_doc_prepare = per chunk of the tape-offset scan
 hipError_t batch_prepare_launch(const DocPrepare& a, hipStream_t stream);
@@ -215,6 +226,12 @@ struct BatchLayout {
     uint64_t n_docs, tape_capacity;
     unsigned long long* tape_offsets;
     bool optimistic_only;
+    // round 6: the pipeline's stage flags (sjmi_api.hip): pipe_flags[0] != 0 = the plain pass over the batch itself was accepted
+    // (stage A), pipe_flags[1] != 0 = A or the repair pass over the sanitized copy (stage B) was -- the tapes are laid out
+    uint32_t* pipe_flags = nullptr;
+    int stage = 0;                         // 0: A (writes both flags), 1: B (writes [1])
+    const uint32_t* gate = nullptr;        // device flag: != 0 -> nothing to do (stage B behind an accepted A)
+    const uint32_t* status_or = nullptr;   // stage B: OR of the documents' verdicts, into the caller's stage-1 record
 };
 hipError_t batch_reject_launch(Stage1Result* d_stage1, hipStream_t stream);  // sjmi_parse_batch_device_optimistic on a batch it cannot even try
 hipError_t batch_layout_launch(const BatchLayout& a, void* d_ws, uint64_t count, const uint32_t* lens, DocMeta* metas,
@@ -291,6 +308,14 @@ void* walk_slow_header(void* d_ws, uint64_t count, uint64_t n_docs);
 hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint32_t* d_out,
                                  uint64_t out_cap, unsigned long long* d_index_offsets, uint32_t* d_doc_status,
                                  uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream, uint64_t total_len, const uint32_t* d_skip = nullptr);
+// the same in two halves (round 6): the VERDICTS only (doc_status[k], counts[k], their OR in batch_status_or(d_counts, n_docs)) --
+// all the repair pass needs -- and the rest (index offsets + the indexes of the passing documents)
+hipError_t batch_verdicts_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint32_t* d_doc_status,
+                                 uint32_t* d_counts, hipStream_t stream, uint64_t total_len, const uint32_t* d_skip);
+hipError_t batch_indexes_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint32_t* d_out,
+                                uint64_t out_cap, unsigned long long* d_index_offsets, uint32_t* d_doc_status, uint32_t* d_counts,
+                                Stage1Result* d_res, hipStream_t stream, uint64_t total_len, const uint32_t* d_skip);
+const uint32_t* batch_status_or(const uint32_t* d_counts, uint64_t n_docs);
 // the optimistic plain pass of the fused batch pipeline (batch.hip)
 hipError_t batch_plain_check_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint64_t total_len,
                                     uint32_t* d_flags, hipStream_t stream);

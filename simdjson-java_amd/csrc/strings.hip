@@ -985,12 +985,15 @@ k_batch_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t ch
 // one wave per document
 __global__ void __launch_bounds__(256)
 k_batch_blank(uint8_t* __restrict__ copy, const unsigned long long* __restrict__ doc_offsets, const unsigned long long* __restrict__ index_offsets,
-              uint64_t n_docs, const uint32_t* __restrict__ skip) {
+              uint64_t n_docs, const uint32_t* __restrict__ skip, const uint32_t* __restrict__ doc_status, unsigned long long total_len) {
     if (skip && *skip) return;
     const int lane = threadIdx.x & 63;
     for (uint64_t k = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < n_docs; k += (uint64_t)gridDim.x * 4) {
-        const unsigned long long lo = doc_offsets[k], hi = doc_offsets[k + 1];
-        if (index_offsets[k + 1] == index_offsets[k]) {
+        // (device-resident offsets cannot be validated by the host: clamped to the copy)
+        unsigned long long lo = doc_offsets[k], hi = doc_offsets[k + 1];
+        if (hi > total_len) hi = total_len;
+        if (lo > hi) lo = hi;
+        if (doc_status ? doc_status[k] != 0 : index_offsets[k + 1] == index_offsets[k]) {
             for (unsigned long long p = lo + lane; p < hi; p += 64) copy[p] = 0x20;
         } else if (lane == 0 && hi > lo) {
             unsigned long long p = hi, run = 0;
@@ -1001,13 +1004,14 @@ k_batch_blank(uint8_t* __restrict__ copy, const unsigned long long* __restrict__
 }
 hipError_t strings_sanitize_launch(const uint8_t* d_buf, uint64_t total_len, const unsigned long long* d_doc_offsets,
                                    const unsigned long long* d_index_offsets, uint64_t n_docs, uint8_t* d_copy, const uint32_t* d_skip,
-                                   hipStream_t stream) {
+                                   hipStream_t stream, const uint32_t* d_doc_status) {
     const uint64_t chunks = (total_len + SJMI_PADDING + 15) / 16;
     const unsigned g1 = (unsigned)((chunks + 255) / 256 < 4096 ? (chunks + 255) / 256 : 4096);
     hipLaunchKernelGGL(k_batch_copy, dim3(g1 ? g1 : 1), dim3(256), 0, stream, reinterpret_cast<const uint4*>(d_buf), reinterpret_cast<uint4*>(d_copy),
                        chunks, d_skip);
     const unsigned g2 = (unsigned)((n_docs + 3) / 4 < 8192 ? (n_docs + 3) / 4 : 8192);
-    hipLaunchKernelGGL(k_batch_blank, dim3(g2 ? g2 : 1), dim3(256), 0, stream, d_copy, d_doc_offsets, d_index_offsets, n_docs, d_skip);
+    hipLaunchKernelGGL(k_batch_blank, dim3(g2 ? g2 : 1), dim3(256), 0, stream, d_copy, d_doc_offsets, d_index_offsets, n_docs, d_skip,
+                       d_doc_status, (unsigned long long)total_len);
     return hipGetLastError();
 }
 

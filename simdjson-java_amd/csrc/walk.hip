@@ -117,10 +117,15 @@ __global__ void __launch_bounds__(1024)
 k_batch_layout(BatchLayout a, uint64_t nchunks) {
     __shared__ unsigned long long s_wave[16];
     __shared__ uint32_t s_acc;
+    if (a.gate && *a.gate != 0) return;  // (the repair pass behind an accepted plain pass)
     if (threadIdx.x == 0) {
         const uint32_t st = a.stage1->status;
         const bool acc = a.flags[0] == 0 && st == 0;
         a.flags[1] = acc ? 1u : 0u;
+        if (a.pipe_flags) {
+            if (a.stage == 0) a.pipe_flags[0] = acc ? 1u : 0u;
+            a.pipe_flags[1] = acc ? 1u : 0u;
+        }
         s_acc = acc ? 1u : 0u;
         WalkResult zw = {};
         *a.walk = zw;
@@ -129,6 +134,8 @@ k_batch_layout(BatchLayout a, uint64_t nchunks) {
         if (acc) u = *a.strings_ws;
         *a.strings_out = u;
         if (!acc && a.optimistic_only) a.stage1_out->status = st | SJMI_ST_REJECTED;
+        // the repair pass was accepted: the batch's verdict is the OR of its documents' (the copy itself is clean by construction)
+        if (acc && a.status_or) a.stage1_out->status = st | (*a.status_or & (0xFFu | SJMI_ST_INTERNAL));
     }
     if (threadIdx.x < 16) static_cast<uint32_t*>(a.slow_header)[threadIdx.x] = 0;
     __syncthreads();

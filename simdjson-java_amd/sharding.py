@@ -85,14 +85,18 @@ class BatchShard:
         self.max_depth = max_depth
         self._ndocs = torch.tensor([self.n_docs], dtype=torch.int64, device=device)
 
-    def step(self, stream=0, exact=False):
+    def step(self, stream=0, exact=False, rejected=False):
         """One step, queued on `stream`.  Default: sjmi_parse_batch_device_optimistic -- only the optimistic pipeline (eight queue
         entries); a batch it cannot take (a document fails stage 1, a separator is missing) comes back with SJMI_ST_REJECTED in
-        its result record and check() makes the exact call then, off the hot path.  exact=True: sjmi_parse_batch_device,
-        everything queued, every document decided on its own whatever the batch contains."""
+        its result record and check() makes the call for rejected batches then (sjmi_parse_batch_device_rejected: per-document
+        verdicts + the pipeline over a sanitized copy), off the hot path.  exact=True: sjmi_parse_batch_device, everything
+        queued, every document decided on its own whatever the batch contains."""
         exact = exact or getattr(self, "rejected_steps", 0) > 0  # (latched: data that was rejected once takes the exact call from then on)
-        fn = self.engine.parse_batch_device if exact or not hasattr(self.engine, "parse_batch_device_optimistic") \
-            else self.engine.parse_batch_device_optimistic
+        if rejected and hasattr(self.engine, "parse_batch_device_rejected"):
+            fn = self.engine.parse_batch_device_rejected
+        else:
+            fn = self.engine.parse_batch_device if exact or rejected or not hasattr(self.engine, "parse_batch_device_optimistic") \
+                else self.engine.parse_batch_device_optimistic
         self._last_stream = stream
         fn(self.buf.data_ptr(), self.n, self.offs.data_ptr(), self.n_docs, self.idx.data_ptr(),
                                        self.index_capacity, self.index_offsets.data_ptr(), self.doc_status.data_ptr(),
@@ -114,7 +118,7 @@ class BatchShard:
         if st1 & 0x800:  # SJMI_ST_REJECTED: not a batch for the optimistic pipeline -- the exact call, here, off the hot path
             import torch
             self.rejected_steps = getattr(self, "rejected_steps", 0) + 1
-            self.step(getattr(self, "_last_stream", 0), exact=True)
+            self.step(getattr(self, "_last_stream", 0), rejected=True)
             torch.cuda.synchronize(self.device)
             r = self.result.cpu().numpy()
             st1, sflags, wflags = int(r[1]) & 0xFFFFFFFF, int(r[4]) & 0xFFFFFFFF, int(r[8]) & 0xFFFFFFFF
