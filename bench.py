@@ -700,6 +700,8 @@ def bench_single(args):
     put("configs3_batch_one_bad_doc_ms", "batch_1m_docs", "rejected_path", "one_bad_doc_ms")
     put("configs3_batch_one_bad_doc_stage2_ms", "batch_1m_docs", "rejected_path", "one_bad_doc_stage2_ms")
     put("configs3_batch_no_separator_ms", "batch_1m_docs", "rejected_path", "no_separator_ms")
+    put("configs3_batch_no_separator_latched_ms", "batch_1m_docs", "rejected_path", "no_separator_latched_ms")
+    put("configs3_batch_one_bad_doc_over_accepted", "batch_1m_docs", "rejected_path", "one_bad_doc_over_accepted")
     put("parse_twitter_json_all_device_ms", "parse_single_document", "twitter_json", "gpu_walker", "ms")
     put("parse_twitter_json_host_walker_ms", "parse_single_document", "twitter_json", "host_walker", "ms")
     put("configs4_1024_trees_ms", "twitter_x1024_as_1024_trees", "value")
@@ -854,11 +856,14 @@ def batch_rejected_path(torch, oracle, shard, offs, st, accepted_ms, steps):
     document with the oracle (check_batch_all) before it is timed:
       exact           sjmi_parse_batch_device on the unchanged batch (everything queued, the device decides);
       one_bad_doc     ONE document of the batch fails stage 1 (a 0xFF byte inside its last string): optimistic call ->
-                      SJMI_ST_REJECTED -> BatchShard.check() makes the exact call -- the whole cliff, both calls and the host
-                      round trip between them, per batch;
+                      SJMI_ST_REJECTED -> BatchShard.check() makes the call for rejected batches (sjmi_parse_batch_device_rejected:
+                      verdicts + the pipeline over a sanitized copy) -- the whole cliff, both calls and the host round trip
+                      between them, per batch;
       one_bad_doc_stage2   ONE document fails stage 2 only (its last '}' replaced by ']'): the plain pass is accepted, the token
                       walker declines the document, the exact walker (list mode) reports its error -- no rejection;
-      no_separator    the '\\n' behind every document replaced by a space: no control-character separators -> rejected -> exact."""
+      no_separator    the '\\n' behind every document replaced by a space: no control-character separators -> rejected -> the call
+                      for rejected batches; no_separator_latched: the steps after that one (BatchShard remembers a rejection for
+                      the batch's FORMAT and goes straight to that call)."""
     import numpy as np
     n_docs = shard.n_docs
     res = {}
@@ -870,6 +875,7 @@ def batch_rejected_path(torch, oracle, shard, offs, st, accepted_ms, steps):
 
     def cliff():
         shard.rejected_steps = 0
+        shard.format_rejected = False
         shard.step(st)
         torch.cuda.synchronize()
         return shard.check()
@@ -910,8 +916,14 @@ def batch_rejected_path(torch, oracle, shard, offs, st, accepted_ms, steps):
     assert shard.rejected_steps == 1
     verified("no_separator", 0)
     res["no_separator_ms"] = timed(cliff)
+    # ... and once BatchShard has latched "rejected for its format": every later step is the call for rejected batches alone
+    cliff()
+    assert shard.format_rejected
+    res["no_separator_latched_ms"] = timed(lambda: shard.step(st))
+    verified("no_separator (latched)", 0)
     shard.buf[sep] = 0x0A
     shard.rejected_steps = 0
+    shard.format_rejected = False
     shard.step(st)
     torch.cuda.synchronize()
     verified("restored", 0)

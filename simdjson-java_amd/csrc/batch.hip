@@ -383,6 +383,44 @@ hipError_t split_docs_launch(const uint32_t* d_idx, const Stage1Result* d_res, c
 struct __attribute__((packed, aligned(1))) DocU16 { uint32_t a, b, c, d; };
 struct __attribute__((packed, aligned(1))) DocU8 { unsigned long long v; };
 
+// the first n (0 .. 64) of a block's 64 bytes (w: its 16 dwords) to a byte-granular address: whole 16-byte chunks, then 8 / 4 / 2 / 1
+__device__ __forceinline__ void doc_store_block(uint8_t* __restrict__ dst, const uint32_t (&w)[16], uint32_t n) {
+    struct __attribute__((packed, aligned(1))) U4 { uint32_t v; };
+    struct __attribute__((packed, aligned(1))) U2 { uint16_t v; };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (n >= 16u * (q + 1)) {
+            const DocU16 v = {w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+            *reinterpret_cast<DocU16*>(dst + 16 * q) = v;
+        } else if (n > 16u * q) {  // (one chunk per block at most)
+            const uint32_t m = n - 16u * q;  // 1 .. 15
+            uint8_t* p = dst + 16 * q;
+            uint32_t a = w[4 * q], b = w[4 * q + 1], c2 = w[4 * q + 2], d = w[4 * q + 3];
+            if (m & 8u) {
+                DocU8 v;
+                v.v = ((unsigned long long)b << 32) | a;
+                *reinterpret_cast<DocU8*>(p) = v;
+                p += 8;
+                a = c2;
+                b = d;
+            }
+            if (m & 4u) {
+                U4 v = {a};
+                *reinterpret_cast<U4*>(p) = v;
+                p += 4;
+                a = b;
+            }
+            if (m & 2u) {
+                U2 v = {(uint16_t)a};
+                *reinterpret_cast<U2*>(p) = v;
+                p += 2;
+                a >>= 16;
+            }
+            if (m & 1u) *p = (uint8_t)a;
+        }
+    }
+}
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t bdpp_add(uint32_t v) {
     return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
@@ -398,9 +436,13 @@ __global__ void __launch_bounds__(256)
 k_doc_pass(const uint8_t* __restrict__ buf, const unsigned long long* __restrict__ doc_offsets, uint64_t n_docs,
            uint32_t* __restrict__ counts, uint32_t* __restrict__ doc_status,
            const unsigned long long* __restrict__ index_offsets, uint32_t* __restrict__ out, uint64_t out_cap,
-           sj_u64 total_len, const uint32_t* __restrict__ skip, uint32_t* __restrict__ status_or) {
+           sj_u64 total_len, const uint32_t* __restrict__ skip, uint32_t* __restrict__ status_or, uint8_t* __restrict__ copy) {
     if (skip && *skip) return;  // (the optimistic plain pass of the fused pipeline was accepted: k_batch_plain_accept)
     uint32_t seen = 0;          // (WRITE = false: the OR of this thread's documents' verdicts, for status_or)
+    // copy (WRITE = false, round 6): the SANITIZED COPY of the batch for the repair pass, made on the way -- every lane stores the
+    // bytes of its blocks as it classifies them, and the blocks of a document whose verdict is not 0 once more as spaces (the
+    // same lane to the same addresses: program order).  Exactly the documents' own bytes are written: a batch whose documents
+    // do not cover the buffer is not one the repair pass takes (k_doc_prepare), and the per-document passes make their own copy.
     const int lane = threadIdx.x & 63;
     const int rl = lane & 15;         // lane inside the row
     const int rshift = lane & ~15;    // first lane of the row
@@ -449,8 +491,9 @@ k_doc_pass(const uint8_t* __restrict__ buf, const unsigned long long* __restrict
                 if (!sj_carry_from_halo(halo, &e_in, &p_in)) sj_carry_slow(buf, s, start, &e_in, &p_in);
             }
             sj_u64 p[8];
-            sj_transpose_butterfly(w, p);
             const sj_u64 rem = len - cblk * 64;
+            if (!WRITE && copy && active) doc_store_block(copy + start, w, rem < 64 ? (uint32_t)rem : 64u);
+            sj_transpose_butterfly(w, p);
             sj_mask_tail(p, rem < 64 ? (uint32_t)rem : 64u);
             SjBlockMasks bm = sj_block(p, e_in, p_in, uc);
             if (!active) {
@@ -488,6 +531,15 @@ k_doc_pass(const uint8_t* __restrict__ buf, const unsigned long long* __restrict
                 doc_status[k] = all;
                 counts[k] = all ? 0u : (uint32_t)cnt;
                 seen |= all;
+            }
+            if (copy && all) {  // (rare) a failing document is blank in the copy
+                uint32_t sp[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sp[i] = 0x20202020u;
+                for (sj_u64 blk = rl; blk < nblocks; blk += 16) {
+                    const sj_u64 rem = len - blk * 64;
+                    doc_store_block(copy + s + blk * 64, sp, rem < 64 ? (uint32_t)rem : 64u);
+                }
             }
         }
     }
@@ -608,7 +660,7 @@ static unsigned doc_pass_grid(uint64_t n_docs) {
     return (unsigned)(want < 8192 ? want : 8192);  // grid-stride over the documents
 }
 hipError_t batch_verdicts_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint32_t* d_doc_status,
-                                 uint32_t* d_counts, hipStream_t stream, uint64_t total_len, const uint32_t* d_skip) {
+                                 uint32_t* d_counts, hipStream_t stream, uint64_t total_len, const uint32_t* d_skip, uint8_t* d_copy) {
     uint8_t* ws = reinterpret_cast<uint8_t*>(d_counts);
     uint32_t* status_or = reinterpret_cast<uint32_t*>(ws + iso_status_offset(n_docs));
     hipError_t e = hipMemsetAsync(status_or, 0, sizeof(uint32_t), stream);
@@ -616,7 +668,7 @@ hipError_t batch_verdicts_launch(const uint8_t* d_buf, const unsigned long long*
     if (n_docs)
         hipLaunchKernelGGL(k_doc_pass<false>, dim3(doc_pass_grid(n_docs)), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_counts,
                            d_doc_status, (const unsigned long long*)nullptr, (uint32_t*)nullptr, (uint64_t)0, (sj_u64)total_len, d_skip,
-                           status_or);
+                           status_or, d_copy);
     return hipGetLastError();
 }
 hipError_t batch_indexes_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint32_t* d_out,
@@ -636,7 +688,7 @@ hipError_t batch_indexes_launch(const uint8_t* d_buf, const unsigned long long* 
                            d_index_offsets, d_skip);
         hipLaunchKernelGGL(k_doc_pass<true>, dim3(doc_pass_grid(n_docs)), dim3(256), 0, stream, d_buf, d_doc_offsets, n_docs, d_counts,
                            d_doc_status, (const unsigned long long*)d_index_offsets, d_out, out_cap, (sj_u64)total_len, d_skip,
-                           (uint32_t*)nullptr);
+                           (uint32_t*)nullptr, (uint8_t*)nullptr);
     }
     return hipGetLastError();
 }
@@ -644,7 +696,7 @@ hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long*
                                  uint32_t* d_out, uint64_t out_cap, unsigned long long* d_index_offsets,
                                  uint32_t* d_doc_status, uint32_t* d_counts, Stage1Result* d_res, hipStream_t stream,
                                  uint64_t total_len, const uint32_t* d_skip) {
-    const hipError_t e = batch_verdicts_launch(d_buf, d_doc_offsets, n_docs, d_doc_status, d_counts, stream, total_len, d_skip);
+    const hipError_t e = batch_verdicts_launch(d_buf, d_doc_offsets, n_docs, d_doc_status, d_counts, stream, total_len, d_skip, nullptr);
     if (e != hipSuccess) return e;
     return batch_indexes_launch(d_buf, d_doc_offsets, n_docs, d_out, out_cap, d_index_offsets, d_doc_status, d_counts, d_res, stream,
                                 total_len, d_skip);

@@ -1383,15 +1383,13 @@ static int parse_batch_pipeline(sjmi_ctx* c, const void* d_buf, uint64_t total_l
         const uint32_t* const skip_b = pf;      // stages B and the verdicts: not behind an accepted A
         const uint32_t* const skip_c = pf + 1;  // stage C: not behind an accepted A or B
         // ---- every document's own stage-1 verdict (B needs nothing else of the per-document passes; C the rest) ----
+        //      with stage B behind it the same pass makes B's sanitized copy on the way: the documents' bytes, a failing one blank
         if (fail(c, "verdicts launch", sjmi::batch_verdicts_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs,
-                                                                   (uint32_t*)d_doc_status, c->d_doccnt, st, total_len, skip_b)))
+                                                                   (uint32_t*)d_doc_status, c->d_doccnt, st, total_len, skip_b,
+                                                                   try_repair ? c->d_copy : nullptr)))
             return SJMI_ERR_HIP;
         c->par_valid = false;  // (whose parities the context holds is decided on the device from here on)
-        // ---- the sanitized copy: failing documents blank (by verdict) ----
-        if (fail(c, "sanitize", sjmi::strings_sanitize_launch((const uint8_t*)d_buf, total_len, (const unsigned long long*)d_doc_offsets,
-                                                              nullptr, n_docs, c->d_copy, skip_b, st, (const uint32_t*)d_doc_status)))
-            return SJMI_ERR_HIP;
-        const unsigned long long* copy_par = c->d_blkpar2;  // the copy's block parities: from B's plain pass, or a parity-only launch
+        const unsigned long long* copy_par = c->d_blkpar2;  // the copy's block parities
         if (try_repair) {
             // ---- stage B: the plain pipeline over the copy.  Its stage-1 launch has a workspace of its own (a launch that may
             //      leave at once cannot take part in the context's two alternating halves) and its string pass a zeroed one ----
@@ -1433,22 +1431,22 @@ static int parse_batch_pipeline(sjmi_ctx* c, const void* d_buf, uint64_t total_l
                 fail(c, "repair: layout launch", sjmi::batch_layout_launch(lb, c->d_ws_walk, bound, wp.lens, wp.metas, (int32_t*)d_doc_errors, st)))
                 return SJMI_ERR_HIP;
             d_laid_out = pf + 1;
-        } else {
-            // (no stage B: the copy's parities from a parity-only launch, as before round 6)
+        }
+        // ---- stage C, every kernel gated on pf[1] == 0: its OWN sanitized copy (the whole buffer, failing documents blank, an odd
+        //      trailing backslash run shortened by one: a batch B does not take may have bytes between its documents and documents
+        //      that end in a backslash) and the copy's block parities from a parity-only launch ----
+        {
             sjmi::Stage1Extras ex;
             ex.blkpar = c->d_blkpar2;
             ex.skip = skip_c;
-            if (fail(c, "parity launch", sjmi::stage1_launch(c->d_copy, total_len, nullptr, 0, c->d_ws_par, steps, st, nullptr, nullptr,
+            if (fail(c, "sanitize", sjmi::strings_sanitize_launch((const uint8_t*)d_buf, total_len, (const unsigned long long*)d_doc_offsets,
+                                                                  nullptr, n_docs, c->d_copy, skip_c, st, (const uint32_t*)d_doc_status)) ||
+                fail(c, "parity launch", sjmi::stage1_launch(c->d_copy, total_len, nullptr, 0, c->d_ws_par, steps, st, nullptr, nullptr,
                                                              (launch_flags(c) & ~sjmi::DBG_NO_LOOKBACK) | sjmi::DBG_NO_WRITE, ex)))
                 return SJMI_ERR_HIP;
             note_launch(c, st);
-            if (!try_plain) {  // (neither A nor B ran: nobody zeroed the records stage C accumulates into)
-                if (fail(c, "memset(results)", hipMemsetAsync(&r->strings, 0, sizeof(sjmi_unescape_result) + sizeof(sjmi_walk_result), st)))
-                    return SJMI_ERR_HIP;
-            }
         }
-        // ---- stage C, every kernel gated on pf[1] == 0: the per-document index arrays, the string pass over the copy (fills the
-        //      record k_batch_layout zeroed), ordinals ----
+        //      ... the per-document index arrays, the string pass over the copy (fills the record k_batch_layout zeroed), ordinals
         if (fail(c, "indexes launch", sjmi::batch_indexes_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs,
                                                                  (uint32_t*)d_indexes, index_capacity, (unsigned long long*)d_index_offsets,
                                                                  (uint32_t*)d_doc_status, c->d_doccnt, (sjmi::Stage1Result*)&r->stage1, st,

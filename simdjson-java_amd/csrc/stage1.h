@@ -311,7 +311,8 @@ hipError_t batch_isolated_launch(const uint8_t* d_buf, const unsigned long long*
 // the same in two halves (round 6): the VERDICTS only (doc_status[k], counts[k], their OR in batch_status_or(d_counts, n_docs)) --
 // all the repair pass needs -- and the rest (index offsets + the indexes of the passing documents)
 hipError_t batch_verdicts_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint32_t* d_doc_status,
-                                 uint32_t* d_counts, hipStream_t stream, uint64_t total_len, const uint32_t* d_skip);
+                                 uint32_t* d_counts, hipStream_t stream, uint64_t total_len, const uint32_t* d_skip, uint8_t* d_copy);
+// (d_copy != nullptr: the sanitized copy for the repair pass made on the way -- the documents' own bytes, a failing document blank)
 hipError_t batch_indexes_launch(const uint8_t* d_buf, const unsigned long long* d_doc_offsets, uint64_t n_docs, uint32_t* d_out,
                                 uint64_t out_cap, unsigned long long* d_index_offsets, uint32_t* d_doc_status, uint32_t* d_counts,
                                 Stage1Result* d_res, hipStream_t stream, uint64_t total_len, const uint32_t* d_skip);

@@ -91,7 +91,12 @@ class BatchShard:
         its result record and check() makes the call for rejected batches then (sjmi_parse_batch_device_rejected: per-document
         verdicts + the pipeline over a sanitized copy), off the hot path.  exact=True: sjmi_parse_batch_device, everything
         queued, every document decided on its own whatever the batch contains."""
-        exact = exact or getattr(self, "rejected_steps", 0) > 0  # (latched: data that was rejected once takes the exact call from then on)
+        # Latched by check(): data that was rejected once does not take the optimistic-only call again (a step whose record says
+        # REJECTED has no valid counts for the gather).  Rejected although every document passed stage 1 = rejected for its FORMAT
+        # (no control-character separators): the next batch will be too, so it goes straight to the call for rejected batches;
+        # rejected for a document that fails stage 1: the exact call, which tries the plain pass first.
+        rejected = rejected or (not exact and getattr(self, "format_rejected", False))
+        exact = exact or getattr(self, "rejected_steps", 0) > 0
         if rejected and hasattr(self.engine, "parse_batch_device_rejected"):
             fn = self.engine.parse_batch_device_rejected
         else:
@@ -118,6 +123,8 @@ class BatchShard:
         if st1 & 0x800:  # SJMI_ST_REJECTED: not a batch for the optimistic pipeline -- the exact call, here, off the hot path
             import torch
             self.rejected_steps = getattr(self, "rejected_steps", 0) + 1
+            if not (st1 & 0xFF):
+                self.format_rejected = True  # (a clean stage-1 verdict and still rejected: the separators)
             self.step(getattr(self, "_last_stream", 0), rejected=True)
             torch.cuda.synchronize(self.device)
             r = self.result.cpu().numpy()

@@ -13,14 +13,18 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 ctx = S.Context(device=0, capacity=1 << 20)
 shard, offs = bench.make_batch_shard(torch, S, W, dev, ctx, 0, n_docs)
+entry = sys.argv[4] if len(sys.argv) > 4 else "exact"   # exact | rejected
 if mode == "bad":
     shard.buf[int(offs[n_docs // 2 + 1]) - 4] = 0xFF
+elif mode == "nosep":
+    import numpy as np
+    shard.buf[torch.from_numpy(np.asarray(offs[1:], dtype=np.int64) - 1).to(dev)] = 0x20
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(2):
-    shard.step(st, exact=True)
+    shard.step(st, exact=(entry == 'exact'), rejected=(entry == 'rejected'))
 torch.cuda.synchronize()
 t = time.perf_counter()
 for _ in range(steps):
-    shard.step(st, exact=True)
+    shard.step(st, exact=(entry == 'exact'), rejected=(entry == 'rejected'))
 torch.cuda.synchronize()
 print("ms per step %.3f" % ((time.perf_counter() - t) / steps * 1e3), shard.check())
