@@ -311,9 +311,13 @@ constexpr uint32_t STR_UQ_ITEMS = 128;  // sequences of one granule that are dec
 template <bool SOFF>
 struct StrWaveLds {
     alignas(16) uint32_t tile[STR_TILE_DW];
-    // per lane, parked for the flush one iteration later (record offsets by ordinal): kept / opening masks, offset
-    sj_u64 pk[SOFF ? 64 : 1], po[SOFF ? 64 : 1];
-    uint32_t pb[SOFF ? 64 : 1];
+    // Record offsets by ordinal (round 6).  A string's record begins at its header, and the header loop below knows where that is
+    // when it writes the length -- so the offset of every string of the granule, relative to the granule's first output byte, is
+    // parked HERE by ordinal inside the granule (one ds_write_b16 per header trip; at most 2048 strings in 4 KiB, offsets below
+    // 8256), and the flush one iteration later, when the granule's prefix is known, stores them coalesced.  (Round 5 parked three
+    // masks per lane and the flush re-derived every offset with two 64-bit popcounts and stored it by itself: a 4-byte store per
+    // string to 64 different lines per trip -- 1.20 GB written for 0.86 GB of records and offsets on the configs[3] batch.)
+    uint16_t so[SOFF ? 2048 : 2];
 };
 
 template <bool SOFF>
@@ -680,14 +684,10 @@ k_strings(const StrArgs a0) {
                         if (pb < nblocks) a.blk_ord[pb] = ordbase + prev_oexcl;
                     }
                     if (a.soff && prev_nopen) {
-                        const sj_u64 K = sh[wave].pk[lane], O = sh[wave].po[lane];
-                        const uint32_t B = sh[wave].pb[lane];
-                        uint32_t r = ordbase + prev_oexcl;
-                        for (sj_u64 o = O; o; o &= o - 1, ++r) {
-                            const sj_u64 lt = (o & (0 - o)) - 1ull;
-                            const uint32_t off = B + (uint32_t)__popcll(K & lt) + 4u * (uint32_t)__popcll(O & lt);
-                            if (r < a.soff_cap) a.soff[r] = (uint32_t)outbase + off;
-                        }
+                        const sj_u64 room = a.soff_cap > ordbase ? a.soff_cap - ordbase : 0;
+                        const uint32_t nst = (sj_u64)prev_nopen < room ? prev_nopen : (uint32_t)room;
+                        const uint16_t* const so = sh[wave].so;
+                        for (uint32_t j = (uint32_t)lane; j < nst; j += 64) a.soff[ordbase + j] = (uint32_t)outbase + so[j];
                     }
                 }
             }
@@ -744,6 +744,11 @@ k_strings(const StrArgs a0) {
                 // where the content of the string that is open (or opens first) begins = its header + 4
                 uint32_t from = (entered_in ? prevD - 1u : B) + 4u;
                 uint32_t slots = entered_in ? B : B + 4u;  // B + 4 x openings in front of the closing quote at hand
+                // the ordinal (inside the granule) of the string the closing quote at hand closes: the lane's own strings from
+                // oexcl on; the string it was entered in is the last one opened in front of the lane (parked by its own lane as
+                // well: the same value)
+                uint16_t* so = nullptr;
+                if constexpr (SOFF) so = sh[wave].so + oexcl - ((entered_in && prevD) ? 1u : 0u);
                 if (entered_in && !prevD) {
                     // opened in an earlier granule (the flush writes that header): pass over the block's first closing quote
                     const uint32_t inlo = CLlo != 0;
@@ -759,6 +764,7 @@ k_strings(const StrArgs a0) {
                     const uint32_t ltc = (1u << (uint32_t)__builtin_ctz(cl)) - 1u;
                     const uint32_t end = (uint32_t)__popc(Klo & ltc) + slots;
                     tile_or(tile, from - 4u, __builtin_bswap32(end - from));
+                    if constexpr (SOFF) *so++ = (uint16_t)(from - 4u);
                     from = end + 4u;
                     slots += 4u;
                 }
@@ -767,10 +773,22 @@ k_strings(const StrArgs a0) {
                     const uint32_t ltc = (1u << (uint32_t)__builtin_ctz(cl)) - 1u;
                     const uint32_t end = (uint32_t)__popc(Khi & ltc) + slots;
                     tile_or(tile, from - 4u, __builtin_bswap32(end - from));
+                    if constexpr (SOFF) *so++ = (uint16_t)(from - 4u);
                     from = end + 4u;
                     slots += 4u;
                 }
+                // the lane's last string stays open: its header is where the next content would begin
+                if constexpr (SOFF) {
+                    if (m.O && m.exit_in) *so = (uint16_t)(from - 4u);
+                }
             } else {  // (rare: some string of the wave's 4 KiB has a malformed escape)
+                if constexpr (SOFF) {  // record offsets: every opening quote by itself
+                    uint16_t* so = sh[wave].so + oexcl;
+                    for (sj_u64 o = m.O; o; o &= o - 1) {
+                        const sj_u64 lt = (o & (0 - o)) - 1ull;
+                        *so++ = (uint16_t)(B + (uint32_t)__popcll(m.K & lt) + 4u * (uint32_t)__popcll(m.O & lt));
+                    }
+                }
                 for (sj_u64 cl = m.CL; cl; cl &= cl - 1) {
                     const uint32_t c = (uint32_t)__builtin_ctzll(cl);
                     const sj_u64 lt_c = (1ull << c) - 1ull;
@@ -858,11 +876,6 @@ k_strings(const StrArgs a0) {
                     if (spilled) old &= ~0u << (8u * spilled);
                     tile_xor(tile, base + sj_str_offset(m, e) - (L - 1u), old ^ nb);
                 }
-            }
-            if constexpr (SOFF) {
-                sh[wave].pk[lane] = m.K;
-                sh[wave].po[lane] = m.O;
-                sh[wave].pb[lane] = base + m.head;
             }
             str_lds_fence();
         }

@@ -15,6 +15,7 @@ for f in stage1.hip strings.hip batch.hip walk.hip coop_walk.hip masks.hip sjmi_
   if [ ! -f $o ] || [ $newest -nt $o ]; then hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -pthread -I include -c simdjson-java_amd/csrc/$f -o $o; fi
   OBJS="$OBJS $o"
 done
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -pthread -I include "$@" -c simdjson-java_amd/csrc/$VS -o /tmp/objs/variant_$name.o
+# (VARIANT_FILE: compile this file in place of the source -- e.g. `git show HEAD:simdjson-java_amd/csrc/strings.hip` saved beside it)
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -pthread -I include "$@" -c ${VARIANT_FILE:-simdjson-java_amd/csrc/$VS} -o /tmp/objs/variant_$name.o
 hipcc --offload-arch=gfx950 -shared -fPIC -pthread /tmp/objs/variant_$name.o $OBJS -o tools/variants/libsjmi_$name.so
 echo built tools/variants/libsjmi_$name.so
