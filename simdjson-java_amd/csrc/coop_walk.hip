@@ -1304,6 +1304,393 @@ k_tok_walk(TokArgs a_by_value) {
     TOK_PROF_END
 }
 
+// ---- the batch walker in STREAM form (round 6) ------------------------------------------------------------------------------
+// k_tok_walk above walks one document per wave at a time, and of its ~500 scalar + ~420 vector instructions per ~1 KB document
+// more than half of the scalar ones are per-DOCUMENT scaffolding (profiles/r5/README.md: four ingest trips, a prefetch a document
+// ahead, prologue, epilogue, a half-empty second token step); it is bound by scalar issue.  k_tok_stream walks a RUN of TS_RUN
+// consecutive documents as ONE token stream: the structurals of a run are contiguous in stage 1's index array, so the ingest never
+// stops at a document, and a token step of 64 tokens may hold the end of one document, a whole small one and the beginning of a
+// third.  Nothing in a step is per document:
+//   * a token carries the run-local number of its document (8 bits of the token word); a token whose predecessor belongs to
+//     another document is a document's first (DS), has "nothing" in front of it, and its predecessor has no successor;
+//   * depth, string ordinal and tape position are ONE three-field scan over the step, continued over the run by three uniform
+//     counters (A_d, A_q, A_w); a document's first token parks the scan values it sees in the document's LDS record, and every
+//     token of the document subtracts them -- document-relative depth / ordinal / position whatever step the document began in;
+//   * containers, comma counts and the grammar table are k_tok_walk's, unchanged: a document's containers all lie behind its
+//     first token, so the last opening bracket of my level in front of me is mine;
+//   * the only token that may stand at depth 0 is a document's first, and it must be an opening bracket: that is "nothing
+//     follows the root's end", "the root is a container" and "a closing bracket too many" in one compare; a document must be
+//     back at depth 0 where the next one starts (the next document's first token looks at it);
+//   * a failing document is a bit in a mask per run: its tokens store nothing from the step on in which it fails, it is listed
+//     for the exact walker at the run's end, and it cannot touch its neighbours (its tokens resolve against its own brackets
+//     or, at depth < 1, against nothing: they are kept out of the LDS operations).
+// The wave-uniform state is small on purpose (the first stream walker, round 5, died of 89-128 spilled SGPRs): three scan
+// counters, the previous token, ring head / tail, the ingest's chunk and separator carries, the failed mask.
+constexpr uint32_t TS_RUN = 16u;    // documents per run (their records live in LDS; a run is ~1,800 tokens = ~28 token steps)
+constexpr uint32_t TS_RING = 128u;  // tokens between the ingest and the token steps
+struct __attribute__((aligned(8))) TsRing {
+    uint2 e[TS_RING];  // .x = position, .y = the token | run-local document << 24
+};
+struct __attribute__((aligned(16))) TsRun {
+    uint4 rec[TS_RUN];       // per (non-empty) document of the run: tape offset lo, hi, room in words, its number in the batch
+    uint4 dyn[TS_RUN];       // ... set by its first token: .x = depth base, .y = string base - its first ordinal, .z = word base - 1
+    uint32_t dso[TS_RUN];    // ... the ordinal of its first string
+    uint32_t from[TS_RUN + 1];  // ... its first structural (index into idx[]); [n] = the run's end
+};
+#ifndef SJMI_TS_WAVES
+#define SJMI_TS_WAVES 6
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SJMI_TS_WAVES, SJMI_TS_WAVES)))
+k_tok_stream(TokArgs a_by_value) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const TokArgs& a = *(const TokArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // (see k_tok_walk)
+    (void)a_by_value;
+#else
+    const TokArgs& a = a_by_value;
+#endif
+    if (a.sel && *a.sel == 0 && !a.tape_alt) return;  // (only the optimistic pipeline was queued and its plain pass was rejected)
+    __shared__ TsRing rings[4];
+    __shared__ PrimQueue queues[4];
+    __shared__ TokLevels levels[4];
+    __shared__ TsRun runs[4];
+    __shared__ uint32_t first_byte_token[256];
+    __shared__ uint8_t grammar[TOK_GRAMMAR_ENTRIES];
+    first_byte_token[threadIdx.x] = tok_of_first_byte(threadIdx.x);
+    for (uint32_t i = threadIdx.x; i < TOK_GRAMMAR_ENTRIES; i += 256u) grammar[i] = (uint8_t)tok_grammar(i);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    TsRing& ring = rings[wv];
+    PrimQueue& pq = queues[wv];
+    TokLevels& lv = levels[wv];
+    TsRun& run = runs[wv];
+    uint32_t qhead = 0, qtail = 0;
+    auto send_to_exact = [&](uint32_t doc) {
+        if (atomicExch(&a.doc_errors[doc], CW_NEEDS_EXACT) != CW_NEEDS_EXACT) {
+            const uint32_t slot = atomicAdd(&a.list[0], 1u);
+            a.list[16 + slot] = doc;
+        }
+    };
+    auto flush_primitives = [&](uint32_t nq) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool live = (uint32_t)lane < nq;
+        const uint32_t e = (qhead + (uint32_t)lane) & 127u;
+        const uint4 q = pq.e[e];
+        const uint32_t p = live ? q.x : 0u, doc = q.y;
+        unsigned long long* const dst = reinterpret_cast<unsigned long long*>(((unsigned long long)q.w << 32) | q.z);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const CW16 win = *reinterpret_cast<const CW16*>(a.buf + p);
+        if (live) {
+            uint32_t ptype = 0;
+            unsigned long long praw = 0;
+            if (cw_primitive(a.buf, win, p, false, 0u, &ptype, &praw) == 0) {
+                dst[0] = tape_word(ptype, 0);
+                if (ptype == 'l' || ptype == 'd') dst[1] = praw;
+            } else {
+                send_to_exact(doc);
+            }
+        }
+        qhead += nq;
+    };
+    const unsigned long long lane_bit = 1ull << lane;
+    const uint32_t below_lo = (uint32_t)(lane_bit - 1ull), below_hi = (uint32_t)((lane_bit - 1ull) >> 32);
+    const uint32_t nwaves = gridDim.x * 4u;
+    unsigned long long* const tape = (a.sel && *a.sel == 0) ? a.tape_alt : a.tape;
+    const bool upstream_failed = (a.dev_count && (a.dev_count->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL))) ||
+                                 (a.dev_strings && (a.dev_strings->flags & 0xFu));
+    const bool string_errors = a.dev_strings && a.dev_strings->first_error_inv != 0;
+    const int depth_limit = (a.max_depth < CW_LEVELS ? a.max_depth : CW_LEVELS) - 1;
+    const uint32_t n_runs = (a.n_docs + TS_RUN - 1u) / TS_RUN;
+    for (uint32_t r = blockIdx.x * 4u + (uint32_t)wv; r < n_runs; r += nwaves) {
+        // ================= the run's documents: lane = document =================
+        const uint32_t k0 = r * TS_RUN;
+        const uint32_t nd = a.n_docs - k0 < TS_RUN ? a.n_docs - k0 : TS_RUN;
+        DocMeta m = {};
+        if ((uint32_t)lane <= nd) m = a.metas[k0 + (uint32_t)lane];  // (n_docs + 1 records: the last one carries the tapes' end)
+        const bool isdoc = (uint32_t)lane < nd;
+        const bool nonempty = isdoc && m.to != m.from;
+        // (more than 2^30 structurals: tape positions keep a flag bit, the comma counters too -- such a document, one that failed
+        //  stage 1 and any document behind a failed launch goes to the exact walker; so does a document without structurals)
+        const bool unwalkable = nonempty && (upstream_failed || m.st != 0 || m.to - m.from >= (1u << 30) || m.to > 0xFFFFFF00u);
+        const unsigned long long NE = cw_ballot(nonempty), UW = cw_ballot(unwalkable);
+        if (isdoc && (!nonempty || UW != 0)) {  // (an unwalkable document in the run: rare enough to send the whole run along)
+            if (a.tape_lens) a.tape_lens[k0 + (uint32_t)lane] = 0u;
+            send_to_exact(k0 + (uint32_t)lane);
+        }
+        if (UW != 0 || NE == 0) continue;
+        const uint32_t rn = (uint32_t)__popcll(NE);
+        {
+            const uint32_t nx_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m.tape_lo, 0x130, 0xf, 0xf, false);  // wave_shl:1
+            const uint32_t nx_hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m.tape_hi, 0x130, 0xf, 0xf, false);
+            const unsigned long long t_off = ((unsigned long long)m.tape_hi << 32) | m.tape_lo;
+            const unsigned long long room64 = (((unsigned long long)nx_hi << 32) | nx_lo) - t_off;
+            const uint32_t room = room64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)room64;
+            const uint32_t slot = cw_below(NE);
+            if (nonempty) {
+                run.rec[slot] = make_uint4(m.tape_lo, m.tape_hi, room, k0 + (uint32_t)lane);
+                run.dso[slot] = m.dso;
+                run.from[slot] = m.from;
+            }
+        }
+        const uint32_t I0 = (uint32_t)__builtin_amdgcn_readlane((int)m.from, __builtin_ctzll(NE));
+        const uint32_t I1 = (uint32_t)__builtin_amdgcn_readlane((int)m.to, 63 - __builtin_clzll(NE));
+        if (lane == 0) run.from[rn] = I1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ================= the stream =================
+        const uint32_t n = I1 - I0, nchunks = (n + 63u) / 64u;
+        uint32_t c = 0, head = 0, tail = 0;
+        unsigned long long SEPp = 0, COLp = 0;
+        uint32_t jc = 0, jn = 1;                       // the document of the chunk's first structural; the next one to start
+        uint32_t nxt_from = run.from[1] - I0;          // ... and where (relative to I0)
+        unsigned long long failed = 0;                 // bit j: document j of the run goes to the exact walker
+        int A_d = 0;                                   // the scan's running totals in front of the step: depth field - tokens,
+        uint32_t A_q = 0, A_w = 0;                     //   strings, tape words
+        uint32_t c_token = (uint32_t)TK_NONE | 0xFF000000u, c_eo = 0;  // the previous step's last token (no document yet)
+        int c_dbase = 0;
+        bool seen = false;
+        unsigned long long PQ = 0;
+        unsigned long long* pq_addr = nullptr;
+        uint32_t pq_off = 0;
+        auto fail_lanes = [&](unsigned long long M, uint32_t dj_v) {  // (rare) the documents of the lanes in M
+            for (; M; M &= M - 1) failed |= 1ull << ((uint32_t)__builtin_amdgcn_readlane((int)dj_v, __builtin_ctzll(M)) & 63u);
+        };
+        // positions are requested two chunks ahead, first bytes one chunk ahead
+        auto pos_of = [&](uint32_t cc) -> uint32_t {
+            const uint32_t i = cc * 64u + (uint32_t)lane;
+            return a.idx[I0 + (i < n ? i : n - 1u)];
+        };
+        uint32_t Pa = pos_of(0), Pb = pos_of(1);
+        uint32_t Ba = a.buf[Pa];
+        auto ingest = [&]() {
+            const uint32_t i0 = c * 64u;
+            const uint32_t nvl = n - i0 < 64u ? n - i0 : 64u;
+            const unsigned long long VL = cw_first(nvl);
+            const uint32_t p = Pa, b0 = Ba;
+            Pa = Pb;
+            Ba = a.buf[Pa];
+            Pb = pos_of(c + 2u);
+            // the documents that start in this chunk (index space: no load)
+            unsigned long long DSc = 0;
+            while (nxt_from < i0 + nvl) {
+                DSc |= 1ull << (nxt_from - i0);
+                ++jn;
+                nxt_from = run.from[jn <= rn ? jn : rn] - I0;
+                if (jn > rn) nxt_from = 0xFFFFFFFFu;
+            }
+            const uint32_t dj = jc + cw_below(DSc) + (cw_lanes(DSc) ? 1u : 0u);
+            jc += (uint32_t)__popcll(DSc);
+            const uint32_t token = first_byte_token[b0];
+            const unsigned long long COL = cw_ballot(b0 == ':') & VL;
+            const unsigned long long SEP = (cw_ballot(b0 == ',') & VL) | COL;
+            // what stands in front of a structural -- nothing, if it is a document's first
+            const unsigned long long S1 = ((SEP << 1) | (SEPp >> 63)) & ~DSc, C1 = ((COL << 1) | (COLp >> 63)) & ~DSc;
+            // never valid: a separator behind a separator, a separator as a document's last structural
+            unsigned long long ends = DSc >> 1;
+            if (nxt_from == i0 + 64u || c + 1u == nchunks) ends |= 1ull << (nvl - 1u);
+            const unsigned long long bad_sep = (SEP & S1) | (SEP & ends);
+            if (bad_sep) fail_lanes(bad_sep, dj);
+            uint32_t pre = cw_lanes(S1) ? TOK_COMMA : 0u;
+            pre = cw_lanes(C1) ? TOK_COLON : pre;
+            const unsigned long long TOK = VL & ~SEP;
+            const uint32_t slot = (tail + cw_below(TOK)) & (TS_RING - 1u);
+            if (cw_lanes(TOK)) ring.e[slot] = make_uint2(p, token | pre | (dj << 24));
+            tail += (uint32_t)__popcll(TOK);
+            SEPp = SEP;
+            COLp = COL;
+            ++c;
+        };
+        for (;;) {
+            while (c < nchunks && tail - head <= TS_RING - 64u) ingest();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t avail = tail - head;
+            if (avail == 0u) break;
+            // ---- one token step ----
+            const uint32_t na = avail < 64u ? avail : 64u;
+            const uint2 re = ring.e[(head + (uint32_t)lane) & (TS_RING - 1u)];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // a step ends in front of an opening bracket whose successor is not at hand (is it an empty container?)
+            const bool more = c < nchunks || avail > 64u;
+            const uint32_t nv = (more && ((uint32_t)__builtin_amdgcn_readlane((int)re.y, 63) & 7u) <= TK_OPEN_O) ? 63u : na;
+            const unsigned long long V = cw_first(nv);
+            const uint32_t p = re.x, token = cw_lanes(V) ? re.y : ((uint32_t)TK_NONE | 0xFF000000u);
+            const uint32_t tk = token & 7u, dj = cw_lanes(V) ? token >> 24 : 0u;
+            const unsigned long long OPEN = cw_ballot(tk <= TK_OPEN_O), CLOSE = cw_ballot(tk <= TK_CLOSE_O) & ~OPEN;
+            const unsigned long long Q = cw_ballot(tk == TK_STRING), PRIM = cw_ballot(tk >= TK_ATOM);
+            // my neighbours' tokens; a document's first token has none in front, its predecessor none behind
+            const uint32_t prev_raw = (uint32_t)__builtin_amdgcn_update_dpp((int)c_token, (int)token, 0x138, 0xf, 0xf, false);   // wave_shr:1
+            const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp((int)TK_NONE, (int)token, 0x130, 0xf, 0xf, false);     // wave_shl:1
+            const unsigned long long DS = cw_ballot(((prev_raw ^ token) >> 24) != 0u) & V;
+            const uint32_t prev = cw_lanes(DS) ? (uint32_t)TK_NONE : prev_raw;
+            // (1) empty containers: an opening bracket directly followed by its closing bracket is ONE value (TapeBuilder.java:205-208)
+            const unsigned long long EO = cw_ballot(((next ^ (tk + 2u)) & (7u | TOK_COMMA | TOK_COLON)) == 0u) & OPEN & ~(DS >> 1);
+            const unsigned long long EC = CLOSE & ((EO << 1) | ((unsigned long long)c_eo & ~DS));
+            // (2) ONE scan, three fields: 1 + up - down | strings << 8 | tape words << 16
+            const uint32_t inc = ((token & TOK_SCAN_FIELDS) >> 5) | (cw_lanes(Q) ? 0x100u : 0u);
+            const uint32_t scan3 = cw_incl_scan(inc);
+            const uint32_t tot3 = cw_last(scan3);
+            const uint32_t excl = scan3 - inc;
+            const int D = A_d + (int)(excl & 0xFFu) - lane;
+            const uint32_t aq = A_q + ((excl >> 8) & 0xFFu), aw = A_w + (excl >> 16);
+            // (3) my document: where its tape goes; its bases (a first token sets them)
+            const uint4 rec = run.rec[dj];
+            if (cw_lanes(DS)) run.dyn[dj] = make_uint4((uint32_t)D, aq - run.dso[dj], aw - 1u, 0u);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint4 dyn = run.dyn[dj];
+            const int h = D - (int)dyn.x;
+            const uint32_t sord = aq - dyn.y, tpos = aw - dyn.z;
+            const uint32_t rec_off = cw_lanes(Q) ? a.soff[sord] : 0u;  // (used one step later)
+            // the depth in front of a document's first token, as the document in front of it counts: it must be back at 0
+            const int dbase_prev = __builtin_amdgcn_update_dpp(c_dbase, (int)dyn.x, 0x138, 0xf, 0xf, false);  // wave_shr:1
+            unsigned long long NC = DS & cw_ballot(D != dbase_prev);
+            if (!seen) NC &= ~1ull;
+            // only a document's first token stands at depth 0 (and the grammar wants an opening bracket there)
+            const unsigned long long LOW = cw_ballot(h < 1) & V & ~DS;
+            const unsigned long long DEEP = cw_ballot(h >= depth_limit);
+            const unsigned long long NOROOM = cw_ballot(tpos + (inc >> 16) >= rec.z) & V;  // (+ the closing root word)
+            // Tokens of a document that failed in an earlier step take no part in the LDS operations below; a token at depth < 1
+            // (it fails its document in this step) adds to no counter -- the level its depth wraps to may be a real one of an
+            // earlier document in the step -- but an opening bracket among them still REGISTERS: the tokens it contains stand at
+            // depth >= 1 and must find it, not the last bracket of an earlier document.
+            const unsigned long long FL0 = failed ? cw_ballot(((uint32_t)(failed >> dj) & 1u) != 0u) : 0ull;
+            const unsigned long long ACT = V & ~LOW & ~FL0;
+            const unsigned long long REG = OPEN & V & ~FL0;
+            // (4) the container of every token (k_tok_walk's scheme: the step's opening brackets by level in LDS, the stack in LDS)
+            const uint32_t lvl = (uint32_t)(h - 1) & 63u;
+            lv.open[lane] = 0ull;
+            lv.cnt[lane] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (cw_lanes(REG)) atomicOr(&lv.open[(uint32_t)h & 63u], lane_bit);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long om = lv.open[lvl];
+            const uint32_t om_lo = (uint32_t)om & below_lo, om_hi = (uint32_t)(om >> 32) & below_hi;
+            const uint32_t lz_hi = om_hi ? (uint32_t)__builtin_clz(om_hi) : 0xFFFFFFFFu;
+            const uint32_t lz_lo = (om_lo ? (uint32_t)__builtin_clz(om_lo) : 0xFFFFFFFFu) | 32u;
+            const uint32_t lz = lz_hi < lz_lo ? lz_hi : lz_lo;
+            const unsigned long long IN_STEP = cw_ballot((int32_t)lz >= 0);
+            const uint32_t par_lane = (63u - lz) & 63u;
+            uint32_t* const my_counter = cw_lanes(IN_STEP) ? &lv.cnt[par_lane] : &lv.stk[lvl].y;
+            uint32_t add = (token >> 3) & 1u;
+            add = cw_lanes(CLOSE & ~EC & IN_STEP) ? add | 0x80000000u : add;
+            if (cw_lanes(ACT)) atomicAdd(my_counter, add);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t se_x = lv.stk[lvl].x;
+            const uint32_t pcnt = *my_counter;
+            const uint32_t own = lv.cnt[lane];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t opener = tpos | ((tk - 1u) & 0x80000000u);  // is-array << 31 (TK_OPEN_A = 0)
+            if (cw_lanes(REG & ~EO & ~cw_ballot((int32_t)own < 0))) lv.stk[(uint32_t)h & 63u] = make_uint2(opener, own);
+            const uint32_t from_step = (uint32_t)__shfl((int)opener, (int)par_lane);
+            const uint32_t par = cw_lanes(IN_STEP) ? from_step : se_x;
+            const uint32_t par_tpos = par & 0x7FFFFFFFu;
+            const uint32_t par_cnt = pcnt & 0x3FFFFFFFu;
+            // (5) the token grammar: one table entry
+            const uint32_t gi = (token & 0x1Fu) | ((prev & 0x17u) << 5) | ((par >> 21) & 0x400u);
+            unsigned long long BAD = ((cw_ballot(grammar[gi] == 0) | NOROOM | (OPEN & ~EO & DEEP)) & V) | LOW;
+            if (string_errors) {
+                bool bad_string = false;
+                if (cw_lanes(Q)) {
+                    const uint8_t* hh = a.sb + rec_off;
+                    bad_string = hh[0] == 0xFF && hh[1] == 0xFF && hh[2] == 0xFF;
+                }
+                BAD |= cw_ballot(bad_string);
+            }
+            unsigned long long FL = FL0;
+            if (BAD | NC) {  // (rare) whose documents fail: a bad token's own, a first token's predecessor's
+                fail_lanes(BAD, dj);
+                const uint32_t dj_prev = prev_raw >> 24;
+                fail_lanes(NC, dj_prev);
+                FL = cw_ballot(((uint32_t)(failed >> dj) & 1u) != 0u);
+            }
+            const unsigned long long LIVE = V & ~FL;
+            // (6) the tape words of this step
+            unsigned long long* const T = tape + ((((unsigned long long)rec.y << 32) | rec.x) + tpos);
+            if (cw_lanes(PQ)) *pq_addr = tape_word('"', a.string_base + pq_off);  // the previous step's strings
+            PQ = Q & LIVE;
+            pq_addr = T;
+            pq_off = rec_off;
+            if (PRIM & LIVE) {  // atoms and numbers: queued, parsed 64 at a time (flush_primitives)
+                const unsigned long long PL = PRIM & LIVE;
+                const uint32_t qs = (qtail + cw_below(PL)) & 127u;
+                if (cw_lanes(PL)) {
+                    const unsigned long long d = reinterpret_cast<unsigned long long>(T);
+                    pq.e[qs] = make_uint4(p, rec.w, (uint32_t)d, (uint32_t)(d >> 32));
+                }
+                qtail += (uint32_t)__popcll(PL);
+            }
+            {   // brackets (as in k_tok_walk)
+                const uint32_t type_hi = __builtin_amdgcn_perm(token, 0u, 0x050C0C0Cu);  // the bracket itself << 24
+                uint32_t pay1 = cw_lanes(EC) ? tpos : par_tpos;
+                pay1 = cw_lanes(EO) ? tpos + 2u : pay1;
+                if (cw_lanes((EO | CLOSE) & LIVE)) T[0] = ((unsigned long long)type_hi << 32) | pay1;
+                uint32_t cnt = par_cnt + 1u;
+                if (cnt > 0xFFFFFFu) cnt = 0xFFFFFFu;
+                if (cw_lanes(CLOSE & ~EC & LIVE)) {
+                    unsigned long long* const TP = T - tpos + par_tpos;
+                    *TP = ((unsigned long long)((type_hi - 0x02000000u) | cnt) << 32) | (tpos + 1u);
+                }
+            }
+            // the document in front of a first token has ended: both its root words, its tape length (visitDocumentEnd,
+            // TapeBuilder.java:45-48); not for one that failed (NC included: it is in `failed` by now)
+            unsigned long long DSW = DS;
+            if (!seen) DSW &= ~1ull;
+            if (DSW) {
+                const uint32_t pj = (prev_raw >> 24) & (TS_RUN - 1u);
+                if (cw_lanes(DSW) && !((uint32_t)(failed >> pj) & 1u)) {
+                    const uint4 rp = run.rec[pj];
+                    const uint32_t t0p = aw - run.dyn[pj].z;  // position of its closing root word
+                    unsigned long long* const TP = tape + (((unsigned long long)rp.y << 32) | rp.x);
+                    TP[t0p] = tape_word('r', 0);
+                    TP[0] = tape_word('r', t0p + 1u);
+                    if (a.tape_lens) a.tape_lens[rp.w] = t0p + 1u;
+                }
+            }
+            // (7) carries
+            const uint32_t lastv = nv - 1u;
+            A_d += (int)(tot3 & 0xFFu) - (int)nv;
+            A_q += (tot3 >> 8) & 0xFFu;
+            A_w += tot3 >> 16;
+            c_token = (uint32_t)__builtin_amdgcn_readlane((int)token, (int)lastv);
+            c_eo = cw_bit(EO, lastv);
+            c_dbase = __builtin_amdgcn_readlane((int)dyn.x, (int)lastv);
+            seen = true;
+            head += nv;
+            if (qtail - qhead >= 64u) flush_primitives(64u);
+        }
+        if (cw_lanes(PQ)) *pq_addr = tape_word('"', a.string_base + pq_off);  // the last step's strings
+        // ================= the run's end: its last document, the failed ones =================
+        if (seen) {
+            const uint32_t pj = (c_token >> 24) & (TS_RUN - 1u);
+            if (A_d != c_dbase) failed |= 1ull << pj;  // the root container is never closed (JsonIterator.java:39-41,:51-53)
+            if (!((failed >> pj) & 1ull) && lane < 2) {
+                const uint4 rp = run.rec[pj];
+                const uint32_t t0p = A_w - run.dyn[pj].z;
+                unsigned long long* const TP = tape + (((unsigned long long)rp.y << 32) | rp.x);
+                TP[lane == 0 ? t0p : 0u] = tape_word('r', lane == 0 ? 0u : t0p + 1u);
+                if (a.tape_lens && lane == 0) a.tape_lens[rp.w] = t0p + 1u;
+            }
+        }
+        // (a document all of whose structurals are separators never reached a step: the ingest failed it)
+        if ((uint32_t)lane < rn && ((failed >> lane) & 1ull)) {
+            const uint32_t g = run.rec[lane].w;
+            if (a.tape_lens) a.tape_lens[g] = 0u;
+            send_to_exact(g);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (qtail != qhead) flush_primitives(qtail - qhead);  // (fewer than 64 by construction)
+}
+
 // ---- the chunk passes around k_coop_walk<true> --------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_chunk_summary(const uint8_t* __restrict__ buf, const uint32_t* __restrict__ idx, const unsigned long long* __restrict__ index_offsets,
@@ -1801,7 +2188,14 @@ hipError_t tok_walk_launch(const TokLaunch& t, hipStream_t stream) {
     const uint64_t want = (t.n_docs + 3) / 4;  // four documents (waves) per workgroup and trip
     static const unsigned tok_grid_max = getenv("SJMI_TOK_GRID") ? (unsigned)atoi(getenv("SJMI_TOK_GRID")) : (unsigned)COOP_WALK_MAX_GRID;
     const unsigned grid = (unsigned)(want < tok_grid_max ? want : tok_grid_max);
-    hipLaunchKernelGGL(k_tok_walk, dim3(grid), dim3(256), 0, stream, a);
+    // (round 6) the stream form walks runs of TS_RUN documents per wave; SJMI_TOK_STREAM=0: the wave-per-document walker
+    static const bool stream_form = !(getenv("SJMI_TOK_STREAM") && atoi(getenv("SJMI_TOK_STREAM")) == 0);
+    if (stream_form) {
+        const uint64_t runs = (t.n_docs + TS_RUN - 1) / TS_RUN, want_s = (runs + 3) / 4;
+        hipLaunchKernelGGL(k_tok_stream, dim3((unsigned)(want_s < tok_grid_max ? want_s : tok_grid_max)), dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(k_tok_walk, dim3(grid), dim3(256), 0, stream, a);
+    }
     ExactMode ex;
     ex.list = t.d_list;
     ex.metas = t.d_metas;
