@@ -1326,7 +1326,10 @@ k_tok_walk(TokArgs a_by_value) {
 //     or, at depth < 1, against nothing: they are kept out of the LDS operations).
 // The wave-uniform state is small on purpose (the first stream walker, round 5, died of 89-128 spilled SGPRs): three scan
 // counters, the previous token, ring head / tail, the ingest's chunk and separator carries, the failed mask.
-constexpr uint32_t TS_RUN = 16u;    // documents per run (their records live in LDS; a run is ~1,800 tokens = ~28 token steps)
+#ifndef SJMI_TS_RUN
+#define SJMI_TS_RUN 16   // (measured: 8 -> 1.183 ms, 16 -> 1.126, 32 -> 1.147 per 1 M documents)
+#endif
+constexpr uint32_t TS_RUN = SJMI_TS_RUN;    // documents per run (their records live in LDS; a run is ~1,800 tokens = ~28 token steps)
 constexpr uint32_t TS_RING = 128u;  // tokens between the ingest and the token steps
 struct __attribute__((aligned(8))) TsRing {
     uint2 e[TS_RING];  // .x = position, .y = the token | run-local document << 24
