@@ -804,7 +804,7 @@ def trees_1024(S, doc, reps=1024, iters=3):
                           "of this batch take ~1 ms" % ((host.size + 4 * 55263 * reps + 440313 * reps) // 1000000)}
 
 
-def batch_single_gpu(torch, S, W, dev, work, args, with_h2d=True, n_docs=None, check=True):
+def batch_single_gpu(torch, S, W, dev, work, args, with_h2d=True, n_docs=None, check=True, rejected=True):
     from oracle import oracle  # (checker of the sample, outside the timed region)
     n_docs = n_docs or args.docs
     ctx = S.Context(device=dev.index, capacity=1 << 20)
@@ -833,7 +833,7 @@ def batch_single_gpu(torch, S, W, dev, work, args, with_h2d=True, n_docs=None, c
                         "kernel": BATCH_KERNELS,
                         "algorithmic_bytes_per_launch": alg,
                         "algorithmic_bytes": "input read once + uint32 indexes + string records + tape words written once"}}
-    if check:
+    if check and rejected:
         out["rejected_path"] = batch_rejected_path(torch, oracle, shard, offs, st, ms, max(3, args.batch_steps // 4))
     if with_h2d:
         host = torch.empty(shard.n, dtype=torch.uint8).pin_memory()

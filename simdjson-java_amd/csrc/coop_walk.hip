@@ -37,6 +37,7 @@
 // 1024 open containers (when the caller raised max_depth), more than 65,536 listed literals in one launch, a document of
 // more than 2^31 - 256 structurals.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -890,6 +891,7 @@ struct TokArgs {
     uint32_t* list;                 // [0] = number of documents for the exact walker, their ids from [16]
     const Stage1Result* dev_count;
     const UnescapeResult* dev_strings;
+    uint32_t run_docs;              // k_tok_stream: documents per run (1 .. TS_RUN), chosen per launch (tok_walk_launch)
 };
 // (token kinds, the first-byte table and the grammar table: sj_tokens.h, shared with the CPU test)
 constexpr uint32_t TOK_RING = 256u;   // a document of up to 256 structurals is ingested whole, before its first token step
@@ -1405,11 +1407,12 @@ k_tok_stream(TokArgs a_by_value) {
                                  (a.dev_strings && (a.dev_strings->flags & 0xFu));
     const bool string_errors = a.dev_strings && a.dev_strings->first_error_inv != 0;
     const int depth_limit = (a.max_depth < CW_LEVELS ? a.max_depth : CW_LEVELS) - 1;
-    const uint32_t n_runs = (a.n_docs + TS_RUN - 1u) / TS_RUN;
+    const uint32_t RUN = a.run_docs;  // (<= TS_RUN, the size of the per-run tables)
+    const uint32_t n_runs = (a.n_docs + RUN - 1u) / RUN;
     for (uint32_t r = blockIdx.x * 4u + (uint32_t)wv; r < n_runs; r += nwaves) {
         // ================= the run's documents: lane = document =================
-        const uint32_t k0 = r * TS_RUN;
-        const uint32_t nd = a.n_docs - k0 < TS_RUN ? a.n_docs - k0 : TS_RUN;
+        const uint32_t k0 = r * RUN;
+        const uint32_t nd = a.n_docs - k0 < RUN ? a.n_docs - k0 : RUN;
         DocMeta m = {};
         if ((uint32_t)lane <= nd) m = a.metas[k0 + (uint32_t)lane];  // (n_docs + 1 records: the last one carries the tapes' end)
         const bool isdoc = (uint32_t)lane < nd;
@@ -2188,13 +2191,37 @@ hipError_t tok_walk_launch(const TokLaunch& t, hipStream_t stream) {
     a.list = t.d_list;
     a.dev_count = t.dev_count;
     a.dev_strings = t.dev_strings;
+    a.run_docs = TS_RUN;
     const uint64_t want = (t.n_docs + 3) / 4;  // four documents (waves) per workgroup and trip
     static const unsigned tok_grid_max = getenv("SJMI_TOK_GRID") ? (unsigned)atoi(getenv("SJMI_TOK_GRID")) : (unsigned)COOP_WALK_MAX_GRID;
     const unsigned grid = (unsigned)(want < tok_grid_max ? want : tok_grid_max);
     // (round 6) the stream form walks runs of TS_RUN documents per wave; SJMI_TOK_STREAM=0: the wave-per-document walker
     static const bool stream_form = !(getenv("SJMI_TOK_STREAM") && atoi(getenv("SJMI_TOK_STREAM")) == 0);
     if (stream_form) {
-        const uint64_t runs = (t.n_docs + TS_RUN - 1) / TS_RUN, want_s = (runs + 3) / 4;
+        // Documents per run, per launch: a wave walks one run at a time and W waves are resident, so a launch takes
+        // j = ceil(runs / W) ROUNDS of runs -- with 16 documents per run a batch of 125,000 (one rank's share of a strong-scaled
+        // million) is 1.27 rounds' worth of work done in 2.  The run is sized so that the rounds come out whole:
+        // j = ceil(n / (W * TS_RUN)), run = ceil(n / (W * j)).  (125,000 documents: 11 per run, 196 -> ~140 us.)
+        static std::atomic<unsigned> resident_waves{0};
+        unsigned W = resident_waves.load(std::memory_order_relaxed);
+        if (!W) {
+            int per_cu = 0, cus = 0, dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tok_stream, 256, 0) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1) {
+                per_cu = 6;
+                cus = 256;
+            }
+            W = (unsigned)per_cu * (unsigned)cus * 4u;
+            resident_waves.store(W, std::memory_order_relaxed);
+        }
+        static const unsigned run_forced = getenv("SJMI_TS_RUN_DOCS") ? (unsigned)atoi(getenv("SJMI_TS_RUN_DOCS")) : 0u;
+        const uint64_t j = (t.n_docs + (uint64_t)W * TS_RUN - 1) / ((uint64_t)W * TS_RUN);
+        uint64_t run = (t.n_docs + (uint64_t)W * j - 1) / ((uint64_t)W * j);
+        if (run_forced >= 1 && run_forced <= TS_RUN) run = run_forced;
+        if (run < 1) run = 1;
+        if (run > TS_RUN) run = TS_RUN;
+        a.run_docs = (uint32_t)run;
+        const uint64_t runs = (t.n_docs + run - 1) / run, want_s = (runs + 3) / 4;
         hipLaunchKernelGGL(k_tok_stream, dim3((unsigned)(want_s < tok_grid_max ? want_s : tok_grid_max)), dim3(256), 0, stream, a);
     } else {
         hipLaunchKernelGGL(k_tok_walk, dim3(grid), dim3(256), 0, stream, a);

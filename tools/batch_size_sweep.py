@@ -28,7 +28,7 @@ def main():
     args = argparse.Namespace(docs=0, batch_steps=a.batch_steps, sample=1000)
     rows = []
     for n in [int(x) for x in a.sizes.split(",")]:
-        r = bench.batch_single_gpu(torch, S, W, dev, work, args, with_h2d=False, n_docs=n, check=(n <= 125000))
+        r = bench.batch_single_gpu(torch, S, W, dev, work, args, with_h2d=False, n_docs=n, check=(n <= 125000), rejected=False)
         rows.append({"documents": n, "docs_per_s": r["value"], "ms_per_batch": r["ms_per_batch"], "bytes": r["counts"]["structurals"] and r["roofline"]["algorithmic_bytes_per_launch"],
                      "roofline_frac": r["roofline"]["frac"]})
         print(rows[-1], flush=True)
