@@ -457,7 +457,7 @@ def check_batch_all(torch, oracle, shard, offs):
 
 
 BATCH_KERNELS = ("k_stage1_batch (one plain pass with per-block side outputs, accepted on the device) + k_strings<true> + k_doc_prepare "
-                 "(separator check, index ranges, string ordinals, predicted tape lengths) + tape-offset scan + k_tok_walk (token walker; "
+                 "(separator check, index ranges, string ordinals, predicted tape lengths) + tape-offset scan + k_tok_stream (token walker over runs of documents; "
                  "k_coop_walk in list mode behind it for the documents it declines)")
 
 

@@ -378,7 +378,7 @@ k_single_finish(const uint8_t* __restrict__ buf, SingleFinish f) {
     cw_single_finish(buf, f, f.tape_lens[0], f.doc_errors[0], wa, wb);
 }
 
-// k_coop_walk<false> as the EXACT walker behind the token walker (see k_tok_walk): which documents, and where their tapes go
+// k_coop_walk<false> as the EXACT walker behind the token walker (see k_tok_stream): which documents, and where their tapes go
 struct ExactMode {
     const uint32_t* list = nullptr;      // [0] = how many, ids from [16]; nullptr: every document
     const DocMeta* metas = nullptr;      // != nullptr: document k's tape at metas[k].tape, room up to metas[k + 1].tape
@@ -407,7 +407,7 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
     if (run_only_if && *run_only_if == 0) return;   // (the single-wave sweep behind a chunked launch: only on fall-back)
     if (CHUNKED && *cw.fallback != 0) return;
     if (!CHUNKED && ex.metas && ex.sel && *ex.sel == 0 && !ex.tape_alt) return;  // (optimistic pipeline only, plain pass rejected)
-    // LIST MODE (the exact walker behind k_tok_walk): the documents are those the token walker listed; a document's tape goes
+    // LIST MODE (the exact walker behind k_tok_stream): the documents are those the token walker listed; a document's tape goes
     // where its DocMeta says -- the final tape when *ex.sel != 0 (then this kernel also counts the failures), else the scratch tape
     const uint32_t* const list = CHUNKED ? nullptr : ex.list;
     const bool final_mode = !CHUNKED && ex.metas && ex.sel && *ex.sel != 0;  // (the tapes were laid out before the walk)
@@ -858,11 +858,11 @@ k_coop_walk(const uint8_t* __restrict__ buf, const unsigned long long* __restric
 
 // ---- the BATCH walker: tokens, not structurals ---------------------------------------------------------------------------
 // k_coop_walk above gives every structural a lane, and nearly half of a document's structurals are ',' and ':' -- they make no
-// tape word, yet they occupy lanes of every scan, ballot and store of a step.  k_tok_walk walks TOKENS: the structurals are
-// ingested 64 at a time (class from the first byte of the 16-byte window, as above), the separators are folded into a two-bit
-// "what stands in front of me" field of the token behind them, and the tokens -- position, class, that field, window -- are
-// compacted into a per-wave ring in LDS; a TOKEN STEP then runs the scans of the cooperative walker over 64 tokens = ~116
-// structurals of a typical record.  Grammar in token form (JsonIterator.java:68-193, the same predicates, re-keyed):
+// tape word, yet they occupy lanes of every scan, ballot and store of a step.  The batch walker (k_tok_stream below) walks
+// TOKENS: the structurals are ingested 64 at a time (ONE byte each: the first byte says what a structural is), the separators
+// are folded into a two-bit "what stands in front of me" field of the token behind them, and the tokens -- position, kind, that
+// field -- are compacted into a per-wave ring in LDS; a TOKEN STEP then runs the scans of the cooperative walker over 64 tokens
+// = ~116 structurals of a typical record.  Grammar in token form (JsonIterator.java:68-193, the same predicates, re-keyed):
 //     first child of '['          no separator, a value            first child of '{'     no separator, a string (key)
 //     behind a key                ':' and a value                  behind a value         ',' + value (array) / ',' + key (object)
 //                                                                                          or no separator + the container's own close
@@ -894,11 +894,6 @@ struct TokArgs {
     uint32_t run_docs;              // k_tok_stream: documents per run (1 .. TS_RUN), chosen per launch (tok_walk_launch)
 };
 // (token kinds, the first-byte table and the grammar table: sj_tokens.h, shared with the CPU test)
-constexpr uint32_t TOK_RING = 256u;   // a document of up to 256 structurals is ingested whole, before its first token step
-constexpr uint32_t TOK_AHEAD = 4u;    // chunks of 64 structurals whose positions / first bytes are requested a document ahead
-struct __attribute__((aligned(8))) TokRing {
-    uint2 e[TOK_RING];  // .x = position, .y = the token
-};
 struct __attribute__((aligned(8))) TokLevels {
     unsigned long long open[64];  // per level: the lanes of this step's opening brackets with that depth in front of them
     uint2 stk[64];                // the open containers of the wave's document by level: .x = tape position of the opening word | is-array << 31, .y = commas so far
@@ -914,8 +909,8 @@ constexpr int32_t CW_NEEDS_EXACT = -100;  // (internal, overwritten by the exact
 struct __attribute__((aligned(16))) PrimQueue {
     uint4 e[128];  // .x = position (its 16-byte window is loaded when the queue is flushed: 64 dense loads), .y = document, .zw = where the words go
 };
-// LANE MASKS AND TABLES.  The kernel was bound by VALU issue (91 % of the SIMD cycles, 887 instructions per document), then --
-// with its predicates as 64-bit lane masks in SGPRs -- by the scalar unit (profiles/r5/README.md).  What is left on either side:
+// LANE MASKS AND TABLES.  The round-4 walker was bound by VALU issue (91 % of the SIMD cycles, 887 instructions per document), the
+// round-5 one -- with its predicates as 64-bit lane masks in SGPRs -- by the scalar unit (profiles/r5/README.md).  The idioms:
 //   * a predicate that gates a store, an LDS operation or a select is a lane mask from ONE v_cmp; it comes back to the lanes
 //     as the condition itself (inverse ballot: no instruction); "how many lanes below me" is v_mbcnt;
 //   * "my predecessor / successor" is one DPP move of the token word (wave_shr / wave_shl), the carry of the neighbouring step
@@ -929,387 +924,11 @@ __device__ __forceinline__ uint32_t cw_below(unsigned long long m) {
 }
 __device__ __forceinline__ unsigned long long cw_first(uint32_t n) { return ~0ull >> (64u - n); }  // lanes [0, n), 1 <= n <= 64
 __device__ __forceinline__ uint32_t cw_bit(unsigned long long m, uint32_t i) { return (uint32_t)(m >> i) & 1u; }
-#ifndef SJMI_TOK_WAVES
-#define SJMI_TOK_WAVES 6
-#endif
-// (measurement builds only: TOK_KEPT(bit, v) is false when `bit` of SJMI_TOK_ABL compiles a store out -- unless its value is a number
-//  it never is, so that whatever computes the value stays in the kernel; in the product build it is the constant true)
-#define TOK_KEPT(bit, v) (!(SJMI_TOK_ABL & (bit)) || (v) == 0x12345678u)
-#ifndef SJMI_TOK_ABL
-#define SJMI_TOK_ABL 0   // (measurement only, tools/abl_tok.sh: 1 no literal parsing, 8 no bracket / string words, 16 no step body, 32 no literal words, 64 no string record offsets)
-#endif
-#ifdef SJMI_TOK_PROF   // (measurement only: where a wave's cycles go, tools/tok_prof.py)
-__device__ unsigned long long g_tok_prof[16];
-#define TOK_PROF_DECL uint32_t tp_acc[8] = {}; uint32_t tp_t0 = (uint32_t)__builtin_readcyclecounter(); const uint32_t tp_start = tp_t0;
-#define TOK_PROF(i) { const uint32_t tp_t1 = (uint32_t)__builtin_readcyclecounter(); tp_acc[i] += tp_t1 - tp_t0; tp_t0 = tp_t1; }
-#define TOK_PROF_END if (lane == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&g_tok_prof[i], (unsigned long long)tp_acc[i]); atomicAdd(&g_tok_prof[8], (unsigned long long)((uint32_t)__builtin_readcyclecounter() - tp_start)); atomicAdd(&g_tok_prof[9], 1ull); }
-#else
-#define TOK_PROF_DECL
-#define TOK_PROF(i)
-#define TOK_PROF_END
-#endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SJMI_TOK_WAVES, SJMI_TOK_WAVES)))
-k_tok_walk(TokArgs a_by_value) {
-    // The kernel's sixteen arguments are 30 SGPRs that would live for the whole kernel although most are rarely used (the
-    // exact walker's list, the error array, the string buffer that is only looked at behind a string error ...), and on gfx950
-    // every spilled SGPR is a v_writelane / v_readlane pair in the VALU: they are read from the kernarg segment where they are
-    // needed instead (the compiler repeats such a scalar load rather than spill its value).
-#if defined(__HIP_DEVICE_COMPILE__)
-    const TokArgs& a = *(const TokArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // (the kernel's only argument: offset 0 of the segment)
-    (void)a_by_value;
-#else
-    const TokArgs& a = a_by_value;
-#endif
-    if (a.sel && *a.sel == 0 && !a.tape_alt) return;  // (only the optimistic pipeline was queued and its plain pass was rejected)
-    __shared__ TokRing rings[4];
-    __shared__ PrimQueue queues[4];
-    __shared__ TokLevels levels[4];
-    __shared__ uint32_t first_byte_token[256];
-    __shared__ uint8_t grammar[TOK_GRAMMAR_ENTRIES];
-    first_byte_token[threadIdx.x] = tok_of_first_byte(threadIdx.x);
-    for (uint32_t i = threadIdx.x; i < TOK_GRAMMAR_ENTRIES; i += 256u) grammar[i] = (uint8_t)tok_grammar(i);
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    TokRing& ring = rings[wv];
-    PrimQueue& pq = queues[wv];
-    TokLevels& lv = levels[wv];
-    uint32_t qhead = 0, qtail = 0;
-    // a document for the exact walker: listed once, whoever finds out first (doc_errors[] starts at 0: k_doc_prepare / k_doc_meta)
-    auto send_to_exact = [&](uint32_t doc) {
-        if (atomicExch(&a.doc_errors[doc], CW_NEEDS_EXACT) != CW_NEEDS_EXACT) {
-            const uint32_t slot = atomicAdd(&a.list[0], 1u);
-            a.list[16 + slot] = doc;
-        }
-    };
-    auto flush_primitives = [&](uint32_t nq) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const bool live = (uint32_t)lane < nq;
-        const uint32_t e = (qhead + (uint32_t)lane) & 127u;
-        const uint4 q = pq.e[e];
-        const uint32_t p = live ? q.x : 0u, doc = q.y;
-        unsigned long long* const dst = reinterpret_cast<unsigned long long*>(((unsigned long long)q.w << 32) | q.z);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const CW16 win = *reinterpret_cast<const CW16*>(a.buf + p);
-        if (live) {
-            uint32_t ptype = 0;
-            unsigned long long praw = 0;
-            if (SJMI_TOK_ABL & 1) {
-                if (TOK_KEPT(32, win.a)) dst[0] = tape_word('n', win.a & 1u);
-            } else if (cw_primitive(a.buf, win, p, false, 0u, &ptype, &praw) == 0) {
-                if (TOK_KEPT(32, praw)) {
-                    dst[0] = tape_word(ptype, 0);
-                    if (ptype == 'l' || ptype == 'd') dst[1] = praw;
-                }
-            } else {
-                send_to_exact(doc);
-            }
-        }
-        qhead += nq;
-    };
-    const unsigned long long lane_bit = 1ull << lane;
-    const uint32_t below_lo = (uint32_t)(lane_bit - 1ull), below_hi = (uint32_t)((lane_bit - 1ull) >> 32);
-    const uint32_t nwaves = gridDim.x * 4u;
-    unsigned long long* const tape = (a.sel && *a.sel == 0) ? a.tape_alt : a.tape;
-    const bool upstream_failed = (a.dev_count && (a.dev_count->status & (SJMI_ST_CAPACITY | SJMI_ST_INTERNAL))) ||
-                                 (a.dev_strings && (a.dev_strings->flags & 0xFu));
-    const bool string_errors = a.dev_strings && a.dev_strings->first_error_inv != 0;
-    const int depth_limit = (a.max_depth < CW_LEVELS ? a.max_depth : CW_LEVELS) - 1;  // an opening bracket with this depth in front of it is one too deep
-    auto load_pos = [&](uint32_t from, uint32_t to, uint32_t c, uint32_t dflt) -> uint32_t {
-        const uint32_t i = from + c * 64u + (uint32_t)lane;
-        return i < to ? a.idx[i] : dflt;
-    };
-    // (the index entries of any other document may be anything: its bytes are not looked at)
-    auto walkable = [&](const DocMeta& d) { return !upstream_failed && d.st == 0 && d.to != d.from && d.to - d.from < (1u << 30) && d.to <= 0xFFFFFF00u; };
-    uint32_t k = blockIdx.x * 4u + (uint32_t)wv;
-    // (the DocMeta records are not written while this kernel runs: constant address space = scalar loads, the kernarg reference
-    //  alone leaves the compiler with vector loads of a uniform address; a record is read TWO documents ahead, so that the
-    //  requests for the next document's positions never wait for it)
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef const DocMeta __attribute__((address_space(4)))* MetaPtr;
-    const MetaPtr metas = (MetaPtr)(unsigned long long)a.metas;
-#else
-    const DocMeta* const metas = a.metas;
-#endif
-    auto load_meta = [&](uint32_t d, DocMeta& out, unsigned long long& end) {
-        out.from = metas[d].from; out.to = metas[d].to; out.dso = metas[d].dso; out.doc_start = metas[d].doc_start;
-        out.doc_end = metas[d].doc_end; out.st = metas[d].st; out.tape_lo = metas[d].tape_lo; out.tape_hi = metas[d].tape_hi;
-        end = ((unsigned long long)metas[d + 1].tape_hi << 32) | metas[d + 1].tape_lo;
-    };
-    DocMeta m = {}, m_next = {}, m_after = {};
-    unsigned long long t_end = 0, t_end_next = 0, t_end_after = 0;
-    // MEMORY.  The walker's loads are short dependent chains (index entry -> first byte), and a wave that waits for each chunk's
-    // round trip spends most of its time waiting.  So a document's positions are requested while the document in front of it is
-    // ingested, its first bytes inside that document's first token step, TOK_AHEAD chunks at a time: a document of up to 256
-    // structurals finds everything in registers.
-    uint32_t P[TOK_AHEAD] = {}, B[TOK_AHEAD] = {}, PN[TOK_AHEAD] = {}, BN[TOK_AHEAD] = {};
-    if (k < a.n_docs) {
-        load_meta(k, m, t_end);
-        if (a.n_docs - k > nwaves) load_meta(k + nwaves, m_next, t_end_next);
-#pragma unroll
-        for (uint32_t j = 0; j < TOK_AHEAD; ++j) P[j] = load_pos(m.from, m.to, j, m.doc_start);
-        if (walkable(m)) {
-#pragma unroll
-            for (uint32_t j = 0; j < TOK_AHEAD; ++j) B[j] = a.buf[P[j]];
-        }
-    }
-    TOK_PROF_DECL
-    for (; k < a.n_docs; k += nwaves) {
-        TOK_PROF(7)
-        const bool more_docs = a.n_docs - k > nwaves;
-        if (a.n_docs - k > 2u * nwaves) load_meta(k + 2u * nwaves, m_after, t_end_after);
-        if (more_docs) {
-#pragma unroll
-            for (uint32_t j = 0; j < TOK_AHEAD; ++j) PN[j] = load_pos(m_next.from, m_next.to, j, m_next.doc_start);
-        }
-        bool bytes_requested = !more_docs;
-        const uint32_t from = m.from, to = m.to, n = to - from;
-        const unsigned long long t_off = ((unsigned long long)m.tape_hi << 32) | m.tape_lo;
-        unsigned long long* const T = tape + t_off;
-        const unsigned long long room64 = t_end - t_off;
-        const uint32_t room = room64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)room64;
-        // (more than 2^30 structurals: tape positions keep a flag bit, the comma counters too -- such a document goes to the exact walker)
-        bool ok = walkable(m);
-        uint32_t tlen = 0;
-        if (ok) {
-            const uint32_t doc_start = m.doc_start;
-            const uint32_t nchunks = (n + 63u) / 64u;
-            // ---- running state (wave-uniform) ----
-            int H0 = 0;
-            uint32_t T0 = 1, S0 = m.dso;
-            uint32_t c_token = TK_NONE, c_empty_open = 0;  // of the last token of the previous step
-            bool root_closed = false;
-            uint32_t pq_tpos = 0, pq_off = 0;
-            unsigned long long PQ = 0;  // the lanes whose string word is still to be written (its record offset was requested a step ago)
-            // ingest state
-            uint32_t c = 0, head = 0, tail = 0;
-            unsigned long long SEPp = 0, COLp = 0;  // separators / colons of the previous chunk (only the last chunk is partial)
-            unsigned long long sep_twice = 0;       // a separator behind a separator: never valid
-            // one chunk of 64 structurals: the separators are folded into the token behind them, the tokens compacted into the ring
-            auto ingest = [&](uint32_t p, uint32_t b0) {
-                const uint32_t nvl = n - c * 64u < 64u ? n - c * 64u : 64u;
-                const unsigned long long VL = cw_first(nvl);
-                const uint32_t token = first_byte_token[b0];
-                const unsigned long long COL = cw_ballot(b0 == ':') & VL;
-                const unsigned long long SEP = (cw_ballot(b0 == ',') & VL) | COL;
-                // what stands in front of a structural: the masks moved up by one lane, the previous chunk's last bit carried in
-                const unsigned long long S1 = (SEP << 1) | (SEPp >> 63), C1 = (COL << 1) | (COLp >> 63);
-                sep_twice |= SEP & S1;
-                uint32_t pre = cw_lanes(S1) ? TOK_COMMA : 0u;
-                pre = cw_lanes(C1) ? TOK_COLON : pre;
-                const unsigned long long TOK = VL & ~SEP;
-                const uint32_t slot = (tail + cw_below(TOK)) & (TOK_RING - 1u);
-                if (cw_lanes(TOK)) ring.e[slot] = make_uint2(p, token | pre);
-                tail += (uint32_t)__popcll(TOK);
-                SEPp = SEP;
-                COLp = COL;
-                ++c;
-                if (c == nchunks) sep_twice |= SEP >> (nvl - 1u);  // a separator behind the last token
-            };
-            TOK_PROF(1)
-#pragma unroll
-            for (uint32_t j = 0; j < TOK_AHEAD; ++j)
-                if (j < nchunks) ingest(P[j], B[j]);
-            TOK_PROF(2)
-            while (ok) {
-                // (a longer document: the rest of its chunks as the ring has room for them, each one a round trip of its own)
-                while (c < nchunks && tail - head <= TOK_RING - 64u) {
-                    const uint32_t p = load_pos(from, to, c, doc_start);
-                    ingest(p, a.buf[p]);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t avail = tail - head;
-                if (sep_twice) ok = false;
-                if (avail == 0u || !ok) break;
-                if (root_closed) {  // something follows the root value (JsonIterator.java:196-198)
-                    ok = false;
-                    break;
-                }
-                // ---- one token step ----
-                const uint32_t na = avail < 64u ? avail : 64u;
-                const uint2 re = ring.e[(head + (uint32_t)lane) & (TOK_RING - 1u)];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                // a step ends in front of an opening bracket whose successor is not at hand (is it an empty container?)
-                const bool more = c < nchunks || avail > 64u;
-                const uint32_t nv = (more && ((uint32_t)__builtin_amdgcn_readlane((int)re.y, 63) & 7u) <= TK_OPEN_O) ? 63u : na;
-                const unsigned long long V = cw_first(nv);
-                const uint32_t p = re.x, token = cw_lanes(V) ? re.y : (uint32_t)TK_NONE;
-                if (SJMI_TOK_ABL & 16) {
-                    head += nv;
-                    T0 += nv + (p & 1u) + (token & 1u);
-                    if (c == nchunks && head == tail) root_closed = true;
-                    continue;
-                }
-                const uint32_t tk = token & 7u;
-                const unsigned long long OPEN = cw_ballot(tk <= TK_OPEN_O), CLOSE = cw_ballot(tk <= TK_CLOSE_O) & ~OPEN;
-                const unsigned long long Q = cw_ballot(tk == TK_STRING), PRIM = cw_ballot(tk >= TK_ATOM);
-                // my neighbours' tokens
-                const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)c_token, (int)token, 0x138, 0xf, 0xf, false);       // wave_shr:1
-                const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp((int)TK_NONE, (int)token, 0x130, 0xf, 0xf, false);       // wave_shl:1
-                // (1) empty containers: an opening bracket directly followed by its closing bracket is ONE value (TapeBuilder.java:205-208)
-                const unsigned long long EO = cw_ballot(((next ^ (tk + 2u)) & (7u | TOK_COMMA | TOK_COLON)) == 0u) & OPEN;
-                const unsigned long long EC = CLOSE & ((EO << 1) | c_empty_open);
-                // (2) depth and (3) tape position in front of every token: one ladder, two fields (1 + up - down | words << 16)
-                const uint32_t inc = (token & TOK_SCAN_FIELDS) >> 5;
-                const uint32_t scan2 = cw_incl_scan(inc);
-                const uint32_t tot2 = cw_last(scan2);
-                if (T0 + (tot2 >> 16) > room) {  // no room for this step's words: the exact walker reports it
-                    ok = false;
-                    break;
-                }
-                TOK_PROF(3)
-                const uint32_t excl = scan2 - inc;
-                const int h = H0 + (int)(excl & 0xFFFFu) - lane;
-                const uint32_t tpos = T0 + (excl >> 16);
-                const uint32_t sord = S0 + cw_below(Q);
-                const uint32_t rec_off = (SJMI_TOK_ABL & 64) ? sord : (cw_lanes(Q) ? a.soff[sord] : 0u);  // (used one step later)
-                const unsigned long long DEEP = cw_ballot(h >= depth_limit);
-                const unsigned long long ROOT_END = cw_ballot(h == 1) & CLOSE;
-                // (4) the container of every token.  The opening brackets of the step put their lane into the word of their level
-                // (LDS, atomic or); a token reads the word of ITS level: the last opening bracket in front of it there is its
-                // container -- or, if there is none, a container opened in an earlier step, which sits on the wave's STACK IN LDS,
-                // entry = level.  Comma counts are LDS atomics -- every token that follows a ',' adds one to its container's counter
-                // (the opener's slot of this step, or the stack entry), every closing bracket marks its opener's slot closed --
-                // and what the next steps need is one LDS write: the openers that were not closed push themselves.
-                const uint32_t lvl = (uint32_t)(h - 1) & 63u;
-                lv.open[lane] = 0ull;
-                lv.cnt[lane] = 0u;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (cw_lanes(OPEN)) atomicOr(&lv.open[(uint32_t)h & 63u], lane_bit);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const unsigned long long om = lv.open[lvl];
-                const uint32_t om_lo = (uint32_t)om & below_lo, om_hi = (uint32_t)(om >> 32) & below_hi;
-                const uint32_t lz_hi = om_hi ? (uint32_t)__builtin_clz(om_hi) : 0xFFFFFFFFu;          // (v_ffbh_u32: ~0 for 0)
-                const uint32_t lz_lo = (om_lo ? (uint32_t)__builtin_clz(om_lo) : 0xFFFFFFFFu) | 32u;
-                const uint32_t lz = lz_hi < lz_lo ? lz_hi : lz_lo;
-                const unsigned long long IN_STEP = cw_ballot((int32_t)lz >= 0);  // my container was opened in this step
-                const uint32_t par_lane = (63u - lz) & 63u;
-                uint32_t* const my_counter = cw_lanes(IN_STEP) ? &lv.cnt[par_lane] : &lv.stk[lvl].y;
-                // one atomic add: 1 for a ',' in front of me, bit 31 from the closing bracket of a container of this step (it does not stay open)
-                uint32_t add = (token >> 3) & 1u;
-                add = cw_lanes(CLOSE & ~EC & IN_STEP) ? add | 0x80000000u : add;
-                atomicAdd(my_counter, add);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t se_x = lv.stk[lvl].x;   // the stack entry of my level as the earlier steps left it
-                const uint32_t pcnt = *my_counter;     // my container's commas (all of them lie in front of its closing bracket)
-                const uint32_t own = lv.cnt[lane];     // an opening bracket's own slot
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t opener = tpos | ((tk - 1u) & 0x80000000u);  // is-array << 31 (TK_OPEN_A = 0)
-                if (cw_lanes(OPEN & ~EO & ~cw_ballot((int32_t)own < 0))) lv.stk[(uint32_t)h & 63u] = make_uint2(opener, own);
-                const uint32_t from_step = (uint32_t)__shfl((int)opener, (int)par_lane);
-                const uint32_t par = cw_lanes(IN_STEP) ? from_step : se_x;
-                const uint32_t par_tpos = par & 0x7FFFFFFFu;
-                const uint32_t par_cnt = pcnt & 0x3FFFFFFFu;
-                // (5) the token grammar: one table entry
-                const uint32_t gi = (token & 0x1Fu) | ((prev & 0x17u) << 5) | ((par >> 21) & 0x400u);
-                unsigned long long BAD = cw_ballot(grammar[gi] == 0) | (OPEN & ~EO & DEEP);            // :69-70 / deeper than the stack
-                if (string_errors) {
-                    // a string the reference's StringParser would have thrown on: record header FF FF FF <code>
-                    bool bad_string = false;
-                    if (cw_lanes(Q)) {
-                        const uint8_t* hh = a.sb + rec_off;
-                        bad_string = hh[0] == 0xFF && hh[1] == 0xFF && hh[2] == 0xFF;
-                    }
-                    BAD |= cw_ballot(bad_string);
-                }
-                // (6) where the root value ends: nothing may follow
-                if (ROOT_END) BAD |= V & ~((ROOT_END & (0ull - ROOT_END)) * 2ull - 1ull);
-                if (BAD) {
-                    ok = false;
-                    break;
-                }
-                if (ROOT_END) root_closed = true;
-                TOK_PROF(4)
-                if (!bytes_requested) {
-                    // the next document's first bytes: its positions have had this document's ingest and most of a step to arrive,
-                    // and nothing younger than this step's record offsets is in flight (a wait here also waits for every store issued so far)
-                    bytes_requested = true;
-                    if (walkable(m_next)) {
-#pragma unroll
-                        for (uint32_t j = 0; j < TOK_AHEAD; ++j) BN[j] = a.buf[PN[j]];
-                    }
-                }
-                // (7) the tape words of this step
-                if (cw_lanes(PQ) && TOK_KEPT(8, pq_off)) T[pq_tpos] = tape_word('"', a.string_base + pq_off);  // the previous step's strings
-                PQ = Q;
-                pq_tpos = tpos;
-                pq_off = rec_off;
-                if (PRIM) {  // atoms and numbers: queued, parsed 64 at a time (flush_primitives)
-                    const uint32_t qs = (qtail + cw_below(PRIM)) & 127u;
-                    if (cw_lanes(PRIM)) {
-                        const unsigned long long d = reinterpret_cast<unsigned long long>(T + tpos);
-                        pq.e[qs] = make_uint4(p, k, (uint32_t)d, (uint32_t)(d >> 32));
-                    }
-                    qtail += (uint32_t)__popcll(PRIM);
-                }
-                {   // brackets: an empty pair is two self-contained words (TapeBuilder.java:205-208); a closing bracket writes its own
-                    // word and its container's opening word (:197-203: element count = commas + 1, saturated)
-                    const uint32_t type_hi = __builtin_amdgcn_perm(token, 0u, 0x050C0C0Cu);  // the bracket itself << 24
-                    uint32_t pay1 = cw_lanes(EC) ? tpos : par_tpos;
-                    pay1 = cw_lanes(EO) ? tpos + 2u : pay1;
-                    if (cw_lanes(EO | CLOSE) && TOK_KEPT(8, pay1)) T[tpos] = ((unsigned long long)type_hi << 32) | pay1;
-                    uint32_t cnt = par_cnt + 1u;
-                    if (cnt > 0xFFFFFFu) cnt = 0xFFFFFFu;
-                    if (cw_lanes(CLOSE & ~EC) && TOK_KEPT(8, cnt)) T[par_tpos] = ((unsigned long long)((type_hi - 0x02000000u) | cnt) << 32) | (tpos + 1u);
-                }
-                // (8) carries
-                const uint32_t lastv = nv - 1u;
-                H0 += (int)(tot2 & 0xFFFFu) - (int)nv;
-                T0 += tot2 >> 16;
-                S0 += (uint32_t)__popcll(Q);
-                c_token = (uint32_t)__builtin_amdgcn_readlane((int)token, (int)lastv);
-                c_empty_open = cw_bit(EO, lastv);
-                head += nv;
-                TOK_PROF(5)
-                if (qtail - qhead >= 64u) { flush_primitives(64u); TOK_PROF(6) }
-            }
-            if (cw_lanes(PQ)) T[pq_tpos] = tape_word('"', a.string_base + pq_off);  // the last step's strings
-            if (ok && !root_closed) ok = false;  // the root container is never closed (JsonIterator.java:39-41,:51-53)
-            if (ok) {
-                tlen = T0 + 1;  // + the closing root word
-                if (tlen <= room) {
-                    // visitDocumentEnd, TapeBuilder.java:45-48: both root words in ONE store (lane 0 the closing one, lane 1 the opening one)
-                    if (lane < 2 && TOK_KEPT(128, tlen)) T[lane == 0 ? T0 : 0u] = tape_word('r', lane == 0 ? 0u : tlen);
-                } else {
-                    ok = false;  // (no room: the exact walker reports it)
-                    tlen = 0;
-                }
-            }
-        }
-        if (lane == 0) {
-            if (a.tape_lens && TOK_KEPT(128, tlen)) a.tape_lens[k] = ok ? tlen : 0u;
-            if (!ok) send_to_exact(k);
-        }
-        if (!bytes_requested && walkable(m_next)) {
-#pragma unroll
-            for (uint32_t j = 0; j < TOK_AHEAD; ++j) BN[j] = a.buf[PN[j]];
-        }
-        m = m_next;
-        t_end = t_end_next;
-        m_next = m_after;
-        t_end_next = t_end_after;
-#pragma unroll
-        for (uint32_t j = 0; j < TOK_AHEAD; ++j) {
-            P[j] = PN[j];
-            B[j] = BN[j];
-        }
-    }
-    if (qtail != qhead) flush_primitives(qtail - qhead);  // (fewer than 64 by construction)
-    TOK_PROF_END
-}
-
 // ---- the batch walker in STREAM form (round 6) ------------------------------------------------------------------------------
-// k_tok_walk above walks one document per wave at a time, and of its ~500 scalar + ~420 vector instructions per ~1 KB document
-// more than half of the scalar ones are per-DOCUMENT scaffolding (profiles/r5/README.md: four ingest trips, a prefetch a document
-// ahead, prologue, epilogue, a half-empty second token step); it is bound by scalar issue.  k_tok_stream walks a RUN of TS_RUN
+// Round 5's k_tok_walk walked one document per wave at a time, and of its ~500 scalar + ~420 vector instructions per ~1 KB document
+// more than half of the scalar ones were per-DOCUMENT scaffolding (profiles/r5/README.md: four ingest trips, a prefetch a document
+// ahead, prologue, epilogue, a half-empty second token step); it was bound by scalar issue and spilled 62 SGPRs.  It is gone
+// (profiles/r6/README.md has the A/B: 1.30 -> 1.12-1.20 ms per 1 M documents, 430 + 374 instructions).  k_tok_stream walks a RUN of TS_RUN
 // consecutive documents as ONE token stream: the structurals of a run are contiguous in stage 1's index array, so the ingest never
 // stops at a document, and a token step of 64 tokens may hold the end of one document, a whole small one and the beginning of a
 // third.  Nothing in a step is per document:
@@ -1318,8 +937,10 @@ k_tok_walk(TokArgs a_by_value) {
 //   * depth, string ordinal and tape position are ONE three-field scan over the step, continued over the run by three uniform
 //     counters (A_d, A_q, A_w); a document's first token parks the scan values it sees in the document's LDS record, and every
 //     token of the document subtracts them -- document-relative depth / ordinal / position whatever step the document began in;
-//   * containers, comma counts and the grammar table are k_tok_walk's, unchanged: a document's containers all lie behind its
-//     first token, so the last opening bracket of my level in front of me is mine;
+//   * containers: every opening bracket of the step puts its lane into the LDS word of its level, a token finds its container as
+//     the last such lane in front of it in the word of ITS level (two v_ffbh), else on the per-wave stack in LDS; commas and
+//     "closed in this step" are one LDS atomic add; the grammar of JsonIterator.java:68-193 is one LDS read of a 2048-entry table.
+//     A document's containers all lie behind its first token, so the last opening bracket of my level in front of me is mine;
 //   * the only token that may stand at depth 0 is a document's first, and it must be an opening bracket: that is "nothing
 //     follows the root's end", "the root is a container" and "a closing bracket too many" in one compare; a document must be
 //     back at depth 0 where the next one starts (the next document's first token looks at it);
@@ -1348,7 +969,7 @@ struct __attribute__((aligned(16))) TsRun {
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SJMI_TS_WAVES, SJMI_TS_WAVES)))
 k_tok_stream(TokArgs a_by_value) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const TokArgs& a = *(const TokArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // (see k_tok_walk)
+    const TokArgs& a = *(const TokArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // (the arguments are read from the kernarg segment where they are needed: as SGPRs held for the whole kernel they would spill -- a v_writelane / v_readlane pair each)
     (void)a_by_value;
 #else
     const TokArgs& a = a_by_value;
@@ -1566,7 +1187,7 @@ k_tok_stream(TokArgs a_by_value) {
             const unsigned long long FL0 = failed ? cw_ballot(((uint32_t)(failed >> dj) & 1u) != 0u) : 0ull;
             const unsigned long long ACT = V & ~LOW & ~FL0;
             const unsigned long long REG = OPEN & V & ~FL0;
-            // (4) the container of every token (k_tok_walk's scheme: the step's opening brackets by level in LDS, the stack in LDS)
+            // (4) the container of every token: the step's opening brackets by level in LDS, the stack in LDS
             const uint32_t lvl = (uint32_t)(h - 1) & 63u;
             lv.open[lane] = 0ull;
             lv.cnt[lane] = 0u;
@@ -1633,7 +1254,8 @@ k_tok_stream(TokArgs a_by_value) {
                 }
                 qtail += (uint32_t)__popcll(PL);
             }
-            {   // brackets (as in k_tok_walk)
+            {   // brackets: an empty pair is two self-contained words (TapeBuilder.java:205-208); a closing bracket writes its own
+                // word and its container's opening word (:197-203: element count = commas + 1, saturated)
                 const uint32_t type_hi = __builtin_amdgcn_perm(token, 0u, 0x050C0C0Cu);  // the bracket itself << 24
                 uint32_t pay1 = cw_lanes(EC) ? tpos : par_tpos;
                 pay1 = cw_lanes(EO) ? tpos + 2u : pay1;
@@ -2192,16 +1814,12 @@ hipError_t tok_walk_launch(const TokLaunch& t, hipStream_t stream) {
     a.dev_count = t.dev_count;
     a.dev_strings = t.dev_strings;
     a.run_docs = TS_RUN;
-    const uint64_t want = (t.n_docs + 3) / 4;  // four documents (waves) per workgroup and trip
-    static const unsigned tok_grid_max = getenv("SJMI_TOK_GRID") ? (unsigned)atoi(getenv("SJMI_TOK_GRID")) : (unsigned)COOP_WALK_MAX_GRID;
-    const unsigned grid = (unsigned)(want < tok_grid_max ? want : tok_grid_max);
-    // (round 6) the stream form walks runs of TS_RUN documents per wave; SJMI_TOK_STREAM=0: the wave-per-document walker
-    static const bool stream_form = !(getenv("SJMI_TOK_STREAM") && atoi(getenv("SJMI_TOK_STREAM")) == 0);
-    if (stream_form) {
+    const uint64_t want = (t.n_docs + 3) / 4;  // (the exact walker behind it: four documents -- waves -- per workgroup and trip)
+    {
         // Documents per run, per launch: a wave walks one run at a time and W waves are resident, so a launch takes
         // j = ceil(runs / W) ROUNDS of runs -- with 16 documents per run a batch of 125,000 (one rank's share of a strong-scaled
         // million) is 1.27 rounds' worth of work done in 2.  The run is sized so that the rounds come out whole:
-        // j = ceil(n / (W * TS_RUN)), run = ceil(n / (W * j)).  (125,000 documents: 11 per run, 196 -> ~140 us.)
+        // j = ceil(n / (W * TS_RUN)), run = ceil(n / (W * j)).  (125,000 documents: 11 per run, 188 -> 167 us.)
         static std::atomic<unsigned> resident_waves{0};
         unsigned W = resident_waves.load(std::memory_order_relaxed);
         if (!W) {
@@ -2214,17 +1832,16 @@ hipError_t tok_walk_launch(const TokLaunch& t, hipStream_t stream) {
             W = (unsigned)per_cu * (unsigned)cus * 4u;
             resident_waves.store(W, std::memory_order_relaxed);
         }
-        static const unsigned run_forced = getenv("SJMI_TS_RUN_DOCS") ? (unsigned)atoi(getenv("SJMI_TS_RUN_DOCS")) : 0u;
+        static const unsigned run_forced = getenv("SJMI_TS_RUN_DOCS") ? (unsigned)atoi(getenv("SJMI_TS_RUN_DOCS")) : 0u;  // (experiments)
         const uint64_t j = (t.n_docs + (uint64_t)W * TS_RUN - 1) / ((uint64_t)W * TS_RUN);
         uint64_t run = (t.n_docs + (uint64_t)W * j - 1) / ((uint64_t)W * j);
         if (run_forced >= 1 && run_forced <= TS_RUN) run = run_forced;
         if (run < 1) run = 1;
         if (run > TS_RUN) run = TS_RUN;
         a.run_docs = (uint32_t)run;
-        const uint64_t runs = (t.n_docs + run - 1) / run, want_s = (runs + 3) / 4;
+        const uint64_t runs = (t.n_docs + run - 1) / run, want_s = (runs + 3) / 4;  // four runs (waves) per workgroup and trip
+        static const unsigned tok_grid_max = getenv("SJMI_TOK_GRID") ? (unsigned)atoi(getenv("SJMI_TOK_GRID")) : (unsigned)COOP_WALK_MAX_GRID;
         hipLaunchKernelGGL(k_tok_stream, dim3((unsigned)(want_s < tok_grid_max ? want_s : tok_grid_max)), dim3(256), 0, stream, a);
-    } else {
-        hipLaunchKernelGGL(k_tok_walk, dim3(grid), dim3(256), 0, stream, a);
     }
     ExactMode ex;
     ex.list = t.d_list;
@@ -2244,13 +1861,4 @@ hipError_t tok_walk_launch(const TokLaunch& t, hipStream_t stream) {
 
 }  // namespace sjmi
 
-#ifdef SJMI_TOK_PROF
-extern "C" int sjmi_debug_tok_prof(unsigned long long* out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(sjmi::g_tok_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[16] = {};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(sjmi::g_tok_prof), z, sizeof z) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
+

@@ -1,4 +1,4 @@
-// The token walker's two tables (coop_walk.hip k_tok_walk), as plain functions shared verbatim with the CPU test
+// The token walker's two tables (coop_walk.hip k_tok_stream), as plain functions shared verbatim with the CPU test
 // (tests/host_sim/tok_sim.cpp, tests/test_host_tokens.py): what a structural's first byte makes of it, and the token grammar of
 // JsonIterator.java:68-193 keyed by {token, separator in front of it, previous token, is my container an array}.
 #pragma once

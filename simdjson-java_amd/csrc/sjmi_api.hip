@@ -1236,7 +1236,7 @@ int sjmi_stage1_batch_isolated(sjmi_ctx* c, const uint8_t* buf, uint64_t total_l
 //             its verdict, has no structurals and a two-word tape slot.
 //   stage C   (every kernel leaves at once when A or B was accepted)  the per-document stage-1 passes with their index arrays,
 //             the string pass over the sanitized copy, ordinals, the walk into scratch tapes + packing.
-//   k_tok_walk, k_coop_walk (list), k_slow_doubles: ONE set of walkers behind all three (a device flag says where the tapes go).
+//   k_tok_stream, k_coop_walk (list), k_slow_doubles: ONE set of walkers behind all three (a device flag says where the tapes go).
 // PIPE_OPTIMISTIC: stage A and the walkers, nothing else; a batch that does not qualify comes back with SJMI_ST_REJECTED.
 // PIPE_EXACT: A, B, C.  PIPE_REJECTED: B, C -- the call to make after SJMI_ST_REJECTED.  No host round trip in any of them.
 enum PipeMode { PIPE_OPTIMISTIC, PIPE_EXACT, PIPE_REJECTED };

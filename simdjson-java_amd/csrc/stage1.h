@@ -162,7 +162,7 @@ struct UnescapeBatch {
 hipError_t split_docs_launch(const uint32_t* d_idx, const Stage1Result* d_res, const unsigned long long* d_doc_offsets,
                              uint64_t n_docs, unsigned long long* d_index_offsets, hipStream_t stream);
 size_t batch_isolated_workspace_bytes(uint64_t n_docs);
-// What the batch walker (coop_walk.hip k_tok_walk) reads per document, one 32-byte record instead of six arrays: n_docs + 1
+// What the batch walker (coop_walk.hip k_tok_stream) reads per document, one 32-byte record instead of six arrays: n_docs + 1
 // records, the last one carrying only `tape` (a document's room on the tape = the next record's `tape` - its own).
 struct DocMeta {
     uint32_t from, to;            // its structurals: indexes[from, to)
@@ -259,7 +259,7 @@ struct WalkPrepared {
     unsigned long long* chunk_sums;
 };
 WalkPrepared walk_prepared(void* d_ws, uint64_t count, uint64_t n_docs);
-// coop_walk.hip: the batch walkers -- k_tok_walk over tokens, then k_coop_walk (list mode) for the documents it declined
+// coop_walk.hip: the batch walkers -- k_tok_stream over tokens, then k_coop_walk (list mode) for the documents it declined
 struct TokLaunch {
     const uint8_t* d_buf;
     const uint32_t* d_idx;

@@ -286,7 +286,7 @@ hipError_t walk_launch(const uint8_t* d_buf, const unsigned long long* d_doc_off
     static const bool tokens_off = getenv("SJMI_TOKEN_WALK") && atoi(getenv("SJMI_TOKEN_WALK")) == 0;
     const uint32_t* packed_skip = nullptr;  // device flag != 0: the tapes were laid out before the walk, nothing is packed behind it
     if (n_docs > 1 && (!tokens_off || optimistic_only)) {
-        // ---- a batch: the token walker (coop_walk.hip k_tok_walk) with the exact walker behind it for what it declines ----
+        // ---- a batch: the token walker (coop_walk.hip k_tok_stream) with the exact walker behind it for what it declines ----
         const WalkPrepared wp = walk_prepared(d_ws, count, n_docs);
         uint32_t* list = reinterpret_cast<uint32_t*>(ws + walk_list_offset(count, n_docs));
         if (d_prepared && !layout_done) {

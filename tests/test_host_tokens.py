@@ -1,5 +1,5 @@
 """CPU check of the token walker's tables (simdjson-java_amd/csrc/sj_tokens.h: what a structural's first byte makes of it, and the
-token grammar that k_tok_walk reads from LDS) against the oracle's stage 2 (JsonIterator.java:68-193 restated in oracle/sj_oracle.c).
+token grammar that k_tok_stream reads from LDS) against the oracle's stage 2 (JsonIterator.java:68-193 restated in oracle/sj_oracle.c).
 
 tests/host_sim/tok_sim.cpp walks a document's structurals sequentially with the kernel's rules around those tables; the header is
 shared verbatim with the HIP kernel.  Checked here without a GPU, over EVERY sequence of up to six tokens (seven with

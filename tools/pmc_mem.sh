@@ -1,5 +1,5 @@
 #!/bin/bash
-# memory-pipeline counters of k_tok_walk (VMEM issue, LDS), tools/batch_nocheck.py; run on the GPU box: tools/pmc_mem.sh lib ...
+# memory-pipeline counters of the batch walker (k_tok_*) (VMEM issue, LDS), tools/batch_nocheck.py; run on the GPU box: tools/pmc_mem.sh lib ...
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 K=${PMC_KERNEL:-k_tok}

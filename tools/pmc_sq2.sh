@@ -1,5 +1,5 @@
 #!/bin/bash
-# more SQ / SQC counters of k_tok_walk (instruction fetch, scalar cache, levels); run on the GPU box: tools/pmc_sq2.sh lib ...
+# more SQ / SQC counters of the batch walker (k_tok_*) (instruction fetch, scalar cache, levels); run on the GPU box: tools/pmc_sq2.sh lib ...
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 for lib in "$@"; do

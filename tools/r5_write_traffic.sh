@@ -1,5 +1,5 @@
 #!/bin/bash
-# WRITE_SIZE / FETCH_SIZE of k_tok_walk (and the batch) for library variants: args = variant names (base = in-tree)
+# WRITE_SIZE / FETCH_SIZE of the batch walker (and the batch) for library variants: args = variant names (base = in-tree)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 cd $R

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Differential soak aimed at the TOKEN WALKER (coop_walk.hip k_tok_walk, round 5's rewrite): documents made of many small tokens
+"""Differential soak aimed at the TOKEN WALKER (coop_walk.hip k_tok_stream; written for round 5's k_tok_walk): documents made of many small tokens
 -- nesting that crosses the 64-token step boundary at every phase, empty containers and keys across it, opening brackets at the
 last lane of a step, depths around the 64-level stack, 1 .. 700 tokens (the whole-document ingest up to 256 structurals, the
 chunk-by-chunk one beyond) -- and every single-token mutation of them (dropped / doubled / swapped tokens and separators).  Both

@@ -1,8 +1,12 @@
 #!/usr/bin/env python
-"""Model of the STREAM form of the batch walker that DESIGN.md 9 names as the next step (nothing of it is built in HIP): one "wave"
+"""Model of the STREAM form of the batch walker, written at the end of round 5 as the design for round 6 and built then:
+simdjson-java_amd/csrc/coop_walk.hip k_tok_stream.  The kernel differs from this model in how it gets a token's
+document-relative depth / ordinal / tape position -- three run-wide counters and per-document bases in LDS instead of a max-scan
+and a shuffle per step -- and in ruling out "something follows the root's end" by ONE compare (only a document's first token may
+stand at depth 0) instead of interval masks; the rest is this.  One "wave"
 walks a RUN of consecutive documents as one token stream -- the structurals of the run are contiguous in stage 1's index array, so
 the ingest never stops at a document, and a token step of 64 tokens may hold the end of one document, a whole small one and the
-beginning of a third.  What round 5 measured makes this the next thing to try: the per-document scaffolding of k_tok_walk (four
+beginning of a third.  What round 5 measured made this the thing to try: the per-document scaffolding of k_tok_walk (four
 ingest trips, prefetch arrays, prologue, epilogue, a second half-empty step) is 56 % of its scalar instructions.
 
 What the model pins down (tests/test_tok_stream_model.py checks it against the oracle, document by document, on runs that mix valid

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
-"""Lane-level model of the batch walker (simdjson-java_amd/csrc/coop_walk.hip k_tok_walk): one "wave" of 64 lanes
-walks one document exactly the way the kernel does -- chunks of 64 structurals ingested into a ring of 256 tokens (separators folded
+"""Lane-level model of round 5's batch walker (k_tok_walk: one document per wave at a time; replaced in round 6 by the stream form,
+k_tok_stream -- tools/tok_stream_model.py -- whose TOKEN STEP is this one's: the same scans, level words, stack, counters and
+grammar table; this model stays as the executable description of that step and as the base tok_stream_model.py imports): one
+"wave" of 64 lanes walks one document exactly the way that kernel did -- chunks of 64 structurals ingested into a ring of 256 tokens (separators folded
 into the token behind them by shifted lane masks), token steps of up to 64 tokens with the trim in front of an opening bracket
 whose successor is not at hand, neighbours by wave shifts with the previous step's last token carried in, depth / tape position
 from one two-field scan, containers from a word of lanes per level + a stack by level + comma counters (the LDS arrays of the

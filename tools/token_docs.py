@@ -1,4 +1,4 @@
-"""Token-level adversarial documents for the batch walker (coop_walk.hip k_tok_walk): documents made of many small tokens -- nesting
+"""Token-level adversarial documents for the batch walker (coop_walk.hip k_tok_stream): documents made of many small tokens -- nesting
 that crosses the 64-token step boundary at every phase, empty containers and keys across it, opening brackets at the last lane of
 a step, depths around the 64-level stack, 1 .. 700 tokens -- and single-token mutations of them (dropped / doubled / swapped tokens
 and separators).  Pure Python: used by tools/soak_tokens.py (GPU) and tests/test_tok_walk_model.py (CPU)."""
