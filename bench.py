@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable)
-PROFILE_ROUND = "r5"
+PROFILE_ROUND = "r6"
 PROFILE_DIR = os.path.join(ROOT, "profiles", PROFILE_ROUND)
 
 
@@ -621,7 +621,8 @@ def bench_single(args):
         del tbuf, rs
     if "batch" in sections:
         # ---- configs[3] on ONE GPU: the batched path, 1,000,000 documents ----
-        extra["batch_1m_docs"] = batch_single_gpu(torch, S, W, dev, work, args)
+        extra["batch_1m_docs"] = batch_single_gpu(torch, S, W, dev, work, args, with_h2d=not args.batch_accepted_only,
+                                                  rejected=not args.batch_accepted_only)
     if "parse" in sections:
         # ---- the drop-in call itself: SimdJsonParser.parse(byte[], len) of ONE twitter.json from a host buffer (H2D, all
         #      stages, outputs back on the host), with the reference's stage 2 on the host or all three stages on the GPU ----
@@ -1184,6 +1185,9 @@ def main():
     ap.add_argument("--docs", type=int, default=1000000, help="documents of the configs[3] batch")
     ap.add_argument("--pool", type=int, default=4000, help="unique documents of the bounded CPU-baseline sample of configs[3]")
     ap.add_argument("--batch-steps", type=int, default=10, help="N=1: timed steps of the configs[3] extra")
+    ap.add_argument("--batch-accepted-only", action="store_true",
+                    help="N=1: the configs[3] extra without its rejected-path and H2D variants (the counter passes of tools/prof_round.sh: "
+                         "the last dispatches of every kernel are then those of an accepted step)")
     ap.add_argument("--no-extras", action="store_true", help="N=1: only the primary workload")
     ap.add_argument("--sections", default="x1024,unescape,synth,batch,parse,select,trees",
                     help="N=1: which extras to run (comma list of x1024, unescape, synth, batch, parse, select); the profiling passes run one each")

@@ -7,7 +7,7 @@
 # Output: gpurun_out/prof_<round>/... ; tools/summarize_prof_round.py turns it into gpurun_out/profiles_<round>/, tools/install_prof.py
 # <round> (in the build container) into the tracked profiles/<round>/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-RD=${1:-r5}
+RD=${1:-r6}
 out=$R/gpurun_out/prof_$RD
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
@@ -16,14 +16,14 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -
 echo "trace rc=$?"; tail -c 400 $out/trace.log | tr '\n' ' ' | cut -c1-300; echo
 P="--steps 3 --warmup 1 --preheat 0 --batch-steps 2"
 for sec in main x1024 unescape synth batch; do
-  if [ $sec = main ]; then S="--no-extras"; else S="--sections $sec --skip-main-timing"; fi
+  if [ $sec = main ]; then S="--no-extras"; else S="--sections $sec --skip-main-timing --batch-accepted-only"; fi
   for ctr in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc $ctr -d $out/pmc_${sec}_$ctr -o p -- $B $P $S > $out/pmc_${sec}_$ctr.log 2>&1
     echo "pmc $sec $ctr rc=$?"
   done
 done
 for sec in unescape batch; do
-  timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $out/pmc_${sec}_SQ -o p -- $B $P --sections $sec --skip-main-timing > $out/pmc_${sec}_SQ.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $out/pmc_${sec}_SQ -o p -- $B $P --sections $sec --skip-main-timing --batch-accepted-only > $out/pmc_${sec}_SQ.log 2>&1
   echo "pmc $sec SQ rc=$?"
 done
 for ctr in FETCH_SIZE WRITE_SIZE; do
