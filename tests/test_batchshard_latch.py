@@ -76,10 +76,13 @@ def test_a_format_rejection_goes_straight_to_the_call_for_rejected_batches():
 
 
 def test_an_engine_without_the_new_entry_falls_back_to_the_exact_call():
-    class Old(_Recorder):
-        parse_batch_device_rejected = None
-    eng = Old([0x800])
-    del Old.parse_batch_device_rejected
+    class Old:  # (round 5's binding: two entries)
+        def __init__(self):
+            self.inner = _Recorder([0x800])
+            self.calls = self.inner.calls
+            self.parse_batch_device_optimistic = self.inner.parse_batch_device_optimistic
+            self.parse_batch_device = self.inner.parse_batch_device
+    eng = Old()
     sh = _shard(eng)
     _step_and_check(sh)
     assert eng.calls == ["optimistic", "exact"]
