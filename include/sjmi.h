@@ -343,8 +343,9 @@ int sjmi_parse_batch_device_optimistic(sjmi_ctx* ctx, const void* d_buf, uint64_
  * every document gets its own stage-1 verdict (16 lanes per document, all carries from zero), the documents that fail are
  * blanked in a sanitized copy, and the optimistic pipeline runs over that copy (REPAIR) -- exact, because every surviving
  * document begins and ends outside a string; documents that are not separated at all are taken too as long as no scalar can run
- * on across a boundary (the last byte of every document is whitespace, an operator or a quote).  Only a batch that fails that
- * rule falls to the per-document index passes.  A repaired batch reports like an accepted one: a document that failed stage 1
+ * on across a boundary (the last byte of every document is whitespace, an operator or a quote).  A batch that fails that rule
+ * (or whose document offsets do not cover the buffer) comes back with SJMI_ST_REJECTED ONCE MORE: sjmi_parse_batch_device then
+ * serves it with the per-document index passes -- three levels, each cheaper than the next, the last one takes anything.  A repaired batch reports like an accepted one: a document that failed stage 1
  * has doc_status[k] / doc_errors[k] set, no structurals and a two-word tape slot with unspecified contents; stage1.status is the
  * OR of the documents' verdicts.  (SJMI_BATCH_REPAIR=0 switches the repair stage off.) */
 int sjmi_parse_batch_device_rejected(sjmi_ctx* ctx, const void* d_buf, uint64_t total_len, const void* d_doc_offsets, uint64_t n_docs,

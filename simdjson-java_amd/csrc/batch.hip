@@ -438,10 +438,11 @@ k_doc_pass(const uint8_t* __restrict__ buf, const unsigned long long* __restrict
            const unsigned long long* __restrict__ index_offsets, uint32_t* __restrict__ out, uint64_t out_cap,
            sj_u64 total_len, const uint32_t* __restrict__ skip, uint32_t* __restrict__ status_or, uint8_t* __restrict__ copy) {
     if (skip && *skip) return;  // (the optimistic plain pass of the fused pipeline was accepted: k_batch_plain_accept)
+    __shared__ uint4 s_rows[WRITE ? 1 : 4][WRITE ? 1 : 64][4];  // (WRITE = false: a wave's 64 blocks on their way to the copy)
     uint32_t seen = 0;          // (WRITE = false: the OR of this thread's documents' verdicts, for status_or)
-    // copy (WRITE = false, round 6): the SANITIZED COPY of the batch for the repair pass, made on the way -- every lane stores the
-    // bytes of its blocks as it classifies them, and the blocks of a document whose verdict is not 0 once more as spaces (the
-    // same lane to the same addresses: program order).  Exactly the documents' own bytes are written: a batch whose documents
+    // copy (WRITE = false, round 6): the SANITIZED COPY of the batch for the repair pass, made on the way -- the row stores the bytes
+    // of its blocks as it classifies them, and the blocks of a document whose verdict is not 0 once more as spaces (behind the
+    // wave-level fence that ends every trip's stores).  Exactly the documents' own bytes are written: a batch whose documents
     // do not cover the buffer is not one the repair pass takes (k_doc_prepare), and the per-document passes make their own copy.
     const int lane = threadIdx.x & 63;
     const int rl = lane & 15;         // lane inside the row
@@ -492,7 +493,35 @@ k_doc_pass(const uint8_t* __restrict__ buf, const unsigned long long* __restrict
             }
             sj_u64 p[8];
             const sj_u64 rem = len - cblk * 64;
-            if (!WRITE && copy && active) doc_store_block(copy + start, w, rem < 64 ? (uint32_t)rem : 64u);
+            if (!WRITE && copy) {
+                // The row's 16 blocks are 1 KiB of CONTIGUOUS copy: stored lane by lane -- a 64-byte block each -- they are four
+                // instructions of 64 scattered 16-byte pieces each (measured: 0.80 ms for the pass).  Through LDS the row's lanes
+                // store NEIGHBOURING 16-byte chunks, chunk c = rl + 16 j of the row in instruction j: 0.67 ms.  (The loads keep
+                // the block-per-lane form: coalesced through LDS as well they cannot overlap the algebra any more, 0.91 ms.)
+                const int wvi = threadIdx.x >> 6;
+                uint4* const mine = &s_rows[wvi][lane][0];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mine[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const sj_u64 row_off = b0 * 64;  // (bytes of the document in front of the row's blocks of this trip)
+                const uint32_t row_valid = (live && len > row_off) ? (len - row_off < 1024 ? (uint32_t)(len - row_off) : 1024u) : 0u;
+                uint8_t* const row_dst = copy + s + row_off;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t c2 = (uint32_t)rl + 16u * j;
+                    const uint4 v = s_rows[wvi][rshift + (c2 >> 2)][c2 & 3u];
+                    if (16u * c2 + 16u <= row_valid) {
+                        const DocU16 o = {v.x, v.y, v.z, v.w};
+                        *reinterpret_cast<DocU16*>(row_dst + 16u * c2) = o;
+                    } else if (16u * c2 < row_valid) {  // (the document's last chunk: one lane of the row, once per document)
+                        const uint32_t wq[16] = {v.x, v.y, v.z, v.w, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                        doc_store_block(row_dst + 16u * c2, wq, row_valid - 16u * c2);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
             sj_transpose_butterfly(w, p);
             sj_mask_tail(p, rem < 64 ? (uint32_t)rem : 64u);
             SjBlockMasks bm = sj_block(p, e_in, p_in, uc);

@@ -1238,7 +1238,8 @@ int sjmi_stage1_batch_isolated(sjmi_ctx* c, const uint8_t* buf, uint64_t total_l
 //             the string pass over the sanitized copy, ordinals, the walk into scratch tapes + packing.
 //   k_tok_stream, k_coop_walk (list), k_slow_doubles: ONE set of walkers behind all three (a device flag says where the tapes go).
 // PIPE_OPTIMISTIC: stage A and the walkers, nothing else; a batch that does not qualify comes back with SJMI_ST_REJECTED.
-// PIPE_EXACT: A, B, C.  PIPE_REJECTED: B, C -- the call to make after SJMI_ST_REJECTED.  No host round trip in any of them.
+// PIPE_EXACT: A, B, C.  PIPE_REJECTED: B and the walkers -- the call to make after SJMI_ST_REJECTED; what B cannot take either comes
+// back REJECTED again and is PIPE_EXACT's.  No host round trip inside any of them.
 enum PipeMode { PIPE_OPTIMISTIC, PIPE_EXACT, PIPE_REJECTED };
 static int parse_batch_pipeline(sjmi_ctx* c, const void* d_buf, uint64_t total_len, const void* d_doc_offsets, uint64_t n_docs,
                                 void* d_indexes, uint64_t index_capacity, void* d_index_offsets, void* d_doc_status,
@@ -1264,6 +1265,10 @@ static int parse_batch_pipeline(sjmi_ctx* c, const void* d_buf, uint64_t total_l
     // stage B needs the FAST kernel (its scanner writes the caller's record: a SAFE launch's record is copied out behind the
     // kernel whether it ran or not) and more than one document
     const bool try_repair = aligned && repair_on && !optimistic_only && n_docs > 1 && !(launch_flags(c) & (sjmi::FLAG_SAFE | sjmi::DBG_NO_LOOKBACK));
+    // PIPE_REJECTED queues the repair stage and the walkers, nothing else: a batch stage B cannot take either (rare: a scalar running
+    // on across a boundary without a separator, a document ending in a backslash) comes back with SJMI_ST_REJECTED once more and is
+    // the exact call's -- stage C's ~20 queue entries (100 us of kernels that leave at once) stay off the repaired batch's path
+    const bool repair_only = mode == PIPE_REJECTED && try_repair;
     if (!grow(c, &c->d_ws_walk, &c->ws_walk_bytes, sjmi::walk_workspace_bytes(bound, n_docs), "hipMalloc(ws_walk)")) return SJMI_ERR_HIP;
     c->accept_valid = false;
     if (!try_plain && !try_repair) {
@@ -1425,6 +1430,7 @@ static int parse_batch_pipeline(sjmi_ctx* c, const void* d_buf, uint64_t total_l
             sjmi::BatchLayout lb = bl;
             lb.flags = flags_b;
             lb.stage = 1;
+            lb.optimistic_only = repair_only;
             lb.gate = skip_b;
             lb.status_or = sjmi::batch_status_or(c->d_doccnt, n_docs);
             if (fail(c, "repair: prepare launch", sjmi::batch_prepare_launch(pb, st)) ||
@@ -1435,7 +1441,7 @@ static int parse_batch_pipeline(sjmi_ctx* c, const void* d_buf, uint64_t total_l
         // ---- stage C, every kernel gated on pf[1] == 0: its OWN sanitized copy (the whole buffer, failing documents blank, an odd
         //      trailing backslash run shortened by one: a batch B does not take may have bytes between its documents and documents
         //      that end in a backslash) and the copy's block parities from a parity-only launch ----
-        {
+        if (!repair_only) {
             sjmi::Stage1Extras ex;
             ex.blkpar = c->d_blkpar2;
             ex.skip = skip_c;
@@ -1447,7 +1453,8 @@ static int parse_batch_pipeline(sjmi_ctx* c, const void* d_buf, uint64_t total_l
             note_launch(c, st);
         }
         //      ... the per-document index arrays, the string pass over the copy (fills the record k_batch_layout zeroed), ordinals
-        if (fail(c, "indexes launch", sjmi::batch_indexes_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs,
+        if (!repair_only &&
+            (fail(c, "indexes launch", sjmi::batch_indexes_launch((const uint8_t*)d_buf, (const unsigned long long*)d_doc_offsets, n_docs,
                                                                  (uint32_t*)d_indexes, index_capacity, (unsigned long long*)d_index_offsets,
                                                                  (uint32_t*)d_doc_status, c->d_doccnt, (sjmi::Stage1Result*)&r->stage1, st,
                                                                  total_len, skip_c)) ||
@@ -1459,7 +1466,7 @@ static int parse_batch_pipeline(sjmi_ctx* c, const void* d_buf, uint64_t total_l
                  sjmi::strings_doc_ordinals_launch(c->d_copy, copy_par, sjmi::StringsAlt(), total_len,
                                                    (const unsigned long long*)d_doc_offsets, n_docs, c->d_blk_ord, c->d_soff,
                                                    (const sjmi::UnescapeResult*)&r->strings, c->d_doc_ord,
-                                                   (unsigned long long*)d_doc_string_offsets, st, skip_c)))
+                                                   (unsigned long long*)d_doc_string_offsets, st, skip_c))))
             return SJMI_ERR_HIP;
     }
     const bool layout_done = try_plain || try_repair;
@@ -1470,7 +1477,7 @@ static int parse_batch_pipeline(sjmi_ctx* c, const void* d_buf, uint64_t total_l
                                (unsigned long long*)d_tape, tape_capacity, (unsigned long long*)d_tape_offsets,
                                (int32_t*)d_doc_errors, c->d_ws_walk, (sjmi::WalkResult*)&r->walk, st,
                                (const sjmi::Stage1Result*)&r->stage1, (const sjmi::UnescapeResult*)&r->strings, c->d_soff, false, false,
-                               sjmi::SingleDocTail(), layout_done ? d_laid_out : nullptr, layout_done, optimistic_only)))
+                               sjmi::SingleDocTail(), layout_done ? d_laid_out : nullptr, layout_done, optimistic_only || repair_only)))
         return SJMI_ERR_HIP;
     return SJMI_OK;
 }

@@ -95,7 +95,7 @@ class BatchShard:
         # REJECTED has no valid counts for the gather).  Rejected although every document passed stage 1 = rejected for its FORMAT
         # (no control-character separators): the next batch will be too, so it goes straight to the call for rejected batches;
         # rejected for a document that fails stage 1: the exact call, which tries the plain pass first.
-        rejected = rejected or (not exact and getattr(self, "format_rejected", False))
+        rejected = rejected or (not exact and getattr(self, "format_rejected", False) and not getattr(self, "unrepairable", False))
         exact = exact or getattr(self, "rejected_steps", 0) > 0
         if rejected and hasattr(self.engine, "parse_batch_device_rejected"):
             fn = self.engine.parse_batch_device_rejected
@@ -125,11 +125,18 @@ class BatchShard:
             self.rejected_steps = getattr(self, "rejected_steps", 0) + 1
             if not (st1 & 0xFF):
                 self.format_rejected = True  # (a clean stage-1 verdict and still rejected: the separators)
-            self.step(getattr(self, "_last_stream", 0), rejected=True)
-            if str(self.device) != "cpu":  # (the CPU tests' stub engines are synchronous)
-                torch.cuda.synchronize(self.device)
-            r = self.result.cpu().numpy()
-            st1, sflags, wflags = int(r[1]) & 0xFFFFFFFF, int(r[4]) & 0xFFFFFFFF, int(r[8]) & 0xFFFFFFFF
+            for entry in ({"rejected": True}, {"exact": True}):
+                # the call for rejected batches (repair on the device); a batch it cannot take either -- documents that are not
+                # separated AND let a scalar run on across a boundary -- says REJECTED once more and is the exact call's
+                self.step(getattr(self, "_last_stream", 0), **entry)
+                if str(self.device) != "cpu":  # (the CPU tests' stub engines are synchronous)
+                    torch.cuda.synchronize(self.device)
+                r = self.result.cpu().numpy()
+                st1, sflags, wflags = int(r[1]) & 0xFFFFFFFF, int(r[4]) & 0xFFFFFFFF, int(r[8]) & 0xFFFFFFFF
+                if not (st1 & 0x800):
+                    break
+                self.format_rejected = False  # (... and so are the batches behind it: the latch below moves to the exact call)
+                self.unrepairable = True
         if st1 & 0x300:
             raise RuntimeError("stage 1 of the shard: capacity / internal error (status 0x%x)" % st1)
         if sflags & 1:
