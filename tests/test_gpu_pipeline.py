@@ -241,6 +241,50 @@ def test_accepted_batch_with_a_large_and_a_deep_document(twitter):
         ctx.close()
 
 
+@pytest.mark.parametrize("sep", [b"\n", b" "], ids=["lf", "space"])
+def test_repaired_batch_with_documents_of_every_size(twitter, sep):
+    """The repair stage's sanitized copy is made by the verdict pass -- a row of 16 lanes per document, 1 KiB per trip, the copy's
+    stores transposed through LDS, a document's last chunk stored byte-precisely, a failing document blanked behind its last
+    trip.  Sizes that stress it: 1 .. 80 bytes (every length modulo 16 and 64), exactly 64 / 1024 / 1025 bytes, a large document
+    (twitter.json: 617 trips of its row), failing documents of every size in between -- a copy with one wrong byte shows up as a
+    wrong tree or a wrong verdict of the document it belongs to.  Through the call for rejected batches, every document against
+    the oracle."""
+    import simdjson_java_amd as S
+    rng = random.Random(23)
+    docs = []
+    for n in list(range(1, 81)) + [127, 128, 129, 1000, 1023, 1024, 1025, 4097]:
+        body = b"[" + b",".join(b"%d" % rng.randrange(10 ** rng.randint(1, 6)) for _ in range(n))
+        good = (body[:max(n - 1, 1)].rstrip(b",-") if n > 2 else b"[") + b"]"
+        docs.append(good)
+        docs.append(b'["' + b"x" * max(n - 3, 0) + b'"]')
+        if n % 3 == 0:
+            docs.append(b'["' + b"y" * n)                      # unclosed string of that size: blanked
+        if n % 5 == 0:
+            docs.append(b'["' + b"z" * (n // 2) + b"\xff" + b'"]')  # invalid UTF-8: blanked
+    docs.insert(40, twitter.rstrip(b"\n"))
+    docs.insert(90, b'{"k":"' + b"w" * 5000 + b'\x01"}')         # a control character inside a long string: blanked
+    ctx = S.Context(0, 4 << 20)
+    try:
+        buf = b"".join(d + sep for d in docs)
+        offs = np.concatenate([[0], np.cumsum([len(d) + len(sep) for d in docs])]).astype(np.uint64)
+        c, tape, to, err, strings, io, idx = _run_shard(ctx, buf, offs, len(docs), exact=False, want_rejected=True)
+        n_bad = 0
+        for k, d in enumerate(docs):
+            want = O.parse(d + sep)
+            assert int(err[k]) == want.error, (k, d[:40], len(d), int(err[k]), want.error)
+            if want.error:
+                n_bad += 1
+                if 1 <= want.error <= 3:
+                    assert int(to[k + 1] - to[k]) == 2, (k, len(d))  # (repaired: the tapes were laid out in advance)
+            else:
+                got_idx = idx[int(io[k]):int(io[k + 1])].astype(np.int64) - int(offs[k])
+                assert np.array_equal(got_idx, O.stage1(d)[0].astype(np.int64)), (k, len(d))
+                assert O.Parsed(tape[int(to[k]):int(to[k + 1])], strings, 0, 0, 0).to_python() == want.to_python(), (k, len(d))
+        assert c["failed_documents"] == n_bad >= 40
+    finally:
+        ctx.close()
+
+
 def test_accepted_batch_delimiters_equal_the_per_document_passes():
     """k_doc_prepare (accepted plain pass) reads a document's index range, first string and tape slot off stage 1's per-block
     side outputs instead of searching / packing.  Layouts that stress it: documents that begin exactly on a block boundary, many
