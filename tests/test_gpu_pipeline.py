@@ -534,6 +534,51 @@ def test_the_repair_stage_takes_what_it_can_and_only_that():
         ctx.close()
 
 
+def test_the_call_for_rejected_batches_on_its_own():
+    """sjmi_parse_batch_device_rejected as the FIRST call on a fresh context (nothing of an optimistic call's state to lean on), on a
+    clean NDJSON batch and on one with failing documents, twice each (the second call reuses every workspace): outputs per document
+    equal to the oracle's, and equal to the exact entry's on the same batch."""
+    import torch
+    import simdjson_java_amd as S
+    from simdjson_java_amd import sharding
+    rng = random.Random(71)
+    good = _small_docs(rng, 2500)
+    for bad in ([], [b'["abc', bytes([0x5B, 0x22, 0xC3, 0x22, 0x5D]), b"[1 1]", b'{"k":"v\x02"}']):
+        docs = list(good)
+        for i, b in enumerate(bad):
+            docs.insert(300 + 500 * i, b)
+        buf = b"".join(d + b"\n" for d in docs)
+        offs = np.concatenate([[0], np.cumsum([len(d) + 1 for d in docs])]).astype(np.uint64)
+        outs = []
+        for entry in ("rejected", "exact"):
+            ctx = S.Context(0, 1 << 20)
+            try:
+                shard = sharding.BatchShard(ctx, buf, offs, torch.device("cuda", 0))
+                for _ in range(2):
+                    shard.step(torch.cuda.current_stream().cuda_stream, exact=(entry == "exact"), rejected=(entry == "rejected"))
+                    torch.cuda.synchronize()
+                st1 = int(shard.result.cpu().numpy()[1]) & 0xFFFFFFFF
+                assert not (st1 & 0x800), (entry, hex(st1))
+                c = shard.check()
+                to = shard.tape_offsets.cpu().numpy()
+                tape = shard.tape.cpu().numpy().view(np.uint64)
+                err = shard.doc_errors.cpu().numpy()[:len(docs)]
+                strings = bytes(shard.sb[:c["string_bytes"]].cpu().numpy())
+                n_bad = 0
+                for k, d in enumerate(docs):
+                    want = O.parse(d + b"\n")
+                    assert int(err[k]) == want.error, (entry, k, d[:40], int(err[k]), want.error)
+                    if want.error:
+                        n_bad += 1
+                    else:
+                        assert O.Parsed(tape[int(to[k]):int(to[k + 1])], strings, 0, 0, 0).to_python() == want.to_python(), (entry, k)
+                assert c["failed_documents"] == n_bad == len(bad), (entry, c)
+                outs.append((err.copy(), c["structurals"], c["string_bytes"], strings))
+            finally:
+                ctx.close()
+        assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
+
+
 def test_pipeline_in_safe_mode_with_a_faked_timeout_and_with_misaligned_buffers():
     """The corners of the re-ordered pipeline (round 5): (a) SAFE liveness mode -- no scanner, so the plain pass's record comes by a
     queued copy and the string workspace is still zeroed by the workers; (b) a FAST plain pass that reports a tripped spin bound
