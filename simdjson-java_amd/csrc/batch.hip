@@ -441,8 +441,8 @@ k_doc_pass(const uint8_t* __restrict__ buf, const unsigned long long* __restrict
     __shared__ uint4 s_rows[WRITE ? 1 : 4][WRITE ? 1 : 64][4];  // (WRITE = false: a wave's 64 blocks on their way to the copy)
     uint32_t seen = 0;          // (WRITE = false: the OR of this thread's documents' verdicts, for status_or)
     // copy (WRITE = false, round 6): the SANITIZED COPY of the batch for the repair pass, made on the way -- the row stores the bytes
-    // of its blocks as it classifies them, and the blocks of a document whose verdict is not 0 once more as spaces (behind the
-    // wave-level fence that ends every trip's stores).  Exactly the documents' own bytes are written: a batch whose documents
+    // of its blocks as it classifies them, and the chunks of a document whose verdict is not 0 once more as spaces (every lane the
+    // chunks it stored: the same lane to the same addresses, program order).  Exactly the documents' own bytes are written: a batch whose documents
     // do not cover the buffer is not one the repair pass takes (k_doc_prepare), and the per-document passes make their own copy.
     const int lane = threadIdx.x & 63;
     const int rl = lane & 15;         // lane inside the row
@@ -562,12 +562,18 @@ k_doc_pass(const uint8_t* __restrict__ buf, const unsigned long long* __restrict
                 seen |= all;
             }
             if (copy && all) {  // (rare) a failing document is blank in the copy
+                // every lane blanks exactly the chunks IT stored above (chunk rl + 16 j of every 1 KiB trip): the same lane to the
+                // same addresses, in program order
                 uint32_t sp[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sp[i] = 0x20202020u;
-                for (sj_u64 blk = rl; blk < nblocks; blk += 16) {
-                    const sj_u64 rem = len - blk * 64;
-                    doc_store_block(copy + s + blk * 64, sp, rem < 64 ? (uint32_t)rem : 64u);
+                for (sj_u64 row_off = 0; row_off < len; row_off += 1024) {
+                    const uint32_t row_valid = len - row_off < 1024 ? (uint32_t)(len - row_off) : 1024u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t c2 = (uint32_t)rl + 16u * j;
+                        if (16u * c2 < row_valid) doc_store_block(copy + s + row_off + 16u * c2, sp, row_valid - 16u * c2 < 16u ? row_valid - 16u * c2 : 16u);
+                    }
                 }
             }
         }
