@@ -35,6 +35,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "sj_block.h"
 #include "sj_block32.h"
@@ -554,6 +555,15 @@ __device__ __forceinline__ void zero_next_workspace(uint4* zero_ptr, uint32_t ze
 constexpr uint32_t TICKET_CLASSES = 8;
 constexpr int LB_K = 1;  // SAFE mode's look-back window = 64 * LB_K granules
 
+#ifndef SJMI_S1_SORT
+#define SJMI_S1_SORT 1       // the expansion's half masks handed out by population (stage1_body, sorted_round)
+#endif
+#ifndef SJMI_S1_SORT_PLAIN
+#define SJMI_S1_SORT_PLAIN 1 // ... in k_stage1 as well as in k_stage1_batch
+#endif
+#ifndef SJMI_S1_SORT_MIN
+#define SJMI_S1_SORT_MIN 192 // ... for a round of more than this many indexes per 4 KiB step (below: the sort costs more than it saves)
+#endif
 // S = 4 KiB steps per granule, LDSW = bytes of LDS per wave
 template <int S>
 struct Parked {
@@ -885,18 +895,7 @@ stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ 
                     // position modulo 4 as their final index, so that whole 16-byte quads of the LDS slice go out as
                     // global_store_dwordx4 (the index array is 16-byte aligned); only the two boundary quads of the run need
                     // element-wise stores.
-                    auto fast_round = [&](int e0, int e1, uint32_t rbase, uint32_t rcount) {
-                        const uint32_t g0 = (uint32_t)((cnt_in + gbase + rbase) & 3ull);
-#pragma unroll
-                        for (int e = 0; e < E; ++e) {
-                            if (e < e0 || e >= e1) continue;  // (wave-uniform; e itself stays a constant: mk / pos are registers)
-                            const uint32_t bstart = (uint32_t)((pblk0 + (sj_u64)(g * E + e) * 64 + lane) * 64);
-                            uint32_t* q = stage + g0 + (pos[e] - rbase);
-                            for (uint32_t lo = (uint32_t)mk[e]; lo; lo &= lo - 1) *q++ = bstart | (uint32_t)__builtin_ctz(lo);
-                            for (uint32_t hi = (uint32_t)(mk[e] >> 32); hi; hi &= hi - 1)
-                                *q++ = bstart | 32u | (uint32_t)__builtin_ctz(hi);
-                        }
-                        wave_lds_fence();
+                    auto flush_round = [&](uint32_t rbase, uint32_t rcount, uint32_t g0) {
                         const uint32_t span = g0 + rcount;
                         uint32_t* gbp = dst0 + rbase - g0;  // 16-byte aligned
                         for (uint32_t qi = lane; qi * 4 < span; qi += 64) {
@@ -913,15 +912,100 @@ stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ 
                         }
                         wave_lds_fence();
                     };
+                    auto fast_round = [&](int e0, int e1, uint32_t rbase, uint32_t rcount) {
+                        const uint32_t g0 = (uint32_t)((cnt_in + gbase + rbase) & 3ull);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            if (e < e0 || e >= e1) continue;  // (wave-uniform; e itself stays a constant: mk / pos are registers)
+                            const uint32_t bstart = (uint32_t)((pblk0 + (sj_u64)(g * E + e) * 64 + lane) * 64);
+                            uint32_t* q = stage + g0 + (pos[e] - rbase);
+                            for (uint32_t lo = (uint32_t)mk[e]; lo; lo &= lo - 1) *q++ = bstart | (uint32_t)__builtin_ctz(lo);
+                            for (uint32_t hi = (uint32_t)(mk[e] >> 32); hi; hi &= hi - 1)
+                                *q++ = bstart | 32u | (uint32_t)__builtin_ctz(hi);
+                        }
+                        wave_lds_fence();
+                        flush_round(rbase, rcount, g0);
+                    };
+                    // The per-bit loops above run as long as the BUSIEST lane of each of their 2 (e1 - e0) trips has bits: 151 trips of
+                    // the loop body per 16 KiB of the configs[3] documents for a mean of 48 indexes per lane (56 for 22 on
+                    // twitter.json) -- a third of the lanes at work.  The sorted form hands the round's 32-bit half masks out again by
+                    // population: a counting sort in LDS (histogram by LDS atomics = the rank inside a bucket, one scan over the 33
+                    // buckets, every half mask with its staging slot and its block stored at its rank), then lane l takes entries
+                    // l, l + 64, ...: a trip's 64 half masks have (nearly) the same number of bits, the empty ones come last and
+                    // their trips are not run (tools/README.md: expansion statistics; profiles/r6/README.md has the A/B).
+                    auto sorted_round = [&](auto e0c, auto e1c, uint32_t rbase, uint32_t rcount) {
+                        constexpr int E0 = decltype(e0c)::value, E1 = decltype(e1c)::value, NI = 2 * (E1 - E0);
+                        static_assert(NI * 128 + 128 <= CAP, "the sort's tables overlay the staging slots");
+                        const uint32_t g0 = (uint32_t)((cnt_in + gbase + rbase) & 3ull);
+                        uint32_t* const hist = stage + NI * 128;  // [64]: half masks by population (0 .. 32)
+                        uint32_t* const bbase = hist + 64;        // [64]: first rank of a bucket, the fullest bucket first
+                        uint2* const items = reinterpret_cast<uint2*>(stage);  // [NI * 64]: .x = half mask, .y = byte offset of its first staging slot | (its first byte's offset in the granule) << 16
+                        hist[lane] = 0u;
+                        wave_lds_fence();
+                        uint32_t hm[NI], cc[NI], rk[NI], inf[NI];
+#pragma unroll
+                        for (int e = E0; e < E1; ++e) {
+                            const int i = 2 * (e - E0);
+                            hm[i] = (uint32_t)mk[e];
+                            hm[i + 1] = (uint32_t)(mk[e] >> 32);
+                            cc[i] = (uint32_t)__popc(hm[i]);
+                            cc[i + 1] = (uint32_t)__popc(hm[i + 1]);
+                            const uint32_t p4 = (pos[e] - rbase + g0) * 4u;
+                            const uint32_t ib = (uint32_t)(((g * E + e) * 64 + lane) * 64) << 16;
+                            inf[i] = p4 | ib;
+                            inf[i + 1] = (p4 + 4u * cc[i]) | (ib + (32u << 16));
+                            rk[i] = atomicAdd(&hist[cc[i]], 1u);
+                            rk[i + 1] = atomicAdd(&hist[cc[i + 1]], 1u);
+                        }
+                        wave_lds_fence();
+                        const uint32_t hv = lane <= 32 ? hist[32 - lane] : 0u;
+                        const uint32_t incl = wave_incl_scan(hv, lane);
+                        if (lane <= 32) bbase[32 - lane] = incl - hv;
+                        const uint32_t nz = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);  // half masks with a bit
+                        wave_lds_fence();
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) items[bbase[cc[i]] + rk[i]] = make_uint2(hm[i], inf[i]);
+                        wave_lds_fence();
+                        const uint32_t trips = (nz + 63u) / 64u;
+                        uint2 it[NI];
+#pragma unroll
+                        for (int r = 0; r < NI; ++r) it[r] = items[r * 64 + lane];
+                        wave_lds_fence();
+                        const uint32_t b32 = (uint32_t)(pblk0 * 64);
+#pragma unroll
+                        for (int r = 0; r < NI; ++r) {
+                            if ((uint32_t)r >= trips) break;  // (wave-uniform)
+                            uint32_t* q = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(stage) + (it[r].y & 0xFFFFu));
+                            const uint32_t bv = b32 + (it[r].y >> 16);
+                            for (uint32_t lo = it[r].x; lo; lo &= lo - 1) *q++ = bv | (uint32_t)__builtin_ctz(lo);
+                        }
+                        wave_lds_fence();
+                        flush_round(rbase, rcount, g0);
+                    };
                     // (a structural every ~5 bytes -- the documents of configs[3] -- makes 3,000 per 16 KiB granule: more than
                     //  the 2,304 slots, but each half of the granule fits)
                     const uint32_t split = E >= 2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)pos[E / 2]) : 0u;
+                    using std::integral_constant;
+                    constexpr bool do_sort = SJMI_S1_SORT && (BATCH || SJMI_S1_SORT_PLAIN);
+                    bool staged = false;
                     if (WT + 3 <= (uint32_t)CAP) {
-                        fast_round(0, E, 0, WT);
-                    } else if (E >= 2 && split + 3 <= (uint32_t)CAP && WT - split + 3 <= (uint32_t)CAP) {
-                        fast_round(0, E / 2, 0, split);
-                        fast_round(E / 2, E, split, WT - split);
-                    } else {
+                        if (do_sort && WT > (uint32_t)(SJMI_S1_SORT_MIN * E)) sorted_round(integral_constant<int, 0>{}, integral_constant<int, E>{}, 0, WT);
+                        else fast_round(0, E, 0, WT);
+                        staged = true;
+                    }
+                    if constexpr (E >= 2) {
+                        if (!staged && split + 3 <= (uint32_t)CAP && WT - split + 3 <= (uint32_t)CAP) {
+                            if (do_sort) {
+                                sorted_round(integral_constant<int, 0>{}, integral_constant<int, E / 2>{}, 0, split);
+                                sorted_round(integral_constant<int, E / 2>{}, integral_constant<int, E>{}, split, WT - split);
+                            } else {
+                                fast_round(0, E / 2, 0, split);
+                                fast_round(E / 2, E, split, WT - split);
+                            }
+                            staged = true;
+                        }
+                    }
+                    if (!staged) {
                         for (uint32_t base = 0; base < WT; base += CAP) {
                             const uint32_t lim = base + CAP;
 #pragma unroll
@@ -988,8 +1072,16 @@ stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ 
 // batch: 0.51 ms instead of 0.43); spilling them is the cheaper way out.
 template <int S, int LDSW, bool SAFE, bool BATCH>
 struct Stage1Kernel;
+// (round 6: the sorted expansion's entries -- 2 registers per half mask -- took k_stage1<4, ...> from 125 to 135 VGPRs = three waves
+//  per SIMD; pinned to four like the batch flavour it allocates 128 without a spilled VGPR)
+#ifndef SJMI_S1_PLAIN_WAVES
+#define SJMI_S1_PLAIN_WAVES 4
+#endif
 template <int S, int LDSW, bool SAFE>
 __global__ void __launch_bounds__(256)
+#if SJMI_S1_PLAIN_WAVES
+__attribute__((amdgpu_waves_per_eu(SJMI_S1_PLAIN_WAVES, SJMI_S1_PLAIN_WAVES)))
+#endif
 k_stage1(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ out, sj_u64 out_cap,
          sj_u64* gstate, uint32_t* ticket, Stage1Result* res, uint32_t ngran, uint32_t dbg, uint4* zero_ptr,
          uint32_t zero_chunks, Stage1Result* result_out, sj_u64* __restrict__ blkpar, const uint32_t* __restrict__ skip,

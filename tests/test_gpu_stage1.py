@@ -279,3 +279,42 @@ def test_index_emission_rounds_by_structural_density(ctx, unit, what):
             _check(ctx, d)
     finally:
         ctx.set_tile_steps(0)
+
+
+def _block_of_population(rng, k):
+    """64 bytes with exactly k structurals, placed at random: operators for the structurals, spaces for the rest (every operator is a
+    structural; nothing else here is)"""
+    b = bytearray(b" " * 64)
+    for p in rng.sample(range(64), k):
+        b[p] = rng.choice(b"[]{}:,")
+    return bytes(b)
+
+
+@pytest.mark.parametrize("steps", [1, 2, 4])
+def test_expansion_sorted_by_population(ctx, steps):
+    """Round 6: the expansion hands a round's 32-bit half masks out again by population (stage1.hip sorted_round: counting sort in
+    LDS, the rank of a half mask from an LDS atomic).  Blocks of EVERY population 0 .. 64 in shuffled order -- all buckets of the
+    histogram in use inside one granule, empty half masks among full ones, rounds on both sides of the sort's threshold, granules
+    that need one round / two rounds / the windowed path -- and runs of equal blocks (every lane in one bucket: the atomics of a
+    whole wave on one counter)."""
+    rng = random.Random(600 + steps)
+    ctx.set_tile_steps(steps)
+    try:
+        for trial in range(6):
+            blocks = []
+            for _ in range(rng.choice([70, 300, 1100])):
+                mode = rng.random()
+                if mode < 0.5:
+                    blocks.append(_block_of_population(rng, rng.randrange(65)))
+                elif mode < 0.7:
+                    blocks += [_block_of_population(rng, rng.choice([0, 1, 2, 31, 32, 33, 63, 64]))] * rng.randrange(1, 70)
+                elif mode < 0.85:
+                    blocks += [b" " * 64] * rng.randrange(1, 130)   # sparse stretches: rounds below the threshold
+                else:
+                    k = rng.randrange(65)
+                    blocks += [_block_of_population(rng, k) for _ in range(rng.randrange(1, 64))]
+            d = b"".join(blocks)
+            d = d[:len(d) - rng.randrange(64)]  # (a ragged tail block)
+            _check(ctx, d)
+    finally:
+        ctx.set_tile_steps(0)

@@ -17,6 +17,8 @@ st = torch.cuda.current_stream().cuda_stream
 for _ in range(2):
     shard.step(st)
 torch.cuda.synchronize()
+if os.environ.get("SJMI_DBG_AFTER_WARMUP"):  # stage-1 ablation flags (stage1.h DBG_*), set once the index array holds a valid step's indexes
+    ctx.debug_set_flags(int(os.environ["SJMI_DBG_AFTER_WARMUP"], 0))
 t = time.perf_counter()
 for _ in range(steps):
     shard.step(st)
