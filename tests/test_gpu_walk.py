@@ -201,3 +201,21 @@ def test_reference_number_vectors_on_the_gpu(ctx):
             assert got == (("l", v["long"]) if "long" in v else ("d", v["double_bits"])), (v["input"][:40], v["cite"], got)
         on_device += 1
     assert on_device == len(vs) >= 158
+
+
+def test_outputs_do_not_depend_on_the_run(ctx):
+    """The same batch of token-level adversarial documents 25 times through the three calls: every tape, the string buffer and every
+    verdict identical to the first run's (which is checked against the oracle) -- nothing in the kernels may depend on timing
+    (tools/determinism_stress.py is the long form: 500 k repeated runs)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from token_docs import document
+    sys.setrecursionlimit(20000)
+    rng = random.Random(2606)
+    docs = [document(rng) for _ in range(1500)]
+    tapes0, strings0, errors0 = gpu_walk(ctx, docs)
+    check_against_oracle(docs, tapes0, strings0, errors0)
+    for _ in range(25):
+        tapes, strings, errors = gpu_walk(ctx, docs)
+        assert np.array_equal(errors, errors0) and strings == strings0
+        assert all((a is None and b is None) or np.array_equal(a, b) for a, b in zip(tapes, tapes0))
