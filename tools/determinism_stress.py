@@ -3,7 +3,7 @@
 thousands of runs a minute): a fault that depends on timing and not on the input -- a race between waves, a chain that is read too
 early -- shows as a run that differs from the others.  Both batch paths: the three calls (stage 1 with the optimistic plain pass ->
 string pass -> walker; what tools/soak_tokens.py checks against the oracle) and the fused pipeline (BatchShard.step).  The first run
-of every batch IS checked against the oracle.  usage: determinism_stress.py <seconds> <seed> [documents per batch = 1500; 0 = mixed sizes]"""
+of every batch IS checked against the oracle.  usage: determinism_stress.py <seconds> <seed> [documents per batch = 1500; 0 = mixed sizes] [docgen]"""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -20,9 +20,9 @@ from token_docs import document  # noqa: E402
 class ThreeCalls:
     """gpu_walk of tests/test_gpu_walk.py with everything kept on the device"""
 
-    def __init__(self, ctx, docs):
-        buf, offs = _pack(docs)
-        self.ctx, self.n, self.nb = ctx, len(docs), len(buf)
+    def __init__(self, ctx, docs, packed=None):
+        buf, offs = packed if packed is not None else _pack(docs)
+        self.ctx, self.n, self.nb = ctx, len(offs) - 1, len(buf)
         self.d_buf = torch.zeros(len(buf) + 128, dtype=torch.uint8, device="cuda")
         self.d_buf[:len(buf)] = torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
         self.d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
@@ -59,8 +59,8 @@ class ThreeCalls:
 
 
 class Fused:
-    def __init__(self, ctx, docs):
-        buf, offs = _pack(docs)
+    def __init__(self, ctx, docs, packed=None):
+        buf, offs = packed if packed is not None else _pack(docs)
         self.shard = sharding.BatchShard(ctx, buf, offs, torch.device("cuda", 0))
 
     def run(self):
@@ -82,12 +82,25 @@ def main():
     t0 = time.time()
     runs = batches = 0
     differing = []
+    docgen = len(sys.argv) > 4 and sys.argv[4] == "docgen"  # the configs[3] documents (tools/docgen.c) instead of the token documents
+    first = 0
     while time.time() - t0 < secs:
         nb = n if n else rng.choice([2, 7, 64, 300, 1500])  # (0: the mixed sizes of tools/soak_tokens.py)
-        docs = [document(rng) for _ in range(nb)]
-        tapes, strings, errors = gpu_walk(ctx, docs)
-        check_against_oracle(docs, tapes, strings, errors)  # the inputs of this batch are right once
-        for name, path in (("three calls", ThreeCalls(ctx, docs)), ("fused", Fused(ctx2, docs))):
+        packed = None
+        if docgen:
+            import workloads as W
+            b, o = W.unique_docs(first, nb, seed=W.DOCGEN_SEED + seed)
+            packed, docs, first = (bytes(b), o), None, first + nb
+            if rng.random() < 0.5:  # one malformed document: the repair stage of the fused pipeline
+                k = rng.randrange(nb)
+                bb = bytearray(packed[0])
+                bb[int(o[k]):int(o[k + 1]) - 1] = b'["unclosed'.ljust(int(o[k + 1]) - 1 - int(o[k]), b" ")
+                packed = (bytes(bb), o)
+        else:
+            docs = [document(rng) for _ in range(nb)]
+            tapes, strings, errors = gpu_walk(ctx, docs)
+            check_against_oracle(docs, tapes, strings, errors)  # the inputs of this batch are right once
+        for name, path in (("three calls", ThreeCalls(ctx, docs, packed)), ("fused", Fused(ctx2, docs, packed))):
             ref = path.run()
             for it in range(150 if nb >= 300 else 40):
                 got = path.run()
