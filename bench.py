@@ -1026,6 +1026,10 @@ def bench_sharded(args, world):
     if ndev < world and os.environ.get("SJMI_BENCH_OVERSUBSCRIBE", "0") != "1":
         print("bench.py: %d ranks but only %d GPU(s) visible -- refusing to run (one rank per GPU)" % (world, ndev), file=sys.stderr)
         sys.exit(3)
+    if ndev < world:
+        # (the test mode: ranks share a GPU, so no rank's persistent FAST-mode grid is resident as a whole -- every context of this
+        #  process starts in ticket mode instead of finding a tripped liveness bound in a result record; one rank per GPU never gets here)
+        os.environ["SJMI_TICKET_MODE"] = "1"
     dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
     if backend == "nccl":

@@ -267,6 +267,8 @@ class Context:
             raise SjmiError("sjmi_create failed (rc=%d): no usable MI355X / HIP device; there is no CPU fallback" % rc)
         self.capacity = capacity
         _live.add(self)
+        if os.environ.get("SJMI_TICKET_MODE") == "1":  # several processes on ONE GPU (bench.py's oversubscribed test mode): the FAST
+            self.set_tile_mode(True)                   # kernel's whole grid cannot be resident beside another process's -- SAFE mode from the start
         if os.environ.get("SJMI_TILE_STEPS"):  # (experiments: the granule size of every stage-1 launch, sjmi_set_tile_steps)
             self.set_tile_steps(int(os.environ["SJMI_TILE_STEPS"]))
 
