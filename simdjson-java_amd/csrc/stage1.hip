@@ -561,6 +561,9 @@ constexpr int LB_K = 1;  // SAFE mode's look-back window = 64 * LB_K granules
 #ifndef SJMI_S1_SORT_PLAIN
 #define SJMI_S1_SORT_PLAIN 1 // ... in k_stage1 as well as in k_stage1_batch
 #endif
+#ifndef SJMI_S1_TWO_ENDED
+#define SJMI_S1_TWO_ENDED 1  // the sorted round's per-bit loop takes the lowest AND the highest set bit a trip (k_stage1_batch 366 -> 356 us; the headline does not notice)
+#endif
 #ifndef SJMI_S1_SORT_MIN
 #define SJMI_S1_SORT_MIN 192 // ... for a round of more than this many indexes per 4 KiB step (below: the sort costs more than it saves)
 #endif
@@ -977,7 +980,20 @@ stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ 
                             if ((uint32_t)r >= trips) break;  // (wave-uniform)
                             uint32_t* q = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(stage) + (it[r].y & 0xFFFFu));
                             const uint32_t bv = b32 + (it[r].y >> 16);
+#if SJMI_S1_TWO_ENDED
+                            // two indexes a trip: the lowest set bit to the front slot, the highest to the back one (a last single
+                            // bit goes to the same slot twice)
+                            uint32_t lo = it[r].x;
+                            uint32_t* qh = q + __popc(lo) - 1;
+                            while (lo) {
+                                const uint32_t lz = (uint32_t)__builtin_clz(lo);
+                                *q++ = bv | (uint32_t)__builtin_ctz(lo);
+                                *qh-- = bv | (lz ^ 31u);
+                                lo = lo & (lo - 1) & ~(0x80000000u >> lz);
+                            }
+#else
                             for (uint32_t lo = it[r].x; lo; lo &= lo - 1) *q++ = bv | (uint32_t)__builtin_ctz(lo);
+#endif
                         }
                         wave_lds_fence();
                         flush_round(rbase, rcount, g0);
