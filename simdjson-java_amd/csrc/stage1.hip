@@ -564,6 +564,9 @@ constexpr int LB_K = 1;  // SAFE mode's look-back window = 64 * LB_K granules
 #ifndef SJMI_S1_TWO_ENDED
 #define SJMI_S1_TWO_ENDED 1  // the sorted round's per-bit loop takes the lowest AND the highest set bit a trip (k_stage1_batch 366 -> 356 us; the headline does not notice)
 #endif
+#ifndef SJMI_S1_NT_STORE
+#define SJMI_S1_NT_STORE 4  // 0: plain index stores; 1: streaming stores everywhere; 4: in the plain 16 KiB-granule kernels only
+#endif
 #ifndef SJMI_S1_SORT_MIN
 #define SJMI_S1_SORT_MIN 192 // ... for a round of more than this many indexes per 4 KiB step (below: the sort costs more than it saves)
 #endif
@@ -905,7 +908,17 @@ stage1_body(const uint8_t* __restrict__ buf, sj_u64 len, uint32_t* __restrict__ 
                             const uint4 v = reinterpret_cast<const uint4*>(stage)[qi];
                             const uint32_t lo = qi * 4;
                             if (lo >= g0 && lo + 4 <= span) {
-                                reinterpret_cast<uint4*>(gbp)[qi] = v;
+                                // (16 KiB granules = large inputs: the index array is a stream nobody reads before it has left the
+                                //  caches anyway -- streaming stores: +1.4 % on the headline, +1.5 % on twitter x1024; small documents keep
+                                //  theirs in L2 for the kernels behind this one, and the batch flavour is 3.5 % SLOWER with them:
+                                //  profiles/r6/README.md)
+                                if constexpr (SJMI_S1_NT_STORE == 1 || (SJMI_S1_NT_STORE == 4 && S == 4 && !BATCH)) {
+                                    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                                    u32x4_t nv = {v.x, v.y, v.z, v.w};
+                                    __builtin_nontemporal_store(nv, reinterpret_cast<u32x4_t*>(gbp) + qi);
+                                } else {
+                                    reinterpret_cast<uint4*>(gbp)[qi] = v;
+                                }
                             } else {
                                 if (lo + 0 >= g0 && lo + 0 < span) gbp[lo + 0] = v.x;
                                 if (lo + 1 >= g0 && lo + 1 < span) gbp[lo + 1] = v.y;
