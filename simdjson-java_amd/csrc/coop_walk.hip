@@ -966,6 +966,9 @@ struct __attribute__((aligned(16))) TsRun {
 #ifndef SJMI_TS_WAVES
 #define SJMI_TS_WAVES 6
 #endif
+#ifndef SJMI_TS_NT_IDX
+#define SJMI_TS_NT_IDX 1  // the positions as streaming loads (the index array is read once, two whole lines an instruction): 1227 / 1231 -> 1212 / 1219 us
+#endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SJMI_TS_WAVES, SJMI_TS_WAVES)))
 k_tok_stream(TokArgs a_by_value) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1087,7 +1090,11 @@ k_tok_stream(TokArgs a_by_value) {
         // positions are requested two chunks ahead, first bytes one chunk ahead
         auto pos_of = [&](uint32_t cc) -> uint32_t {
             const uint32_t i = cc * 64u + (uint32_t)lane;
+#if SJMI_TS_NT_IDX
+            return __builtin_nontemporal_load(&a.idx[I0 + (i < n ? i : n - 1u)]);
+#else
             return a.idx[I0 + (i < n ? i : n - 1u)];
+#endif
         };
         uint32_t Pa = pos_of(0), Pb = pos_of(1);
         uint32_t Ba = a.buf[Pa];
