@@ -674,6 +674,15 @@ def bench_single(args):
     # the other configs' figures once more as flat scalars (a driver that keeps only the contract's keys keeps `config` and
     # `roofline` but not `extra` or nested objects)
     rf = line["roofline"]
+    if reps == W.TWITTER_4G_REPS and not args.no_extras:
+        # the memory system's rate for THIS traffic on THIS box, beside the nominal peak: a kernel that does nothing but read 4 GiB in
+        # 4 KiB steps per wave and store 0.34 bytes per byte read in 5.6 KB bursts (tools/ubench/load_pattern.hip, built by
+        # __graft_entry__.build(); a reported yardstick, never part of `value` or `frac`)
+        ms = memory_system_rate()
+        if ms:
+            rf["same_traffic_do_nothing_kernel"] = ms
+            rf["same_traffic_do_nothing_kernel_GBps_of_input"] = round(1e3 * max(ms["read_plus_index_stores_TBps_of_input"], ms["read_plus_streaming_index_stores_TBps_of_input"]), 1)
+            rf["achieved_over_same_traffic_do_nothing_kernel"] = round(rf["achieved"] / rf["same_traffic_do_nothing_kernel_GBps_of_input"], 4)
     rf["settled_frac"], rf["settled_avg_kernel_ms"] = rf["settled"]["frac"], rf["settled"]["avg_kernel_ms"]
     rf["cold_frac"], rf["cold_avg_kernel_ms"] = rf["cold"]["frac"], rf["cold"]["avg_kernel_ms"]
     flat = line["config"]
@@ -994,6 +1003,26 @@ def batch_rejected_path(torch, oracle, shard, offs, st, accepted_ms, steps):
 # ---------------------------------------------------------------------------------------------------------------
 # N > 1: the sharded batch
 # ---------------------------------------------------------------------------------------------------------------
+def memory_system_rate():
+    """tools/ubench/load_pattern q -> its three figures (TB/s), or None when the binary is not there / does not run"""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "ubench", "load_pattern")
+    if not os.path.exists(exe):
+        return None
+    try:
+        import torch
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()  # (the microbenchmark allocates 5.5 GB of its own)
+        out = subprocess.run([exe, "q"], capture_output=True, text=True, timeout=120)
+        last = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(last)
+        d["what"] = ("tools/ubench/load_pattern.hip on this box, in this run: 1,024 persistent workgroups, a wave reads 4 KiB steps of a 4 GiB buffer "
+                     "(k_stage1's load pattern) and stores 0.34 bytes per byte read contiguously in 5.6 KB bursts (twitter.json's indexes: 0.35)")
+        return d
+    except Exception:  # a yardstick only: never in the way of the line
+        return None
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:

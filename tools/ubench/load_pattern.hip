@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+static double g_last_tbps = 0;
 template <int PATTERN, int WRITE>
 __global__ void __launch_bounds__(256) k(const uint4* __restrict__ src, uint64_t nsteps, uint4* __restrict__ dst, uint32_t* sink) {
     const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (uint64_t)gridDim.x * 4;
@@ -38,6 +39,7 @@ static void run(const char* name, const uint4* src, uint64_t nsteps, uint4* dst,
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
     printf("%-44s %.3f ms  %.2f TB/s of input\n", name, ms, nsteps * 4096.0 / ms / 1e9);
+    g_last_tbps = nsteps * 4096.0 / ms / 1e9;
 }
 
 // ... and the SIZE of a wave's write burst: G steps read, then 88 * G x 16 bytes stored contiguously (k_stage1: G = 4)
@@ -72,12 +74,24 @@ static void runb(const char* name, const uint4* src, uint64_t nsteps, uint4* dst
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
     printf("%-44s %.3f ms  %.2f TB/s of input\n", name, ms, nsteps * 4096.0 / ms / 1e9);
+    g_last_tbps = nsteps * 4096.0 / ms / 1e9;
 }
-int main() {
+int main(int argc, char** argv) {
+    const bool quick = argc > 1 && argv[1][0] == 'q';  // bench.py: three figures as one JSON object
     const uint64_t bytes = 4ull << 30, nsteps = bytes / 4096;
     uint4 *src, *dst; uint32_t* sink;
     hipMalloc(&src, bytes); hipMalloc(&dst, nsteps * 88 * 16 + 4096); hipMalloc(&sink, 4);
     hipMemset(src, 1, bytes);
+    if (quick) {
+        run<0, 0>("read only", src, nsteps, dst, sink);
+        const double ro = g_last_tbps;
+        runb<4, 0>("read + 0.34 B/B stored, 5.6 KB bursts", src, nsteps, dst, sink);
+        const double rw = g_last_tbps;
+        runb<4, 1>("... streaming stores", src, nsteps, dst, sink);
+        const double rwnt = g_last_tbps;
+        printf("{\"read_only_TBps\": %.3f, \"read_plus_index_stores_TBps_of_input\": %.3f, \"read_plus_streaming_index_stores_TBps_of_input\": %.3f}\n", ro, rw, rwnt);
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         run<0, 0>("A quarter-of-a-line loads, read only", src, nsteps, dst, sink);
         run<1, 0>("B coalesced loads, read only", src, nsteps, dst, sink);
