@@ -48,3 +48,11 @@ def test_bench_line_carries_the_flag():
     r = bench.roofline(1000, 1.0, 1000, "k", 1, traffic=1234)
     assert r["traffic"] == 1234 and isinstance(r["traffic_stale"], bool) and r["traffic_source"]
     assert "traffic_stale" not in bench.roofline(1000, 1.0, 1000, "k", 1)
+
+
+def test_the_memory_system_yardstick_is_optional(tmp_path, monkeypatch):
+    """bench.memory_system_rate(): the do-nothing kernel's figures beside the roofline are a yardstick -- without the binary
+    (tools/ubench/load_pattern, built by __graft_entry__.build()) the line simply does not carry them."""
+    import bench
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.memory_system_rate() is None
